@@ -1,0 +1,320 @@
+"""Generate tests/golden/*.npz by running the REFERENCE implementation (imported from
+/root/reference/endiffusion) on seeded inputs with the synthetic weights of hierdiff_amd.weights.
+
+Runs only in the build container (the reference does not exist on the GPU box).  The fixtures are
+data: inputs + the reference's outputs.  While generating, every fixture is also replayed through
+oracle/egnn_oracle.py and the two are required to agree to fp32 round-off, which pins the oracle.
+
+    python oracle/make_golden.py            # rewrites tests/golden/*.npz
+
+Import recipe: only `endiffusion/` goes on sys.path; `pytorch_lightning`
+and `hydra` are replaced by in-memory stubs because they are not installed here.
+"""
+from __future__ import annotations
+
+import contextlib
+import io
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference/endiffusion"
+sys.path.insert(0, REPO)
+
+from hierdiff_amd.weights import synthetic_state_dict  # noqa: E402
+from oracle import egnn_oracle as orc  # noqa: E402
+
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+
+class AttrDict(dict):
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+def import_reference():
+    pl = types.ModuleType("pytorch_lightning")
+
+    class LightningModule(torch.nn.Module):
+        def save_hyperparameters(self, *a, **k):
+            pass
+
+        def log(self, *a, **k):
+            pass
+
+    pl.LightningModule = LightningModule
+    sys.modules["pytorch_lightning"] = pl
+    hydra = types.ModuleType("hydra")
+    hydra_utils = types.ModuleType("hydra.utils")
+    hydra_utils.instantiate = lambda *a, **k: None
+    hydra.utils = hydra_utils
+    sys.modules["hydra"] = hydra
+    sys.modules["hydra.utils"] = hydra_utils
+    sys.path.insert(0, REF)
+    from train_module.diffusion_qm9 import DiffusionQM9  # type: ignore
+    return DiffusionQM9
+
+
+def make_cfg(hidden_nf, n_layers, context_node_nf=0, normalization_factor=10, inv_sublayers=2):
+    return AttrDict(
+        pocket=False, node_coarse_type="prop", loss_type="vlb", hcontinous=True,
+        noise_schedule="learned", timesteps=1000, norm_values=[1.0, 1.0, 1.0],
+        norm_biases=[None, 0.0, 0.0], parametrization="eps", include_charges=True, dataset="qm9",
+        data_augmentation=False,
+        pre_noise=AttrDict(noise_schedule="learned", timesteps=1000, precision=1e-4),
+        dynamics=AttrDict(in_node_nf=0, context_node_nf=context_node_nf, n_dims=3,
+                          hidden_nf=hidden_nf, act_fn="silu", n_layers=n_layers, attention=True,
+                          condition_time=True, tanh=True, mode="egnn_dynamics", norm_constant=0,
+                          inv_sublayers=inv_sublayers, sin_embedding=False,
+                          normalization_factor=normalization_factor, aggregation_method="sum"),
+        analyze=os.path.join(REF, "conf/analyze/GEOM.yaml"),
+    )
+
+
+def build_reference(DiffusionQM9, hidden_nf, n_layers, context_node_nf=0, seed=0, coord_gain=0.001):
+    cfg = make_cfg(hidden_nf, n_layers, context_node_nf)
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = DiffusionQM9(cfg)
+    sd_np = synthetic_state_dict(9, context_node_nf, hidden_nf, n_layers, 2, True, seed, coord_gain)
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd_np.items()})
+    model.eval()
+    ocfg = orc.DynCfg(in_node_nf=9, context_node_nf=context_node_nf, hidden_nf=hidden_nf,
+                      n_layers=n_layers, normalization_factor=10.0)
+    return model, orc.as_torch_sd(sd_np), ocfg
+
+
+def rel_l2(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def check(name, got, ref, tol=2e-6):
+    r = rel_l2(got, ref)
+    m = float(np.max(np.abs(np.asarray(got, dtype=np.float64) - np.asarray(ref, dtype=np.float64))))
+    print(f"  oracle-vs-reference {name}: rel_l2={r:.2e} max_abs={m:.2e}")
+    assert r < tol, f"{name}: oracle deviates from the reference (rel_l2={r})"
+
+
+def save(name, **arrays):
+    path = os.path.join(GOLDEN, name + ".npz")
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrays.items()})
+    print(f"wrote {path} ({os.path.getsize(path)} bytes)")
+
+
+def fixture_forward(DiffusionQM9, name, n_list, hidden_nf, n_layers, seed, coord_gain, t_values,
+                    n_max=None, with_trace=False):
+    """F1 / F2 / F6 / F7: EGNN_dynamics_QM9._forward on canonical masks."""
+    model, sd, ocfg = build_reference(DiffusionQM9, hidden_nf, n_layers, 0, seed, coord_gain)
+    xh, nm, em = orc.random_inputs(n_list, 8, seed=seed + 100, n_max=n_max)
+    B, N = xh.shape[:2]
+    out = {"xh": xh.numpy(), "node_mask": nm.numpy(), "edge_mask": em.numpy(),
+           "n_list": np.array(n_list), "hidden_nf": hidden_nf, "n_layers": n_layers,
+           "weight_seed": seed, "coord_gain": coord_gain, "t_values": np.array(t_values, np.float32)}
+    with torch.no_grad():
+        for k, tv in enumerate(t_values):
+            t = torch.full((B, 1), float(tv))
+            ref = model.dynamics._forward(t, xh.clone(), nm, em, None, None)
+            got = orc.dynamics_forward(sd, ocfg, t, xh, nm, em, None, None, prefix="dynamics.egnn.")
+            check(f"{name}[t={tv}]", got.numpy(), ref.numpy())
+            out[f"out_t{k}"] = ref.numpy()
+        # scalar-t variant (en_dynamics.py:67-69) and mol_shape == N (the sampler's call)
+        t1 = torch.tensor([float(t_values[0])])
+        ref = model.dynamics._forward(t1, xh.clone(), nm, em, None, N)
+        got = orc.dynamics_forward(sd, ocfg, t1, xh, nm, em, None, N, prefix="dynamics.egnn.")
+        check(f"{name}[scalar t]", got.numpy(), ref.numpy())
+        out["out_scalar_t"] = ref.numpy()
+        # per-row distinct t
+        trow = torch.linspace(0.05, 0.95, B).view(B, 1)
+        ref = model.dynamics._forward(trow, xh.clone(), nm, em, None, None)
+        got = orc.dynamics_forward(sd, ocfg, trow, xh, nm, em, None, None, prefix="dynamics.egnn.")
+        check(f"{name}[row t]", got.numpy(), ref.numpy())
+        out["t_rows"] = trow.numpy()
+        out["out_row_t"] = ref.numpy()
+        if with_trace:
+            # F2: per-layer intermediates of the reference via forward hooks on its own modules
+            inter = {}
+            hooks = []
+            egnn = model.dynamics.egnn
+            for i in range(n_layers):
+                blk = egnn._modules[f"e_block_{i}"]
+                hooks.append(blk.register_forward_hook(
+                    lambda m, a, o, i=i: inter.update({f"blk{i}_h": o[0].numpy().copy(),
+                                                       f"blk{i}_x": o[1].numpy().copy()})))
+                for j in range(2):
+                    g = blk._modules[f"gcl_{j}"]
+                    hooks.append(g.register_forward_hook(
+                        lambda m, a, o, i=i, j=j: inter.update({f"blk{i}_gcl{j}_h": o[0].numpy().copy()})))
+            t = torch.full((B, 1), float(t_values[0]))
+            model.dynamics._forward(t, xh.clone(), nm, em, None, None)
+            for hk in hooks:
+                hk.remove()
+            trace = []
+            orc.dynamics_forward(sd, ocfg, t, xh, nm, em, None, None, prefix="dynamics.egnn.", trace=trace)
+            for (tag, a, b) in trace:
+                short = tag.replace("dynamics.egnn.e_block_", "blk").replace(".gcl_", "_gcl")
+                if "_gcl" in short:
+                    check(f"{name} trace {short}", a.numpy(), inter[short + "_h"])
+                else:
+                    check(f"{name} trace {short} h", a.numpy(), inter[short + "_h"])
+                    check(f"{name} trace {short} x", b.numpy(), inter[short + "_x"])
+            out.update({"trace_" + k: v for k, v in inter.items()})
+    save(name, **out)
+
+
+def fixture_conditional(DiffusionQM9, name, hidden_nf, n_layers, seed, coord_gain):
+    """F3 (BASELINE config 5): context feature, fixed trailing nodes (mol_shape < N),
+    block-diagonal edge mask, fix_noise -> one sample_p_zs_given_zt."""
+    model, sd, ocfg = build_reference(DiffusionQM9, hidden_nf, n_layers, 1, seed, coord_gain)
+    rng = np.random.Generator(np.random.PCG64(seed + 7))
+    B, N, mol = 4, 8, 6
+    n_list = [6, 4, 5, 6]         # molecule sizes within the first `mol` slots
+    n_fix = [2, 2, 1, 0]          # valid fixed ("pocket") nodes in slots mol..N-1
+    node_mask = torch.zeros(B, N, 1)
+    edge_mask = torch.zeros(B, N, N)
+    for b in range(B):
+        node_mask[b, :n_list[b]] = 1
+        node_mask[b, mol:mol + n_fix[b]] = 1
+        edge_mask[b, :n_list[b], :n_list[b]] = 1 - torch.eye(n_list[b])
+        if n_fix[b]:
+            edge_mask[b, mol:mol + n_fix[b], mol:mol + n_fix[b]] = 1 - torch.eye(n_fix[b])
+    node_mask, edge_mask = node_mask.bool(), edge_mask.bool()
+    nmf = node_mask.float()
+    z = torch.from_numpy(rng.standard_normal((B, N, 11)).astype(np.float32)) * nmf
+    zx = orc.remove_mean_with_mask(z[:, :mol, :3], nmf[:, :mol])      # molecule part centred
+    z = torch.cat([torch.cat([zx, z[:, :mol, 3:]], dim=2), z[:, mol:]], dim=1)
+    context = torch.zeros(B, N, 1) + 2.3                                # unmasked, as diffusion_qm9.py:352
+    s = torch.full((B, 1), 499, dtype=torch.int64) / 1000
+    t = torch.full((B, 1), 500, dtype=torch.int64) / 1000
+    raw_x = torch.from_numpy(rng.standard_normal((1, mol, 3)).astype(np.float32))
+    raw_h = torch.from_numpy(rng.standard_normal((1, mol, 8)).astype(np.float32))
+
+    draws = [raw_x, raw_h]
+    orig_randn = torch.randn
+
+    def fake_randn(size, device=None, **kw):
+        r = draws.pop(0)
+        assert tuple(r.shape) == tuple(size), (r.shape, size)
+        return r.clone()
+
+    with torch.no_grad():
+        eps_ref = model.dynamics._forward(t, z.clone(), node_mask, edge_mask, context, mol)
+        eps_got = orc.dynamics_forward(sd, ocfg, t, z, node_mask, edge_mask, context, mol,
+                                       prefix="dynamics.egnn.")
+        check(f"{name} eps", eps_got.numpy(), eps_ref.numpy())
+        torch.randn = fake_randn
+        try:
+            zs_ref = model.sample_p_zs_given_zt(s, t, z.clone(), node_mask, edge_mask, context,
+                                                fix_noise=True, mol_shape=mol)
+        finally:
+            torch.randn = orig_randn
+        zs_got = orc.posterior_step(sd, ocfg, s, t, z, node_mask, edge_mask, context, (raw_x, raw_h),
+                                    mol_shape=mol)
+        check(f"{name} zs", zs_got.numpy(), zs_ref.numpy())
+    save(name, z=z.numpy(), node_mask=node_mask.numpy(), edge_mask=edge_mask.numpy(),
+         context=context.numpy(), s=s.numpy(), t=t.numpy(), mol_shape=mol, raw_x=raw_x.numpy(),
+         raw_h=raw_h.numpy(), eps=eps_ref.numpy(), zs=zs_ref.numpy(), hidden_nf=hidden_nf,
+         n_layers=n_layers, weight_seed=seed, coord_gain=coord_gain)
+
+
+def fixture_schedule(DiffusionQM9, name, seed):
+    """F4: gamma table on the 1001-point grid + derived per-step scalars."""
+    model, sd, _ = build_reference(DiffusionQM9, 32, 1, 0, seed, 0.001)
+    T = 1000
+    with torch.no_grad():
+        k = torch.arange(0, T + 1, dtype=torch.int64).view(-1, 1)
+        g = model.gamma(k / T)
+        gs, gt = g[:-1], g[1:]
+        zt = torch.zeros(T, 1, 1)
+        s2, s_ts, a_ts = model.sigma_and_alpha_t_given_s(gt, gs, zt)
+        sig_s, sig_t = model.sigma(gs, zt), model.sigma(gt, zt)
+    tab = orc.schedule_table(sd, T)
+    check(f"{name} gamma", tab["gamma"], g.view(-1).numpy(), tol=1e-7)
+    check(f"{name} sigma2", tab["sigma2_t_given_s"], s2.view(-1).numpy(), tol=1e-7)
+    check(f"{name} alpha", tab["alpha_t_given_s"], a_ts.view(-1).numpy(), tol=1e-7)
+    save(name, gamma=g.view(-1).numpy(), sigma2_t_given_s=s2.view(-1).numpy(),
+         sigma_t_given_s=s_ts.view(-1).numpy(), alpha_t_given_s=a_ts.view(-1).numpy(),
+         sigma_s=sig_s.view(-1).numpy(), sigma_t=sig_t.view(-1).numpy(), weight_seed=seed, T=T)
+
+
+def fixture_chain(DiffusionQM9, name, hidden_nf, n_layers, seed, coord_gain, T, n_list):
+    """F5: DiffusionQM9.sample with T patched small, N pinned and recorded noise."""
+    model, sd, ocfg = build_reference(DiffusionQM9, hidden_nf, n_layers, 0, seed, coord_gain)
+    model.T = T
+    model.nodes_dist.sample = lambda n: list(n_list)
+    B, N = len(n_list), max(n_list)
+    rng = np.random.Generator(np.random.PCG64(seed + 11))
+    raws = []
+    for _ in range(T + 2):
+        raws.append((torch.from_numpy(rng.standard_normal((B, N, 3)).astype(np.float32)),
+                     torch.from_numpy(rng.standard_normal((B, N, 8)).astype(np.float32))))
+    queue = [r for pair in raws for r in pair]
+    orig_randn = torch.randn
+
+    def fake_randn(size, device=None, **kw):
+        r = queue.pop(0)
+        assert tuple(r.shape) == tuple(size), (r.shape, size)
+        return r.clone()
+
+    torch.randn = fake_randn
+    try:
+        with torch.no_grad():
+            res = model.sample(B, "cpu")
+    finally:
+        torch.randn = orig_randn
+    assert not queue
+    nm, em = orc.canonical_masks(n_list)
+    x_got, h_got = orc.sample_chain(sd, ocfg, T, nm, em, None, raws)
+    x_ref = np.zeros((B, N, 3), np.float32)
+    h_ref = np.zeros((B, N, 8), np.float32)
+    for b, r in enumerate(res):
+        x_ref[b, :n_list[b]] = r["x"].numpy()
+        h_ref[b, :n_list[b]] = r["h"].numpy()
+    nmf = nm.float().numpy()
+    check(f"{name} x", x_got.numpy() * nmf, x_ref, tol=2e-5)
+    check(f"{name} h", h_got.numpy(), h_ref, tol=2e-5)
+    save(name, raw_x=np.stack([r[0].numpy() for r in raws]), raw_h=np.stack([r[1].numpy() for r in raws]),
+         n_list=np.array(n_list), x=x_ref, h=h_ref, T=T, hidden_nf=hidden_nf, n_layers=n_layers,
+         weight_seed=seed, coord_gain=coord_gain)
+
+
+def main():
+    os.makedirs(GOLDEN, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    DiffusionQM9 = import_reference()
+    # F1 + F2: BASELINE config 1 (B=4, N=8, L=3, H=256), with per-layer intermediates
+    fixture_forward(DiffusionQM9, "f1_cfg1_h256_l3", [8, 5, 3, 7], 256, 3, 0, 0.001,
+                    [0.5, 0.001, 1.0], with_trace=True)
+    # same shape with the coordinate head x1000 so tanh*coords_range is exercised
+    fixture_forward(DiffusionQM9, "f1b_cfg1_h256_l3_gain1", [8, 5, 3, 7], 256, 3, 1, 1.0, [0.5])
+    # F7: small-H variants for fast unit tests; includes a single-node molecule and padding
+    fixture_forward(DiffusionQM9, "f7_h32_l2", [8, 1, 3, 7, 2], 32, 2, 2, 1.0, [0.3], n_max=10,
+                    with_trace=True)
+    fixture_forward(DiffusionQM9, "f7_h64_l2", [12, 5, 9], 64, 2, 3, 1.0, [0.7])
+    fixture_forward(DiffusionQM9, "f7_h128_l1", [6, 4], 128, 1, 4, 1.0, [0.2])
+    # F6: production shape slice, B=16, N=30, L=9
+    fixture_forward(DiffusionQM9, "f6_b16_n30_h256_l9", [30] * 12 + [17, 25, 29, 2], 256, 9, 5, 1.0, [0.5])
+    # production YAML depth L=6 with ragged sizes padded to 48 (BASELINE config 3 flavour)
+    fixture_forward(DiffusionQM9, "f6b_n48_h256_l6", [48, 14, 33, 9, 21, 1], 256, 6, 6, 1.0, [0.9], n_max=48)
+    # F3: conditional step
+    fixture_conditional(DiffusionQM9, "f3_cond_h256_l3", 256, 3, 7, 1.0)
+    fixture_conditional(DiffusionQM9, "f3_cond_h32_l2", 32, 2, 8, 1.0)
+    # F4: schedule
+    fixture_schedule(DiffusionQM9, "f4_schedule", 0)
+    # F5: 3-step chain
+    fixture_chain(DiffusionQM9, "f5_chain_h256_l3", 256, 3, 9, 1.0, 3, [8, 5, 3, 7])
+    fixture_chain(DiffusionQM9, "f5_chain_h32_l2", 32, 2, 10, 1.0, 4, [6, 1, 4])
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,92 @@
+"""CPU: the oracle (oracle/egnn_oracle.py) reproduces every golden vector generated from the
+reference (tests/golden/*.npz, made by oracle/make_golden.py).  This is what pins the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import egnn_oracle as orc
+from tests.helpers import assert_parity, fixture_model, load
+
+FORWARD_FIXTURES = ["f1_cfg1_h256_l3", "f1b_cfg1_h256_l3_gain1", "f7_h32_l2", "f7_h64_l2", "f7_h128_l1",
+                    "f6b_n48_h256_l6"]
+
+
+@pytest.mark.parametrize("name", FORWARD_FIXTURES)
+def test_forward_matches_reference(name):
+    fx = load(name)
+    _, sd, cfg = fixture_model(fx)
+    xh, nm, em = (torch.from_numpy(fx[k]) for k in ("xh", "node_mask", "edge_mask"))
+    B, N = xh.shape[:2]
+    with torch.no_grad():
+        for k, tv in enumerate(fx["t_values"]):
+            out = orc.dynamics_forward(sd, cfg, torch.full((B, 1), float(tv)), xh, nm, em, None, None,
+                                       prefix="dynamics.egnn.")
+            assert_parity(out.numpy(), fx[f"out_t{k}"], f"{name} t={tv}", 2e-6, 2e-5)
+        out = orc.dynamics_forward(sd, cfg, torch.tensor([float(fx["t_values"][0])]), xh, nm, em, None, N,
+                                   prefix="dynamics.egnn.")
+        assert_parity(out.numpy(), fx["out_scalar_t"], f"{name} scalar t", 2e-6, 2e-5)
+        out = orc.dynamics_forward(sd, cfg, torch.from_numpy(fx["t_rows"]), xh, nm, em, None, None,
+                                   prefix="dynamics.egnn.")
+        assert_parity(out.numpy(), fx["out_row_t"], f"{name} row t", 2e-6, 2e-5)
+    # masked rows exactly zero
+    assert np.all(out.numpy()[~fx["node_mask"][..., 0]] == 0.0)
+
+
+def test_trace_matches_reference():
+    fx = load("f7_h32_l2")
+    _, sd, cfg = fixture_model(fx)
+    xh, nm, em = (torch.from_numpy(fx[k]) for k in ("xh", "node_mask", "edge_mask"))
+    trace = []
+    with torch.no_grad():
+        orc.dynamics_forward(sd, cfg, torch.full((xh.shape[0], 1), float(fx["t_values"][0])), xh, nm, em,
+                             None, None, prefix="dynamics.egnn.", trace=trace)
+    seen = 0
+    for tag, a, b in trace:
+        short = tag.replace("dynamics.egnn.e_block_", "blk").replace(".gcl_", "_gcl")
+        if "_gcl" in short:
+            assert_parity(a.numpy(), fx["trace_" + short + "_h"], short, 2e-6, 2e-5)
+        else:
+            assert_parity(a.numpy(), fx["trace_" + short + "_h"], short + " h", 2e-6, 2e-5)
+            assert_parity(b.numpy(), fx["trace_" + short + "_x"], short + " x", 2e-6, 2e-5)
+        seen += 1
+    assert seen == cfg.n_layers * (cfg.inv_sublayers + 1)
+
+
+@pytest.mark.parametrize("name", ["f3_cond_h256_l3", "f3_cond_h32_l2"])
+def test_conditional_step_matches_reference(name):
+    fx = load(name)
+    _, sd, cfg = fixture_model(fx, context_node_nf=1)
+    z, nm, em, ctx = (torch.from_numpy(fx[k]) for k in ("z", "node_mask", "edge_mask", "context"))
+    mol = int(fx["mol_shape"])
+    with torch.no_grad():
+        eps = orc.dynamics_forward(sd, cfg, torch.from_numpy(fx["t"]), z, nm, em, ctx, mol,
+                                   prefix="dynamics.egnn.")
+        assert_parity(eps.numpy(), fx["eps"], name + " eps", 2e-6, 2e-5)
+        zs = orc.posterior_step(sd, cfg, torch.from_numpy(fx["s"]), torch.from_numpy(fx["t"]), z, nm, em, ctx,
+                                (torch.from_numpy(fx["raw_x"]), torch.from_numpy(fx["raw_h"])), mol_shape=mol)
+        assert_parity(zs.numpy(), fx["zs"], name + " zs", 2e-6, 2e-5)
+    # fixed rows of eps hold -mean(vel), not zero (SURVEY.md appendix A quirk vi)
+    assert np.abs(fx["eps"][:, mol:, :3][fx["node_mask"][:, mol:, 0]]).max() > 0
+
+
+def test_schedule_matches_reference():
+    fx = load("f4_schedule")
+    from hierdiff_amd.weights import synthetic_state_dict
+    sd = orc.as_torch_sd(synthetic_state_dict(9, 0, 32, 1, 2, True, int(fx["weight_seed"])))
+    tab = orc.schedule_table(sd, int(fx["T"]))
+    for k in ("gamma", "sigma2_t_given_s", "sigma_t_given_s", "alpha_t_given_s", "sigma_s", "sigma_t"):
+        assert_parity(tab[k], fx[k], k, 1e-7, 1e-6)
+    assert abs(tab["gamma"][0] + 5.0) < 1e-6 and abs(tab["gamma"][-1] - 10.0) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["f5_chain_h256_l3", "f5_chain_h32_l2"])
+def test_chain_matches_reference(name):
+    fx = load(name)
+    _, sd, cfg = fixture_model(fx)
+    n_list = [int(v) for v in fx["n_list"]]
+    nm, em = orc.canonical_masks(n_list)
+    raws = [(torch.from_numpy(fx["raw_x"][i]), torch.from_numpy(fx["raw_h"][i])) for i in range(len(fx["raw_x"]))]
+    with torch.no_grad():
+        x, h = orc.sample_chain(sd, cfg, int(fx["T"]), nm, em, None, raws)
+    assert_parity(x.numpy() * nm.float().numpy(), fx["x"], name + " x", 2e-5, 2e-4)
+    assert_parity(h.numpy(), fx["h"], name + " h", 2e-5, 2e-4)
