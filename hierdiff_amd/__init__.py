@@ -1,0 +1,17 @@
+"""hierdiff_amd -- MI355X-native implementation of HierDiff's coarse-grained diffusion sampling hot path.
+
+Public surface mirrors the reference (qiangbo1222/HierDiff, endiffusion/):
+  EGNN_dynamics_QM9        models/module/en_dynamics.py
+  DiffusionQM9             train_module/diffusion_qm9.py (sampling half)
+  EnVariationalDiffusion   equivariant_diffusion/en_diffusion.py sample() signature
+  GammaNetwork, PredefinedNoiseSchedule, DistributionNodes
+The compute lives in lib/libhierdiff_hip.so (include/hierdiff_hip.h); build it with
+`python -m hierdiff_amd.build`.
+"""
+from .diffusion import AttrDict, DiffusionQM9, EnVariationalDiffusion, default_config  # noqa: F401
+from .distributions import DistributionNodes  # noqa: F401
+from .dynamics import EGNN_dynamics_QM9, Topology  # noqa: F401
+from .noise_model import GammaNetwork, PredefinedNoiseSchedule  # noqa: F401
+
+__all__ = ["EGNN_dynamics_QM9", "DiffusionQM9", "EnVariationalDiffusion", "GammaNetwork",
+           "PredefinedNoiseSchedule", "DistributionNodes", "Topology", "AttrDict", "default_config"]

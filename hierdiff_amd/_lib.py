@@ -1,0 +1,90 @@
+"""ctypes binding of libhierdiff_hip.so (include/hierdiff_hip.h).
+
+There is no CPU fallback: if the shared library is missing or no HIP device is visible, every
+compute entry point raises.  Loading the library and resolving its symbols works without a GPU
+(used by the CPU test tier).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "lib", "libhierdiff_hip.so")
+
+
+class HdConfig(C.Structure):
+    _fields_ = [
+        ("in_node_nf", C.c_int32), ("context_node_nf", C.c_int32), ("n_dims", C.c_int32),
+        ("hidden_nf", C.c_int32), ("n_layers", C.c_int32), ("inv_sublayers", C.c_int32),
+        ("attention", C.c_int32), ("tanh", C.c_int32), ("condition_time", C.c_int32),
+        ("norm_constant", C.c_float), ("normalization_factor", C.c_float), ("coords_range", C.c_float),
+    ]
+
+
+# name -> (restype, argtypes); mirrors include/hierdiff_hip.h one to one
+_VP, _FP, _U8P = C.c_void_p, C.c_void_p, C.c_void_p
+SIGNATURES = {
+    "hd_version": (C.c_int, []),
+    "hd_last_error": (C.c_char_p, []),
+    "hd_device_count": (C.c_int, []),
+    "hd_create": (C.c_int, [C.POINTER(HdConfig), C.c_int, C.POINTER(_VP)]),
+    "hd_destroy": (C.c_int, [_VP]),
+    "hd_weight_count": (C.c_longlong, [_VP]),
+    "hd_set_weights": (C.c_int, [_VP, _FP, C.c_longlong, C.c_int, _VP]),
+    "hd_topology_create": (C.c_int, [_VP, _U8P, _U8P, C.c_int, C.c_int, C.POINTER(_VP)]),
+    "hd_topology_destroy": (C.c_int, [_VP]),
+    "hd_topology_info": (C.c_int, [_VP, C.POINTER(C.c_longlong)]),
+    "hd_egnn_forward": (C.c_int, [_VP, _VP, _FP, _FP, C.c_int, _FP, C.c_int, _FP, _VP]),
+    "hd_nan_events": (C.c_int, [_VP, _VP, C.POINTER(C.c_longlong)]),
+    "hd_posterior_step": (C.c_int, [_VP, _VP, _FP, _FP, _FP, C.c_int, _FP, _FP, C.c_int, C.c_int, _FP, _VP]),
+    "hd_final_decode": (C.c_int, [_VP, _VP, _FP, _FP, C.POINTER(C.c_float), _FP, _FP, C.c_int, C.c_uint64, C.c_uint64,
+                               C.c_uint32, C.c_int, _FP, _FP, _VP]),
+    "hd_noise": (C.c_int, [_VP, _VP, _FP, _FP, C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int, _FP, _VP]),
+    "hd_set_schedule": (C.c_int, [_VP, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "hd_sample_loop": (C.c_int, [_VP, _VP, _FP, _FP, C.c_int, C.c_int, C.c_int, _FP, _FP, C.c_int,
+                                 C.c_uint64, C.c_uint64, C.c_int, _VP]),
+    "hd_philox_normal_host": (C.c_float, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]),
+    "hd_profile_enable": (C.c_int, [_VP, C.c_int]),
+    "hd_profile_read": (C.c_int, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+class HierDiffHipError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """dlopen the in-tree library and type every exported symbol.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HierDiffHipError(
+            f"{LIB_PATH} is missing: build it with `python -m hierdiff_amd.build` "
+            "(there is no CPU fallback for the HIP hot path)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.hd_version() != 1:
+        raise HierDiffHipError(f"ABI version mismatch: library reports {lib.hd_version()}, binding expects 1")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().hd_last_error().decode(errors="replace")
+        raise HierDiffHipError(f"{what or 'hierdiff_hip'} failed ({rc}): {msg}")
+
+
+def require_gpu() -> None:
+    lib = load()
+    if lib.hd_device_count() < 1:
+        raise HierDiffHipError("no HIP device visible: the HierDiff hot path runs only on an MI355X "
+                               "(there is no CPU fallback)")

@@ -1,0 +1,754 @@
+// Device kernels of libhierdiff_hip.so -- gfx950 (CDNA4) only.
+//
+// Design:
+//   * the dense all-pairs edge list of the reference (en_dynamics.py:124-143) is never
+//     materialised: only unmasked edges exist, packed in tiles of 32 edge rows;
+//   * the first edge Linear is factorised, W1.[h_i;h_j;r;d0]+b = (W1a.h_i+b) + W1b.h_j + r.w_r + d0.w_d,
+//     so per edge only an H x H contraction remains; it runs on the exact-fp32 matrix cores
+//     (v_mfma_f32_32x32x2_f32), one 32-edge x H tile per 64-wide wavefront;
+//   * per-node sums over neighbours are wavefront-local (shuffle reductions), written as per-tile
+//     partial sums that the consuming node kernel adds in a fixed order (bit-reproducible).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define HD_DEVINL __device__ __forceinline__
+
+// ----------------------------------------------------------------------------- math helpers
+
+// x * sigmoid(x).  exp(-x) = 2^(-x*log2e) with a compensated product so the exponent argument
+// keeps ~1 ulp over the whole range (v_exp_f32 and v_rcp_f32 are 1-ulp instructions).
+HD_DEVINL float silu_f(float x) {
+    const float L2E_HI = 1.44269502162933349609375f;   // float(log2 e)
+    const float L2E_LO = 1.925962991e-8f;              // log2 e - L2E_HI
+    const float LN2 = 0.693147180559945309f;
+    float nx = -x;
+    float t = nx * L2E_HI;
+    float tlo = __builtin_fmaf(nx, L2E_HI, -t) + nx * L2E_LO;
+    float e = __builtin_amdgcn_exp2f(t);
+    e = e * __builtin_fmaf(tlo, LN2, 1.0f);       // stays +inf for x << 0 (an fma(e, d, e) would give NaN)
+    return x * __builtin_amdgcn_rcpf(1.0f + e);
+}
+
+HD_DEVINL float sigmoid_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// ----------------------------------------------------------------------------- Philox4x32-10
+
+HD_DEVINL void philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t k0, uint32_t k1) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+    uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+    uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+    uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+}
+
+// normal(seed, sample, draw, index): counter = (index/2, draw, sample.lo, sample.hi), key = seed.
+// Each counter block yields two Box-Muller normals; index & 1 selects one.
+HD_DEVINL float philox_normal(uint64_t seed, uint64_t sample, uint32_t draw, uint32_t index) {
+    uint32_t c0 = index >> 1, c1 = draw, c2 = (uint32_t)sample, c3 = (uint32_t)(sample >> 32);
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c0, c1, c2, c3, k0, k1);
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    float u1 = ((float)(c0 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    float u2 = ((float)(c1 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    float rad = sqrtf(-2.0f * logf(u1));
+    float ang = 6.283185307179586f * u2;
+    return (index & 1) ? rad * sinf(ang) : rad * cosf(ang);
+}
+
+// ----------------------------------------------------------------------------- node init
+// xh*mask -> x0/xcur; [h*mask | t | context] -> embedding (en_dynamics.py:57-79, egnn_new.py:197).
+
+struct InitArgs {
+    const float* xh;        // [B*N][D]
+    const float* t;         // [1] or [B]
+    const float* ctx;       // [B*N][C] or null
+    const int* node_of;     // [M] compact -> flat
+    const float* nmask;     // [M_pad] 0/1
+    const float* embT;      // [fin][H]
+    const float* emb_b;     // [H]
+    float* h;               // [M_pad][H]
+    float* x0;              // [M_pad][4]
+    float* xcur;            // [M_pad][4]
+    int M, N, D, F, C, H, t_stride, cond_time;
+};
+
+__global__ void k_node_init(InitArgs a) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    int i = idx / a.H, c = idx - i * a.H;
+    if (i >= a.M) return;
+    int flat = a.node_of[i];
+    float m = a.nmask[i];
+    const float* row = a.xh + (size_t)flat * a.D;
+    float acc = a.emb_b[c];
+    int f = 0;
+    for (; f < a.F; ++f) acc = __builtin_fmaf(row[3 + f] * m, a.embT[f * a.H + c], acc);
+    if (a.cond_time) {
+        float tv = a.t[(flat / a.N) * a.t_stride];
+        acc = __builtin_fmaf(tv, a.embT[f * a.H + c], acc);
+        ++f;
+    }
+    for (int k = 0; k < a.C; ++k, ++f) acc = __builtin_fmaf(a.ctx[(size_t)flat * a.C + k], a.embT[f * a.H + c], acc);
+    a.h[(size_t)i * a.H + c] = acc;
+    if (c < 4) {
+        float v = (c < 3) ? row[c] * m : 0.0f;
+        a.x0[(size_t)i * 4 + c] = v;
+        a.xcur[(size_t)i * 4 + c] = v;
+    }
+}
+
+// ----------------------------------------------------------------------------- node GEMM (fp32 MFMA)
+// C[M][Nc] = epi(A[M][K] * Wt[K][Nc] + bias).  Workgroup tile (32*WM) x (32*WN), one 32x32
+// v_mfma_f32_32x32x2_f32 accumulator per wavefront, K in chunks of 32 double-buffered through LDS.
+// The K index inside a chunk is permuted (lane half h owns k = 16h..16h+15) so that both
+// operands are fetched with one ds_read_b128 per four MFMAs; weights are pre-packed in that image.
+
+enum { EPI_BIAS = 0, EPI_BIAS_SILU = 1, EPI_RESID_MASK = 2 };
+
+struct GemmArgs {
+    const float* A;       // [M_pad][lda], columns k < K1
+    const float* part;    // CAT: per-part partial neighbour sums [P][K - K1]
+    const int* pstart;    // CAT: [M+1] part range of each node
+    const float* Bimg;    // packed weight image
+    const float* bias;    // [Nc]
+    const float* nmask;   // [M_pad] (EPI_RESID_MASK)
+    float* C;             // [M_pad][ldc]
+    float norm;           // CAT: divide the summed parts by this (normalization_factor)
+    int lda, ldc, K1, K, M, Nc;
+};
+
+template <int WM, int WN, int EPI, bool CAT>
+__global__ __launch_bounds__(WM * WN * 64) void k_gemm(GemmArgs g) {
+    constexpr int BM = 32 * WM, BN = 32 * WN, NT = 64 * WM * WN;
+    constexpr int A_F4 = BM * 8 / NT, B_F4 = BN * 8 / NT;
+    constexpr int LDA_S = 36;
+    __shared__ __attribute__((aligned(16))) float As[2][BM * LDA_S];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BN * 32];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave / WN, wc = wave % WN;
+    const int hh = lane >> 5, m = lane & 31;
+    const int row0 = blockIdx.x * BM;
+    const int nchunk = g.K >> 5;
+    const float* Bsrc = g.Bimg + (size_t)blockIdx.y * nchunk * (BN * 32);
+
+    f32x4 ra[A_F4], rb[B_F4];
+
+    auto load_tiles = [&](int c) {
+        const int k0 = c << 5;
+#pragma unroll
+        for (int u = 0; u < A_F4; ++u) {
+            int idx = tid + u * NT;
+            int r = idx >> 3, sg = idx & 7;
+            int row = row0 + r;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (!CAT || k0 < g.K1) {
+                v = *reinterpret_cast<const f32x4*>(g.A + (size_t)row * g.lda + k0 + 4 * sg);
+            } else if (row < g.M) {
+                int p0 = g.pstart[row], p1 = g.pstart[row + 1];
+                const int kw = g.K - g.K1;
+                for (int p = p0; p < p1; ++p)
+                    v += *reinterpret_cast<const f32x4*>(g.part + (size_t)p * kw + (k0 - g.K1) + 4 * sg);
+                v = v / g.norm;
+            }
+            ra[u] = v;
+        }
+#pragma unroll
+        for (int u = 0; u < B_F4; ++u)
+            rb[u] = reinterpret_cast<const f32x4*>(Bsrc + (size_t)c * (BN * 32))[tid + u * NT];
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < A_F4; ++u) {
+            int idx = tid + u * NT;
+            int r = idx >> 3, sg = idx & 7;
+            *reinterpret_cast<f32x4*>(&As[buf][r * LDA_S + 4 * sg]) = ra[u];
+        }
+#pragma unroll
+        for (int u = 0; u < B_F4; ++u) reinterpret_cast<f32x4*>(Bs[buf])[tid + u * NT] = rb[u];
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    for (int c = 0; c < nchunk; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunk) load_tiles(c + 1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 av = *reinterpret_cast<const f32x4*>(&As[buf][(32 * wr + m) * LDA_S + 16 * hh + 4 * q]);
+            f32x4 bv = *reinterpret_cast<const f32x4*>(&Bs[buf][((wc * 4 + q) * 64 + lane) * 4]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc, 0, 0, 0);
+        }
+        if (c + 1 < nchunk) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+    const int col = blockIdx.y * BN + 32 * wc + m;
+    const float bv = g.bias[col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        int row = row0 + 32 * wr + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        if (row < g.M) {
+            float v = acc[r] + bv;
+            float* dst = g.C + (size_t)row * g.ldc + col;
+            if (EPI == EPI_BIAS_SILU) v = silu_f(v);
+            if (EPI == EPI_RESID_MASK) v = (*dst + v) * g.nmask[row];
+            *dst = v;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------- edge kernel
+// One wavefront = one tile of 32 edge rows x H output columns (NCT accumulators of 32x32).
+//   P[e][k]   = silu(A_i[k] + B_j[k] + r_e*w_r[k] + d0_e*w_d[k])      (A operand, built in registers)
+//   M[e][c]   = silu(sum_k P[e][k] * W2[c][k] + b2[c])                 (fp32 MFMA, W2 streamed via LDS)
+//   GCL  : att_e = sigmoid(wa.M[e] + ba);  partial[i] += M[e]*att_e    (egnn_new.py:35-56)
+//   COORD: phi_e = w7.M[e]; trans = u_ij * tanh(phi_e) * range         (egnn_new.py:91-104)
+// Rows of a tile are consecutive entries of the edge list (sorted by receiving node i); a tile may
+// hold several receiving nodes ("segments") and a node's edges may span tiles ("parts").
+
+struct EdgeArgs {
+    const float* AB;        // [M_pad][2H]: cols <H: W1a.h+b1 ; cols >=H: W1b.h
+    const float* wrd;       // [2][H]: w_r (current radial column), w_d (initial distance column)
+    const float* W2img;     // [H/32 chunks][32*H] packed
+    const float* b2;        // [H]
+    const float* wa;        // [H]  (att_mlp.0.weight, or coord_mlp.4.weight)
+    const int* ei;          // [E_pad] receiving node (compact)
+    const int* ej;          // [E_pad] sending node
+    const uint8_t* eseg;    // [E_pad] segment index inside the tile, 255 = padding row
+    const int* tile_pbase;  // [n_tiles] first part id of the tile
+    const int* tile_nseg;   // [n_tiles]
+    const float* xcur;      // [M_pad][4] coordinates at block start
+    const float* x0;        // [M_pad][4] coordinates at network input
+    float* part;            // GCL: [P][H];  COORD: [P][4]
+    float ba;               // att bias
+    float norm_constant;
+    float coords_range;     // per-block range
+    int attention, use_tanh;
+    int n_tiles, n_wg;
+};
+
+HD_DEVINL void glds16(const void* gsrc, void* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+template <int H, bool COORD>
+__global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
+    constexpr int NCT = H / 32;          // 32-column tiles
+    constexpr int NCH = H / 32;          // 32-wide K chunks
+    constexpr int CHF = 32 * H;          // floats per W2 chunk image
+    constexpr int GL_PER_WAVE = CHF / (4 * 256);   // 1 KiB pieces per wave per chunk
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* wbuf = smem;                   // [2][CHF]
+    float* wrd_s = smem + 2 * CHF;        // [2][H]
+    float* scratch = wrd_s + 2 * H;       // per wave: 32 (phi) + 96 (trans) + 8 (seg bytes)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hh = lane >> 5, n = lane & 31;
+
+    // XCD-aware remap: consecutive logical workgroups (neighbouring molecules, shared AB rows) land
+    // on the same XCD's L2.  Speed only; any placement is correct.
+    int wg;
+    {
+        const int bid = blockIdx.x, nwg = a.n_wg;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile = wg * 4 + wave;
+    const bool tile_ok = tile < a.n_tiles;
+    float* my_scr = scratch + wave * 136;
+    uint32_t* seg_s = reinterpret_cast<uint32_t*>(my_scr + 128);
+
+    // ---- per-row metadata (lane n and n+32 both describe row n)
+    const int e = tile * 32 + n;
+    int ni = 0, nj = 0;
+    uint32_t segb = 255;
+    if (tile_ok) { ni = a.ei[e]; nj = a.ej[e]; segb = a.eseg[e]; }
+    f32x4 xi = *reinterpret_cast<const f32x4*>(a.xcur + (size_t)ni * 4);
+    f32x4 xj = *reinterpret_cast<const f32x4*>(a.xcur + (size_t)nj * 4);
+    f32x4 yi = *reinterpret_cast<const f32x4*>(a.x0 + (size_t)ni * 4);
+    f32x4 yj = *reinterpret_cast<const f32x4*>(a.x0 + (size_t)nj * 4);
+    const float dx = xi[0] - xj[0], dy = xi[1] - xj[1], dz = xi[2] - xj[2];
+    const float radial = dx * dx + dy * dy + dz * dz;
+    const float ex = yi[0] - yj[0], ey = yi[1] - yj[1], ez = yi[2] - yj[2];
+    const float d0 = ex * ex + ey * ey + ez * ez;
+    if (hh == 0) reinterpret_cast<uint8_t*>(seg_s)[n] = (uint8_t)segb;
+
+    // ---- stage w_r / w_d once, start streaming W2
+    for (int k = tid; k < 2 * H; k += 256) wrd_s[k] = a.wrd[k];
+    auto issue_chunk = [&](int c, int buf) {
+        const float* src = a.W2img + (size_t)c * CHF;
+        float* dst = wbuf + buf * CHF;
+#pragma unroll
+        for (int u = 0; u < GL_PER_WAVE; ++u) {
+            const int piece = wave * GL_PER_WAVE + u;           // 1 KiB pieces
+            glds16(src + piece * 256 + lane * 4, dst + piece * 256);
+        }
+    };
+    issue_chunk(0, 0);
+
+    const float* Arow = a.AB + (size_t)ni * (2 * H) + 16 * hh;
+    const float* Brow = a.AB + (size_t)nj * (2 * H) + H + 16 * hh;
+    f32x4 pa[4], pb[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        pa[u] = *reinterpret_cast<const f32x4*>(Arow + 4 * u);
+        pb[u] = *reinterpret_cast<const f32x4*>(Brow + 4 * u);
+    }
+
+    f32x16 acc[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+
+#pragma unroll 1
+    for (int c = 0; c < NCH; ++c) {
+        const int buf = c & 1;
+        __syncthreads();     // chunk c landed (vmcnt(0)) and every wave is done with the other buffer
+        if (c + 1 < NCH) issue_chunk(c + 1, buf ^ 1);
+        // A operand for this chunk
+        float P[16];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            f32x4 wr4 = *reinterpret_cast<const f32x4*>(wrd_s + 32 * c + 16 * hh + 4 * u);
+            f32x4 wd4 = *reinterpret_cast<const f32x4*>(wrd_s + H + 32 * c + 16 * hh + 4 * u);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float pre = pa[u][j] + pb[u][j];
+                pre = __builtin_fmaf(radial, wr4[j], pre);
+                pre = __builtin_fmaf(d0, wd4[j], pre);
+                P[4 * u + j] = silu_f(pre);
+            }
+        }
+        if (c + 1 < NCH) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                pa[u] = *reinterpret_cast<const f32x4*>(Arow + 32 * (c + 1) + 4 * u);
+                pb[u] = *reinterpret_cast<const f32x4*>(Brow + 32 * (c + 1) + 4 * u);
+            }
+        }
+        const float* wb = wbuf + buf * CHF;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 bv[NCT];
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+                bv[ct] = *reinterpret_cast<const f32x4*>(wb + ((q * NCT + ct) * 64 + lane) * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct)
+                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(P[4 * q + j], bv[ct][j], acc[ct], 0, 0, 0);
+        }
+    }
+
+    if (!tile_ok) return;
+
+    // ---- epilogue.  acc[ct][r] = row rho(r) = (r&3) + 8*(r>>2) + 4*hh, column 32*ct + n.
+    float dot[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dot[r] = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+        const float b2v = a.b2[32 * ct + n];
+        const float wav = a.wa[32 * ct + n];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float mv = silu_f(acc[ct][r] + b2v);
+            acc[ct][r] = mv;
+            dot[r] = __builtin_fmaf(mv, wav, dot[r]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float d = dot[r];
+        d += __shfl_xor(d, 1);
+        d += __shfl_xor(d, 2);
+        d += __shfl_xor(d, 4);
+        d += __shfl_xor(d, 8);
+        d += __shfl_xor(d, 16);
+        dot[r] = d;
+    }
+    const int pbase = a.tile_pbase[tile];
+    const int nseg = a.tile_nseg[tile];
+
+    if (!COORD) {
+        // segment byte of each of this lane's 16 rows: rows 8q+4hh .. +3 share one dword
+        uint32_t sw[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sw[q] = seg_s[2 * q + hh];
+        float w[16];
+        int sg[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            sg[r] = (sw[r >> 2] >> (8 * (r & 3))) & 255;
+            float att = a.attention ? sigmoid_acc(dot[r] + a.ba) : 1.0f;
+            w[r] = (sg[r] != 255) ? att : 0.0f;
+        }
+        for (int s = 0; s < nseg; ++s) {
+            float ws[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ws[r] = (sg[r] == s) ? w[r] : 0.0f;
+            float* dst = a.part + (size_t)(pbase + s) * H + n;
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                float sum = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sum = __builtin_fmaf(ws[r], acc[ct][r], sum);
+                sum += __shfl_xor(sum, 32);
+                if (hh == 0) dst[32 * ct] = sum;
+            }
+        }
+    } else {
+        // phi of row rho(r) is in every lane of half hh; publish per row, then lane n handles row n
+        if (n == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) my_scr[(r & 3) + 8 * (r >> 2) + 4 * hh] = dot[r];
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (hh == 0) {
+            float phi = my_scr[n];
+            float nrm = sqrtf(radial + 1e-8f) + a.norm_constant;
+            float sc = a.use_tanh ? tanhf(phi) * a.coords_range : phi;
+            float valid = (segb != 255) ? 1.0f : 0.0f;
+            float* tr = my_scr + 32;
+            tr[n * 3 + 0] = (dx / nrm) * sc * valid;
+            tr[n * 3 + 1] = (dy / nrm) * sc * valid;
+            tr[n * 3 + 2] = (dz / nrm) * sc * valid;
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (lane < nseg) {
+            const uint8_t* sb = reinterpret_cast<const uint8_t*>(seg_s);
+            const float* tr = my_scr + 32;
+            float sx = 0.f, sy = 0.f, sz = 0.f;
+            for (int rr = 0; rr < 32; ++rr) {
+                if (sb[rr] == lane) { sx += tr[rr * 3]; sy += tr[rr * 3 + 1]; sz += tr[rr * 3 + 2]; }
+            }
+            f32x4 o = {sx, sy, sz, 0.f};
+            *reinterpret_cast<f32x4*>(a.part + (size_t)(pbase + lane) * 4) = o;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------- coordinate update
+// x_i <- (x_i + sum_parts / normalization_factor) * mask_i   (egnn_new.py:100-110)
+
+struct XupdArgs {
+    const float* part;    // [P][4]
+    const int* pstart;    // [M+1]
+    const float* nmask;
+    float* xcur;          // [M_pad][4]
+    float norm;
+    int M;
+};
+
+__global__ void k_xupd(XupdArgs a) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.M) return;
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (int p = a.pstart[i]; p < a.pstart[i + 1]; ++p) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(a.part + (size_t)p * 4);
+        sx += v[0]; sy += v[1]; sz += v[2];
+    }
+    float m = a.nmask[i];
+    f32x4 x = *reinterpret_cast<const f32x4*>(a.xcur + (size_t)i * 4);
+    x[0] = (x[0] + sx / a.norm) * m;
+    x[1] = (x[1] + sy / a.norm) * m;
+    x[2] = (x[2] + sz / a.norm) * m;
+    *reinterpret_cast<f32x4*>(a.xcur + (size_t)i * 4) = x;
+}
+
+// ----------------------------------------------------------------------------- output stage
+// per node: embedding_out (only the F kept columns), vel = (x_final - x_in)*mask, NaN detection
+// (egnn_new.py:202-204, en_dynamics.py:83-111).  One wavefront per node.
+
+struct Post1Args {
+    const float* h;       // [M_pad][H]
+    const float* outW;    // [fin][H]
+    const float* out_b;   // [fin]
+    const float* x0;
+    const float* xcur;
+    const int* node_of;
+    const float* nmask;
+    float* out;           // [B*N][D]
+    int* nanflag;
+    int M, N, D, F, H, mol_shape;
+};
+
+__global__ void k_post1(Post1Args a) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (i >= a.M) return;
+    const int flat = a.node_of[i];
+    const float m = a.nmask[i];
+    float* orow = a.out + (size_t)flat * a.D;
+    for (int f = 0; f < a.F; ++f) {
+        float s = 0.f;
+        for (int c = lane; c < a.H; c += 64) s = __builtin_fmaf(a.h[(size_t)i * a.H + c], a.outW[f * a.H + c], s);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) orow[3 + f] = (s + a.out_b[f]) * m;
+    }
+    if (lane < 3) {
+        const int nloc = flat % a.N;
+        float v = 0.f;
+        if (a.mol_shape < 0 || nloc < a.mol_shape) v = (a.xcur[(size_t)i * 4 + lane] - a.x0[(size_t)i * 4 + lane]) * m;
+        orow[lane] = v;
+        if (v != v) atomicOr(a.nanflag, 1);
+    }
+}
+
+// per molecule: NaN reset, centre-of-gravity removal over all N nodes, zero rows of inactive
+// nodes (en_dynamics.py:109-116, models/utils.py:43-57).  One wavefront per molecule.
+
+struct Post2Args {
+    const int* slot_of;   // [B*N] compact id or -1
+    const float* nmask;   // [M_pad]
+    const int* nvalid;    // [B] count of node_mask
+    float* out;           // [B*N][D]
+    const int* nanflag;
+    long long* nan_events;
+    int B, N, D;
+};
+
+__global__ void k_post2(Post2Args a) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (b >= a.B) return;
+    const bool nan = (*a.nanflag) != 0;
+    if (nan && b == 0 && lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(a.nan_events), 1ULL);
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (int nn = lane; nn < a.N; nn += 64) {
+        const int flat = b * a.N + nn;
+        float* orow = a.out + (size_t)flat * a.D;
+        if (a.slot_of[flat] < 0) {
+            for (int d = 0; d < a.D; ++d) orow[d] = 0.f;
+        } else if (nan) {
+            orow[0] = 0.f; orow[1] = 0.f; orow[2] = 0.f;
+        } else {
+            sx += orow[0]; sy += orow[1]; sz += orow[2];
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { sx += __shfl_xor(sx, o); sy += __shfl_xor(sy, o); sz += __shfl_xor(sz, o); }
+    const int cnt = a.nvalid[b];
+    if (cnt == 0) return;
+    const float mx = sx / (float)cnt, my = sy / (float)cnt, mz = sz / (float)cnt;
+    for (int nn = lane; nn < a.N; nn += 64) {
+        const int flat = b * a.N + nn;
+        const int s = a.slot_of[flat];
+        if (s < 0) continue;
+        const float m = a.nmask[s];
+        float* orow = a.out + (size_t)flat * a.D;
+        orow[0] -= mx * m; orow[1] -= my * m; orow[2] -= mz * m;
+    }
+}
+
+// ----------------------------------------------------------------------------- sampling maths
+// One wavefront per molecule; all reductions are over <= N nodes.
+
+struct NoiseSrc {
+    const float* raw_x;   // [rows][mol][3] or null -> Philox
+    const float* raw_h;   // [rows][mol][F]
+    int rows;             // 1 = shared row (fix_noise)
+    uint64_t seed, sample_base;
+    uint32_t draw;
+    int share;            // Philox: all rows use sample_base
+};
+
+HD_DEVINL float raw_noise(const NoiseSrc& s, int b, int nn, int c, int mol, int F) {
+    if (s.raw_x) {
+        const int rb = (s.rows == 1) ? 0 : b;
+        return (c < 3) ? s.raw_x[((size_t)rb * mol + nn) * 3 + c] : s.raw_h[((size_t)rb * mol + nn) * F + (c - 3)];
+    }
+    const uint64_t sid = s.sample_base + (s.share ? 0 : (uint64_t)b);
+    return philox_normal(s.seed, sid, s.draw, (uint32_t)(nn * (3 + F) + c));
+}
+
+struct StepArgs {
+    const float* zt;      // [B][N][D]
+    const float* eps;     // [B][N][D]
+    const float* coef;    // [rows][4]
+    const uint8_t* nm;    // [B*N] node mask bytes
+    float* zs;            // [B][out_stride][D]
+    NoiseSrc noise;
+    const uint32_t* draw_ptr;   // optional device-side draw counter (graph replay); overrides noise.draw
+    const int* step_ptr;        // optional device-side step index into coef (graph replay)
+    uint32_t draw0;             // draw index of the first replayed step (raw-noise offset base)
+    int coef_rows, B, N, D, F, mol, out_stride;
+};
+
+// sample_p_zs_given_zt after the network call (diffusion_qm9.py:326-345) + sample_normal.
+__global__ void k_post_step(StepArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (b >= a.B) return;
+    NoiseSrc ns = a.noise;
+    if (a.draw_ptr) {
+        ns.draw = *a.draw_ptr;
+        if (ns.raw_x) {
+            const size_t k = (size_t)(ns.draw - a.draw0) * ns.rows * a.mol;
+            ns.raw_x += k * 3;
+            ns.raw_h += k * a.F;
+        }
+    }
+    const float* cf = a.coef + (a.step_ptr ? (size_t)(*a.step_ptr) * 4 : (size_t)((a.coef_rows == 1) ? 0 : b) * 4);
+    const float alpha_ts = cf[0], sigma2_ts = cf[1], sigma_t = cf[2], sigma = cf[3];
+    const float ceps = (sigma2_ts / alpha_ts) / sigma_t;
+    const int mol = a.mol, D = a.D;
+    // pass 1: masked sums of eps_x and of raw x-noise, node count
+    float ex = 0.f, ey = 0.f, ez = 0.f, nx = 0.f, ny = 0.f, nz = 0.f, cnt = 0.f;
+    for (int nn = lane; nn < mol; nn += 64) {
+        const float m = a.nm[b * a.N + nn] ? 1.f : 0.f;
+        const float* er = a.eps + ((size_t)b * a.N + nn) * D;
+        ex += er[0]; ey += er[1]; ez += er[2];
+        nx += raw_noise(ns, b, nn, 0, mol, a.F) * m;
+        ny += raw_noise(ns, b, nn, 1, mol, a.F) * m;
+        nz += raw_noise(ns, b, nn, 2, mol, a.F) * m;
+        cnt += m;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        ex += __shfl_xor(ex, o); ey += __shfl_xor(ey, o); ez += __shfl_xor(ez, o);
+        nx += __shfl_xor(nx, o); ny += __shfl_xor(ny, o); nz += __shfl_xor(nz, o);
+        cnt += __shfl_xor(cnt, o);
+    }
+    const float emx = ex / cnt, emy = ey / cnt, emz = ez / cnt;
+    const float nmx = nx / cnt, nmy = ny / cnt, nmz = nz / cnt;
+    // pass 2: zs before the final re-centring; accumulate its x sum
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (int nn = lane; nn < mol; nn += 64) {
+        const float m = a.nm[b * a.N + nn] ? 1.f : 0.f;
+        const float* zr = a.zt + ((size_t)b * a.N + nn) * D;
+        const float* er = a.eps + ((size_t)b * a.N + nn) * D;
+        float* o = a.zs + ((size_t)b * a.out_stride + nn) * D;
+        const float em[3] = {emx, emy, emz}, nmn[3] = {nmx, nmy, nmz};
+        float v[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float e = er[c] - em[c] * m;
+            float nz_ = raw_noise(ns, b, nn, c, mol, a.F) * m - nmn[c] * m;
+            float mu = zr[c] / alpha_ts - ceps * e;
+            v[c] = mu + sigma * nz_;
+        }
+        sx += v[0]; sy += v[1]; sz += v[2];
+        o[0] = v[0]; o[1] = v[1]; o[2] = v[2];
+        for (int c = 3; c < D; ++c) {
+            float mu = zr[c] / alpha_ts - ceps * er[c];
+            o[c] = mu + sigma * (raw_noise(ns, b, nn, c, mol, a.F) * m);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { sx += __shfl_xor(sx, o); sy += __shfl_xor(sy, o); sz += __shfl_xor(sz, o); }
+    const float mx = sx / cnt, my = sy / cnt, mz = sz / cnt;
+    for (int nn = lane; nn < mol; nn += 64) {
+        const float m = a.nm[b * a.N + nn] ? 1.f : 0.f;
+        float* o = a.zs + ((size_t)b * a.out_stride + nn) * D;
+        o[0] -= mx * m; o[1] -= my * m; o[2] -= mz * m;
+    }
+}
+
+// sample_p_xh_given_z0 after the network call + unnormalize with unit norm values
+// (diffusion_qm9.py:302-310,174-179): x = (1/alpha_0 * (z0 - sigma_0*eps) + sigma_x*noise)[:3],
+// h = z0[3:] * mask.
+struct DecodeArgs {
+    const float* z0;
+    const float* eps;
+    const uint8_t* nm;
+    float* x;             // [B][N][3]
+    float* hfeat;         // [B][N][F]
+    NoiseSrc noise;
+    float sigma_0, alpha_0, sigma_x;
+    int B, N, D, F;
+};
+
+__global__ void k_final_decode(DecodeArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (b >= a.B) return;
+    float nx = 0.f, ny = 0.f, nz = 0.f, cnt = 0.f;
+    for (int nn = lane; nn < a.N; nn += 64) {
+        const float m = a.nm[b * a.N + nn] ? 1.f : 0.f;
+        nx += raw_noise(a.noise, b, nn, 0, a.N, a.F) * m;
+        ny += raw_noise(a.noise, b, nn, 1, a.N, a.F) * m;
+        nz += raw_noise(a.noise, b, nn, 2, a.N, a.F) * m;
+        cnt += m;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        nx += __shfl_xor(nx, o); ny += __shfl_xor(ny, o); nz += __shfl_xor(nz, o); cnt += __shfl_xor(cnt, o);
+    }
+    const float nmn[3] = {nx / cnt, ny / cnt, nz / cnt};
+    const float inv_a = 1.0f / a.alpha_0;
+    for (int nn = lane; nn < a.N; nn += 64) {
+        const float m = a.nm[b * a.N + nn] ? 1.f : 0.f;
+        const size_t r = (size_t)b * a.N + nn;
+        const float* zr = a.z0 + r * a.D;
+        const float* er = a.eps + r * a.D;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float nz_ = raw_noise(a.noise, b, nn, c, a.N, a.F) * m - nmn[c] * m;
+            a.x[r * 3 + c] = inv_a * (zr[c] - a.sigma_0 * er[c]) + a.sigma_x * nz_;
+        }
+        for (int f = 0; f < a.F; ++f) a.hfeat[r * a.F + f] = zr[3 + f] * m;
+    }
+}
+
+// sample_combined_position_feature_noise (diffusion_qm9.py:445-456).
+struct NoiseArgs {
+    const uint8_t* nm;
+    float* z;             // [B][N][D]
+    NoiseSrc noise;
+    int B, N, D, F;
+};
+
+__global__ void k_noise(NoiseArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (b >= a.B) return;
+    float nx = 0.f, ny = 0.f, nz = 0.f, cnt = 0.f;
+    for (int nn = lane; nn < a.N; nn += 64) {
+        const float m = a.nm[b * a.N + nn] ? 1.f : 0.f;
+        nx += raw_noise(a.noise, b, nn, 0, a.N, a.F) * m;
+        ny += raw_noise(a.noise, b, nn, 1, a.N, a.F) * m;
+        nz += raw_noise(a.noise, b, nn, 2, a.N, a.F) * m;
+        cnt += m;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        nx += __shfl_xor(nx, o); ny += __shfl_xor(ny, o); nz += __shfl_xor(nz, o); cnt += __shfl_xor(cnt, o);
+    }
+    const float nmn[3] = {nx / cnt, ny / cnt, nz / cnt};
+    for (int nn = lane; nn < a.N; nn += 64) {
+        const float m = a.nm[b * a.N + nn] ? 1.f : 0.f;
+        float* o = a.z + ((size_t)b * a.N + nn) * a.D;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o[c] = raw_noise(a.noise, b, nn, c, a.N, a.F) * m - nmn[c] * m;
+        for (int c = 3; c < a.D; ++c) o[c] = raw_noise(a.noise, b, nn, c, a.N, a.F) * m;
+    }
+}
+
+// graph-replay helper: advances the device-side step / draw counters after each captured step
+__global__ void k_advance(int* step, uint32_t* draw, float* t_cur, const float* tau) {
+    int s = *step - 1;
+    *step = s;
+    *draw = *draw + 1;
+    *t_cur = tau[s + 1 >= 0 ? s + 1 : 0];
+}

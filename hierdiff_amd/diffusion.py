@@ -1,0 +1,402 @@
+"""Sampling half of the reference's `DiffusionQM9` (endiffusion/train_module/diffusion_qm9.py) on MI355X.
+
+Same entry points and result format as the reference:
+  DiffusionQM9.sample(num_samples, device, context=None, pocket_cond=None)        :347-395
+  DiffusionQM9.sample_batches(batch_size, num_batches, device, context_range, ..) :397-436
+  DiffusionQM9.sample_p_zs_given_zt / sample_p_xh_given_z0 / phi / sigma / alpha   :135-158, 294-345
+plus the EDM-style signature named by the north star,
+  EnVariationalDiffusion.sample(n_samples, n_nodes, node_mask, edge_mask, context, fix_noise=False)
+  (endiffusion/equivariant_diffusion/en_diffusion.py:634-667; dead code in the reference).
+
+The 1000-step loop runs inside libhierdiff_hip.so (hd_sample_loop): per step ~70 kernels, no host
+sync, optionally replayed from one captured hipGraph.  Training (compute_loss, kl_prior, Lightning
+hooks) is out of scope.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .distributions import DistributionNodes
+from .dynamics import EGNN_dynamics_QM9, Topology, _ptr, _stream
+from .geom_stats import GEOM_FRAGMENT_HISTOGRAM
+from .noise_model import (GammaNetwork, PredefinedNoiseSchedule, decode_coefficients, evaluate_gamma,
+                          schedule_tables, sigma_and_alpha_t_given_s, step_coefficients)
+
+try:  # the reference class is a LightningModule; use it when the package exists so the module nests
+    import pytorch_lightning as _pl  # type: ignore
+    _Base = _pl.LightningModule
+except Exception:  # pragma: no cover - not installed in this image
+    _Base = nn.Module
+
+
+class AttrDict(dict):
+    """dict with attribute access, standing in for the OmegaConf node the reference passes around."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+def default_config(hidden_nf: int = 256, n_layers: int = 6, context_node_nf: int = 0, timesteps: int = 1000,
+                   inv_sublayers: int = 2, normalization_factor: float = 10.0) -> AttrDict:
+    """The production hyper-parameters of endiffusion/conf/model/ddpmgblur.yaml:2-38."""
+    return AttrDict(
+        pocket=False, node_coarse_type="prop", loss_type="vlb", hcontinous=True, noise_schedule="learned",
+        timesteps=timesteps, norm_values=[1.0, 1.0, 1.0], norm_biases=[None, 0.0, 0.0], parametrization="eps",
+        include_charges=True, dataset="qm9", conditioning=[], data_augmentation=False,
+        pre_noise=AttrDict(noise_schedule="learned", timesteps=timesteps, precision=1e-4),
+        dynamics=AttrDict(in_node_nf=0, context_node_nf=context_node_nf, n_dims=3, hidden_nf=hidden_nf,
+                          act_fn="silu", n_layers=n_layers, attention=True, condition_time=True, tanh=True,
+                          mode="egnn_dynamics", norm_constant=0, inv_sublayers=inv_sublayers, sin_embedding=False,
+                          normalization_factor=normalization_factor, aggregation_method="sum"),
+        analyze=None,
+    )
+
+
+def _get(cfg, key, default=None):
+    try:
+        return cfg[key]
+    except Exception:
+        return getattr(cfg, key, default)
+
+
+class DiffusionQM9(_Base):
+    """Sampler with the reference's constructor contract: `DiffusionQM9(cfg)` where `cfg` carries the
+    keys of conf/model/ddpmgblur.yaml (diffusion_qm9.py:37-115)."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        self.pocket = bool(_get(cfg, "pocket", False))
+        if self.pocket:
+            raise NotImplementedError("pocket-conditioned sampling is a 'next' row (SURVEY.md section 8f rank 3)")
+        self.node_coarse_type = _get(cfg, "node_coarse_type")
+        if self.node_coarse_type == "prop":
+            self.in_node_nf = 8
+        elif self.node_coarse_type == "elem":
+            self.in_node_nf = 3
+        else:
+            raise NotImplementedError("node_coarse_type should be prop or elem")
+        dyn = dict(_get(cfg, "dynamics"))
+        dyn["in_node_nf"] = self.in_node_nf
+        assert _get(cfg, "loss_type") in {'vlb', 'l2'}
+        self.loss_type = _get(cfg, "loss_type")
+        self.include_charges = _get(cfg, "include_charges")
+        assert _get(cfg, "parametrization") == 'eps'
+        if _get(cfg, "noise_schedule") == 'learned':
+            assert self.loss_type == 'vlb', 'A noise schedule can only be learned with a vlb objective.'
+            self.gamma = GammaNetwork()
+        else:
+            self.gamma = PredefinedNoiseSchedule(**dict(_get(cfg, "pre_noise")))
+        self.hcontinous = _get(cfg, "hcontinous")
+        if dyn.get("condition_time", True):
+            dyn["in_node_nf"] += 1
+        self.dynamics = EGNN_dynamics_QM9(**dyn)
+        self.n_dims = dyn["n_dims"]
+        self.T = int(_get(cfg, "timesteps"))
+        self.parametrization = _get(cfg, "parametrization")
+        self.norm_values = list(_get(cfg, "norm_values"))
+        self.norm_biases = list(_get(cfg, "norm_biases"))
+        if [float(v) for v in self.norm_values] != [1.0, 1.0, 1.0] or (self.norm_biases[1] or 0.0) != 0.0:
+            raise NotImplementedError("only norm_values [1,1,1] / norm_biases [None,0,0] (ddpmgblur.yaml:10-11)")
+        self.register_buffer('buffer', torch.zeros(1))
+        self.data_augmentation = _get(cfg, "data_augmentation", False)
+        analyze = _get(cfg, "analyze", None)
+        if isinstance(analyze, dict):
+            histogram = analyze
+        elif isinstance(analyze, str):
+            import yaml
+            with open(analyze) as fh:
+                histogram = yaml.safe_load(fh)
+        else:
+            histogram = GEOM_FRAGMENT_HISTOGRAM
+        self.nodes_dist = DistributionNodes(histogram=histogram)
+        # sampling knobs of this implementation (not in the reference)
+        self.noise_mode = "philox"      # "philox": in-kernel counter RNG; "torch": torch.randn draws
+        self.seed = 2022
+        self.use_graph = True
+        self.debug_checks = False       # True re-enables the reference's host-synchronising asserts
+        self.schedule_gammas = None     # optional [T+1] gamma grid overriding the network (replay a run)
+        self._sched_key = None
+        self._sched = None
+
+    # ------------------------------------------------------------------ schedule algebra (reference API)
+    def phi(self, x, t, node_mask, edge_mask, context, mol_shape=None):
+        return self.dynamics._forward(t, x, node_mask, edge_mask, context, mol_shape)
+
+    def inflate_batch_array(self, array, target):
+        return array.view((array.size(0),) + (1,) * (len(target.size()) - 1))
+
+    def sigma(self, gamma, target_tensor):
+        return self.inflate_batch_array(torch.sqrt(torch.sigmoid(gamma)), target_tensor)
+
+    def alpha(self, gamma, target_tensor):
+        return self.inflate_batch_array(torch.sqrt(torch.sigmoid(-gamma)), target_tensor)
+
+    def SNR(self, gamma):
+        return torch.exp(-gamma)
+
+    def sigma_and_alpha_t_given_s(self, gamma_t, gamma_s, target_tensor):
+        s2, s, a = sigma_and_alpha_t_given_s(gamma_t, gamma_s)
+        return (self.inflate_batch_array(s2, target_tensor), self.inflate_batch_array(s, target_tensor),
+                self.inflate_batch_array(a, target_tensor))
+
+    def compute_x_pred(self, net_out, zt, gamma_t):
+        sigma_t = self.sigma(gamma_t, target_tensor=net_out)
+        alpha_t = self.alpha(gamma_t, target_tensor=net_out)
+        return 1. / alpha_t * (zt - sigma_t * net_out)
+
+    def unnormalize(self, x, h, node_mask):
+        x = x * self.norm_values[0]
+        h = (h * self.norm_values[1] + self.norm_biases[1]) * node_mask
+        return x, h
+
+    # ------------------------------------------------------------------ HIP plumbing
+    def _lib_handle(self):
+        self.dynamics.sync_weights()
+        return self.dynamics._handle()
+
+    def _schedule(self):
+        """Tabulated schedule, uploaded to the handle (hd_set_schedule); recomputed when gamma changes."""
+        key = (self.T, self.dynamics._hd[0].value if self.dynamics._hd else None) + tuple(
+            (p.data_ptr(), p._version) for p in self.gamma.parameters()) + (id(self.schedule_gammas),)
+        if key != self._sched_key:
+            tabs = schedule_tables(self.gamma, self.T, self.schedule_gammas)
+            tau = tabs["tau"].numpy().astype(np.float32)
+            coef = tabs["coef"].numpy().astype(np.float32).reshape(-1)
+            _lib.check(_lib.load().hd_set_schedule(
+                self._lib_handle(), self.T, tau.ctypes.data_as(C.POINTER(C.c_float)),
+                coef.ctypes.data_as(C.POINTER(C.c_float))), "hd_set_schedule")
+            self._sched = tabs
+            key = (self.T, self.dynamics._hd[0].value) + key[2:]
+            self._sched_key = key
+        return self._sched
+
+    def _check_masked(self, x, node_mask, what):
+        if self.debug_checks:
+            bad = (x * (~node_mask.bool())).abs().max().item()
+            assert bad < 1e-4, f'{what}: variables not masked properly ({bad})'
+
+    def _check_mean_zero(self, x, node_mask):
+        if self.debug_checks:
+            self._check_masked(x, node_mask, "assert_mean_zero_with_mask")
+            largest = x.abs().max().item()
+            err = torch.sum(x, dim=1, keepdim=True).abs().max().item()
+            assert err / (largest + 1e-10) < 1e-2, f'Mean is not zero, relative_error {err / (largest + 1e-10)}'
+
+    # ------------------------------------------------------------------ single transitions (reference API)
+    def sample_combined_position_feature_noise(self, n_samples, n_nodes, node_mask):
+        """diffusion_qm9.py:445-456 with torch.randn draws on node_mask.device (x first, then h)."""
+        dev = node_mask.device
+        nm = node_mask.to(torch.float32)
+        raw_x = torch.randn((n_samples, n_nodes, self.n_dims), device=dev)
+        raw_h = torch.randn((n_samples, n_nodes, self.in_node_nf), device=dev)
+        zx = raw_x * nm
+        zx = zx - (zx.sum(1, keepdim=True) / nm.sum(1, keepdim=True)) * nm
+        return torch.cat([zx, raw_h * nm], dim=2)
+
+    def sample_p_zs_given_zt(self, s, t, zt, node_mask, edge_mask, context, fix_noise=False, mol_shape=None,
+                             raw_noise: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
+                             gammas: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
+        """zs ~ p(zs | zt) (diffusion_qm9.py:312-345).  Returns [B, mol_shape, D]: the reference
+        appends an empty slice because `zt` was re-bound to its first mol_shape nodes (:326,:345).
+        raw_noise / gammas optionally inject the two randn draws / (gamma_s, gamma_t)."""
+        dev = zt.device
+        B, N, D = zt.shape
+        mol = N if mol_shape is None else min(int(mol_shape), N)
+        if gammas is None:
+            gammas = (evaluate_gamma(self.gamma, s), evaluate_gamma(self.gamma, t))
+        coef = step_coefficients(gammas[0].detach().float().cpu().reshape(-1, 1),
+                                 gammas[1].detach().float().cpu().reshape(-1, 1)).to(dev)
+        zt_c = zt.detach().to(torch.float32).contiguous()
+        eps = self.phi(zt_c, t, node_mask, edge_mask, context, mol_shape)
+        self._check_mean_zero(zt_c[:, :mol, :self.n_dims], node_mask[:, :mol])
+        nb = 1 if fix_noise else B
+        if raw_noise is None:
+            raw_x = torch.randn((nb, mol, self.n_dims), device=dev)
+            raw_h = torch.randn((nb, mol, self.in_node_nf), device=dev)
+        else:
+            raw_x, raw_h = (r.to(dev, torch.float32).contiguous() for r in raw_noise)
+        topo = self.dynamics.topology(node_mask, edge_mask, B, N)
+        zs = torch.empty((B, mol, D), device=dev, dtype=torch.float32)
+        _lib.check(_lib.load().hd_posterior_step(
+            self._lib_handle(), topo.ptr, zt_c.data_ptr(), eps.data_ptr(), coef.data_ptr(), coef.shape[0],
+            raw_x.data_ptr(), raw_h.data_ptr(), raw_x.shape[0], mol, zs.data_ptr(), _stream(dev)), "hd_posterior_step")
+        return zs
+
+    def sample_p_xh_given_z0(self, z0, node_mask, edge_mask, context, fix_noise=False,
+                             raw_noise: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
+                             gamma_0: Optional[torch.Tensor] = None):
+        """x ~ p(x | z0), h = z0 features (diffusion_qm9.py:294-310)."""
+        dev = z0.device
+        B, N, D = z0.shape
+        zeros = torch.zeros(size=(B, 1), device=dev)
+        if gamma_0 is None:
+            gamma_0 = evaluate_gamma(self.gamma, torch.zeros(1, 1))
+        z0_c = z0.detach().to(torch.float32).contiguous()
+        eps = self.phi(z0_c, zeros, node_mask, edge_mask, context)
+        coef3 = decode_coefficients(gamma_0.detach().float().cpu()).numpy()
+        return self._final_decode(z0_c, eps, node_mask, edge_mask, coef3, fix_noise, raw_noise)
+
+    def _final_decode(self, z0, eps, node_mask, edge_mask, coef3, fix_noise, raw_noise, philox=None):
+        """raw_noise: (randn_x, randn_h) or None -> torch.randn; philox=(sample_id_base, draw) uses the
+        library's counter RNG instead."""
+        dev = z0.device
+        B, N, D = z0.shape
+        nb = 1 if fix_noise else B
+        raw_x = raw_h = None
+        if philox is None:
+            if raw_noise is None:
+                raw_x = torch.randn((nb, N, self.n_dims), device=dev)
+                raw_h = torch.randn((nb, N, self.in_node_nf), device=dev)
+            else:
+                raw_x, raw_h = (r.to(dev, torch.float32).contiguous() for r in raw_noise)
+            nb = raw_x.shape[0]
+        topo = self.dynamics.topology(node_mask, edge_mask, B, N)
+        x = torch.empty((B, N, self.n_dims), device=dev, dtype=torch.float32)
+        h = torch.empty((B, N, self.in_node_nf), device=dev, dtype=torch.float32)
+        c3 = np.ascontiguousarray(coef3, dtype=np.float32)
+        _lib.check(_lib.load().hd_final_decode(
+            self._lib_handle(), topo.ptr, z0.data_ptr(), eps.data_ptr(), c3.ctypes.data_as(C.POINTER(C.c_float)),
+            _ptr(raw_x), _ptr(raw_h), nb, self.seed, philox[0] if philox else 0, philox[1] if philox else 0,
+            int(fix_noise), x.data_ptr(), h.data_ptr(), _stream(dev)), "hd_final_decode")
+        return x, h
+
+    def sample_normal(self, mu, sigma, node_mask, fix_noise=False):
+        bs = 1 if fix_noise else mu.size(0)
+        return mu + sigma * self.sample_combined_position_feature_noise(bs, mu.size(1), node_mask)
+
+    # ------------------------------------------------------------------ full reverse process
+    @torch.no_grad()
+    def sample_from_masks(self, node_mask: torch.Tensor, edge_mask: Optional[torch.Tensor], context=None,
+                          fix_noise: bool = False, raw_noises: Optional[Sequence[Tuple[torch.Tensor, torch.Tensor]]] = None,
+                          sample_id_base: int = 0, z_init: Optional[torch.Tensor] = None):
+        """z_T -> (x, h) for given masks: draw z_T, T posterior steps, final decode.
+
+        raw_noises: optional T+2 (randn_x[b,N,3], randn_h[b,N,F]) pairs in the reference's draw order
+        (z_T, steps s=T-1..0, decode) for bit-for-bit comparable trajectories; otherwise noise comes
+        from `noise_mode` ("philox": sample ids sample_id_base + b, independent of batch split)."""
+        dev = node_mask.device
+        if dev.type != "cuda":
+            raise _lib.HierDiffHipError("sampling runs only on an MI355X (no CPU fallback)")
+        B, N = node_mask.shape[0], node_mask.shape[1]
+        D = self.n_dims + self.in_node_nf
+        lib = _lib.load()
+        h = self._lib_handle()
+        tabs = self._schedule()
+        topo = self.dynamics.topology(node_mask, edge_mask, B, N)
+        ctx = None
+        if self.dynamics.context_node_nf > 0:
+            if context is None:
+                raise ValueError("context required")
+            ctx = context.to(dev, torch.float32).reshape(B * N, -1).contiguous()
+        stream = _stream(dev)
+        nb = 1 if fix_noise else B
+        T = self.T
+        z = torch.empty((B, N, D), device=dev, dtype=torch.float32)
+        if raw_noises is not None:
+            assert len(raw_noises) == T + 2, "need T+2 raw noise pairs"
+            rx = [r[0].to(dev, torch.float32).contiguous() for r in raw_noises]
+            rh = [r[1].to(dev, torch.float32).contiguous() for r in raw_noises]
+            _lib.check(lib.hd_noise(h, topo.ptr, rx[0].data_ptr(), rh[0].data_ptr(), rx[0].shape[0], 0, 0, 0, 0,
+                                    z.data_ptr(), stream), "hd_noise")
+            step_x = torch.stack(rx[1:T + 1]).contiguous()
+            step_h = torch.stack(rh[1:T + 1]).contiguous()
+            _lib.check(lib.hd_sample_loop(h, topo.ptr, z.data_ptr(), _ptr(ctx), -1, T, 0, step_x.data_ptr(),
+                                          step_h.data_ptr(), step_x.shape[1], 0, 0, int(self.use_graph), stream),
+                       "hd_sample_loop")
+            final_raw = (rx[T + 1], rh[T + 1])
+        elif self.noise_mode == "torch":
+            z = self.sample_combined_position_feature_noise(nb, N, node_mask)
+            if nb == 1 and B > 1:
+                z = z.expand(B, -1, -1).contiguous()
+            em = edge_mask
+            for s in reversed(range(0, T)):
+                s_array = torch.full((B, 1), fill_value=s, device=dev)
+                t_array = s_array + 1
+                z = self.sample_p_zs_given_zt(s_array / T, t_array / T, z, node_mask, em, context,
+                                              fix_noise=fix_noise, mol_shape=N)
+            final_raw = None
+        else:
+            if z_init is not None:
+                z.copy_(z_init)
+            else:
+                _lib.check(lib.hd_noise(h, topo.ptr, None, None, nb, self.seed, sample_id_base, 0, int(fix_noise),
+                                        z.data_ptr(), stream), "hd_noise")
+            _lib.check(lib.hd_sample_loop(h, topo.ptr, z.data_ptr(), _ptr(ctx), -1, T, 0, None, None, nb, self.seed,
+                                          sample_id_base, int(self.use_graph), stream), "hd_sample_loop")
+            # decode noise: draw T+1 of the same counter stream, materialised through hd_noise's raw form
+            final_raw = "philox"
+        self._check_mean_zero(z[:, :, :self.n_dims], node_mask)
+        zeros = torch.zeros((B, 1), device=dev)
+        eps = self.dynamics.forward_with_topology(topo, zeros, z, ctx, None)
+        coef3 = tabs["decode"].numpy()
+        if final_raw == "philox":
+            x, hfeat = self._final_decode(z, eps, node_mask, edge_mask, coef3, fix_noise, None,
+                                          philox=(sample_id_base, T + 1))
+        else:
+            x, hfeat = self._final_decode(z, eps, node_mask, edge_mask, coef3, fix_noise, final_raw)
+        return x, hfeat
+
+    @torch.no_grad()
+    def sample(self, num_samples, device, context=None, pocket_cond=None, sample_id_base: int = 0):
+        """diffusion_qm9.py:347-395: list of {'x': [n_i,3], 'h': [n_i,8], ('context': [n_i,1])} on the CPU."""
+        if pocket_cond is not None:
+            raise NotImplementedError("pocket-conditioned sampling is a 'next' row (SURVEY.md section 8f rank 3)")
+        device = torch.device(device)
+        sample_n = self.nodes_dist.sample(num_samples)
+        n_max = max(sample_n)
+        sizes = torch.tensor(sample_n)
+        ar = torch.arange(n_max)
+        node_mask = (ar[None, :] < sizes[:, None]).unsqueeze(-1)
+        if context is not None:
+            context = torch.zeros([num_samples, n_max, 1]).to(device) + context
+        node_mask = node_mask.to(device)
+        x, h = self.sample_from_masks(node_mask, None, context, sample_id_base=sample_id_base)
+        x, h = x.cpu(), h.cpu()
+        xs = [x[i, :sample_n[i]].clone() for i in range(num_samples)]
+        hs = [h[i, :sample_n[i]].clone() for i in range(num_samples)]
+        if context is not None:
+            ctx = context.cpu()
+            return [{'x': xs[i], 'h': hs[i], 'context': ctx[i, :sample_n[i]].clone()} for i in range(num_samples)]
+        return [{'x': xs[i], 'h': hs[i]} for i in range(num_samples)]
+
+    def sample_batches(self, batch_size, num_batches, device, context_range=None, protein_data_all=None,
+                       sample_id_base: int = 0):
+        """diffusion_qm9.py:397-436 (protein branch not supported)."""
+        if protein_data_all is not None:
+            raise NotImplementedError("pocket-conditioned sampling is a 'next' row (SURVEY.md section 8f rank 3)")
+        results, test_names = [], []
+        for i in range(num_batches):
+            ctx = None if context_range is None else context_range[i % len(context_range)]
+            results.extend(self.sample(batch_size, device, context=ctx, pocket_cond=None,
+                                       sample_id_base=sample_id_base + i * batch_size))
+        return results, test_names
+
+
+class EnVariationalDiffusion(DiffusionQM9):
+    """EDM-style entry point (en_diffusion.py:634-667): masks supplied by the caller, fix_noise honoured."""
+
+    @torch.no_grad()
+    def sample(self, n_samples, n_nodes, node_mask, edge_mask, context, fix_noise=False):  # type: ignore[override]
+        assert node_mask.shape[0] == n_samples and node_mask.shape[1] == n_nodes
+        x, h = self.sample_from_masks(node_mask, edge_mask, context, fix_noise=fix_noise)
+        if self.debug_checks:
+            self._check_mean_zero(x, node_mask)
+        max_cog = torch.sum(x, dim=1, keepdim=True).abs().max()
+        if self.debug_checks and max_cog.item() > 5e-2:
+            print(f'Warning cog drift with error {max_cog.item():.3f}. Projecting the positions down.')
+            nm = node_mask.to(torch.float32)
+            x = x - (x.sum(1, keepdim=True) / nm.sum(1, keepdim=True)) * nm
+        return x, h

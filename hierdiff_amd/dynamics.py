@@ -1,0 +1,286 @@
+"""Drop-in for the reference's `EGNN_dynamics_QM9` (endiffusion/models/module/en_dynamics.py:8-143).
+
+Same constructor, same `state_dict` keys (`egnn.embedding.weight`, `egnn.e_block_{i}.gcl_{j}.edge_mlp.0.weight`,
+... -- SURVEY.md section 8b), same `_forward(t, xh, node_mask, edge_mask, context, mol_shape=None)`
+signature and return value, so it nests inside the reference's `DiffusionQM9` / Lightning pipeline
+unchanged.  The arithmetic runs in hand-written HIP kernels behind the C ABI of
+include/hierdiff_hip.h; the torch modules below only hold parameters.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import weakref
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import HdConfig, HierDiffHipError
+
+
+# ----------------------------------------------------------------------------- parameter holders
+# Mirrors of the reference module tree; they are never called, only hold tensors so that
+# state_dict()/load_state_dict()/.to()/DDP-style broadcast see the reference's key layout.
+
+class _GCLParams(nn.Module):
+    """egnn_new.py:9-33"""
+
+    def __init__(self, hidden_nf: int, edges_in_d: int, attention: bool):
+        super().__init__()
+        self.edge_mlp = nn.Sequential(nn.Linear(2 * hidden_nf + edges_in_d, hidden_nf), nn.SiLU(),
+                                      nn.Linear(hidden_nf, hidden_nf), nn.SiLU())
+        self.node_mlp = nn.Sequential(nn.Linear(2 * hidden_nf, hidden_nf), nn.SiLU(),
+                                      nn.Linear(hidden_nf, hidden_nf))
+        if attention:
+            self.att_mlp = nn.Sequential(nn.Linear(hidden_nf, 1), nn.Sigmoid())
+
+
+class _EquivariantUpdateParams(nn.Module):
+    """egnn_new.py:74-89"""
+
+    def __init__(self, hidden_nf: int, edges_in_d: int):
+        super().__init__()
+        layer = nn.Linear(hidden_nf, 1, bias=False)
+        torch.nn.init.xavier_uniform_(layer.weight, gain=0.001)
+        self.coord_mlp = nn.Sequential(nn.Linear(2 * hidden_nf + edges_in_d, hidden_nf), nn.SiLU(),
+                                       nn.Linear(hidden_nf, hidden_nf), nn.SiLU(), layer)
+
+
+class _EquivariantBlockParams(nn.Module):
+    """egnn_new.py:114-137"""
+
+    def __init__(self, hidden_nf: int, n_layers: int, attention: bool):
+        super().__init__()
+        for i in range(n_layers):
+            self.add_module("gcl_%d" % i, _GCLParams(hidden_nf, 2, attention))
+        self.add_module("gcl_equiv", _EquivariantUpdateParams(hidden_nf, 2))
+
+
+class _EGNNParams(nn.Module):
+    """egnn_new.py:155-190"""
+
+    def __init__(self, in_node_nf: int, hidden_nf: int, n_layers: int, inv_sublayers: int, attention: bool):
+        super().__init__()
+        self.embedding = nn.Linear(in_node_nf, hidden_nf)
+        self.embedding_out = nn.Linear(hidden_nf, in_node_nf)
+        for i in range(n_layers):
+            self.add_module("e_block_%d" % i, _EquivariantBlockParams(hidden_nf, inv_sublayers, attention))
+
+    def forward(self, *a, **k):
+        raise NotImplementedError("parameters only; the arithmetic lives in libhierdiff_hip.so")
+
+
+# ----------------------------------------------------------------------------- topology cache
+
+class Topology:
+    """Index tables + activation workspace for one (node_mask, edge_mask) pair (hd_topology)."""
+
+    def __init__(self, owner: "EGNN_dynamics_QM9", node_mask: torch.Tensor, edge_mask: Optional[torch.Tensor],
+                 B: int, N: int):
+        lib = _lib.load()
+        nm = node_mask.reshape(B * N).to(torch.bool).cpu().contiguous().numpy().astype(np.uint8)
+        em_ptr = None
+        if edge_mask is not None:
+            em = edge_mask.reshape(B * N * N).to(torch.bool).cpu().contiguous().numpy().astype(np.uint8)
+            em_ptr = em.ctypes.data
+        self._h = C.c_void_p()
+        _lib.check(lib.hd_topology_create(owner._handle(), nm.ctypes.data, em_ptr, B, N, C.byref(self._h)),
+                   "hd_topology_create")
+        self.B, self.N = B, N
+        self._finalizer = weakref.finalize(self, lib.hd_topology_destroy, self._h)
+
+    @property
+    def ptr(self) -> C.c_void_p:
+        return self._h
+
+    def info(self) -> Dict[str, int]:
+        buf = (C.c_longlong * 6)()
+        _lib.check(_lib.load().hd_topology_info(self._h, buf), "hd_topology_info")
+        return dict(zip(("B", "N", "nodes", "edges", "tiles", "parts"), (int(v) for v in buf)))
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _stream(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _as_f32(t: torch.Tensor, device: torch.device) -> torch.Tensor:
+    return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+
+class EGNN_dynamics_QM9(nn.Module):
+    """HIP implementation of en_dynamics.py:8-143 (mode 'egnn_dynamics')."""
+
+    def __init__(self, in_node_nf, context_node_nf, n_dims, hidden_nf=64, act_fn="silu", n_layers=4,
+                 attention=False, condition_time=True, tanh=False, mode='egnn_dynamics', norm_constant=0,
+                 inv_sublayers=2, sin_embedding=False, normalization_factor=100, aggregation_method='sum'):
+        super().__init__()
+        if mode != 'egnn_dynamics':
+            raise NotImplementedError(f"mode {mode!r}: only 'egnn_dynamics' is on the sampling hot path")
+        if sin_embedding:
+            raise NotImplementedError("sin_embedding=True is config-off in the reference (ddpmgblur.yaml:35)")
+        if aggregation_method != 'sum':
+            raise NotImplementedError("aggregation_method must be 'sum' (ddpmgblur.yaml:37)")
+        if not (act_fn == "silu" or isinstance(act_fn, nn.SiLU)):
+            raise NotImplementedError("act_fn must be 'silu'")
+        if n_dims != 3:
+            raise NotImplementedError("n_dims must be 3")
+        if hidden_nf not in (32, 64, 128, 256):
+            raise NotImplementedError("hidden_nf must be one of 32, 64, 128, 256")
+        self.mode = mode
+        self.egnn = _EGNNParams(in_node_nf + context_node_nf, hidden_nf, n_layers, inv_sublayers, bool(attention))
+        self.in_node_nf = in_node_nf
+        self.context_node_nf = context_node_nf
+        self.n_dims = n_dims
+        self.condition_time = condition_time
+        self._edges_dict = {}       # kept for attribute parity with the reference; unused
+        self._cfg = HdConfig(in_node_nf=in_node_nf, context_node_nf=context_node_nf, n_dims=n_dims,
+                             hidden_nf=hidden_nf, n_layers=n_layers, inv_sublayers=inv_sublayers,
+                             attention=int(bool(attention)), tanh=int(bool(tanh)),
+                             condition_time=int(bool(condition_time)), norm_constant=float(norm_constant),
+                             normalization_factor=float(normalization_factor), coords_range=30.0)
+        self._hd = None              # (handle, device index)
+        self._weights_key = None
+        self._topo_cache: Dict[Tuple, Topology] = {}
+        self.debug_checks = False
+
+    # ------------------------------------------------------------------ reference API surface
+    def forward(self, t, xh, node_mask, edge_mask, context=None):
+        raise NotImplementedError
+
+    def wrap_forward(self, node_mask, edge_mask, context):
+        def fwd(time, state):
+            return self._forward(time, state, node_mask, edge_mask, context)
+        return fwd
+
+    def unwrap_forward(self):
+        return self._forward
+
+    # ------------------------------------------------------------------ handle / weights
+    def _device(self) -> torch.device:
+        return self.egnn.embedding.weight.device
+
+    def _handle(self) -> C.c_void_p:
+        dev = self._device()
+        if dev.type != "cuda":
+            raise HierDiffHipError("EGNN_dynamics_QM9 runs only on an MI355X: move the module to a cuda device "
+                                   "(there is no CPU fallback)")
+        _lib.require_gpu()
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        if self._hd is None or self._hd[1] != idx:
+            self._release()
+            lib = _lib.load()
+            h = C.c_void_p()
+            _lib.check(lib.hd_create(C.byref(self._cfg), idx, C.byref(h)), "hd_create")
+            self._hd = (h, idx)
+            self._weights_key = None
+            self._finalizer = weakref.finalize(self, lib.hd_destroy, h)
+        return self._hd[0]
+
+    def _release(self):
+        self._topo_cache.clear()
+        if self._hd is not None:
+            self._finalizer()
+            self._hd = None
+
+    def canonical_blob(self) -> torch.Tensor:
+        """Parameters flattened in registration order (== hierdiff_amd.weights.flatten_dynamics)."""
+        return torch.cat([p.detach().reshape(-1).to(torch.float32) for p in self.egnn.parameters()])
+
+    def sync_weights(self, force: bool = False) -> None:
+        """(Re)pack the parameters into the HIP handle when they changed since the last call."""
+        h = self._handle()
+        key = tuple((p.data_ptr(), p._version) for p in self.egnn.parameters())
+        if not force and key == self._weights_key:
+            return
+        blob = self.canonical_blob().contiguous()
+        lib = _lib.load()
+        expect = lib.hd_weight_count(h)
+        if blob.numel() != expect:
+            raise HierDiffHipError(f"parameter count {blob.numel()} != library layout {expect}")
+        _lib.check(lib.hd_set_weights(h, blob.data_ptr(), blob.numel(), 1, _stream(blob.device)), "hd_set_weights")
+        self._weights_key = key
+
+    # ------------------------------------------------------------------ topology
+    def topology(self, node_mask: torch.Tensor, edge_mask: Optional[torch.Tensor], B: int, N: int) -> Topology:
+        """Cached per mask tensors (identity + in-place version), as the reference caches its edge
+        lists per (n_nodes, batch_size) in `_edges_dict` (en_dynamics.py:124-143)."""
+        self._handle()
+        key = (id(node_mask), node_mask._version, None if edge_mask is None else id(edge_mask),
+               None if edge_mask is None else edge_mask._version, B, N)
+        hit = self._topo_cache.get(key)
+        if hit is not None and hit[1] is node_mask and hit[2] is edge_mask:
+            return hit[0]
+        if len(self._topo_cache) >= 8:
+            self._topo_cache.pop(next(iter(self._topo_cache)))
+        topo = Topology(self, node_mask, edge_mask, B, N)
+        self._topo_cache[key] = (topo, node_mask, edge_mask)     # holding the tensors pins their ids
+        return topo
+
+    # ------------------------------------------------------------------ forward
+    def _forward(self, t, xh, node_mask, edge_mask, context, mol_shape=None):
+        """en_dynamics.py:49-122.  Returns a new [B, N, 3+F] fp32 tensor on xh.device."""
+        if xh.device.type != "cuda":
+            raise HierDiffHipError("EGNN_dynamics_QM9._forward needs cuda tensors (no CPU fallback)")
+        bs, n_nodes, dims = xh.shape
+        if dims - self.n_dims != self.in_node_nf - (1 if self.condition_time else 0):
+            raise ValueError(f"xh has {dims - self.n_dims} feature columns, model expects "
+                             f"{self.in_node_nf - (1 if self.condition_time else 0)}")
+        self.sync_weights()
+        topo = self.topology(node_mask, edge_mask, bs, n_nodes)
+        return self.forward_with_topology(topo, t, xh, context, mol_shape)
+
+    def forward_with_topology(self, topo: Topology, t, xh, context, mol_shape=None) -> torch.Tensor:
+        dev = xh.device
+        bs, n_nodes, dims = xh.shape
+        xh_c = _as_f32(xh, dev)
+        t_c = None
+        t_numel = 1
+        if self.condition_time:
+            t_c = _as_f32(t, dev).reshape(-1)
+            t_numel = t_c.numel()
+            if t_numel not in (1, bs):
+                raise ValueError("t must have 1 or batch_size elements")
+        ctx_c = None
+        if self.context_node_nf > 0:
+            if context is None:
+                raise ValueError("model has context_node_nf > 0 but context is None")
+            ctx_c = _as_f32(context, dev).reshape(bs * n_nodes, self.context_node_nf)
+        out = torch.empty((bs, n_nodes, dims), device=dev, dtype=torch.float32)
+        _lib.check(_lib.load().hd_egnn_forward(self._handle(), topo.ptr, xh_c.data_ptr(), _ptr(t_c), t_numel,
+                                               _ptr(ctx_c), -1 if mol_shape is None else int(mol_shape),
+                                               out.data_ptr(), _stream(dev)), "hd_egnn_forward")
+        if self.debug_checks:
+            cnt = C.c_longlong()
+            _lib.check(_lib.load().hd_nan_events(self._handle(), _stream(dev), C.byref(cnt)))
+            if cnt.value:
+                print('Warning: detected nan, resetting EGNN output to zero.')
+        return out
+
+    def get_adj_matrix(self, n_nodes, batch_size):
+        """Reference helper (en_dynamics.py:124-143); the HIP path never materialises the dense edge
+        list, this exists for callers that want it."""
+        ar = torch.arange(n_nodes)
+        rows = ar.repeat_interleave(n_nodes).repeat(batch_size)
+        cols = ar.repeat(n_nodes).repeat(batch_size)
+        off = (torch.arange(batch_size) * n_nodes).repeat_interleave(n_nodes * n_nodes)
+        return [rows + off, cols + off]
+
+    def _apply(self, fn, *a, **k):
+        # .to()/.cuda() replace parameter storage: force a re-pack on the next call
+        self._weights_key = None
+        return super()._apply(fn, *a, **k)
+
+    def load_numpy_state_dict(self, sd: Dict[str, np.ndarray], prefix: str = "") -> None:
+        """Convenience: load a {name: ndarray} dict (e.g. hierdiff_amd.weights.synthetic_*)."""
+        own = self.state_dict()
+        with torch.no_grad():
+            for k in own:
+                own[k].copy_(torch.from_numpy(np.asarray(sd[prefix + k])).to(own[k].device))
+        self._weights_key = None

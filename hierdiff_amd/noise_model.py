@@ -1,0 +1,162 @@
+"""Noise schedules gamma(t) of the sampler, as torch modules with the reference's state_dict keys.
+
+  GammaNetwork            <- endiffusion/models/noise_model.py:163-200 (PositiveLinear :75-105)
+  PredefinedNoiseSchedule <- endiffusion/models/noise_model.py:125-160 (schedules :18-68)
+
+These are evaluated at most a few thousand scalar times per sampling run (the 1001-point grid is
+tabulated once, see `schedule_tables`), so they stay plain torch ops; the per-step arithmetic that
+uses the table is in the HIP kernels.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+class PositiveLinear(torch.nn.Module):
+    """Linear layer whose effective weight is softplus(weight) (noise_model.py:75-105)."""
+
+    def __init__(self, in_features: int, out_features: int, bias: bool = True, weight_init_offset: int = -2):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = torch.nn.Parameter(torch.empty((out_features, in_features)))
+        self.bias = torch.nn.Parameter(torch.empty(out_features)) if bias else None
+        self.weight_init_offset = weight_init_offset
+        torch.nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        with torch.no_grad():
+            self.weight.add_(weight_init_offset)
+        if self.bias is not None:
+            bound = 1 / math.sqrt(in_features) if in_features > 0 else 0
+            torch.nn.init.uniform_(self.bias, -bound, bound)
+
+    def forward(self, x):
+        return F.linear(x, F.softplus(self.weight), self.bias)
+
+
+class GammaNetwork(torch.nn.Module):
+    """Monotone gamma(t) = gamma_0 + (gamma_1 - gamma_0) * normalised(l1(t) + l3(sigmoid(l2(l1(t)))))."""
+
+    def __init__(self):
+        super().__init__()
+        self.l1 = PositiveLinear(1, 1)
+        self.l2 = PositiveLinear(1, 1024)
+        self.l3 = PositiveLinear(1024, 1)
+        self.gamma_0 = torch.nn.Parameter(torch.tensor([-5.]))
+        self.gamma_1 = torch.nn.Parameter(torch.tensor([10.]))
+
+    def gamma_tilde(self, t):
+        l1_t = self.l1(t)
+        return l1_t + self.l3(torch.sigmoid(self.l2(l1_t)))
+
+    def forward(self, t):
+        g0 = self.gamma_tilde(torch.zeros_like(t))
+        g1 = self.gamma_tilde(torch.ones_like(t))
+        gt = self.gamma_tilde(t)
+        return self.gamma_0 + (self.gamma_1 - self.gamma_0) * ((gt - g0) / (g1 - g0))
+
+
+def _clip_noise_schedule(alphas2, clip_value=0.001):
+    alphas2 = np.concatenate([np.ones(1), alphas2], axis=0)
+    step = np.clip(alphas2[1:] / alphas2[:-1], a_min=clip_value, a_max=1.)
+    return np.cumprod(step, axis=0)
+
+
+def polynomial_schedule(timesteps: int, s=1e-4, power=3.):
+    steps = timesteps + 1
+    x = np.linspace(0, steps, steps)
+    alphas2 = _clip_noise_schedule((1 - np.power(x / steps, power)) ** 2, clip_value=0.001)
+    return (1 - 2 * s) * alphas2 + s
+
+
+def cosine_beta_schedule(timesteps, s=0.008, raise_to_power: float = 1):
+    steps = timesteps + 2
+    x = np.linspace(0, steps, steps)
+    ac = np.cos(((x / steps) + s) / (1 + s) * np.pi * 0.5) ** 2
+    ac = ac / ac[0]
+    betas = np.clip(1 - (ac[1:] / ac[:-1]), a_min=0, a_max=0.999)
+    ac = np.cumprod(1. - betas, axis=0)
+    return np.power(ac, raise_to_power) if raise_to_power != 1 else ac
+
+
+class PredefinedNoiseSchedule(torch.nn.Module):
+    """Lookup-table schedule (noise_model.py:125-160)."""
+
+    def __init__(self, noise_schedule, timesteps, precision):
+        super().__init__()
+        self.timesteps = timesteps
+        if noise_schedule == 'cosine':
+            alphas2 = cosine_beta_schedule(timesteps)
+        elif 'polynomial' in noise_schedule:
+            parts = noise_schedule.split('_')
+            assert len(parts) == 2
+            alphas2 = polynomial_schedule(timesteps, s=precision, power=float(parts[1]))
+        else:
+            raise ValueError(noise_schedule)
+        sigmas2 = 1 - alphas2
+        self.gamma = torch.nn.Parameter(torch.from_numpy(-(np.log(alphas2) - np.log(sigmas2))).float(),
+                                        requires_grad=False)
+
+    def forward(self, t):
+        return self.gamma[torch.round(t * self.timesteps).long()]
+
+
+def sigma_and_alpha_t_given_s(gamma_t: torch.Tensor, gamma_s: torch.Tensor):
+    """diffusion_qm9.py:181-204 without the inflation: (sigma2_t|s, sigma_t|s, alpha_t|s)."""
+    sigma2 = -torch.expm1(F.softplus(gamma_s) - F.softplus(gamma_t))
+    alpha = torch.exp(0.5 * (F.logsigmoid(-gamma_t) - F.logsigmoid(-gamma_s)))
+    return sigma2, torch.sqrt(sigma2), alpha
+
+
+def step_coefficients(gamma_s: torch.Tensor, gamma_t: torch.Tensor) -> torch.Tensor:
+    """[rows, 4] = {alpha_t|s, sigma2_t|s, sigma_t, sigma_t|s * sigma_s / sigma_t} for the HIP
+    posterior-step kernel (diffusion_qm9.py:317-334)."""
+    sigma2_ts, sigma_ts, alpha_ts = sigma_and_alpha_t_given_s(gamma_t, gamma_s)
+    sigma_s = torch.sqrt(torch.sigmoid(gamma_s))
+    sigma_t = torch.sqrt(torch.sigmoid(gamma_t))
+    sigma = sigma_ts * sigma_s / sigma_t
+    return torch.cat([alpha_ts.reshape(-1, 1), sigma2_ts.reshape(-1, 1), sigma_t.reshape(-1, 1),
+                      sigma.reshape(-1, 1)], dim=1).to(torch.float32).contiguous()
+
+
+def evaluate_gamma(gamma_module: torch.nn.Module, t: torch.Tensor) -> torch.Tensor:
+    """gamma(t) as fp32, evaluated in fp64 on the CPU.
+
+    GammaNetwork is ill-conditioned in fp32: gamma is a normalised difference of 1024-term sums, so an
+    fp32 evaluation carries ~1e-4 absolute noise that depends on the BLAS summation order (CPU model,
+    batch size, CPU vs GPU), and sigma2_{t|s} - itself a difference of neighbouring gammas - moves by
+    ~1% between machines.  The reference inherits that irreproducibility; evaluating in fp64 and
+    rounding once gives the same table everywhere and sits inside the reference's own spread."""
+    import copy
+    with torch.no_grad():
+        m64 = copy.deepcopy(gamma_module).to("cpu").double()
+        return m64(t.detach().to("cpu", torch.float64)).to(torch.float32)
+
+
+def decode_coefficients(gamma_0: torch.Tensor) -> torch.Tensor:
+    """{sigma_0, alpha_0, sigma_x = exp(0.5*gamma_0)} (diffusion_qm9.py:148-158, 296-299)."""
+    g0 = gamma_0.reshape(-1)[0:1].to(torch.float32)
+    sigma_x = torch.exp(-(-0.5 * g0))
+    return torch.stack([torch.sqrt(torch.sigmoid(g0)).view(()), torch.sqrt(torch.sigmoid(-g0)).view(()),
+                        sigma_x.view(())]).to(torch.float32)
+
+
+@torch.no_grad()
+def schedule_tables(gamma_module: torch.nn.Module, T: int, gammas=None) -> Dict[str, torch.Tensor]:
+    """Schedule on the sampling grid tau_k = int64(k) / T (fp32; diffusion_qm9.py:376-379).  Returns CPU
+    tensors: tau [T+1], gamma [T+1], coef [T,4] (row s: transition t=s+1 -> s; diffusion_qm9.py:314-334),
+    decode {sigma_0, alpha_0, sigma_x}.  `gammas` ([T+1] fp32) overrides the network, e.g. to replay the
+    exact schedule another run used."""
+    k = torch.arange(0, T + 1, dtype=torch.int64).view(-1, 1)
+    tau = k / T
+    if gammas is None:
+        g = evaluate_gamma(gamma_module, tau)
+    else:
+        g = torch.as_tensor(gammas, dtype=torch.float32).reshape(-1, 1)
+        assert g.shape[0] == T + 1, "need T+1 gamma values"
+    coef = step_coefficients(g[:-1], g[1:])
+    return {"tau": tau.view(-1).to(torch.float32).contiguous(), "gamma": g.view(-1).contiguous(),
+            "coef": coef, "decode": decode_coefficients(g[0])}

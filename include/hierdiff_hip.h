@@ -1,0 +1,161 @@
+/*
+ * hierdiff_hip.h -- C ABI of libhierdiff_hip.so: the MI355X (gfx950) implementation of HierDiff's
+ * coarse-grained reverse-diffusion hot path (EGNN dynamics forward + posterior step).
+ *
+ * Every entry point takes plain pointers and sizes; there are no torch / C++ types in the
+ * signatures.  Device pointers are raw HIP device addresses (tensor.data_ptr()), `stream` is a
+ * hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream), NULL = default stream.
+ *
+ * Conventions
+ *   - return value 0 = OK, negative = error (HD_E_*); the message is in hd_last_error()
+ *     (thread-local).  No exceptions or aborts cross the ABI.  Kernel faults surface at the
+ *     caller's next synchronisation.
+ *   - one handle per (device, stream of use); calls on one handle must be serialised by the
+ *     caller; distinct handles are independent.
+ *   - the handle OWNS a repacked device copy of the weights; a topology OWNS its index tables
+ *     and activation workspace; the caller owns every tensor it passes in.
+ *
+ * Reference interfaces replaced (file:line under /root/reference/endiffusion):
+ *   hd_create / hd_set_weights   <- EGNN_dynamics_QM9.__init__ + load_state_dict
+ *                                   (models/module/en_dynamics.py:9-36, sampler.py:27-34)
+ *   hd_topology_create           <- get_adj_matrix + the mask tensors built in
+ *                                   DiffusionQM9.sample (en_dynamics.py:124-143,
+ *                                   train_module/diffusion_qm9.py:350-359)
+ *   hd_egnn_forward              <- EGNN_dynamics_QM9._forward (en_dynamics.py:49-122), i.e.
+ *                                   DiffusionQM9.phi (diffusion_qm9.py:135-138)
+ *   hd_posterior_step            <- the arithmetic of sample_p_zs_given_zt after the network call
+ *                                   (diffusion_qm9.py:328-345) incl. sample_normal (:438-456)
+ *   hd_final_decode              <- sample_p_xh_given_z0 after the network call (:302-310)
+ *   hd_noise                     <- sample_combined_position_feature_noise (:445-456)
+ *   hd_sample_loop               <- the timestep loop of DiffusionQM9.sample (:375-384)
+ */
+#ifndef HIERDIFF_HIP_H
+#define HIERDIFF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HD_ABI_VERSION 1
+
+#define HD_OK 0
+#define HD_E_INVALID (-1)      /* bad argument / unsupported configuration */
+#define HD_E_HIP (-2)          /* a HIP runtime call failed */
+#define HD_E_NOMEM (-3)
+#define HD_E_STATE (-4)        /* e.g. weights or schedule not set */
+
+typedef struct hd_handle hd_handle;
+typedef struct hd_topology hd_topology;
+
+/* Mirrors EGNN_dynamics_QM9's constructor arguments (en_dynamics.py:9-13) that are on the path.
+ * Unsupported values (mode != egnn_dynamics, sin_embedding, aggregation 'mean', act_fn != silu)
+ * are rejected by the Python wrapper before this struct is built. */
+typedef struct hd_config {
+    int32_t in_node_nf;          /* node features INCLUDING the time column, excluding context */
+    int32_t context_node_nf;
+    int32_t n_dims;              /* must be 3 */
+    int32_t hidden_nf;           /* 32, 64, 128 or 256 */
+    int32_t n_layers;            /* number of EquivariantBlocks */
+    int32_t inv_sublayers;       /* GCLs per block */
+    int32_t attention;           /* 0/1 */
+    int32_t tanh;                /* 0/1 */
+    int32_t condition_time;      /* 0/1 */
+    float norm_constant;
+    float normalization_factor;
+    float coords_range;          /* EGNN default 30; per-block range = coords_range / n_layers */
+} hd_config;
+
+int hd_version(void);
+const char* hd_last_error(void);
+
+/* Number of HIP devices visible (0 when there is no GPU; never fails). */
+int hd_device_count(void);
+
+int hd_create(const hd_config* cfg, int device, hd_handle** out);
+int hd_destroy(hd_handle* h);
+
+/* Number of fp32 values in the canonical weight blob: the dynamics parameters flattened in
+ * state_dict registration order (hierdiff_amd/weights.py::dynamics_param_shapes). */
+long long hd_weight_count(const hd_handle* h);
+
+/* Load the canonical weight blob (host or device pointer). The library repacks it into its
+ * kernel layouts; the source is not referenced after return. */
+int hd_set_weights(hd_handle* h, const float* blob, long long n, int on_device, void* stream);
+
+/* Build index tables for one (node_mask, edge_mask) pair.  Masks are HOST byte arrays
+ * (0 = false): node_mask [B*N], edge_mask [B*N*N] row-major (b, i, j) or NULL for the canonical
+ * mask node_mask[i] & node_mask[j] & (i != j). */
+int hd_topology_create(hd_handle* h, const uint8_t* node_mask, const uint8_t* edge_mask, int B, int N,
+                       hd_topology** out);
+int hd_topology_destroy(hd_topology* t);
+/* info[0..5] = {B, N, active nodes, valid edges, edge tiles (32 edges), aggregation parts} */
+int hd_topology_info(const hd_topology* t, long long* info6);
+
+/* out[B,N,3+F] = EGNN_dynamics_QM9._forward(t, xh, node_mask, edge_mask, context, mol_shape).
+ *   xh      device [B,N,3+F], F = in_node_nf - condition_time
+ *   t       device, t_numel == 1 (broadcast) or B
+ *   context device [B,N,context_node_nf] or NULL when context_node_nf == 0
+ *   mol_shape  < 0 for None; otherwise nodes >= mol_shape keep their input coordinates
+ * Stream-ordered; the NaN guard (whole-call reset of the velocity, en_dynamics.py:109-111) is
+ * applied on the device without a host sync. */
+int hd_egnn_forward(hd_handle* h, hd_topology* topo, const float* xh, const float* t, int t_numel,
+                    const float* context, int mol_shape, float* out, void* stream);
+
+/* Number of forwards since creation whose velocity contained NaN (syncs the stream). */
+int hd_nan_events(hd_handle* h, void* stream, long long* count);
+
+/* zs[B,mol,D] = posterior sample given the network output eps[B,N,D] (diffusion_qm9.py:326-345).
+ *   coef   device [B,4] or [1,4] (coef_rows = B or 1): {alpha_t_given_s, sigma2_t_given_s,
+ *          sigma_t, sigma = sigma_t_given_s * sigma_s / sigma_t}
+ *   raw_x  device [noise_rows, mol, 3], raw_h device [noise_rows, mol, F]: the two randn draws;
+ *          noise_rows = 1 reproduces fix_noise=True.  mol = mol_shape (< 0: N).
+ *   zs may alias zt only when mol == N. */
+int hd_posterior_step(hd_handle* h, hd_topology* topo, const float* zt, const float* eps, const float* coef,
+                      int coef_rows, const float* raw_x, const float* raw_h, int noise_rows, int mol_shape,
+                      float* zs, void* stream);
+
+/* x[B,N,3], hfeat[B,N,F] = sample_p_xh_given_z0 after the network call.
+ *   coef3 host {sigma_0, alpha_0, sigma_x}; noise as in hd_noise (raw normals or, with
+ *   raw_x == NULL, the counter-based generator at (seed, sample_id_base + b, draw)). */
+int hd_final_decode(hd_handle* h, hd_topology* topo, const float* z0, const float* eps, const float* coef3,
+                    const float* raw_x, const float* raw_h, int noise_rows, uint64_t seed,
+                    uint64_t sample_id_base, uint32_t draw, int share_rows, float* x, float* hfeat,
+                    void* stream);
+
+/* z[rows,N,3+F] = masked, centre-of-gravity-free combined noise from raw normals (rows = B), or,
+ * with raw_x == NULL, from the library's counter-based generator (Philox4x32-10 + Box-Muller):
+ * normal(seed, sample_id_base + b, draw, n*D + c).  share_rows != 0 draws one row (sample id
+ * sample_id_base) and broadcasts it over the batch before masking (fix_noise). */
+int hd_noise(hd_handle* h, hd_topology* topo, const float* raw_x, const float* raw_h, int noise_rows,
+             uint64_t seed, uint64_t sample_id_base, uint32_t draw, int share_rows, float* z, void* stream);
+
+/* Schedule for hd_sample_loop: host arrays of T+1 time values tau[k] = fp32(k)/T and T rows of
+ * {alpha_t_given_s, sigma2_t_given_s, sigma_t, sigma} for s = 0..T-1 (t = s+1). */
+int hd_set_schedule(hd_handle* h, int T, const float* tau, const float* coef4);
+
+/* Runs posterior steps s = s_hi-1 ... s_lo on z[B,N,D] in place (rows >= mol_shape untouched):
+ * per step one hd_egnn_forward at tau[s+1] and one hd_posterior_step.
+ *   raw_x/raw_h  device [(s_hi-s_lo), noise_rows, mol, 3|F] in step order (first = s_hi-1), or NULL
+ *                to use the counter-based generator with draw = T - s (draw 0 is z_T).
+ *   use_graph    capture one step into a hipGraph and replay it (0 = plain launches). */
+int hd_sample_loop(hd_handle* h, hd_topology* topo, float* z, const float* context, int mol_shape,
+                   int s_hi, int s_lo, const float* raw_x, const float* raw_h, int noise_rows,
+                   uint64_t seed, uint64_t sample_id_base, int use_graph, void* stream);
+
+/* Host implementation of the library's normal generator (same bits as the device one up to libm
+ * round-off); used by tests and by callers that want to reproduce a draw on the CPU. */
+float hd_philox_normal_host(uint64_t seed, uint64_t sample_id, uint32_t draw, uint32_t index);
+
+/* Kernel timing of the most recent hd_egnn_forward when profiling is enabled: per-kernel-family
+ * accumulated milliseconds measured with HIP events on the caller's stream.
+ * families: 0 edge (GCL+coord), 1 node GEMMs, 2 other.  Enabling inserts event records only. */
+int hd_profile_enable(hd_handle* h, int on);
+int hd_profile_read(hd_handle* h, double* ms3, long long* launches3);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIERDIFF_HIP_H */

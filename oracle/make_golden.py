@@ -220,7 +220,14 @@ def fixture_conditional(DiffusionQM9, name, hidden_nf, n_layers, seed, coord_gai
         zs_got = orc.posterior_step(sd, ocfg, s, t, z, node_mask, edge_mask, context, (raw_x, raw_h),
                                     mol_shape=mol)
         check(f"{name} zs", zs_got.numpy(), zs_ref.numpy())
-    save(name, z=z.numpy(), node_mask=node_mask.numpy(), edge_mask=edge_mask.numpy(),
+        # the schedule values this run used (fp32, this host's BLAS): recorded because gamma(t) is
+        # ill-conditioned in fp32 and not reproducible across CPUs
+        gamma_s, gamma_t = model.gamma(s), model.gamma(t)
+        zs_inj = orc.posterior_step(sd, ocfg, s, t, z, node_mask, edge_mask, context, (raw_x, raw_h),
+                                    mol_shape=mol, gammas=(gamma_s, gamma_t))
+        check(f"{name} zs (injected gammas)", zs_inj.numpy(), zs_ref.numpy())
+    save(name, gamma_s=gamma_s.numpy(), gamma_t=gamma_t.numpy(),
+         z=z.numpy(), node_mask=node_mask.numpy(), edge_mask=edge_mask.numpy(),
          context=context.numpy(), s=s.numpy(), t=t.numpy(), mol_shape=mol, raw_x=raw_x.numpy(),
          raw_h=raw_h.numpy(), eps=eps_ref.numpy(), zs=zs_ref.numpy(), hidden_nf=hidden_nf,
          n_layers=n_layers, weight_seed=seed, coord_gain=coord_gain)
@@ -266,14 +273,27 @@ def fixture_chain(DiffusionQM9, name, hidden_nf, n_layers, seed, coord_gain, T, 
         return r.clone()
 
     torch.randn = fake_randn
+    seen = []          # (tau row 0, gamma row 0) of every schedule evaluation of the run
+    hook = model.gamma.register_forward_hook(
+        lambda m, a, o: seen.append((float(a[0][0, 0]), float(o[0, 0]), bool((o == o[0:1]).all()))))
     try:
         with torch.no_grad():
             res = model.sample(B, "cpu")
     finally:
         torch.randn = orig_randn
+        hook.remove()
     assert not queue
+    gamma_grid = np.full(T + 1, np.nan, np.float32)
+    assert all(rows_equal for _, _, rows_equal in seen), "schedule rows differ within the batch: pick another B"
+    for tau, g, _ in seen:
+        k = int(round(tau * T))
+        assert np.isnan(gamma_grid[k]) or gamma_grid[k] == np.float32(g), "schedule not a function of tau?"
+        gamma_grid[k] = g
+    assert not np.isnan(gamma_grid).any()
     nm, em = orc.canonical_masks(n_list)
     x_got, h_got = orc.sample_chain(sd, ocfg, T, nm, em, None, raws)
+    x_inj, h_inj = orc.sample_chain(sd, ocfg, T, nm, em, None, raws, gamma_grid=torch.from_numpy(gamma_grid))
+    assert torch.equal(x_inj, x_got) and torch.equal(h_inj, h_got)
     x_ref = np.zeros((B, N, 3), np.float32)
     h_ref = np.zeros((B, N, 8), np.float32)
     for b, r in enumerate(res):
@@ -283,7 +303,7 @@ def fixture_chain(DiffusionQM9, name, hidden_nf, n_layers, seed, coord_gain, T, 
     check(f"{name} x", x_got.numpy() * nmf, x_ref, tol=2e-5)
     check(f"{name} h", h_got.numpy(), h_ref, tol=2e-5)
     save(name, raw_x=np.stack([r[0].numpy() for r in raws]), raw_h=np.stack([r[1].numpy() for r in raws]),
-         n_list=np.array(n_list), x=x_ref, h=h_ref, T=T, hidden_nf=hidden_nf, n_layers=n_layers,
+         n_list=np.array(n_list), x=x_ref, h=h_ref, T=T, gamma_grid=gamma_grid, hidden_nf=hidden_nf, n_layers=n_layers,
          weight_seed=seed, coord_gain=coord_gain)
 
 
@@ -313,7 +333,7 @@ def main():
     fixture_schedule(DiffusionQM9, "f4_schedule", 0)
     # F5: 3-step chain
     fixture_chain(DiffusionQM9, "f5_chain_h256_l3", 256, 3, 9, 1.0, 3, [8, 5, 3, 7])
-    fixture_chain(DiffusionQM9, "f5_chain_h32_l2", 32, 2, 10, 1.0, 4, [6, 1, 4])
+    fixture_chain(DiffusionQM9, "f5_chain_h32_l2", 32, 2, 10, 1.0, 4, [6, 1, 4, 5])
 
 
 if __name__ == "__main__":

@@ -1,0 +1,119 @@
+"""CPU tier: the C-ABI library builds/loads and exports every symbol include/hierdiff_hip.h declares;
+host-side logic (weight layout, module key layout, schedule tables, node distribution)."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from hierdiff_amd import _lib
+from hierdiff_amd.weights import (dynamics_param_count, dynamics_param_shapes, flatten_dynamics,
+                                  synthetic_state_dict)
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from hierdiff_amd import build
+    build.build(verbose=False)
+    return _lib.load()
+
+
+def test_header_symbols_all_exported(lib):
+    hdr = open(os.path.join(REPO, "include", "hierdiff_hip.h")).read()
+    declared = set(re.findall(r"\b(hd_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.hd_version() == 1
+
+
+def test_no_gpu_fails_loudly(lib):
+    if lib.hd_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    import ctypes as C
+    cfg = _lib.HdConfig(9, 0, 3, 32, 1, 2, 1, 1, 1, 0.0, 10.0, 30.0)
+    h = C.c_void_p()
+    rc = lib.hd_create(C.byref(cfg), 0, C.byref(h))
+    assert rc != 0 and b"HIP device" in lib.hd_last_error()
+    with pytest.raises(_lib.HierDiffHipError):
+        _lib.require_gpu()
+    from hierdiff_amd import EGNN_dynamics_QM9
+    m = EGNN_dynamics_QM9(9, 0, 3, hidden_nf=32, n_layers=1, attention=True, tanh=True, normalization_factor=10)
+    xh = torch.zeros(1, 2, 11)
+    with pytest.raises(_lib.HierDiffHipError):
+        m._forward(torch.zeros(1, 1), xh, torch.ones(1, 2, 1).bool(), torch.ones(1, 2, 2).bool(), None)
+
+
+def test_philox_host_twin_statistics(lib):
+    v = np.array([lib.hd_philox_normal_host(2022, 7, 3, i) for i in range(20000)], dtype=np.float64)
+    assert abs(v.mean()) < 0.03 and abs(v.std() - 1.0) < 0.03
+    # distinct (sample, draw) streams are uncorrelated, identical arguments reproduce
+    w = np.array([lib.hd_philox_normal_host(2022, 8, 3, i) for i in range(20000)], dtype=np.float64)
+    assert abs(np.corrcoef(v, w)[0, 1]) < 0.03
+    assert lib.hd_philox_normal_host(1, 2, 3, 4) == lib.hd_philox_normal_host(1, 2, 3, 4)
+
+
+@pytest.mark.parametrize("H,L,C_", [(256, 3, 0), (256, 6, 0), (256, 9, 0), (32, 2, 1)])
+def test_param_layout_matches_reference_counts(H, L, C_):
+    from hierdiff_amd import EGNN_dynamics_QM9
+    m = EGNN_dynamics_QM9(9, C_, 3, hidden_nf=H, n_layers=L, attention=True, tanh=True, normalization_factor=10)
+    shapes = dynamics_param_shapes(9, C_, H, L, 2, True)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(shapes.keys())
+    assert all(tuple(sd[k].shape) == shapes[k] for k in shapes)
+    n = dynamics_param_count(9, C_, H, L, 2, True)
+    if C_ == 0 and H == 256:
+        assert n == {3: 2968591, 6: 5932309, 9: 8896027}[L]
+    syn = synthetic_state_dict(9, C_, H, L)
+    m.load_numpy_state_dict(syn, prefix="dynamics.")
+    blob = m.canonical_blob().numpy()
+    ref = flatten_dynamics(syn, 9, C_, H, L, 2, True, prefix="dynamics.")
+    assert blob.shape == ref.shape == (n,) and np.array_equal(blob, ref)
+
+
+def test_diffusion_state_dict_keys_and_schedule():
+    from hierdiff_amd import DiffusionQM9, default_config
+    from hierdiff_amd.noise_model import schedule_tables
+    from tests.helpers import load
+    model = DiffusionQM9(default_config(hidden_nf=32, n_layers=1))
+    syn = synthetic_state_dict(9, 0, 32, 1)
+    assert sorted(model.state_dict().keys()) == sorted(syn.keys())
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in syn.items()})
+    fx = load("f4_schedule")
+    # 1) the network evaluated in fp64 agrees with the reference's fp32 run within fp32's own noise
+    tabs = schedule_tables(model.gamma, 1000)
+    assert np.abs(tabs["gamma"].numpy() - fx["gamma"]).max() < 1e-3
+    assert np.all(np.diff(tabs["gamma"].numpy()) > 0), "fp64-evaluated schedule must be monotone"
+    # 2) given the reference's gamma grid, the derived per-step coefficients are the reference's
+    tabs = schedule_tables(model.gamma, 1000, gammas=fx["gamma"])
+    np.testing.assert_allclose(tabs["coef"][:, 0].numpy(), fx["alpha_t_given_s"], rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(tabs["coef"][:, 1].numpy(), fx["sigma2_t_given_s"], rtol=2e-4, atol=1e-7)
+    np.testing.assert_allclose(tabs["coef"][:, 2].numpy(), fx["sigma_t"], rtol=2e-6, atol=1e-7)
+    sig = fx["sigma_t_given_s"] * fx["sigma_s"] / fx["sigma_t"]
+    np.testing.assert_allclose(tabs["coef"][:, 3].numpy(), sig, rtol=2e-4, atol=1e-7)
+    assert abs(float(tabs["tau"][999]) - 0.99900001287) < 1e-9
+
+
+def test_nodes_distribution_follows_histogram():
+    from hierdiff_amd import DistributionNodes
+    from hierdiff_amd.geom_stats import GEOM_FRAGMENT_HISTOGRAM as H
+    d = DistributionNodes(H)
+    torch.manual_seed(0)
+    s = d.sample(20000)
+    assert min(s) >= 1 and max(s) <= 83
+    tot = sum(H.values())
+    mean = sum(k * v for k, v in H.items()) / tot
+    assert abs(np.mean(s) - mean) < 0.15
+    assert len(H) == 67 and list(H)[:3] == [26, 14, 17]
+
+
+def test_unsupported_modes_raise():
+    from hierdiff_amd import EGNN_dynamics_QM9
+    for kw in (dict(mode="gnn_dynamics"), dict(sin_embedding=True), dict(aggregation_method="mean"),
+               dict(act_fn="relu"), dict(hidden_nf=48)):
+        with pytest.raises(NotImplementedError):
+            EGNN_dynamics_QM9(9, 0, 3, **kw)
