@@ -66,7 +66,10 @@ struct hd_handle {
     float* d_tcur;
     hipStream_t own_stream;     // capture stream used when the caller passes the legacy NULL stream
     // profiling
-    bool prof;
+    int prof;                   // bitmask of kernel families bracketed with events
+    int prof_stride;            // bracket every prof_stride-th forward
+    long long prof_fwd;
+    bool prof_now;
     std::vector<ProfRec> recs;
     std::vector<hipEvent_t> pool;
     size_t pool_used;
@@ -156,7 +159,10 @@ extern "C" int hd_create(const hd_config* cfg, int device, hd_handle** out) {
     h->dw_floats = 0;
     h->T = 0;
     h->d_tau = h->d_coef = nullptr;
-    h->prof = false;
+    h->prof = 0;
+    h->prof_stride = 1;
+    h->prof_fwd = 0;
+    h->prof_now = false;
     h->pool_used = 0;
     h->own_stream = nullptr;
     int r = dev_alloc(&h->d_nanflag, 1);
@@ -439,7 +445,10 @@ extern "C" int hd_topology_info(const hd_topology* t, long long* info6) {
 
 extern "C" int hd_profile_enable(hd_handle* h, int on) {
     if (!h) return fail(HD_E_INVALID, "hd_profile_enable: null handle");
-    h->prof = on != 0;
+    h->prof = on & 7;
+    h->prof_stride = std::max(1, on >> 8);
+    h->prof_fwd = 0;
+    h->prof_now = false;
     h->recs.clear();
     h->pool_used = 0;
     return HD_OK;
@@ -457,10 +466,10 @@ static hipEvent_t prof_event(hd_handle* h) {
 struct ProfScope {
     hd_handle* h; hipStream_t s; int fam; hipEvent_t a;
     ProfScope(hd_handle* h_, hipStream_t s_, int fam_) : h(h_), s(s_), fam(fam_), a(nullptr) {
-        if (h->prof) { a = prof_event(h); hipEventRecord(a, s); }
+        if (h->prof_now && (h->prof & (1 << fam))) { a = prof_event(h); hipEventRecord(a, s); }
     }
     ~ProfScope() {
-        if (h->prof) { hipEvent_t b = prof_event(h); hipEventRecord(b, s); h->recs.push_back({fam, a, b}); }
+        if (a) { hipEvent_t b = prof_event(h); hipEventRecord(b, s); h->recs.push_back({fam, a, b}); }
     }
 };
 
@@ -542,6 +551,7 @@ static int forward_impl(hd_handle* h, hd_topology* t, const float* xh, const flo
     const hd_config& c = h->cfg;
     const int H = h->H, M = t->M;
     const float* W = h->dw;
+    h->prof_now = h->prof != 0 && (h->prof_fwd++ % h->prof_stride) == 0;
     HIP_TRY(hipMemsetAsync(h->d_nanflag, 0, sizeof(int), s));
     if (M > 0) {
         {
@@ -757,8 +767,8 @@ extern "C" int hd_sample_loop(hd_handle* h, hd_topology* topo, float* z, const f
         return HD_OK;
     }
     // hipGraph: capture one step whose step index / draw / time live in device memory, replay it.
-    const bool was_prof = h->prof;
-    h->prof = false;
+    const int was_prof = h->prof;
+    h->prof = 0;
     const int s0 = s_hi - 1;
     const uint32_t d0 = draw0;
     HIP_TRY(hipMemcpyAsync(h->d_step, &s0, sizeof(int), hipMemcpyHostToDevice, s));

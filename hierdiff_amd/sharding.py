@@ -1,0 +1,55 @@
+"""Multi-GPU sampling: independent sample shards, one process per GPU.
+
+Every molecule of a batch is independent (no cross-sample op anywhere on the path),
+so N GPUs run N shards with no data-path collective.  The only collective is one broadcast of rank 0's
+parameters at start-up (RCCL over xGMI when the backend is "nccl"; "gloo" in the CPU tests).  Noise comes
+from a counter-based generator keyed by the GLOBAL sample id, so a sample does not depend on which rank
+(or how many ranks) produced it.
+"""
+from __future__ import annotations
+
+from typing import List, Tuple
+
+import torch
+
+
+def shard_sample_ids(first_id: int, total: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous split of the global ids [first_id, first_id + total) over `world` ranks.
+    Returns (first id of this rank, count); the first `total % world` ranks get one extra."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError("bad rank/world")
+    q, r = divmod(total, world)
+    count = q + (1 if rank < r else 0)
+    start = first_id + rank * q + min(rank, r)
+    return start, count
+
+
+def shard_sizes(total: int, world: int) -> List[int]:
+    return [shard_sample_ids(0, total, r, world)[1] for r in range(world)]
+
+
+def pack_parameters(module: torch.nn.Module) -> torch.Tensor:
+    """All parameters and buffers of `module` flattened into one fp32 tensor (registration order)."""
+    tensors = list(module.parameters()) + list(module.buffers())
+    return torch.cat([t.detach().reshape(-1).to(torch.float32) for t in tensors])
+
+
+@torch.no_grad()
+def unpack_parameters(module: torch.nn.Module, flat: torch.Tensor) -> None:
+    off = 0
+    for t in list(module.parameters()) + list(module.buffers()):
+        n = t.numel()
+        t.copy_(flat[off:off + n].view_as(t).to(t.dtype))
+        off += n
+    if off != flat.numel():
+        raise ValueError("parameter blob size mismatch")
+
+
+@torch.no_grad()
+def broadcast_model_weights(module: torch.nn.Module, src: int = 0) -> int:
+    """One broadcast of the packed parameters from `src` (23.7 MB at L=6); returns the element count."""
+    import torch.distributed as dist
+    flat = pack_parameters(module).contiguous()
+    dist.broadcast(flat, src=src)
+    unpack_parameters(module, flat)
+    return int(flat.numel())

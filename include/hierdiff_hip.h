@@ -151,7 +151,10 @@ float hd_philox_normal_host(uint64_t seed, uint64_t sample_id, uint32_t draw, ui
 
 /* Kernel timing of the most recent hd_egnn_forward when profiling is enabled: per-kernel-family
  * accumulated milliseconds measured with HIP events on the caller's stream.
- * families: 0 edge (GCL+coord), 1 node GEMMs, 2 other.  Enabling inserts event records only. */
+ * families: 0 edge (GCL+coord), 1 node GEMMs, 2 other.  `on` is a bitmask of the families to bracket
+ * (1 = edge kernels only, 7 = all, 0 = off), optionally OR-ed with (stride << 8) to bracket only every
+ * stride-th forward; enabling inserts event records only.  Launches replayed from a hipGraph are not
+ * bracketed. */
 int hd_profile_enable(hd_handle* h, int on);
 int hd_profile_read(hd_handle* h, double* ms3, long long* launches3);
 
