@@ -36,13 +36,14 @@ def pack_parameters(module: torch.nn.Module) -> torch.Tensor:
 
 @torch.no_grad()
 def unpack_parameters(module: torch.nn.Module, flat: torch.Tensor) -> None:
+    tensors = list(module.parameters()) + list(module.buffers())
+    if sum(t.numel() for t in tensors) != flat.numel():
+        raise ValueError("parameter blob size mismatch")
     off = 0
-    for t in list(module.parameters()) + list(module.buffers()):
+    for t in tensors:
         n = t.numel()
         t.copy_(flat[off:off + n].view_as(t).to(t.dtype))
         off += n
-    if off != flat.numel():
-        raise ValueError("parameter blob size mismatch")
 
 
 @torch.no_grad()

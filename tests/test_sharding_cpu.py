@@ -1,0 +1,88 @@
+"""CPU tier: the N>1 path (world_size 2, gloo): rank 0's parameters reach every rank with one broadcast,
+global sample ids are split without gaps or overlap, and the counter RNG depends only on the global id."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from hierdiff_amd.sharding import (broadcast_model_weights, pack_parameters, shard_sample_ids, shard_sizes,
+                                   unpack_parameters)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hierdiff_amd import DiffusionQM9, _lib, default_config
+    from hierdiff_amd.weights import synthetic_state_dict
+    torch.manual_seed(100 + rank)                       # ranks start from different random inits
+    model = DiffusionQM9(default_config(hidden_nf=32, n_layers=2))
+    if rank == 0:
+        sd = synthetic_state_dict(9, 0, 32, 2, 2, True, 3)
+        model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+    n = broadcast_model_weights(model, src=0)
+    flat = pack_parameters(model)
+    # every rank now holds rank 0's synthetic weights
+    ref = synthetic_state_dict(9, 0, 32, 2, 2, True, 3)
+    for k, v in model.state_dict().items():
+        assert np.array_equal(v.numpy(), ref[k]), k
+    # this rank's shard of 11 global samples starting at id 1000, and its share of one noise draw
+    start, count = shard_sample_ids(1000, 11, rank, world)
+    lib = _lib.load()
+    draws = np.array([[lib.hd_philox_normal_host(2022, start + b, 5, i) for i in range(8)] for b in range(count)],
+                     dtype=np.float32)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), start=start, count=count, draws=draws, n=n,
+             checksum=float(flat.double().sum()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world2_broadcast_and_sharding(tmp_path):
+    from hierdiff_amd import build
+    build.build(verbose=False)
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [dict(np.load(tmp_path / f"rank{k}.npz")) for k in range(world)]
+    assert r[0]["checksum"] == r[1]["checksum"] and r[0]["n"] == r[1]["n"]
+    assert int(r[0]["start"]) == 1000 and int(r[0]["count"]) == 6
+    assert int(r[1]["start"]) == 1006 and int(r[1]["count"]) == 5
+    # single-process reference for the same global ids
+    from hierdiff_amd import _lib
+    lib = _lib.load()
+    full = np.array([[lib.hd_philox_normal_host(2022, 1000 + b, 5, i) for i in range(8)] for b in range(11)],
+                    dtype=np.float32)
+    assert np.array_equal(np.concatenate([r[0]["draws"], r[1]["draws"]]), full)
+
+
+@pytest.mark.parametrize("total,world", [(2048, 8), (10, 4), (3, 8), (0, 2), (257, 2)])
+def test_shard_partition_is_exact(total, world):
+    spans = [shard_sample_ids(7, total, r, world) for r in range(world)]
+    assert sum(c for _, c in spans) == total and shard_sizes(total, world) == [c for _, c in spans]
+    nxt = 7
+    for s, c in spans:
+        assert s == nxt and c >= 0
+        nxt += c
+    assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
+
+
+def test_pack_unpack_roundtrip():
+    m = torch.nn.Sequential(torch.nn.Linear(3, 5), torch.nn.BatchNorm1d(5))
+    flat = pack_parameters(m)
+    m2 = torch.nn.Sequential(torch.nn.Linear(3, 5), torch.nn.BatchNorm1d(5))
+    unpack_parameters(m2, flat)
+    for (k, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a.float(), b.float()), k
+    with pytest.raises(ValueError):
+        unpack_parameters(m2, flat[:-1])
