@@ -11,7 +11,7 @@ import os
 from typing import Optional
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "lib", "libhierdiff_hip.so")
+LIB_PATH = os.environ.get("HIERDIFF_LIB") or os.path.join(PKG, "lib", "libhierdiff_hip.so")
 
 
 class HdConfig(C.Structure):
@@ -20,6 +20,7 @@ class HdConfig(C.Structure):
         ("hidden_nf", C.c_int32), ("n_layers", C.c_int32), ("inv_sublayers", C.c_int32),
         ("attention", C.c_int32), ("tanh", C.c_int32), ("condition_time", C.c_int32),
         ("norm_constant", C.c_float), ("normalization_factor", C.c_float), ("coords_range", C.c_float),
+        ("precision", C.c_int32),
     ]
 
 

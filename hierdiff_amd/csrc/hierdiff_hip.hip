@@ -7,8 +7,11 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
+
+static int g_edge_grid = 512;      // persistent edge-kernel grid: 2 workgroups per CU (set in hd_create)
 
 // ----------------------------------------------------------------------------- errors
 
@@ -140,6 +143,7 @@ extern "C" int hd_create(const hd_config* cfg, int device, hd_handle** out) {
     const int F = cfg->in_node_nf - (cfg->condition_time ? 1 : 0);
     if (F < 1) return fail(HD_E_INVALID, "hd_create: in_node_nf must leave at least one feature column");
     if (cfg->context_node_nf < 0) return fail(HD_E_INVALID, "hd_create: context_node_nf < 0");
+    if (cfg->precision != 0 && cfg->precision != 1) return fail(HD_E_INVALID, "hd_create: precision must be 0 (fp32) or 1 (bf16x3)");
     if (!(cfg->normalization_factor != 0.0f)) return fail(HD_E_INVALID, "hd_create: normalization_factor == 0");
     if (hd_device_count() <= device || device < 0)
         return fail(HD_E_HIP, "hd_create: no such HIP device (is a GPU visible?)");
@@ -175,6 +179,12 @@ extern "C" int hd_create(const hd_config* cfg, int device, hd_handle** out) {
     HIP_TRY(hipMemset(h->d_nan_events, 0, sizeof(long long)));
     r = prepare_kernels(H);
     if (r != HD_OK) { hd_destroy(h); return r; }
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+            g_edge_grid = 2 * prop.multiProcessorCount;
+        if (const char* e = getenv("HD_EDGE_GRID")) g_edge_grid = std::max(1, atoi(e));
+    }
     *out = h;
     return HD_OK;
 }
@@ -225,6 +235,66 @@ static void pack_edge_w2(std::vector<float>& dst, size_t off, int H, const float
                     }
 }
 
+// bf16 round-to-nearest-even of an fp32 value (bit pattern in the low 16 bits)
+static inline uint16_t bf16_rne(float v) {
+    uint32_t u;
+    std::memcpy(&u, &v, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static inline float bf16_to_f32(uint16_t b) {
+    uint32_t u = (uint32_t)b << 16;
+    float v;
+    std::memcpy(&v, &u, 4);
+    return v;
+}
+static inline void bf16_split(float v, uint16_t& hi, uint16_t& lo) {
+    hi = bf16_rne(v);
+    lo = bf16_rne(v - bf16_to_f32(hi));
+}
+
+// bf16x3 images (same byte size as the fp32 ones: 2 B head + 2 B tail per weight).
+// node GEMM: per (col tile, 32-wide K chunk): [hi|lo][2 k-steps][WN][64 lanes][8], k = 32c + 16s + 8*(lane>>5) + i.
+template <typename Fn>
+static void pack_gemm_b_bf(std::vector<float>& dstf, size_t off, int K, int Nc, int WN, Fn W) {
+    uint16_t* dst = reinterpret_cast<uint16_t*>(dstf.data() + off);
+    const int BN = 32 * WN, ntile = Nc / BN, nchunk = K / 32;
+    for (int ct = 0; ct < ntile; ++ct)
+        for (int c = 0; c < nchunk; ++c)
+            for (int st = 0; st < 2; ++st)
+                for (int wc = 0; wc < WN; ++wc)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int i = 0; i < 8; ++i) {
+                            const int k = 32 * c + 16 * st + 8 * (lane >> 5) + i;
+                            const int col = ct * BN + 32 * wc + (lane & 31);
+                            uint16_t hi, lo;
+                            bf16_split(W(col, k), hi, lo);
+                            const size_t blk = (size_t)(ct * nchunk + c) * (BN * 32 * 2);
+                            dst[blk + (((size_t)(0 * 2 + st) * WN + wc) * 64 + lane) * 8 + i] = hi;
+                            dst[blk + (((size_t)(1 * 2 + st) * WN + wc) * 64 + lane) * 8 + i] = lo;
+                        }
+}
+
+// edge kernel: per K chunk [hi|lo][2 k-steps][H/32 ct][64 lanes][8], k = 32c + 16*(lane>>5) + 8s + i.
+static void pack_edge_w2_bf(std::vector<float>& dstf, size_t off, int H, const float* W2) {
+    uint16_t* dst = reinterpret_cast<uint16_t*>(dstf.data() + off);
+    const int NCT = H / 32;
+    for (int c = 0; c < H / 32; ++c)
+        for (int st = 0; st < 2; ++st)
+            for (int ct = 0; ct < NCT; ++ct)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int i = 0; i < 8; ++i) {
+                        const int k = 32 * c + 16 * (lane >> 5) + 8 * st + i;
+                        const int col = 32 * ct + (lane & 31);
+                        uint16_t hi, lo;
+                        bf16_split(W2[(size_t)col * H + k], hi, lo);
+                        const size_t blk = (size_t)c * 32 * H * 2;
+                        dst[blk + (((size_t)(0 * 2 + st) * NCT + ct) * 64 + lane) * 8 + i] = hi;
+                        dst[blk + (((size_t)(1 * 2 + st) * NCT + ct) * 64 + lane) * 8 + i] = lo;
+                    }
+}
+
 extern "C" int hd_set_weights(hd_handle* h, const float* blob, long long n, int on_device, void* stream) {
     if (!h || !blob) return fail(HD_E_INVALID, "hd_set_weights: null argument");
     if (n != h->n_weights)
@@ -241,6 +311,7 @@ extern "C" int hd_set_weights(hd_handle* h, const float* blob, long long n, int 
     const hd_config& c = h->cfg;
     const int H = h->H, fin = h->fin, WN = h->WN;
     const int L = c.n_layers, S = c.inv_sublayers;
+    const bool bf = c.precision != 0;
     // layout of the packed buffer
     size_t off = 0;
     auto take = [&](size_t cnt) { size_t o = off; off += (cnt + 3) & ~size_t(3); return o; };
@@ -277,9 +348,11 @@ extern "C" int hd_set_weights(hd_handle* h, const float* blob, long long n, int 
     auto pack_first = [&](LayerW& w, const float* W1, const float* b1) {
         // W1 [H][2H+2]: columns [h_row(H) | h_col(H) | radial_cur | radial_init] (egnn_new.py:39,93,144)
         const int ld = 2 * H + 2;
-        pack_gemm_b(pk, w.ab_img, H, 2 * H, WN, [&](int col, int k) {
+        auto wab = [&](int col, int k) {
             return (col < H) ? W1[(size_t)col * ld + k] : W1[(size_t)(col - H) * ld + H + k];
-        });
+        };
+        if (bf) pack_gemm_b_bf(pk, w.ab_img, H, 2 * H, WN, wab);
+        else pack_gemm_b(pk, w.ab_img, H, 2 * H, WN, wab);
         for (int k = 0; k < H; ++k) {
             pk[w.ab_bias + k] = b1[k];
             pk[w.ab_bias + H + k] = 0.0f;
@@ -295,11 +368,19 @@ extern "C" int hd_set_weights(hd_handle* h, const float* blob, long long n, int 
             const float* W3 = next((size_t)H * 2 * H);       const float* b3 = next(H);
             const float* W4 = next((size_t)H * H);           const float* b4 = next(H);
             pack_first(w, W1, b1);
-            pack_edge_w2(pk, w.w2_img, H, W2);
+            auto w3 = [&](int col, int k) { return W3[(size_t)col * 2 * H + k]; };
+            auto w4 = [&](int col, int k) { return W4[(size_t)col * H + k]; };
+            if (bf) {
+                pack_edge_w2_bf(pk, w.w2_img, H, W2);
+                pack_gemm_b_bf(pk, w.w3_img, 2 * H, H, WN, w3);
+                pack_gemm_b_bf(pk, w.w4_img, H, H, WN, w4);
+            } else {
+                pack_edge_w2(pk, w.w2_img, H, W2);
+                pack_gemm_b(pk, w.w3_img, 2 * H, H, WN, w3);
+                pack_gemm_b(pk, w.w4_img, H, H, WN, w4);
+            }
             std::copy(b2, b2 + H, pk.begin() + w.b2);
-            pack_gemm_b(pk, w.w3_img, 2 * H, H, WN, [&](int col, int k) { return W3[(size_t)col * 2 * H + k]; });
             std::copy(b3, b3 + H, pk.begin() + w.b3);
-            pack_gemm_b(pk, w.w4_img, H, H, WN, [&](int col, int k) { return W4[(size_t)col * H + k]; });
             std::copy(b4, b4 + H, pk.begin() + w.b4);
             if (c.attention) {
                 const float* wa = next(H); const float* ba = next(1);
@@ -314,7 +395,8 @@ extern "C" int hd_set_weights(hd_handle* h, const float* blob, long long n, int 
         const float* W6 = next((size_t)H * H);           const float* b6 = next(H);
         const float* w7 = next(H);
         pack_first(w, W5, b5);
-        pack_edge_w2(pk, w.w2_img, H, W6);
+        if (bf) pack_edge_w2_bf(pk, w.w2_img, H, W6);
+        else pack_edge_w2(pk, w.w2_img, H, W6);
         std::copy(b6, b6 + H, pk.begin() + w.b2);
         std::copy(w7, w7 + H, pk.begin() + w.wa);
         w.ba = 0.0f;
@@ -491,28 +573,67 @@ extern "C" int hd_profile_read(hd_handle* h, double* ms3, long long* launches3) 
 // ----------------------------------------------------------------------------- forward
 
 template <int WM, int WN>
-static void launch_gemm(int epi, bool cat, const GemmArgs& g, hipStream_t s) {
+static void launch_gemm(int prec, int epi, bool cat, const GemmArgs& g, hipStream_t s) {
     dim3 grid((g.M + 32 * WM - 1) / (32 * WM), g.Nc / (32 * WN));
     dim3 block(WM * WN * 64);
-    if (cat) hipLaunchKernelGGL((k_gemm<WM, WN, EPI_BIAS_SILU, true>), grid, block, 0, s, g);
-    else if (epi == EPI_BIAS) hipLaunchKernelGGL((k_gemm<WM, WN, EPI_BIAS, false>), grid, block, 0, s, g);
-    else hipLaunchKernelGGL((k_gemm<WM, WN, EPI_RESID_MASK, false>), grid, block, 0, s, g);
+    if (prec == 0) {
+        if (cat) hipLaunchKernelGGL((k_gemm<WM, WN, EPI_BIAS_SILU, true>), grid, block, 0, s, g);
+        else if (epi == EPI_BIAS) hipLaunchKernelGGL((k_gemm<WM, WN, EPI_BIAS, false>), grid, block, 0, s, g);
+        else hipLaunchKernelGGL((k_gemm<WM, WN, EPI_RESID_MASK, false>), grid, block, 0, s, g);
+    } else {
+        if (cat) hipLaunchKernelGGL((k_gemm_bf<WM, WN, EPI_BIAS_SILU, true>), grid, block, 0, s, g);
+        else if (epi == EPI_BIAS) hipLaunchKernelGGL((k_gemm_bf<WM, WN, EPI_BIAS, false>), grid, block, 0, s, g);
+        else hipLaunchKernelGGL((k_gemm_bf<WM, WN, EPI_RESID_MASK, false>), grid, block, 0, s, g);
+    }
 }
 
 static void gemm(hd_handle* h, int epi, bool cat, const GemmArgs& g, hipStream_t s) {
     ProfScope ps(h, s, 1);
-    if (h->WM == 4) launch_gemm<4, 1>(epi, cat, g, s);
-    else launch_gemm<2, 2>(epi, cat, g, s);
+    if (h->WM == 4) launch_gemm<4, 1>(h->cfg.precision, epi, cat, g, s);
+    else launch_gemm<2, 2>(h->cfg.precision, epi, cat, g, s);
 }
 
 template <int H>
 static int edge_lds_bytes() { return (2 * 32 * H + 2 * H + 4 * 136) * 4; }
 
 template <int H>
-static int launch_edge_h(bool coord, const EdgeArgs& a, hipStream_t s) {
+static int launch_edge_h(int prec, bool coord, const EdgeArgs& a, hipStream_t s) {
     const int lds = edge_lds_bytes<H>();
-    if (coord) hipLaunchKernelGGL((k_edge<H, true>), dim3(a.n_wg), dim3(256), lds, s, a);
-    else hipLaunchKernelGGL((k_edge<H, false>), dim3(a.n_wg), dim3(256), lds, s, a);
+    const dim3 grid(std::min(a.n_wg, g_edge_grid)), block(256);
+    if constexpr (H == 256) {
+        static int abl = -1;
+        if (abl < 0) { const char* e = getenv("HD_ABLATE"); abl = e ? atoi(e) : 0; }
+        if (abl && prec == 1 && !coord) {
+            static bool attr = false;
+            if (!attr) {
+                hipFuncSetAttribute((const void*)k_edge<256, false, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                hipFuncSetAttribute((const void*)k_edge<256, false, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                hipFuncSetAttribute((const void*)k_edge<256, false, 1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                hipFuncSetAttribute((const void*)k_edge<256, false, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                hipFuncSetAttribute((const void*)k_edge<256, false, 1, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                hipFuncSetAttribute((const void*)k_edge<256, false, 1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                hipFuncSetAttribute((const void*)k_edge<256, false, 1, 15>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                attr = true;
+            }
+            switch (abl) {
+                case 1: hipLaunchKernelGGL((k_edge<256, false, 1, 1>), grid, block, lds, s, a); return HD_OK;
+                case 2: hipLaunchKernelGGL((k_edge<256, false, 1, 2>), grid, block, lds, s, a); return HD_OK;
+                case 3: hipLaunchKernelGGL((k_edge<256, false, 1, 3>), grid, block, lds, s, a); return HD_OK;
+                case 4: hipLaunchKernelGGL((k_edge<256, false, 1, 4>), grid, block, lds, s, a); return HD_OK;
+                case 7: hipLaunchKernelGGL((k_edge<256, false, 1, 7>), grid, block, lds, s, a); return HD_OK;
+                case 8: hipLaunchKernelGGL((k_edge<256, false, 1, 8>), grid, block, lds, s, a); return HD_OK;
+                case 15: hipLaunchKernelGGL((k_edge<256, false, 1, 15>), grid, block, lds, s, a); return HD_OK;
+                default: break;
+            }
+        }
+    }
+    if (prec == 0) {
+        if (coord) hipLaunchKernelGGL((k_edge<H, true, 0>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((k_edge<H, false, 0>), grid, block, lds, s, a);
+    } else {
+        if (coord) hipLaunchKernelGGL((k_edge<H, true, 1>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((k_edge<H, false, 1>), grid, block, lds, s, a);
+    }
     return HD_OK;
 }
 
@@ -521,8 +642,10 @@ static int launch_edge_h(bool coord, const EdgeArgs& a, hipStream_t s) {
 template <int H>
 static int prepare_edge_h() {
     const int lds = edge_lds_bytes<H>();
-    HIP_TRY(hipFuncSetAttribute((const void*)k_edge<H, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    HIP_TRY(hipFuncSetAttribute((const void*)k_edge<H, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_edge<H, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_edge<H, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_edge<H, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_edge<H, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     return HD_OK;
 }
 
@@ -539,10 +662,10 @@ static int edge(hd_handle* h, bool coord, const EdgeArgs& a, hipStream_t s) {
     if (a.n_wg == 0) return HD_OK;
     ProfScope ps(h, s, 0);
     switch (h->H) {
-        case 32: return launch_edge_h<32>(coord, a, s);
-        case 64: return launch_edge_h<64>(coord, a, s);
-        case 128: return launch_edge_h<128>(coord, a, s);
-        default: return launch_edge_h<256>(coord, a, s);
+        case 32: return launch_edge_h<32>(h->cfg.precision, coord, a, s);
+        case 64: return launch_edge_h<64>(h->cfg.precision, coord, a, s);
+        case 128: return launch_edge_h<128>(h->cfg.precision, coord, a, s);
+        default: return launch_edge_h<256>(h->cfg.precision, coord, a, s);
     }
 }
 

@@ -11,6 +11,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -33,7 +34,28 @@ HD_DEVINL float silu_f(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
-HD_DEVINL float sigmoid_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
+// 1 / (1 + exp(-x)) with the same compensated exponent (~2 ulp); saturates to 0 / 1.
+HD_DEVINL float sigmoid_f(float x) {
+    const float L2E_HI = 1.44269502162933349609375f, L2E_LO = 1.925962991e-8f, LN2 = 0.693147180559945309f;
+    float nx = -x;
+    float t = nx * L2E_HI;
+    float tlo = __builtin_fmaf(nx, L2E_HI, -t) + nx * L2E_LO;
+    float e = __builtin_amdgcn_exp2f(t) * __builtin_fmaf(tlo, LN2, 1.0f);
+    return __builtin_amdgcn_rcpf(1.0f + e);
+}
+
+// SiLU of the edge kernels.  PREC 0 (exact-fp32 matrix path): the compensated form above.  PREC 1 (bf16x3
+// path, whose contraction error is ~1e-6 anyway): plain exp2(-x*log2e), 5 instructions; the exponent
+// argument is then off by <= |x|*1.7e-7, i.e. a relative error of that size on an already saturated value.
+template <int PREC>
+HD_DEVINL float silu_p(float x) {
+    if constexpr (PREC == 0) {
+        return silu_f(x);
+    } else {
+        float e = __builtin_amdgcn_exp2f(x * -1.44269502162933349609375f);
+        return x * __builtin_amdgcn_rcpf(1.0f + e);
+    }
+}
 
 // ----------------------------------------------------------------------------- Philox4x32-10
 
@@ -210,6 +232,110 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm(GemmArgs g) {
     }
 }
 
+// bf16x3 variant of the node GEMM (see k_edge PREC 1): activations are split into bf16 head/tail in
+// the tile loader, weights are pre-split; three v_mfma_f32_32x32x16_bf16 per 16-wide k-step.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <int WM, int WN, int EPI, bool CAT>
+__global__ __launch_bounds__(WM * WN * 64) void k_gemm_bf(GemmArgs g) {
+    constexpr int BM = 32 * WM, BN = 32 * WN, NT = 64 * WM * WN;
+    constexpr int A_F4 = BM * 8 / NT;
+    constexpr int B_U4 = BN * 32 * 4 / 16 / NT;          // 16-byte pieces of the hi+lo image per thread
+    constexpr int LDA_S = 40;                             // bf16 per A row (32 + 8 pad: 80 B, conflict-free b128)
+    __shared__ __attribute__((aligned(16))) __bf16 Ah[2][BM * LDA_S];
+    __shared__ __attribute__((aligned(16))) __bf16 Al[2][BM * LDA_S];
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[2][BN * 32 * 2];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave / WN, wc = wave % WN;
+    const int hh = lane >> 5, m = lane & 31;
+    const int row0 = blockIdx.x * BM;
+    const int nchunk = g.K >> 5;
+    const u32x4* Bsrc = reinterpret_cast<const u32x4*>(g.Bimg) + (size_t)blockIdx.y * nchunk * (BN * 32 * 4 / 16);
+
+    f32x4 ra[A_F4];
+    u32x4 rb[B_U4];
+
+    auto load_tiles = [&](int c) {
+        const int k0 = c << 5;
+#pragma unroll
+        for (int u = 0; u < A_F4; ++u) {
+            int idx = tid + u * NT;
+            int r = idx >> 3, sg = idx & 7;
+            int row = row0 + r;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (!CAT || k0 < g.K1) {
+                v = *reinterpret_cast<const f32x4*>(g.A + (size_t)row * g.lda + k0 + 4 * sg);
+            } else if (row < g.M) {
+                int p0 = g.pstart[row], p1 = g.pstart[row + 1];
+                const int kw = g.K - g.K1;
+                for (int p = p0; p < p1; ++p)
+                    v += *reinterpret_cast<const f32x4*>(g.part + (size_t)p * kw + (k0 - g.K1) + 4 * sg);
+                v = v / g.norm;
+            }
+            ra[u] = v;
+        }
+#pragma unroll
+        for (int u = 0; u < B_U4; ++u) rb[u] = Bsrc[(size_t)c * (BN * 32 * 4 / 16) + tid + u * NT];
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < A_F4; ++u) {
+            int idx = tid + u * NT;
+            int r = idx >> 3, sg = idx & 7;
+            const f32x4 v = ra[u];
+            const __bf16 h0 = (__bf16)v[0], h1 = (__bf16)v[1], h2 = (__bf16)v[2], h3 = (__bf16)v[3];
+            const bf16x4_t vh = {h0, h1, h2, h3};
+            const bf16x4_t vl = {(__bf16)(v[0] - (float)h0), (__bf16)(v[1] - (float)h1),
+                                 (__bf16)(v[2] - (float)h2), (__bf16)(v[3] - (float)h3)};
+            *reinterpret_cast<bf16x4_t*>(&Ah[buf][r * LDA_S + 4 * sg]) = vh;
+            *reinterpret_cast<bf16x4_t*>(&Al[buf][r * LDA_S + 4 * sg]) = vl;
+        }
+#pragma unroll
+        for (int u = 0; u < B_U4; ++u) reinterpret_cast<u32x4*>(Bs[buf])[tid + u * NT] = rb[u];
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    for (int c = 0; c < nchunk; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunk) load_tiles(c + 1);
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const bf16x8_t ah = *reinterpret_cast<const bf16x8_t*>(&Ah[buf][(32 * wr + m) * LDA_S + 16 * st + 8 * hh]);
+            const bf16x8_t al = *reinterpret_cast<const bf16x8_t*>(&Al[buf][(32 * wr + m) * LDA_S + 16 * st + 8 * hh]);
+            const bf16x8_t bh = *reinterpret_cast<const bf16x8_t*>(&Bs[buf][(((0 * 2 + st) * WN + wc) * 64 + lane) * 8]);
+            const bf16x8_t bl = *reinterpret_cast<const bf16x8_t*>(&Bs[buf][(((1 * 2 + st) * WN + wc) * 64 + lane) * 8]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+        }
+        if (c + 1 < nchunk) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+    const int col = blockIdx.y * BN + 32 * wc + m;
+    const float bv = g.bias[col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        int row = row0 + 32 * wr + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        if (row < g.M) {
+            float v = acc[r] + bv;
+            float* dst = g.C + (size_t)row * g.ldc + col;
+            if (EPI == EPI_BIAS_SILU) v = silu_f(v);
+            if (EPI == EPI_RESID_MASK) v = (*dst + v) * g.nmask[row];
+            *dst = v;
+        }
+    }
+}
+
 // ----------------------------------------------------------------------------- edge kernel
 // One wavefront = one tile of 32 edge rows x H output columns (NCT accumulators of 32x32).
 //   P[e][k]   = silu(A_i[k] + B_j[k] + r_e*w_r[k] + d0_e*w_d[k])      (A operand, built in registers)
@@ -237,7 +363,7 @@ struct EdgeArgs {
     float norm_constant;
     float coords_range;     // per-block range
     int attention, use_tanh;
-    int n_tiles, n_wg;
+    int n_tiles, n_wg;      // n_wg = number of 128-edge workgroup-tiles
 };
 
 HD_DEVINL void glds16(const void* gsrc, void* lds_dst) {
@@ -245,8 +371,63 @@ HD_DEVINL void glds16(const void* gsrc, void* lds_dst) {
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-template <int H, bool COORD>
-__global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
+// PREC 0: exact fp32 (v_mfma_f32_32x32x2_f32).  PREC 1: "bf16x3" - both operands are split into a bf16
+// head and a bf16 tail (a = ah + al, |a - ah - al| <= 2^-18 |a|) and the product is formed as
+// ah*bh + al*bh + ah*bl with fp32 accumulation on v_mfma_f32_32x32x16_bf16: 3 matrix instructions at
+// 16x the fp32 rate, per-product error ~1e-5 (the dropped al*bl term), i.e. ~1e-6 on a 256-term dot.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#ifndef HD_EDGE_GRP
+#define HD_EDGE_GRP 2
+#endif
+#ifndef HD_SCHED_VALU
+#define HD_SCHED_VALU 4
+#endif
+#ifndef HD_EDGE_WPS
+#define HD_EDGE_WPS 2
+#endif
+
+// Four LDS fragment reads / a counted wait that releases them (see k_edge).  The reads are inline asm so
+// they stay where they are written (hipcc otherwise sinks every LDS read next to its MFMA to save registers,
+// exposing the LDS latency once per fragment); the wait lists the registers as read-write, so their
+// consumers cannot be scheduled above it and the compiler cannot touch them between read and wait.
+template <typename V, unsigned O0, unsigned O1, unsigned O2, unsigned O3>
+HD_DEVINL void lds_read4(V (&f)[4], unsigned addr) {
+    asm volatile("ds_read_b128 %0, %4 offset:%5\n\t"
+                 "ds_read_b128 %1, %4 offset:%6\n\t"
+                 "ds_read_b128 %2, %4 offset:%7\n\t"
+                 "ds_read_b128 %3, %4 offset:%8"
+                 : "=&v"(f[0]), "=&v"(f[1]), "=&v"(f[2]), "=&v"(f[3])
+                 : "v"(addr), "i"(O0), "i"(O1), "i"(O2), "i"(O3));
+}
+template <int N, typename V>
+HD_DEVINL void lds_wait4(V (&f)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]) : "i"(N));
+}
+// compile-time loop: f(std::integral_constant<int, I>) for I = 0..N-1
+template <int I, int N, typename F>
+HD_DEVINL void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// byte offset (from the lane's base) of a B fragment inside a chunk image
+//   bf16x3: unit u = (k-step, column tile), hl = head (0) / tail (1);   fp32: fragment u = (q, column tile)
+template <int NCT>
+constexpr unsigned frag_off_bf(int u, int hl) { return (unsigned)((((hl * 2 + u / NCT) * NCT + u % NCT) * 64) * 16); }
+constexpr unsigned frag_off_f32(int u) { return (unsigned)(u * 64 * 16); }
+
+// ABL: ablation switches for bottleneck hunting (never set in production launches):
+//   1 = skip the epilogue, 2 = skip operand generation (SiLU etc.), 4 = no per-chunk barrier / W2 streaming,
+//   8 = no AB row gathers
+//
+// Persistent workgroups: gridDim.x <= 2 per CU; each workgroup walks the 128-edge workgroup-tiles of its
+// XCD's contiguous share of the edge list (neighbouring tiles = same molecule = same AB rows in that XCD's
+// L2), keeps the W2 chunk stream running across tiles and fetches the next tile's row metadata while the
+// current tile's epilogue runs.
+template <int H, bool COORD, int PREC, int ABL = 0>
+__global__ __launch_bounds__(256, HD_EDGE_WPS) void k_edge(EdgeArgs a) {
     constexpr int NCT = H / 32;          // 32-column tiles
     constexpr int NCH = H / 32;          // 32-wide K chunks
     constexpr int CHF = 32 * H;          // floats per W2 chunk image
@@ -259,36 +440,23 @@ __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hh = lane >> 5, n = lane & 31;
-
-    // XCD-aware remap: consecutive logical workgroups (neighbouring molecules, shared AB rows) land
-    // on the same XCD's L2.  Speed only; any placement is correct.
-    int wg;
-    {
-        const int bid = blockIdx.x, nwg = a.n_wg;
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int tile = wg * 4 + wave;
-    const bool tile_ok = tile < a.n_tiles;
     float* my_scr = scratch + wave * 136;
     uint32_t* seg_s = reinterpret_cast<uint32_t*>(my_scr + 128);
 
-    // ---- per-row metadata (lane n and n+32 both describe row n)
-    const int e = tile * 32 + n;
-    int ni = 0, nj = 0;
-    uint32_t segb = 255;
-    if (tile_ok) { ni = a.ei[e]; nj = a.ej[e]; segb = a.eseg[e]; }
-    f32x4 xi = *reinterpret_cast<const f32x4*>(a.xcur + (size_t)ni * 4);
-    f32x4 xj = *reinterpret_cast<const f32x4*>(a.xcur + (size_t)nj * 4);
-    f32x4 yi = *reinterpret_cast<const f32x4*>(a.x0 + (size_t)ni * 4);
-    f32x4 yj = *reinterpret_cast<const f32x4*>(a.x0 + (size_t)nj * 4);
-    const float dx = xi[0] - xj[0], dy = xi[1] - xj[1], dz = xi[2] - xj[2];
-    const float radial = dx * dx + dy * dy + dz * dz;
-    const float ex = yi[0] - yj[0], ey = yi[1] - yj[1], ez = yi[2] - yj[2];
-    const float d0 = ex * ex + ey * ey + ez * ez;
-    if (hh == 0) reinterpret_cast<uint8_t*>(seg_s)[n] = (uint8_t)segb;
+    // this workgroup's share of the workgroup-tiles
+    int wt_first, wt_count, wt_step;
+    {
+        const int bid = blockIdx.x, G = gridDim.x, nwt = a.n_wg;
+        const int xcd = bid & 7, slot = bid >> 3;
+        const int q = nwt >> 3, r = nwt & 7;
+        const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        const int len = q + (xcd < r ? 1 : 0);
+        wt_step = (G - xcd + 7) >> 3;                     // workgroups of this launch on the same XCD
+        wt_first = start + slot;
+        wt_count = slot < len ? (len - slot + wt_step - 1) / wt_step : 0;
+    }
+    if (wt_count == 0) return;
 
-    // ---- stage w_r / w_d once, start streaming W2
     for (int k = tid; k < 2 * H; k += 256) wrd_s[k] = a.wrd[k];
     auto issue_chunk = [&](int c, int buf) {
         const float* src = a.W2img + (size_t)c * CHF;
@@ -301,148 +469,273 @@ __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
     };
     issue_chunk(0, 0);
 
-    const float* Arow = a.AB + (size_t)ni * (2 * H) + 16 * hh;
-    const float* Brow = a.AB + (size_t)nj * (2 * H) + H + 16 * hh;
-    f32x4 pa[4], pb[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        pa[u] = *reinterpret_cast<const f32x4*>(Arow + 4 * u);
-        pb[u] = *reinterpret_cast<const f32x4*>(Brow + 4 * u);
-    }
-
-    f32x16 acc[NCT];
-#pragma unroll
-    for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
-
-#pragma unroll 1
-    for (int c = 0; c < NCH; ++c) {
-        const int buf = c & 1;
-        __syncthreads();     // chunk c landed (vmcnt(0)) and every wave is done with the other buffer
-        if (c + 1 < NCH) issue_chunk(c + 1, buf ^ 1);
-        // A operand for this chunk
-        float P[16];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            f32x4 wr4 = *reinterpret_cast<const f32x4*>(wrd_s + 32 * c + 16 * hh + 4 * u);
-            f32x4 wd4 = *reinterpret_cast<const f32x4*>(wrd_s + H + 32 * c + 16 * hh + 4 * u);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float pre = pa[u][j] + pb[u][j];
-                pre = __builtin_fmaf(radial, wr4[j], pre);
-                pre = __builtin_fmaf(d0, wd4[j], pre);
-                P[4 * u + j] = silu_f(pre);
-            }
+    // per-row metadata of a tile (lanes n and n+32 both describe row n)
+    int ni = 0, nj = 0;
+    uint32_t segb = 255;
+    auto load_meta = [&](int tile) {
+        ni = 0; nj = 0; segb = 255;
+        if (tile < a.n_tiles) {
+            const int e = tile * 32 + n;
+            ni = a.ei[e]; nj = a.ej[e]; segb = a.eseg[e];
         }
-        if (c + 1 < NCH) {
+    };
+    load_meta(wt_first * 4 + wave);
+
+    int gc = 0;                                            // global chunk counter: buffer = gc & 1
+#pragma unroll 1
+    for (int it = 0; it < wt_count; ++it) {
+        const int tile = (wt_first + it * wt_step) * 4 + wave;
+        const bool tile_ok = tile < a.n_tiles;
+        const bool last_it = it + 1 == wt_count;
+
+        f32x4 xi = *reinterpret_cast<const f32x4*>(a.xcur + (size_t)ni * 4);
+        f32x4 xj = *reinterpret_cast<const f32x4*>(a.xcur + (size_t)nj * 4);
+        f32x4 yi = *reinterpret_cast<const f32x4*>(a.x0 + (size_t)ni * 4);
+        f32x4 yj = *reinterpret_cast<const f32x4*>(a.x0 + (size_t)nj * 4);
+        const float dx = xi[0] - xj[0], dy = xi[1] - xj[1], dz = xi[2] - xj[2];
+        const float radial = dx * dx + dy * dy + dz * dz;
+        const float ex = yi[0] - yj[0], ey = yi[1] - yj[1], ez = yi[2] - yj[2];
+        const float d0 = ex * ex + ey * ey + ez * ez;
+        const uint32_t segb_t = segb;
+        if (hh == 0) reinterpret_cast<uint8_t*>(seg_s)[n] = (uint8_t)segb_t;
+
+        const float* Arow = a.AB + (size_t)ni * (2 * H) + 16 * hh;
+        const float* Brow = a.AB + (size_t)nj * (2 * H) + H + 16 * hh;
+        f32x4 pa[4], pb[4];
+        auto load_rows = [&](int c) {
+            if constexpr (ABL & 8) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { pa[u] = f32x4{radial, d0, radial, d0}; pb[u] = pa[u]; }
+                return;
+            }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                pa[u] = *reinterpret_cast<const f32x4*>(Arow + 32 * (c + 1) + 4 * u);
-                pb[u] = *reinterpret_cast<const f32x4*>(Brow + 32 * (c + 1) + 4 * u);
+                pa[u] = *reinterpret_cast<const f32x4*>(Arow + 32 * c + 4 * u);
+                pb[u] = *reinterpret_cast<const f32x4*>(Brow + 32 * c + 4 * u);
+            }
+        };
+        // first-layer activations of this lane's edge row for K chunk c (k = 32c + 16*hh + 0..15)
+        auto make_P = [&](int c, float (&P)[16]) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                f32x4 wr4 = *reinterpret_cast<const f32x4*>(wrd_s + 32 * c + 16 * hh + 4 * u);
+                f32x4 wd4 = *reinterpret_cast<const f32x4*>(wrd_s + H + 32 * c + 16 * hh + 4 * u);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float pre = pa[u][j] + pb[u][j];
+                    pre = __builtin_fmaf(radial, wr4[j], pre);
+                    pre = __builtin_fmaf(d0, wd4[j], pre);
+                    if constexpr (ABL & 2) P[4 * u + j] = pa[u][j];
+                    else P[4 * u + j] = silu_p<PREC>(pre);
+                }
+            }
+        };
+        auto split_P = [&](const float (&P)[16], bf16x8 (&ph)[2], bf16x8 (&pl)[2]) {
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float x = P[8 * st + i];
+                    const __bf16 xh = (__bf16)x;
+                    ph[st][i] = xh;
+                    pl[st][i] = (__bf16)(x - (float)xh);
+                }
+        };
+
+        f32x16 acc[NCT];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+
+        // Software pipeline: the operands of chunk c+1 are produced (VALU) while the matrix pipe works on
+        // chunk c; the AB rows are fetched two chunks ahead.
+        load_rows(0);
+        __syncthreads();                   // chunk 0 of this tile landed (w_r / w_d staged on the first pass)
+        float Pc[16];
+        bf16x8 phc[2], plc[2];
+        make_P(0, Pc);
+        if constexpr (PREC == 1) split_P(Pc, phc, plc);
+        if (NCH > 1) load_rows(1);
+
+#pragma unroll 1
+        for (int c = 0; c < NCH; ++c, ++gc) {
+            const int buf = (ABL & 4) ? 0 : (gc & 1);
+            if constexpr (!(ABL & 4)) {
+                if (c > 0) __syncthreads();    // chunk c landed (vmcnt(0)); every wave is done with the other buffer
+                if (c + 1 < NCH) issue_chunk(c + 1, buf ^ 1);
+                else if (!last_it) issue_chunk(0, buf ^ 1);        // keep the stream running into the next tile
+            }
+            // Branch-free from here to the end of the body (one scheduling region): the last iteration
+            // recomputes the final chunk's operands and refetches its rows, results unused.
+            float Pn[16];
+            bf16x8 phn[2], pln[2];
+            make_P(c + 1 < NCH ? c + 1 : NCH - 1, Pn);
+            if constexpr (PREC == 1) split_P(Pn, phn, pln);
+            load_rows(c + 2 < NCH ? c + 2 : NCH - 1);
+            const float* wb = wbuf + buf * CHF;
+            const unsigned wb_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)wb + lane * 16;
+            if constexpr (PREC == 0) {
+                // chunk image: [4 q][NCT][64 lanes][4 floats]: fragment (q, ct) holds k = 32c + 16h + 4q + j, j = 0..3,
+                // of column 32ct + n.  Four fragments (16 MFMAs) per group, next group's reads in flight.
+                constexpr int NG = NCT;                     // 4*NCT fragments / 4
+                f32x4 f0[4], f1[4];
+                lds_read4<f32x4, frag_off_f32(0), frag_off_f32(1), frag_off_f32(2), frag_off_f32(3)>(f0, wb_lds);
+                static_for<0, NG>([&](auto Gc) {
+                    constexpr int g = decltype(Gc)::value;
+                    f32x4(&cur)[4] = (g & 1) ? f1 : f0;
+                    f32x4(&nxt)[4] = (g & 1) ? f0 : f1;
+                    if constexpr (g + 1 < NG) {
+                        constexpr int u = 4 * (g + 1);
+                        lds_read4<f32x4, frag_off_f32(u), frag_off_f32(u + 1), frag_off_f32(u + 2), frag_off_f32(u + 3)>(nxt, wb_lds);
+                        lds_wait4<4>(cur);
+                    } else {
+                        lds_wait4<0>(cur);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int u = 4 * g + k, q = u / NCT, ct = u % NCT;
+                            acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(Pc[4 * q + j], cur[k][j], acc[ct], 0, 0, 0);
+                        }
+                });
+#pragma unroll
+                for (int i = 0; i < 16; ++i) Pc[i] = Pn[i];
+            } else {
+                // chunk image: [hi|lo][2 k-steps][NCT][64 lanes][8 bf16]; lane (h, n), element i of step s is
+                // W2[32ct + n][32c + 16h + 8s + i] - the same k order as P[8s + i].  Units u = (k-step, ct) of
+                // three MFMAs (head*head, tail*head, head*tail) on one accumulator, two units per group.
+                constexpr int NG = NCT;                     // 2*NCT units / 2
+                bf16x8 f0[4], f1[4];
+                lds_read4<bf16x8, frag_off_bf<NCT>(0, 0), frag_off_bf<NCT>(0, 1), frag_off_bf<NCT>(1, 0), frag_off_bf<NCT>(1, 1)>(f0, wb_lds);
+                static_for<0, NG>([&](auto Gc) {
+                    constexpr int g = decltype(Gc)::value;
+                    bf16x8(&cur)[4] = (g & 1) ? f1 : f0;
+                    bf16x8(&nxt)[4] = (g & 1) ? f0 : f1;
+                    if constexpr (g + 1 < NG) {
+                        constexpr int u = 2 * (g + 1);
+                        lds_read4<bf16x8, frag_off_bf<NCT>(u, 0), frag_off_bf<NCT>(u, 1), frag_off_bf<NCT>(u + 1, 0),
+                                  frag_off_bf<NCT>(u + 1, 1)>(nxt, wb_lds);
+                        lds_wait4<4>(cur);
+                    } else {
+                        lds_wait4<0>(cur);
+                    }
+                    constexpr int u0 = 2 * g, u1 = 2 * g + 1;
+                    constexpr int s0 = u0 / NCT, c0 = u0 % NCT, s1 = u1 / NCT, c1 = u1 % NCT;
+                    acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(phc[s0], cur[0], acc[c0], 0, 0, 0);
+                    acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(phc[s1], cur[2], acc[c1], 0, 0, 0);
+                    acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(plc[s0], cur[0], acc[c0], 0, 0, 0);
+                    acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(plc[s1], cur[2], acc[c1], 0, 0, 0);
+                    acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(phc[s0], cur[1], acc[c0], 0, 0, 0);
+                    acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(phc[s1], cur[3], acc[c1], 0, 0, 0);
+                });
+#pragma unroll
+                for (int st = 0; st < 2; ++st) { phc[st] = phn[st]; plc[st] = pln[st]; }
             }
         }
-        const float* wb = wbuf + buf * CHF;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            f32x4 bv[NCT];
+
+        // next tile's row metadata: in flight while this tile's epilogue runs
+        if (!last_it) load_meta((wt_first + (it + 1) * wt_step) * 4 + wave);
+
+        if (!tile_ok) continue;
+        if constexpr (ABL & 1) {
+            float sacc = 0.f;
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct)
-                bv[ct] = *reinterpret_cast<const f32x4*>(wb + ((q * NCT + ct) * 64 + lane) * 4);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int ct = 0; ct < NCT; ++ct)
-                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(P[4 * q + j], bv[ct][j], acc[ct], 0, 0, 0);
+                for (int r = 0; r < 16; ++r) sacc += acc[ct][r];
+            if (sacc == 123.456f) a.part[lane] = sacc;
+            continue;
         }
-    }
 
-    if (!tile_ok) return;
-
-    // ---- epilogue.  acc[ct][r] = row rho(r) = (r&3) + 8*(r>>2) + 4*hh, column 32*ct + n.
-    float dot[16];
+        // ---- epilogue.  acc[ct][r] = row rho(r) = (r&3) + 8*(r>>2) + 4*hh, column 32*ct + n.
+        float dot[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) dot[r] = 0.f;
+        for (int r = 0; r < 16; ++r) dot[r] = 0.f;
 #pragma unroll
-    for (int ct = 0; ct < NCT; ++ct) {
-        const float b2v = a.b2[32 * ct + n];
-        const float wav = a.wa[32 * ct + n];
+        for (int ct = 0; ct < NCT; ++ct) {
+            const float b2v = a.b2[32 * ct + n];
+            const float wav = a.wa[32 * ct + n];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float mv = silu_f(acc[ct][r] + b2v);
-            acc[ct][r] = mv;
-            dot[r] = __builtin_fmaf(mv, wav, dot[r]);
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        float d = dot[r];
-        d += __shfl_xor(d, 1);
-        d += __shfl_xor(d, 2);
-        d += __shfl_xor(d, 4);
-        d += __shfl_xor(d, 8);
-        d += __shfl_xor(d, 16);
-        dot[r] = d;
-    }
-    const int pbase = a.tile_pbase[tile];
-    const int nseg = a.tile_nseg[tile];
-
-    if (!COORD) {
-        // segment byte of each of this lane's 16 rows: rows 8q+4hh .. +3 share one dword
-        uint32_t sw[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) sw[q] = seg_s[2 * q + hh];
-        float w[16];
-        int sg[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            sg[r] = (sw[r >> 2] >> (8 * (r & 3))) & 255;
-            float att = a.attention ? sigmoid_acc(dot[r] + a.ba) : 1.0f;
-            w[r] = (sg[r] != 255) ? att : 0.0f;
-        }
-        for (int s = 0; s < nseg; ++s) {
-            float ws[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) ws[r] = (sg[r] == s) ? w[r] : 0.0f;
-            float* dst = a.part + (size_t)(pbase + s) * H + n;
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) {
-                float sum = 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) sum = __builtin_fmaf(ws[r], acc[ct][r], sum);
-                sum += __shfl_xor(sum, 32);
-                if (hh == 0) dst[32 * ct] = sum;
+            for (int r = 0; r < 16; ++r) {
+                float mv = silu_p<PREC>(acc[ct][r] + b2v);
+                acc[ct][r] = mv;
+                dot[r] = __builtin_fmaf(mv, wav, dot[r]);
             }
         }
-    } else {
-        // phi of row rho(r) is in every lane of half hh; publish per row, then lane n handles row n
-        if (n == 0) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) my_scr[(r & 3) + 8 * (r >> 2) + 4 * hh] = dot[r];
+        for (int r = 0; r < 16; ++r) {
+            float d = dot[r];
+            d += __shfl_xor(d, 1);
+            d += __shfl_xor(d, 2);
+            d += __shfl_xor(d, 4);
+            d += __shfl_xor(d, 8);
+            d += __shfl_xor(d, 16);
+            dot[r] = d;
         }
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        if (hh == 0) {
-            float phi = my_scr[n];
-            float nrm = sqrtf(radial + 1e-8f) + a.norm_constant;
-            float sc = a.use_tanh ? tanhf(phi) * a.coords_range : phi;
-            float valid = (segb != 255) ? 1.0f : 0.0f;
-            float* tr = my_scr + 32;
-            tr[n * 3 + 0] = (dx / nrm) * sc * valid;
-            tr[n * 3 + 1] = (dy / nrm) * sc * valid;
-            tr[n * 3 + 2] = (dz / nrm) * sc * valid;
-        }
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        if (lane < nseg) {
-            const uint8_t* sb = reinterpret_cast<const uint8_t*>(seg_s);
-            const float* tr = my_scr + 32;
-            float sx = 0.f, sy = 0.f, sz = 0.f;
-            for (int rr = 0; rr < 32; ++rr) {
-                if (sb[rr] == lane) { sx += tr[rr * 3]; sy += tr[rr * 3 + 1]; sz += tr[rr * 3 + 2]; }
+        const int pbase = a.tile_pbase[tile];
+        const int nseg = a.tile_nseg[tile];
+
+        if (!COORD) {
+            // segment byte of each of this lane's 16 rows: rows 8q+4hh .. +3 share one dword
+            uint32_t sw[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sw[q] = seg_s[2 * q + hh];
+            float w[16];
+            int sg[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                sg[r] = (sw[r >> 2] >> (8 * (r & 3))) & 255;
+                float att = a.attention ? sigmoid_f(dot[r] + a.ba) : 1.0f;
+                w[r] = (sg[r] != 255) ? att : 0.0f;
             }
-            f32x4 o = {sx, sy, sz, 0.f};
-            *reinterpret_cast<f32x4*>(a.part + (size_t)(pbase + lane) * 4) = o;
+            for (int s = 0; s < nseg; ++s) {
+                float ws[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ws[r] = (sg[r] == s) ? w[r] : 0.0f;
+                float* dst = a.part + (size_t)(pbase + s) * H + n;
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) {
+                    float sum = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sum = __builtin_fmaf(ws[r], acc[ct][r], sum);
+                    sum += __shfl_xor(sum, 32);
+                    if (hh == 0) dst[32 * ct] = sum;
+                }
+            }
+        } else {
+            // phi of row rho(r) is in every lane of half hh; publish per row, then lane n handles row n
+            if (n == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) my_scr[(r & 3) + 8 * (r >> 2) + 4 * hh] = dot[r];
+            }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (hh == 0) {
+                float phi = my_scr[n];
+                float nrm = sqrtf(radial + 1e-8f) + a.norm_constant;
+                float sc = a.use_tanh ? tanhf(phi) * a.coords_range : phi;
+                float valid = (segb_t != 255) ? 1.0f : 0.0f;
+                float* tr = my_scr + 32;
+                tr[n * 3 + 0] = (dx / nrm) * sc * valid;
+                tr[n * 3 + 1] = (dy / nrm) * sc * valid;
+                tr[n * 3 + 2] = (dz / nrm) * sc * valid;
+            }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (lane < nseg) {
+                const uint8_t* sb = reinterpret_cast<const uint8_t*>(seg_s);
+                const float* tr = my_scr + 32;
+                float sx = 0.f, sy = 0.f, sz = 0.f;
+                for (int rr = 0; rr < 32; ++rr) {
+                    if (sb[rr] == lane) { sx += tr[rr * 3]; sy += tr[rr * 3 + 1]; sz += tr[rr * 3 + 2]; }
+                }
+                f32x4 o = {sx, sy, sz, 0.f};
+                *reinterpret_cast<f32x4*>(a.part + (size_t)(pbase + lane) * 4) = o;
+            }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
     }
 }

@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 import weakref
 from typing import Dict, Optional, Tuple
 
@@ -20,6 +21,9 @@ import torch.nn as nn
 from . import _lib
 from ._lib import HdConfig, HierDiffHipError
 
+
+PRECISIONS = {"fp32": 0, "bf16x3": 1}
+DEFAULT_PRECISION = "fp32"
 
 # ----------------------------------------------------------------------------- parameter holders
 # Mirrors of the reference module tree; they are never called, only hold tensors so that
@@ -144,11 +148,27 @@ class EGNN_dynamics_QM9(nn.Module):
                              hidden_nf=hidden_nf, n_layers=n_layers, inv_sublayers=inv_sublayers,
                              attention=int(bool(attention)), tanh=int(bool(tanh)),
                              condition_time=int(bool(condition_time)), norm_constant=float(norm_constant),
-                             normalization_factor=float(normalization_factor), coords_range=30.0)
+                             normalization_factor=float(normalization_factor), coords_range=30.0,
+                             precision=PRECISIONS[os.environ.get("HIERDIFF_PRECISION", DEFAULT_PRECISION)])
         self._hd = None              # (handle, device index)
         self._weights_key = None
         self._topo_cache: Dict[Tuple, Topology] = {}
         self.debug_checks = False
+
+    # ------------------------------------------------------------------ precision of the matrix-core path
+    @property
+    def precision(self) -> str:
+        return {v: k for k, v in PRECISIONS.items()}[self._cfg.precision]
+
+    @precision.setter
+    def precision(self, name: str) -> None:
+        """"fp32": exact fp32 matrix instructions.  "bf16x3": fp32 operands split into bf16 head+tail, three
+        bf16 matrix instructions with fp32 accumulation (error ~1e-6 per contraction, ~5x the throughput)."""
+        if name not in PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(PRECISIONS)}")
+        if PRECISIONS[name] != self._cfg.precision:
+            self._release()
+            self._cfg.precision = PRECISIONS[name]
 
     # ------------------------------------------------------------------ reference API surface
     def forward(self, t, xh, node_mask, edge_mask, context=None):

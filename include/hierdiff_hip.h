@@ -66,6 +66,10 @@ typedef struct hd_config {
     float norm_constant;
     float normalization_factor;
     float coords_range;          /* EGNN default 30; per-block range = coords_range / n_layers */
+    int32_t precision;           /* matrix-core arithmetic of the H x H contractions:
+                                    0 = exact fp32 (v_mfma_f32_32x32x2_f32),
+                                    1 = "bf16x3": fp32 operands split into bf16 head + tail, 3 bf16 MFMAs with
+                                        fp32 accumulation (~1e-6 relative on a 256-term dot product) */
 } hd_config;
 
 int hd_version(void);

@@ -42,11 +42,16 @@ FORWARD_FIXTURES = ["f1_cfg1_h256_l3", "f1b_cfg1_h256_l3_gain1", "f7_h32_l2", "f
                     "f6_b16_n30_h256_l9", "f6b_n48_h256_l6"]
 
 
+PRECISIONS = ["fp32", "bf16x3"]
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("name", FORWARD_FIXTURES)
-def test_forward_golden(name):
+def test_forward_golden(name, precision):
     fx = load(name)
     sd_np, _, _ = fixture_model(fx)
     dyn = build_dynamics(sd_np, int(fx["hidden_nf"]), int(fx["n_layers"]))
+    dyn.precision = precision
     xh = torch.from_numpy(fx["xh"]).to(DEV)
     nm = torch.from_numpy(fx["node_mask"]).to(DEV)
     em = torch.from_numpy(fx["edge_mask"]).to(DEV)
@@ -66,7 +71,7 @@ def test_forward_golden(name):
     topo = dyn.topology(nm, None, B, N)
     out2 = dyn.forward_with_topology(topo, torch.from_numpy(fx["t_rows"]).to(DEV), xh, None, None)
     assert torch.equal(out, out2)
-    print(f"{name}: worst rel_l2 {worst:.2e}")
+    print(f"{name} [{precision}]: worst rel_l2 {worst:.2e}")
 
 
 @pytest.mark.parametrize("name", ["f3_cond_h256_l3", "f3_cond_h32_l2"])
@@ -120,23 +125,26 @@ def _oracle_case(n_list, H, L, seed, n_max=None, coord_gain=1.0, C_=0):
     ([83, 3], 128, 1, None),                  # largest GEOM molecule
     ([17, 9, 30, 12, 25, 7, 14, 21], 256, 6, 48),   # config-3 flavour, production depth
 ])
-def test_forward_vs_oracle(n_list, H, L, n_max):
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_forward_vs_oracle(n_list, H, L, n_max, precision):
     sd_np, sd, cfg, xh, nm, em = _oracle_case(n_list, H, L, seed=40 + len(n_list), n_max=n_max)
     B, N = xh.shape[:2]
     t = torch.linspace(0.1, 0.9, B).view(B, 1)
     with torch.no_grad():
         ref = orc.dynamics_forward(sd, cfg, t, xh, nm, em, None, None, prefix="dynamics.egnn.")
     dyn = build_dynamics(sd_np, H, L)
+    dyn.precision = precision
     out = dyn._forward(t.to(DEV), xh.to(DEV), nm.to(DEV), em.to(DEV), None, None).cpu()
-    assert_parity(out.numpy(), ref.numpy(), f"n={n_list} H={H} L={L}")
+    assert_parity(out.numpy(), ref.numpy(), f"n={n_list} H={H} L={L} {precision}")
     assert np.all(out.numpy()[~nm.numpy()[..., 0]] == 0.0)
     vel_sum = (out[:, :, :3] * nm.float()).sum(1).abs().max().item()
     bound = 2e-6 * N * max(1.0, out[:, :, :3].abs().max().item())
     assert vel_sum < bound, f"centre of gravity of vel {vel_sum} (bound {bound})"
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("scale", [30.0, 300.0])
-def test_saturating_activations_vs_oracle(scale):
+def test_saturating_activations_vs_oracle(scale, precision):
     """Coordinates far from the origin push the edge pre-activations beyond +-88 (exp overflow range):
     SiLU must saturate to 0 / x like the reference instead of producing NaN."""
     sd_np, sd, cfg, xh, nm, em = _oracle_case([12, 20, 7], 64, 2, seed=91)
@@ -146,8 +154,9 @@ def test_saturating_activations_vs_oracle(scale):
         ref = orc.dynamics_forward(sd, cfg, t, xh, nm, em, None, None, prefix="dynamics.egnn.")
     assert torch.isfinite(ref).all()
     dyn = build_dynamics(sd_np, 64, 2)
+    dyn.precision = precision
     out = dyn._forward(t.to(DEV), xh.to(DEV), nm.to(DEV), em.to(DEV), None, None).cpu()
-    assert_parity(out.numpy(), ref.numpy(), f"saturating scale={scale}")
+    assert_parity(out.numpy(), ref.numpy(), f"saturating scale={scale} {precision}")
 
 
 def test_general_edge_mask_and_options_vs_oracle():
