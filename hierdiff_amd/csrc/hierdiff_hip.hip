@@ -47,7 +47,7 @@ struct ProfRec { int fam; hipEvent_t a, b; };
 struct hd_handle {
     hd_config cfg;
     int device;
-    int H, fin, F, D, WM, WN;
+    int H, fin, F, D, NS;       // NS: 32-column sub-tiles per node-GEMM workgroup tile
     long long n_weights;
     bool weights_set;
     float* dw;                  // packed weights
@@ -87,7 +87,7 @@ struct hd_topology {
     uint8_t *eseg, *nm_bytes;
     float* nmask;
     // workspace
-    float *hbuf, *AB, *Tb, *x0, *xcur, *part, *xpart, *eps;
+    float *hbuf, *AB, *Tb, *agg, *x0, *xcur, *part, *xpart, *eps;
 };
 
 // ----------------------------------------------------------------------------- small helpers
@@ -155,8 +155,7 @@ extern "C" int hd_create(const hd_config* cfg, int device, hd_handle** out) {
     h->fin = cfg->in_node_nf + cfg->context_node_nf;
     h->F = F;
     h->D = 3 + F;
-    h->WM = (H == 32) ? 4 : 2;
-    h->WN = (H == 32) ? 1 : 2;
+    h->NS = (H == 32) ? 1 : 2;
     h->n_weights = weight_count(*cfg);
     h->weights_set = false;
     h->dw = nullptr;
@@ -309,7 +308,7 @@ extern "C" int hd_set_weights(hd_handle* h, const float* blob, long long n, int 
         src = host.data();
     }
     const hd_config& c = h->cfg;
-    const int H = h->H, fin = h->fin, WN = h->WN;
+    const int H = h->H, fin = h->fin, WN = h->NS;
     const int L = c.n_layers, S = c.inv_sublayers;
     const bool bf = c.precision != 0;
     // layout of the packed buffer
@@ -370,12 +369,12 @@ extern "C" int hd_set_weights(hd_handle* h, const float* blob, long long n, int 
             pack_first(w, W1, b1);
             auto w3 = [&](int col, int k) { return W3[(size_t)col * 2 * H + k]; };
             auto w4 = [&](int col, int k) { return W4[(size_t)col * H + k]; };
+            if (bf) pack_edge_w2_bf(pk, w.w2_img, H, W2);
+            else pack_edge_w2(pk, w.w2_img, H, W2);
             if (bf) {
-                pack_edge_w2_bf(pk, w.w2_img, H, W2);
                 pack_gemm_b_bf(pk, w.w3_img, 2 * H, H, WN, w3);
                 pack_gemm_b_bf(pk, w.w4_img, H, H, WN, w4);
             } else {
-                pack_edge_w2(pk, w.w2_img, H, W2);
                 pack_gemm_b(pk, w.w3_img, 2 * H, H, WN, w3);
                 pack_gemm_b(pk, w.w4_img, H, H, WN, w4);
             }
@@ -422,7 +421,7 @@ extern "C" int hd_topology_destroy(hd_topology* t) {
     (void)hipDeviceSynchronize();
     hipFree(t->node_of); hipFree(t->slot_of); hipFree(t->ei); hipFree(t->ej); hipFree(t->tile_pbase);
     hipFree(t->tile_nseg); hipFree(t->pstart); hipFree(t->nvalid); hipFree(t->eseg); hipFree(t->nm_bytes);
-    hipFree(t->nmask); hipFree(t->hbuf); hipFree(t->AB); hipFree(t->Tb); hipFree(t->x0); hipFree(t->xcur);
+    hipFree(t->nmask); hipFree(t->hbuf); hipFree(t->AB); hipFree(t->Tb); hipFree(t->agg); hipFree(t->x0); hipFree(t->xcur);
     hipFree(t->part); hipFree(t->xpart); hipFree(t->eps);
     delete t;
     return HD_OK;
@@ -504,13 +503,13 @@ extern "C" int hd_topology_create(hd_handle* h, const uint8_t* node_mask, const 
     ok(dev_upload(&t->pstart, pstart)); ok(dev_upload(&t->nvalid, nvalid)); ok(dev_upload(&t->eseg, eseg));
     ok(dev_upload(&t->nm_bytes, nm_bytes)); ok(dev_upload(&t->nmask, nmask));
     ok(dev_alloc(&t->hbuf, (size_t)M_pad * H)); ok(dev_alloc(&t->AB, (size_t)M_pad * 2 * H));
-    ok(dev_alloc(&t->Tb, (size_t)M_pad * H)); ok(dev_alloc(&t->x0, (size_t)M_pad * 4));
+    ok(dev_alloc(&t->Tb, (size_t)M_pad * H)); ok(dev_alloc(&t->agg, (size_t)M_pad * H)); ok(dev_alloc(&t->x0, (size_t)M_pad * 4));
     ok(dev_alloc(&t->xcur, (size_t)M_pad * 4)); ok(dev_alloc(&t->part, (size_t)std::max(1, n_parts) * H));
     ok(dev_alloc(&t->xpart, (size_t)std::max(1, n_parts) * 4)); ok(dev_alloc(&t->eps, BN * h->D));
     if (r != HD_OK) { hd_topology_destroy(t); return r; }
     // pad rows stay zero for the lifetime of the topology (kernels never write them)
     hipMemset(t->hbuf, 0, (size_t)M_pad * H * 4); hipMemset(t->AB, 0, (size_t)M_pad * 2 * H * 4);
-    hipMemset(t->Tb, 0, (size_t)M_pad * H * 4); hipMemset(t->x0, 0, (size_t)M_pad * 16);
+    hipMemset(t->Tb, 0, (size_t)M_pad * H * 4); hipMemset(t->agg, 0, (size_t)M_pad * H * 4); hipMemset(t->x0, 0, (size_t)M_pad * 16);
     hipMemset(t->xcur, 0, (size_t)M_pad * 16);
     HIP_TRY(hipDeviceSynchronize());
     *out = t;
@@ -572,25 +571,29 @@ extern "C" int hd_profile_read(hd_handle* h, double* ms3, long long* launches3) 
 
 // ----------------------------------------------------------------------------- forward
 
-template <int WM, int WN>
-static void launch_gemm(int prec, int epi, bool cat, const GemmArgs& g, hipStream_t s) {
-    dim3 grid((g.M + 32 * WM - 1) / (32 * WM), g.Nc / (32 * WN));
+template <int WM, int WN, int CN, int PREC>
+static void launch_gemm_p(int epi, bool cat, const GemmArgs& g, hipStream_t s) {
+    const int nrt = (g.M + 32 * WM - 1) / (32 * WM), nct = g.Nc / (32 * WN * CN);
+    dim3 grid(8 * ((nrt + 7) / 8) * nct);
     dim3 block(WM * WN * 64);
-    if (prec == 0) {
-        if (cat) hipLaunchKernelGGL((k_gemm<WM, WN, EPI_BIAS_SILU, true>), grid, block, 0, s, g);
-        else if (epi == EPI_BIAS) hipLaunchKernelGGL((k_gemm<WM, WN, EPI_BIAS, false>), grid, block, 0, s, g);
-        else hipLaunchKernelGGL((k_gemm<WM, WN, EPI_RESID_MASK, false>), grid, block, 0, s, g);
-    } else {
-        if (cat) hipLaunchKernelGGL((k_gemm_bf<WM, WN, EPI_BIAS_SILU, true>), grid, block, 0, s, g);
-        else if (epi == EPI_BIAS) hipLaunchKernelGGL((k_gemm_bf<WM, WN, EPI_BIAS, false>), grid, block, 0, s, g);
-        else hipLaunchKernelGGL((k_gemm_bf<WM, WN, EPI_RESID_MASK, false>), grid, block, 0, s, g);
-    }
+    if (cat) hipLaunchKernelGGL((k_gemm<WM, WN, CN, EPI_BIAS_SILU, true, PREC>), grid, block, 0, s, g);
+    else if (epi == EPI_BIAS) hipLaunchKernelGGL((k_gemm<WM, WN, CN, EPI_BIAS, false, PREC>), grid, block, 0, s, g);
+    else hipLaunchKernelGGL((k_gemm<WM, WN, CN, EPI_RESID_MASK, false, PREC>), grid, block, 0, s, g);
 }
 
+template <int WM, int WN, int CN>
+static void launch_gemm(int prec, int epi, bool cat, const GemmArgs& g, hipStream_t s) {
+    if (prec == 0) launch_gemm_p<WM, WN, CN, 0>(epi, cat, g, s);
+    else launch_gemm_p<WM, WN, CN, 1>(epi, cat, g, s);
+}
+
+// Node-GEMM tile shape per hidden size: (waves M, waves N, accumulators per wave); the weight images are
+// packed for the matching number of 32-column sub-tiles NS = WN*CN.
 static void gemm(hd_handle* h, int epi, bool cat, const GemmArgs& g, hipStream_t s) {
     ProfScope ps(h, s, 1);
-    if (h->WM == 4) launch_gemm<4, 1>(h->cfg.precision, epi, cat, g, s);
-    else launch_gemm<2, 2>(h->cfg.precision, epi, cat, g, s);
+
+    if (h->NS == 1) launch_gemm<4, 1, 1>(h->cfg.precision, epi, cat, g, s);        // H = 32: 128 x 32 tiles
+    else launch_gemm<2, 2, 1>(h->cfg.precision, epi, cat, g, s);                   // 64 x 64 tiles (fastest measured)
 }
 
 template <int H>
@@ -599,7 +602,7 @@ static int edge_lds_bytes() { return (2 * 32 * H + 2 * H + 4 * 136) * 4; }
 template <int H>
 static int launch_edge_h(int prec, bool coord, const EdgeArgs& a, hipStream_t s) {
     const int lds = edge_lds_bytes<H>();
-    const dim3 grid(std::min(a.n_wg, g_edge_grid)), block(256);
+    const dim3 grid(HD_EDGE_PERSIST ? std::min(a.n_wg, g_edge_grid) : a.n_wg), block(256);
     if constexpr (H == 256) {
         static int abl = -1;
         if (abl < 0) { const char* e = getenv("HD_ABLATE"); abl = e ? atoi(e) : 0; }
@@ -695,7 +698,7 @@ static int forward_impl(hd_handle* h, hd_topology* t, const float* xh, const flo
                 GemmArgs g;
                 std::memset(&g, 0, sizeof(g));
                 g.A = t->hbuf; g.lda = H; g.K1 = H; g.K = H; g.Bimg = W + w.ab_img; g.bias = W + w.ab_bias;
-                g.C = t->AB; g.ldc = 2 * H; g.M = M; g.Nc = 2 * H; g.nmask = t->nmask; g.norm = 1.f;
+                g.C = t->AB; g.ldc = 2 * H; g.M = M; g.Nc = 2 * H; g.nmask = t->nmask;
                 gemm(h, EPI_BIAS, false, g, s);
                 EdgeArgs e;
                 std::memset(&e, 0, sizeof(e));
@@ -708,14 +711,22 @@ static int forward_impl(hd_handle* h, hd_topology* t, const float* xh, const flo
                 if (!coord) {
                     GemmArgs g1;
                     std::memset(&g1, 0, sizeof(g1));
-                    g1.A = t->hbuf; g1.lda = H; g1.K1 = H; g1.K = 2 * H; g1.part = t->part; g1.pstart = t->pstart;
-                    g1.norm = c.normalization_factor; g1.Bimg = W + w.w3_img; g1.bias = W + w.b3; g1.C = t->Tb;
+                    {
+                        ProfScope ps(h, s, 2);
+                        AggArgs ag;
+                        ag.part = t->part; ag.pstart = t->pstart; ag.agg = t->agg; ag.norm = c.normalization_factor;
+                        ag.M = M; ag.H = H;
+                        const long long total = (long long)M * (H / 4);
+                        hipLaunchKernelGGL(k_agg, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ag);
+                    }
+                    g1.A = t->hbuf; g1.lda = H; g1.K1 = H; g1.K = 2 * H; g1.A2 = t->agg;
+                    g1.Bimg = W + w.w3_img; g1.bias = W + w.b3; g1.C = t->Tb;
                     g1.ldc = H; g1.M = M; g1.Nc = H; g1.nmask = t->nmask;
                     gemm(h, EPI_BIAS_SILU, true, g1, s);
                     GemmArgs g2;
                     std::memset(&g2, 0, sizeof(g2));
                     g2.A = t->Tb; g2.lda = H; g2.K1 = H; g2.K = H; g2.Bimg = W + w.w4_img; g2.bias = W + w.b4;
-                    g2.C = t->hbuf; g2.ldc = H; g2.M = M; g2.Nc = H; g2.nmask = t->nmask; g2.norm = 1.f;
+                    g2.C = t->hbuf; g2.ldc = H; g2.M = M; g2.Nc = H; g2.nmask = t->nmask;
                     gemm(h, EPI_RESID_MASK, false, g2, s);
                 } else {
                     ProfScope ps(h, s, 2);

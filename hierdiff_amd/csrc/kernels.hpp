@@ -18,6 +18,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define HD_DEVINL __device__ __forceinline__
 
+HD_DEVINL void glds16(const void* gsrc, void* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
 // ----------------------------------------------------------------------------- math helpers
 
 // x * sigmoid(x).  exp(-x) = 2^(-x*log2e) with a compensated product so the exponent argument
@@ -54,6 +59,15 @@ HD_DEVINL float silu_p(float x) {
     } else {
         float e = __builtin_amdgcn_exp2f(x * -1.44269502162933349609375f);
         return x * __builtin_amdgcn_rcpf(1.0f + e);
+    }
+}
+
+// compile-time loop: f(std::integral_constant<int, I>) for I = 0..N-1
+template <int I, int N, typename F>
+HD_DEVINL void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
     }
 }
 
@@ -135,130 +149,68 @@ enum { EPI_BIAS = 0, EPI_BIAS_SILU = 1, EPI_RESID_MASK = 2 };
 
 struct GemmArgs {
     const float* A;       // [M_pad][lda], columns k < K1
-    const float* part;    // CAT: per-part partial neighbour sums [P][K - K1]
-    const int* pstart;    // CAT: [M+1] part range of each node
+    const float* A2;      // CAT: [M_pad][K - K1], columns k >= K1 (the aggregated neighbour messages)
     const float* Bimg;    // packed weight image
     const float* bias;    // [Nc]
     const float* nmask;   // [M_pad] (EPI_RESID_MASK)
     float* C;             // [M_pad][ldc]
-    float norm;           // CAT: divide the summed parts by this (normalization_factor)
     int lda, ldc, K1, K, M, Nc;
 };
 
-template <int WM, int WN, int EPI, bool CAT>
-__global__ __launch_bounds__(WM * WN * 64) void k_gemm(GemmArgs g) {
-    constexpr int BM = 32 * WM, BN = 32 * WN, NT = 64 * WM * WN;
-    constexpr int A_F4 = BM * 8 / NT, B_F4 = BN * 8 / NT;
-    constexpr int LDA_S = 36;
-    __shared__ __attribute__((aligned(16))) float As[2][BM * LDA_S];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BN * 32];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave / WN, wc = wave % WN;
-    const int hh = lane >> 5, m = lane & 31;
-    const int row0 = blockIdx.x * BM;
-    const int nchunk = g.K >> 5;
-    const float* Bsrc = g.Bimg + (size_t)blockIdx.y * nchunk * (BN * 32);
-
-    f32x4 ra[A_F4], rb[B_F4];
-
-    auto load_tiles = [&](int c) {
-        const int k0 = c << 5;
-#pragma unroll
-        for (int u = 0; u < A_F4; ++u) {
-            int idx = tid + u * NT;
-            int r = idx >> 3, sg = idx & 7;
-            int row = row0 + r;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (!CAT || k0 < g.K1) {
-                v = *reinterpret_cast<const f32x4*>(g.A + (size_t)row * g.lda + k0 + 4 * sg);
-            } else if (row < g.M) {
-                int p0 = g.pstart[row], p1 = g.pstart[row + 1];
-                const int kw = g.K - g.K1;
-                for (int p = p0; p < p1; ++p)
-                    v += *reinterpret_cast<const f32x4*>(g.part + (size_t)p * kw + (k0 - g.K1) + 4 * sg);
-                v = v / g.norm;
-            }
-            ra[u] = v;
-        }
-#pragma unroll
-        for (int u = 0; u < B_F4; ++u)
-            rb[u] = reinterpret_cast<const f32x4*>(Bsrc + (size_t)c * (BN * 32))[tid + u * NT];
-    };
-    auto store_tiles = [&](int buf) {
-#pragma unroll
-        for (int u = 0; u < A_F4; ++u) {
-            int idx = tid + u * NT;
-            int r = idx >> 3, sg = idx & 7;
-            *reinterpret_cast<f32x4*>(&As[buf][r * LDA_S + 4 * sg]) = ra[u];
-        }
-#pragma unroll
-        for (int u = 0; u < B_F4; ++u) reinterpret_cast<f32x4*>(Bs[buf])[tid + u * NT] = rb[u];
-    };
-
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-
-    load_tiles(0);
-    store_tiles(0);
-    __syncthreads();
-    for (int c = 0; c < nchunk; ++c) {
-        const int buf = c & 1;
-        if (c + 1 < nchunk) load_tiles(c + 1);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            f32x4 av = *reinterpret_cast<const f32x4*>(&As[buf][(32 * wr + m) * LDA_S + 16 * hh + 4 * q]);
-            f32x4 bv = *reinterpret_cast<const f32x4*>(&Bs[buf][((wc * 4 + q) * 64 + lane) * 4]);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc, 0, 0, 0);
-        }
-        if (c + 1 < nchunk) store_tiles(buf ^ 1);
-        __syncthreads();
-    }
-
-    const int col = blockIdx.y * BN + 32 * wc + m;
-    const float bv = g.bias[col];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        int row = row0 + 32 * wr + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        if (row < g.M) {
-            float v = acc[r] + bv;
-            float* dst = g.C + (size_t)row * g.ldc + col;
-            if (EPI == EPI_BIAS_SILU) v = silu_f(v);
-            if (EPI == EPI_RESID_MASK) v = (*dst + v) * g.nmask[row];
-            *dst = v;
-        }
-    }
-}
-
-// bf16x3 variant of the node GEMM (see k_edge PREC 1): activations are split into bf16 head/tail in
-// the tile loader, weights are pre-split; three v_mfma_f32_32x32x16_bf16 per 16-wide k-step.
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-template <int WM, int WN, int EPI, bool CAT>
-__global__ __launch_bounds__(WM * WN * 64) void k_gemm_bf(GemmArgs g) {
-    constexpr int BM = 32 * WM, BN = 32 * WN, NT = 64 * WM * WN;
-    constexpr int A_F4 = BM * 8 / NT;
-    constexpr int B_U4 = BN * 32 * 4 / 16 / NT;          // 16-byte pieces of the hi+lo image per thread
-    constexpr int LDA_S = 40;                             // bf16 per A row (32 + 8 pad: 80 B, conflict-free b128)
-    __shared__ __attribute__((aligned(16))) __bf16 Ah[2][BM * LDA_S];
-    __shared__ __attribute__((aligned(16))) __bf16 Al[2][BM * LDA_S];
-    __shared__ __attribute__((aligned(16))) __bf16 Bs[2][BN * 32 * 2];
+// WM x WN wavefronts, each owning 32 rows x (32*CN) columns (CN accumulators); workgroup tile
+// (32*WM) x (32*WN*CN).  PREC 0: exact fp32 MFMA.  PREC 1: bf16x3 (see k_edge) - activations are split into
+// bf16 head/tail by the tile loader, weights are pre-split.  Weight image per (column tile, 32-wide K chunk):
+//   fp32  : [NS][4 q][64 lanes][4 j]          k = 32c + 16*(lane>>5) + 4q + j
+//   bf16x3: [hi|lo][2 k-steps][NS][64 lanes][8 i]   k = 32c + 16s + 8*(lane>>5) + i
+// with NS = WN*CN 32-column sub-tiles, column = tile*32*NS + 32*sub + (lane&31).
+template <int WM, int WN, int CN, int EPI, bool CAT, int PREC>
+__global__ __launch_bounds__(WM * WN * 64) void k_gemm(GemmArgs g) {
+    constexpr int NS = WN * CN;
+    constexpr int BM = 32 * WM, BN = 32 * NS, NT = 64 * WM * WN;
+    constexpr int A_F4 = BM * 8 / NT;                    // float4 of the A tile per thread
+    constexpr int B_U4 = BN * 32 * 4 / 16 / NT;          // 16-byte pieces of the B image per thread
+    constexpr int LDA_F = 36;                            // fp32 A row: 32 + 4 pad floats
+    constexpr int LDA_H = 40;                            // bf16 A row: 32 + 8 pad (80 B): conflict-free b128
+    constexpr int A_BYTES = PREC == 0 ? BM * LDA_F * 4 : 2 * BM * LDA_H * 2;
+    constexpr int B_BYTES = BN * 32 * 4;
+    __shared__ __attribute__((aligned(16))) char smem_g[2 * (A_BYTES + B_BYTES)];
+    auto As_f = [&](int buf) { return reinterpret_cast<float*>(smem_g + buf * (A_BYTES + B_BYTES)); };
+    auto As_h = [&](int buf) { return reinterpret_cast<__bf16*>(smem_g + buf * (A_BYTES + B_BYTES)); };
+    auto As_l = [&](int buf) { return reinterpret_cast<__bf16*>(smem_g + buf * (A_BYTES + B_BYTES)) + BM * LDA_H; };
+    auto Bs = [&](int buf) { return smem_g + buf * (A_BYTES + B_BYTES) + A_BYTES; };
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave / WN, wc = wave % WN;
     const int hh = lane >> 5, m = lane & 31;
-    const int row0 = blockIdx.x * BM;
+    // XCD-aware tile order (1-D grid of 8 * ceil(nrt/8) * nct blocks, block b runs on XCD b % 8): every XCD owns
+    // a contiguous range of row tiles and walks (row tile, column tile) with the column tile fastest, so the
+    // A rows - written by the previous kernel, i.e. resident in Infinity Cache, not in this XCD's L2 - cross
+    // the fabric once per XCD instead of once per column tile.  Speed only.
+    int rt, ctile;
+    {
+        const int nrt = (g.M + BM - 1) / BM, nct = g.Nc / BN;
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int q = nrt >> 3, r = nrt & 7;
+        const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        const int len = q + (xcd < r ? 1 : 0);
+        if (idx >= len * nct) return;
+        rt = start + idx / nct;
+        ctile = idx % nct;
+    }
+    const int row0 = rt * BM;
     const int nchunk = g.K >> 5;
-    const u32x4* Bsrc = reinterpret_cast<const u32x4*>(g.Bimg) + (size_t)blockIdx.y * nchunk * (BN * 32 * 4 / 16);
+    const u32x4* Bsrc = reinterpret_cast<const u32x4*>(g.Bimg) + (size_t)ctile * nchunk * (B_BYTES / 16);
 
-    f32x4 ra[A_F4];
-    u32x4 rb[B_U4];
+    // Global loads run three chunks ahead of the MFMAs (register ring), LDS is double-buffered: with only a
+    // few workgroups per CU the ~1-2 us L2/MALL latency per chunk is otherwise exposed nchunk times.
+    f32x4 ra3[3][A_F4];
+    u32x4 rb3[3][B_U4];
 
-    auto load_tiles = [&](int c) {
+    auto load_tiles = [&](int c, f32x4 (&ra)[A_F4], u32x4 (&rb)[B_U4]) {
         const int k0 = c << 5;
 #pragma unroll
         for (int u = 0; u < A_F4; ++u) {
@@ -266,72 +218,112 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_bf(GemmArgs g) {
             int r = idx >> 3, sg = idx & 7;
             int row = row0 + r;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (!CAT || k0 < g.K1) {
-                v = *reinterpret_cast<const f32x4*>(g.A + (size_t)row * g.lda + k0 + 4 * sg);
-            } else if (row < g.M) {
-                int p0 = g.pstart[row], p1 = g.pstart[row + 1];
-                const int kw = g.K - g.K1;
-                for (int p = p0; p < p1; ++p)
-                    v += *reinterpret_cast<const f32x4*>(g.part + (size_t)p * kw + (k0 - g.K1) + 4 * sg);
-                v = v / g.norm;
-            }
+            if (!CAT || k0 < g.K1) v = *reinterpret_cast<const f32x4*>(g.A + (size_t)row * g.lda + k0 + 4 * sg);
+            else v = *reinterpret_cast<const f32x4*>(g.A2 + (size_t)row * (g.K - g.K1) + (k0 - g.K1) + 4 * sg);
             ra[u] = v;
         }
 #pragma unroll
-        for (int u = 0; u < B_U4; ++u) rb[u] = Bsrc[(size_t)c * (BN * 32 * 4 / 16) + tid + u * NT];
+        for (int u = 0; u < B_U4; ++u) rb[u] = Bsrc[(size_t)c * (B_BYTES / 16) + tid + u * NT];
     };
-    auto store_tiles = [&](int buf) {
+    auto store_tiles = [&](int buf, const f32x4 (&ra)[A_F4], const u32x4 (&rb)[B_U4]) {
 #pragma unroll
         for (int u = 0; u < A_F4; ++u) {
             int idx = tid + u * NT;
             int r = idx >> 3, sg = idx & 7;
-            const f32x4 v = ra[u];
-            const __bf16 h0 = (__bf16)v[0], h1 = (__bf16)v[1], h2 = (__bf16)v[2], h3 = (__bf16)v[3];
-            const bf16x4_t vh = {h0, h1, h2, h3};
-            const bf16x4_t vl = {(__bf16)(v[0] - (float)h0), (__bf16)(v[1] - (float)h1),
-                                 (__bf16)(v[2] - (float)h2), (__bf16)(v[3] - (float)h3)};
-            *reinterpret_cast<bf16x4_t*>(&Ah[buf][r * LDA_S + 4 * sg]) = vh;
-            *reinterpret_cast<bf16x4_t*>(&Al[buf][r * LDA_S + 4 * sg]) = vl;
+            if constexpr (PREC == 0) {
+                *reinterpret_cast<f32x4*>(As_f(buf) + r * LDA_F + 4 * sg) = ra[u];
+            } else {
+                const f32x4 v = ra[u];
+                const __bf16 h0 = (__bf16)v[0], h1 = (__bf16)v[1], h2 = (__bf16)v[2], h3 = (__bf16)v[3];
+                const bf16x4_t vh = {h0, h1, h2, h3};
+                const bf16x4_t vl = {(__bf16)(v[0] - (float)h0), (__bf16)(v[1] - (float)h1),
+                                     (__bf16)(v[2] - (float)h2), (__bf16)(v[3] - (float)h3)};
+                *reinterpret_cast<bf16x4_t*>(As_h(buf) + r * LDA_H + 4 * sg) = vh;
+                *reinterpret_cast<bf16x4_t*>(As_l(buf) + r * LDA_H + 4 * sg) = vl;
+            }
         }
 #pragma unroll
-        for (int u = 0; u < B_U4; ++u) reinterpret_cast<u32x4*>(Bs[buf])[tid + u * NT] = rb[u];
+        for (int u = 0; u < B_U4; ++u) reinterpret_cast<u32x4*>(Bs(buf))[tid + u * NT] = rb[u];
     };
 
-    f32x16 acc;
+    f32x16 acc[CN];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int cn = 0; cn < CN; ++cn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[cn][r] = 0.f;
 
-    load_tiles(0);
-    store_tiles(0);
-    __syncthreads();
-    for (int c = 0; c < nchunk; ++c) {
-        const int buf = c & 1;
-        if (c + 1 < nchunk) load_tiles(c + 1);
+    auto compute = [&](int buf) {
+        if constexpr (PREC == 0) {
+            const float* Bf = reinterpret_cast<const float*>(Bs(buf));
 #pragma unroll
-        for (int st = 0; st < 2; ++st) {
-            const bf16x8_t ah = *reinterpret_cast<const bf16x8_t*>(&Ah[buf][(32 * wr + m) * LDA_S + 16 * st + 8 * hh]);
-            const bf16x8_t al = *reinterpret_cast<const bf16x8_t*>(&Al[buf][(32 * wr + m) * LDA_S + 16 * st + 8 * hh]);
-            const bf16x8_t bh = *reinterpret_cast<const bf16x8_t*>(&Bs[buf][(((0 * 2 + st) * WN + wc) * 64 + lane) * 8]);
-            const bf16x8_t bl = *reinterpret_cast<const bf16x8_t*>(&Bs[buf][(((1 * 2 + st) * WN + wc) * 64 + lane) * 8]);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 av = *reinterpret_cast<const f32x4*>(As_f(buf) + (32 * wr + m) * LDA_F + 16 * hh + 4 * q);
+                f32x4 bv[CN];
+#pragma unroll
+                for (int cn = 0; cn < CN; ++cn)
+                    bv[cn] = *reinterpret_cast<const f32x4*>(Bf + (((wc * CN + cn) * 4 + q) * 64 + lane) * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int cn = 0; cn < CN; ++cn)
+                        acc[cn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[cn][j], acc[cn], 0, 0, 0);
+            }
+        } else {
+            const __bf16* Bh = reinterpret_cast<const __bf16*>(Bs(buf));
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const bf16x8_t ah = *reinterpret_cast<const bf16x8_t*>(As_h(buf) + (32 * wr + m) * LDA_H + 16 * st + 8 * hh);
+                const bf16x8_t al = *reinterpret_cast<const bf16x8_t*>(As_l(buf) + (32 * wr + m) * LDA_H + 16 * st + 8 * hh);
+                bf16x8_t bh[CN], bl[CN];
+#pragma unroll
+                for (int cn = 0; cn < CN; ++cn) {
+                    bh[cn] = *reinterpret_cast<const bf16x8_t*>(Bh + (((0 * 2 + st) * NS + wc * CN + cn) * 64 + lane) * 8);
+                    bl[cn] = *reinterpret_cast<const bf16x8_t*>(Bh + (((1 * 2 + st) * NS + wc * CN + cn) * 64 + lane) * 8);
+                }
+#pragma unroll
+                for (int cn = 0; cn < CN; ++cn) acc[cn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[cn], acc[cn], 0, 0, 0);
+#pragma unroll
+                for (int cn = 0; cn < CN; ++cn) acc[cn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[cn], acc[cn], 0, 0, 0);
+#pragma unroll
+                for (int cn = 0; cn < CN; ++cn) acc[cn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[cn], acc[cn], 0, 0, 0);
+            }
         }
-        if (c + 1 < nchunk) store_tiles(buf ^ 1);
-        __syncthreads();
+    };
+
+    load_tiles(0, ra3[0], rb3[0]);
+    if (nchunk > 1) load_tiles(1, ra3[1], rb3[1]);
+    if (nchunk > 2) load_tiles(2, ra3[2], rb3[2]);
+    store_tiles(0, ra3[0], rb3[0]);
+    __syncthreads();
+    // chunk c: compute from LDS[c&1]; stage chunk c+1 (ring slot (c+1)%3) into the other LDS buffer; refill
+    // ring slot c%3 with chunk c+3.  Unrolled by 3 so the ring slots are compile-time.
+    for (int c0 = 0; c0 < nchunk; c0 += 3) {
+        static_for<0, 3>([&](auto Rc) {
+            constexpr int rslot = decltype(Rc)::value;
+            const int c = c0 + rslot;
+            if (c < nchunk) {
+                compute(c & 1);
+                if (c + 1 < nchunk) store_tiles((c + 1) & 1, ra3[(rslot + 1) % 3], rb3[(rslot + 1) % 3]);
+                if (c + 3 < nchunk) load_tiles(c + 3, ra3[rslot], rb3[rslot]);
+                __syncthreads();
+            }
+        });
     }
 
-    const int col = blockIdx.y * BN + 32 * wc + m;
-    const float bv = g.bias[col];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        int row = row0 + 32 * wr + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        if (row < g.M) {
-            float v = acc[r] + bv;
-            float* dst = g.C + (size_t)row * g.ldc + col;
-            if (EPI == EPI_BIAS_SILU) v = silu_f(v);
-            if (EPI == EPI_RESID_MASK) v = (*dst + v) * g.nmask[row];
-            *dst = v;
+    for (int cn = 0; cn < CN; ++cn) {
+        const int col = ctile * BN + 32 * (wc * CN + cn) + m;
+        const float bv = g.bias[col];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int row = row0 + 32 * wr + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            if (row < g.M) {
+                float v = acc[cn][r] + bv;
+                float* dst = g.C + (size_t)row * g.ldc + col;
+                if (EPI == EPI_BIAS_SILU) v = silu_f(v);
+                if (EPI == EPI_RESID_MASK) v = (*dst + v) * g.nmask[row];
+                *dst = v;
+            }
         }
     }
 }
@@ -366,16 +358,18 @@ struct EdgeArgs {
     int n_tiles, n_wg;      // n_wg = number of 128-edge workgroup-tiles
 };
 
-HD_DEVINL void glds16(const void* gsrc, void* lds_dst) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
-}
 
 // PREC 0: exact fp32 (v_mfma_f32_32x32x2_f32).  PREC 1: "bf16x3" - both operands are split into a bf16
 // head and a bf16 tail (a = ah + al, |a - ah - al| <= 2^-18 |a|) and the product is formed as
 // ah*bh + al*bh + ah*bl with fp32 accumulation on v_mfma_f32_32x32x16_bf16: 3 matrix instructions at
 // 16x the fp32 rate, per-product error ~1e-5 (the dropped al*bl term), i.e. ~1e-6 on a 256-term dot.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#ifndef HD_GEMM_ABL
+#define HD_GEMM_ABL 0
+#endif
+#ifndef HD_EDGE_PERSIST
+#define HD_EDGE_PERSIST 0
+#endif
 #ifndef HD_EDGE_GRP
 #define HD_EDGE_GRP 2
 #endif
@@ -402,14 +396,6 @@ HD_DEVINL void lds_read4(V (&f)[4], unsigned addr) {
 template <int N, typename V>
 HD_DEVINL void lds_wait4(V (&f)[4]) {
     asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]) : "i"(N));
-}
-// compile-time loop: f(std::integral_constant<int, I>) for I = 0..N-1
-template <int I, int N, typename F>
-HD_DEVINL void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
 }
 
 // byte offset (from the lane's base) of a B fragment inside a chunk image
@@ -456,6 +442,10 @@ __global__ __launch_bounds__(256, HD_EDGE_WPS) void k_edge(EdgeArgs a) {
         wt_count = slot < len ? (len - slot + wt_step - 1) / wt_step : 0;
     }
     if (wt_count == 0) return;
+    // HD_EDGE_PERSIST == 0 (default): the host launches one workgroup per workgroup-tile and the loop below runs
+    // once.  Measured on MI355X the persistent form is no faster (118.5 vs 121.5 us) and its longer live
+    // ranges cost ~25 spilled registers, so the single-pass form ships; the walk stays for experiments.
+    const int n_it = HD_EDGE_PERSIST ? wt_count : 1;
 
     for (int k = tid; k < 2 * H; k += 256) wrd_s[k] = a.wrd[k];
     auto issue_chunk = [&](int c, int buf) {
@@ -483,10 +473,10 @@ __global__ __launch_bounds__(256, HD_EDGE_WPS) void k_edge(EdgeArgs a) {
 
     int gc = 0;                                            // global chunk counter: buffer = gc & 1
 #pragma unroll 1
-    for (int it = 0; it < wt_count; ++it) {
+    for (int it = 0; it < n_it; ++it) {
         const int tile = (wt_first + it * wt_step) * 4 + wave;
         const bool tile_ok = tile < a.n_tiles;
-        const bool last_it = it + 1 == wt_count;
+        const bool last_it = it + 1 == n_it;
 
         f32x4 xi = *reinterpret_cast<const f32x4*>(a.xcur + (size_t)ni * 4);
         f32x4 xj = *reinterpret_cast<const f32x4*>(a.xcur + (size_t)nj * 4);
@@ -577,29 +567,19 @@ __global__ __launch_bounds__(256, HD_EDGE_WPS) void k_edge(EdgeArgs a) {
             const unsigned wb_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)wb + lane * 16;
             if constexpr (PREC == 0) {
                 // chunk image: [4 q][NCT][64 lanes][4 floats]: fragment (q, ct) holds k = 32c + 16h + 4q + j, j = 0..3,
-                // of column 32ct + n.  Four fragments (16 MFMAs) per group, next group's reads in flight.
-                constexpr int NG = NCT;                     // 4*NCT fragments / 4
-                f32x4 f0[4], f1[4];
-                lds_read4<f32x4, frag_off_f32(0), frag_off_f32(1), frag_off_f32(2), frag_off_f32(3)>(f0, wb_lds);
-                static_for<0, NG>([&](auto Gc) {
-                    constexpr int g = decltype(Gc)::value;
-                    f32x4(&cur)[4] = (g & 1) ? f1 : f0;
-                    f32x4(&nxt)[4] = (g & 1) ? f0 : f1;
-                    if constexpr (g + 1 < NG) {
-                        constexpr int u = 4 * (g + 1);
-                        lds_read4<f32x4, frag_off_f32(u), frag_off_f32(u + 1), frag_off_f32(u + 2), frag_off_f32(u + 3)>(nxt, wb_lds);
-                        lds_wait4<4>(cur);
-                    } else {
-                        lds_wait4<0>(cur);
-                    }
+                // of column 32ct + n (64-cycle fp32 MFMAs hide the LDS latency without explicit prefetch).
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 bv[NCT];
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct)
+                        bv[ct] = *reinterpret_cast<const f32x4*>(wb + ((q * NCT + ct) * 64 + lane) * 4);
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const int u = 4 * g + k, q = u / NCT, ct = u % NCT;
-                            acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(Pc[4 * q + j], cur[k][j], acc[ct], 0, 0, 0);
-                        }
-                });
+                        for (int ct = 0; ct < NCT; ++ct)
+                            acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(Pc[4 * q + j], bv[ct][j], acc[ct], 0, 0, 0);
+                }
 #pragma unroll
                 for (int i = 0; i < 16; ++i) Pc[i] = Pn[i];
             } else {
@@ -766,6 +746,25 @@ __global__ void k_xupd(XupdArgs a) {
     x[1] = (x[1] + sy / a.norm) * m;
     x[2] = (x[2] + sz / a.norm) * m;
     *reinterpret_cast<f32x4*>(a.xcur + (size_t)i * 4) = x;
+}
+
+// agg_i = (sum of node i's partial neighbour sums, fixed order) / normalization_factor   (egnn_new.py:52-56,280-282)
+struct AggArgs {
+    const float* part;    // [P][H]
+    const int* pstart;    // [M+1]
+    float* agg;           // [M_pad][H]
+    float norm;
+    int M, H;
+};
+
+__global__ void k_agg(AggArgs a) {
+    const int q = a.H >> 2;                                   // float4 per row
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = idx / q, c4 = idx - i * q;
+    if (i >= a.M) return;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    for (int p = a.pstart[i]; p < a.pstart[i + 1]; ++p) v += *reinterpret_cast<const f32x4*>(a.part + (size_t)p * a.H + 4 * c4);
+    *reinterpret_cast<f32x4*>(a.agg + (size_t)i * a.H + 4 * c4) = v / a.norm;
 }
 
 // ----------------------------------------------------------------------------- output stage
