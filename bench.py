@@ -31,7 +31,9 @@ if REPO not in sys.path:
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+# /opt/skills/guides/MI355X_MICROARCH.md, dense matrix peaks: v_mfma_f32_32x32x2_f32 157.3 TFLOP/s,
+# bf16 MFMA ~2.5 PFLOP/s.  The bf16x3 path executes 3 bf16 MFMA flops per algorithmic flop.
+MFMA_PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0}
 
 
 def edge_flops_per_launch(n_edges: int, H: int) -> float:
@@ -58,6 +60,8 @@ def main() -> None:
     ap.add_argument("--layers", type=int, default=6)
     ap.add_argument("--hidden", type=int, default=256)
     ap.add_argument("--timesteps", type=int, default=1000)
+    ap.add_argument("--precision", choices=["bf16x3", "fp32"], default="bf16x3",
+                    help="matrix-core arithmetic of the H x H contractions (both meet the 1e-4 parity bar)")
     ap.add_argument("--graph", action="store_true", help="replay each diffusion step from a captured hipGraph")
     ap.add_argument("--no-graph", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--event-stride", type=int, default=8,
@@ -93,6 +97,7 @@ def main() -> None:
         sd = synthetic_state_dict(9, 0, H, L, S, True, seed=0, coord_gain=1.0)
         model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
     model = model.to(dev)
+    model.dynamics.precision = args.precision
     if world > 1:
         broadcast_model_weights(model, src=0)          # one RCCL broadcast of the packed parameters
     # The timed region brackets the dominant kernel's launches with HIP events (roofline.achieved), which a
@@ -147,11 +152,19 @@ def main() -> None:
             if os.path.exists(tpath) and (B, N, H) == (256, 30, 256):
                 with open(tpath) as fh:
                     traffic = json.load(fh).get("hbm_bytes_per_launch")
+            peak = MFMA_PEAK_TFLOPS[args.precision]
             roofline = {"bound": "mfma", "kernel": "k_edge<256> (GCL + coordinate variants)",
-                        "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                        "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                        "frac": round(achieved / peak, 4), "traffic": traffic,
                         "launches": int(cnt[0]), "avg_launch_us": round(avg_s * 1e6, 2),
                         "flops_per_launch": fl}
+            if args.precision == "bf16x3":
+                # fp32 operands are split head+tail: each algorithmic flop costs 3 bf16 MFMA flops
+                roofline["executed_mfma_tflops"] = round(3 * achieved, 2)
+                roofline["executed_frac"] = round(3 * achieved / peak, 4)
+                roofline["note"] = ("fp32-accurate contraction emulated with 3 bf16 MFMAs per product (bf16x3); "
+                                    "achieved counts algorithmic flops; a pure bf16 MFMA loop on random data "
+                                    "sustains 1734 TFLOP/s on this chip (scratch/mb/mb.hip)")
 
     if rank != 0:
         if world > 1:
@@ -166,10 +179,12 @@ def main() -> None:
         "metric": "sampled molecules/sec (1000 diffusion steps, B=256, N=30)",
         "value": round(value, 3), "unit": "molecules/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 (bf16x3 split MFMA, fp32 accumulate)" if args.precision == "bf16x3" else "f32", "data": "synthetic",
         "config": {"workload": f"DiffusionQM9.sample: {T}-step reverse diffusion + decode ({n_fwd} EGNN forwards), "
                                f"B={B} per GPU, N={N} all valid, H={H}, L={L}, S=2",
                    "batch_per_gpu": B, "n_nodes": N, "hidden_nf": H, "n_layers": L, "timesteps": T,
+                   "precision": args.precision,
                    "launch": "hipGraph replay" if model.use_graph else "plain launches",
                    "parallelism": f"{world} independent shards, RCCL weight broadcast only"},
         "ms_per_forward": round(elapsed / args.steps / n_fwd * 1e3, 4),

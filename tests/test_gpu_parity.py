@@ -25,10 +25,12 @@ def build_dynamics(sd_np, H, L, C_=0, **kw):
     return m.to(DEV)
 
 
-def build_diffusion(sd_np, H, L, C_=0, T=1000):
+def build_diffusion(sd_np, H, L, C_=0, T=1000, precision=None):
     from hierdiff_amd import DiffusionQM9, default_config
     m = DiffusionQM9(default_config(hidden_nf=H, n_layers=L, context_node_nf=C_, timesteps=T))
     m.load_state_dict({k: torch.from_numpy(np.asarray(v).copy()) for k, v in sd_np.items()})
+    if precision is not None:
+        m.dynamics.precision = precision
     return m.to(DEV)
 
 
@@ -42,7 +44,7 @@ FORWARD_FIXTURES = ["f1_cfg1_h256_l3", "f1b_cfg1_h256_l3_gain1", "f7_h32_l2", "f
                     "f6_b16_n30_h256_l9", "f6b_n48_h256_l6"]
 
 
-PRECISIONS = ["fp32", "bf16x3"]
+PRECISIONS = ["fp32", "bf16x3"]     # exact-fp32 matrix path / 3-term bf16 split; both must meet the same bar
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
@@ -74,11 +76,12 @@ def test_forward_golden(name, precision):
     print(f"{name} [{precision}]: worst rel_l2 {worst:.2e}")
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("name", ["f3_cond_h256_l3", "f3_cond_h32_l2"])
-def test_conditional_step_golden(name):
+def test_conditional_step_golden(name, precision):
     fx = load(name)
     sd_np, _, _ = fixture_model(fx, context_node_nf=1)
-    model = build_diffusion(sd_np, int(fx["hidden_nf"]), int(fx["n_layers"]), C_=1)
+    model = build_diffusion(sd_np, int(fx["hidden_nf"]), int(fx["n_layers"]), C_=1, precision=precision)
     z, nm, em, ctx = (torch.from_numpy(fx[k]).to(DEV) for k in ("z", "node_mask", "edge_mask", "context"))
     mol = int(fx["mol_shape"])
     s, t = torch.from_numpy(fx["s"]).to(DEV), torch.from_numpy(fx["t"]).to(DEV)
@@ -91,13 +94,14 @@ def test_conditional_step_golden(name):
     assert_parity(zs.cpu().numpy(), fx["zs"], name + " zs")
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("name,graph", [("f5_chain_h256_l3", False), ("f5_chain_h256_l3", True),
                                         ("f5_chain_h32_l2", True)])
-def test_chain_golden(name, graph):
+def test_chain_golden(name, graph, precision):
     fx = load(name)
     sd_np, _, _ = fixture_model(fx)
     T = int(fx["T"])
-    model = build_diffusion(sd_np, int(fx["hidden_nf"]), int(fx["n_layers"]), T=T)
+    model = build_diffusion(sd_np, int(fx["hidden_nf"]), int(fx["n_layers"]), T=T, precision=precision)
     model.use_graph = graph
     model.schedule_gammas = fx["gamma_grid"]        # replay the schedule values the reference run used
     n_list = [int(v) for v in fx["n_list"]]
