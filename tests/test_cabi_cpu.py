@@ -117,3 +117,33 @@ def test_unsupported_modes_raise():
                dict(act_fn="relu"), dict(hidden_nf=48)):
         with pytest.raises(NotImplementedError):
             EGNN_dynamics_QM9(9, 0, 3, **kw)
+
+
+def test_sample_results_wire_format(tmp_path):
+    """`sample_results.pkl` = pickle((results, test_names)); the stage-2 consumer does pickle.load(f)[0] and reads
+    'x' [n,3] / 'h' [n,8] float tensors per molecule (generation/ar_sampling_nosize.py:328-329,387-388)."""
+    import pickle
+    from hierdiff_amd.sampler import load_reference_state_dict, read_results, write_results
+    res = [{"x": torch.randn(5, 3), "h": torch.randn(5, 8)}, {"x": torch.randn(2, 3), "h": torch.randn(2, 8)}]
+    path = tmp_path / "sample_results.pkl"
+    write_results(str(path), res)
+    with open(path, "rb") as f:
+        blob = pickle.load(f)
+    assert isinstance(blob, tuple) and len(blob) == 2 and blob[1] == []
+    got = blob[0]
+    assert len(got) == 2 and torch.equal(got[0]["x"], res[0]["x"]) and got[1]["h"].shape == (2, 8)
+    assert torch.round(got[0]["h"][:, :5]).shape == (5, 5)          # what the consumer does with it
+    r2, names = read_results(str(path))
+    assert names == [] and torch.equal(r2[1]["h"], res[1]["h"])
+    # a Lightning-style checkpoint with the reference's optional 'model.' prefix loads key-for-key
+    from hierdiff_amd import DiffusionQM9, default_config
+    from hierdiff_amd.weights import synthetic_state_dict
+    syn = synthetic_state_dict(9, 0, 32, 1)
+    ck = tmp_path / "diffusion.ckpt"
+    torch.save({"state_dict": {("model." + k if i % 2 else k): torch.from_numpy(v.copy()) for i, (k, v) in enumerate(syn.items())},
+                "epoch": 3}, ck)
+    sd = load_reference_state_dict(str(ck))
+    assert sorted(sd) == sorted(syn)
+    m = DiffusionQM9(default_config(hidden_nf=32, n_layers=1))
+    m.load_state_dict(sd)
+    assert np.array_equal(m.state_dict()["dynamics.egnn.embedding.weight"].numpy(), syn["dynamics.egnn.embedding.weight"])
