@@ -367,6 +367,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef HD_GEMM_ABL
 #define HD_GEMM_ABL 0
 #endif
+#ifndef HD_EDGE_PRIO
+#define HD_EDGE_PRIO 0
+#endif
 #ifndef HD_EDGE_PERSIST
 #define HD_EDGE_PERSIST 0
 #endif
@@ -588,6 +591,9 @@ __global__ __launch_bounds__(256, HD_EDGE_WPS) void k_edge(EdgeArgs a) {
                 // three MFMAs (head*head, tail*head, head*tail) on one accumulator, two units per group.
                 constexpr int NG = NCT;                     // 2*NCT units / 2
                 bf16x8 f0[4], f1[4];
+#if HD_EDGE_PRIO
+                __builtin_amdgcn_s_setprio(HD_EDGE_PRIO);
+#endif
                 lds_read4<bf16x8, frag_off_bf<NCT>(0, 0), frag_off_bf<NCT>(0, 1), frag_off_bf<NCT>(1, 0), frag_off_bf<NCT>(1, 1)>(f0, wb_lds);
                 static_for<0, NG>([&](auto Gc) {
                     constexpr int g = decltype(Gc)::value;
@@ -610,6 +616,9 @@ __global__ __launch_bounds__(256, HD_EDGE_WPS) void k_edge(EdgeArgs a) {
                     acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(phc[s0], cur[1], acc[c0], 0, 0, 0);
                     acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(phc[s1], cur[3], acc[c1], 0, 0, 0);
                 });
+#if HD_EDGE_PRIO
+                __builtin_amdgcn_s_setprio(0);
+#endif
 #pragma unroll
                 for (int st = 0; st < 2; ++st) { phc[st] = phn[st]; plc[st] = pln[st]; }
             }

@@ -71,6 +71,29 @@ def _get(cfg, key, default=None):
         return getattr(cfg, key, default)
 
 
+RESIDUE_LIST = ["ALA", "ARG", "ASN", "ASP", "CYS", "GLN", "GLU", "GLY", "HIS", "ILE", "LEU", "LYS", "MET", "PHE", "PRO",
+                "SER", "THR", "TRP", "TYR", "VAL"]
+
+
+def pocket_tensors(protein_data_all):
+    """Padded pocket tensors [feat (long, 0 = pad), pos, node_mask, edge_mask] as `sample_batches` builds them
+    (diffusion_qm9.py:399-420): residue type index + 1, all-pairs-minus-diagonal edge mask per pocket."""
+    feats = [torch.tensor([RESIDUE_LIST.index(r) + 1 for r in p["residue_type"]]) for p in protein_data_all]
+    poss = [torch.tensor(np.array(p["coord"])) for p in protein_data_all]
+    n, pmax = len(feats), max(f.shape[0] for f in feats)
+    feat = torch.zeros(n, pmax, dtype=torch.long)
+    pos = torch.zeros(n, pmax, 3)
+    nmask = torch.zeros(n, pmax, 1, dtype=torch.bool)
+    emask = torch.zeros(n, pmax, pmax, dtype=torch.bool)
+    for i, (f, p) in enumerate(zip(feats, poss)):
+        k = f.shape[0]
+        feat[i, :k] = f
+        pos[i, :k] = p
+        nmask[i, :k, 0] = True
+        emask[i, :k, :k] = ~torch.eye(k, dtype=torch.bool)
+    return [feat, pos, nmask, emask]
+
+
 class DiffusionQM9(_Base):
     """Sampler with the reference's constructor contract: `DiffusionQM9(cfg)` where `cfg` carries the
     keys of conf/model/ddpmgblur.yaml (diffusion_qm9.py:37-115)."""
@@ -79,8 +102,6 @@ class DiffusionQM9(_Base):
         super().__init__()
         self.cfg = cfg
         self.pocket = bool(_get(cfg, "pocket", False))
-        if self.pocket:
-            raise NotImplementedError("pocket-conditioned sampling is a 'next' row (SURVEY.md section 8f rank 3)")
         self.node_coarse_type = _get(cfg, "node_coarse_type")
         if self.node_coarse_type == "prop":
             self.in_node_nf = 8
@@ -88,6 +109,8 @@ class DiffusionQM9(_Base):
             self.in_node_nf = 3
         else:
             raise NotImplementedError("node_coarse_type should be prop or elem")
+        if self.pocket:
+            self.pocket_embed = nn.Embedding(21, self.in_node_nf)       # diffusion_qm9.py:55-56
         dyn = dict(_get(cfg, "dynamics"))
         dyn["in_node_nf"] = self.in_node_nf
         assert _get(cfg, "loss_type") in {'vlb', 'l2'}
@@ -281,12 +304,15 @@ class DiffusionQM9(_Base):
     @torch.no_grad()
     def sample_from_masks(self, node_mask: torch.Tensor, edge_mask: Optional[torch.Tensor], context=None,
                           fix_noise: bool = False, raw_noises: Optional[Sequence[Tuple[torch.Tensor, torch.Tensor]]] = None,
-                          sample_id_base: int = 0, z_init: Optional[torch.Tensor] = None):
+                          sample_id_base: int = 0, z_init: Optional[torch.Tensor] = None, pocket=None):
         """z_T -> (x, h) for given masks: draw z_T, T posterior steps, final decode.
 
         raw_noises: optional T+2 (randn_x[b,N,3], randn_h[b,N,F]) pairs in the reference's draw order
         (z_T, steps s=T-1..0, decode) for bit-for-bit comparable trajectories; otherwise noise comes
-        from `noise_mode` ("philox": sample ids sample_id_base + b, independent of batch split)."""
+        from `noise_mode` ("philox": sample ids sample_id_base + b, independent of batch split).
+        pocket: optional (pos [B,P,3], feat [B,P,F] already embedded, node_mask [B,P,1], edge_mask [B,P,P]) of fixed
+        residue nodes: appended to z for every network call with a block-diagonal edge mask and never updated
+        (diffusion_qm9.py:362-371,381-382); the final decode sees the molecule alone (:386-387)."""
         dev = node_mask.device
         if dev.type != "cuda":
             raise _lib.HierDiffHipError("sampling runs only on an MI355X (no CPU fallback)")
@@ -301,7 +327,31 @@ class DiffusionQM9(_Base):
             if context is None:
                 raise ValueError("context required")
             ctx = context.to(dev, torch.float32).reshape(B * N, -1).contiguous()
+        topo_loop, tail = topo, None
+        if pocket is not None:
+            if ctx is not None or self.noise_mode == "torch":
+                raise NotImplementedError("pocket conditioning: context=None and library/injected noise only")
+            p_pos, p_feat, p_nm, p_em = pocket
+            P = p_pos.shape[1]
+            tail = torch.cat([p_pos.to(dev, torch.float32), p_feat.to(dev, torch.float32)], dim=-1)
+            nmb = node_mask.to(torch.bool)
+            em_mol = edge_mask.to(torch.bool).reshape(B, N, N) if edge_mask is not None else \
+                (nmb & nmb.transpose(1, 2) & ~torch.eye(N, dtype=torch.bool, device=dev)[None])
+            self._nm_cat = torch.cat([nmb, p_nm.to(dev).bool()], dim=1)
+            self._em_cat = torch.zeros(B, N + P, N + P, dtype=torch.bool, device=dev)
+            self._em_cat[:, :N, :N] = em_mol
+            self._em_cat[:, N:, N:] = p_em.to(dev).bool()
+            topo_loop = self.dynamics.topology(self._nm_cat, self._em_cat, B, N + P)
         stream = _stream(dev)
+
+        def run_loop(z_mol, rx, rh, rows, seed, base):
+            """T posterior steps on [B,N,D]; with a pocket the fixed rows ride along behind the molecule."""
+            zz = z_mol if tail is None else torch.cat([z_mol, tail], dim=1).contiguous()
+            _lib.check(lib.hd_sample_loop(h, topo_loop.ptr, zz.data_ptr(), _ptr(ctx), -1 if tail is None else N, T, 0,
+                                          _ptr(rx), _ptr(rh), rows, seed, base, int(self.use_graph), stream),
+                       "hd_sample_loop")
+            return zz if tail is None else zz[:, :N].contiguous()
+
         nb = 1 if fix_noise else B
         T = self.T
         z = torch.empty((B, N, D), device=dev, dtype=torch.float32)
@@ -313,9 +363,7 @@ class DiffusionQM9(_Base):
                                     z.data_ptr(), stream), "hd_noise")
             step_x = torch.stack(rx[1:T + 1]).contiguous()
             step_h = torch.stack(rh[1:T + 1]).contiguous()
-            _lib.check(lib.hd_sample_loop(h, topo.ptr, z.data_ptr(), _ptr(ctx), -1, T, 0, step_x.data_ptr(),
-                                          step_h.data_ptr(), step_x.shape[1], 0, 0, int(self.use_graph), stream),
-                       "hd_sample_loop")
+            z = run_loop(z, step_x, step_h, step_x.shape[1], 0, 0)
             final_raw = (rx[T + 1], rh[T + 1])
         elif self.noise_mode == "torch":
             z = self.sample_combined_position_feature_noise(nb, N, node_mask)
@@ -334,8 +382,7 @@ class DiffusionQM9(_Base):
             else:
                 _lib.check(lib.hd_noise(h, topo.ptr, None, None, nb, self.seed, sample_id_base, 0, int(fix_noise),
                                         z.data_ptr(), stream), "hd_noise")
-            _lib.check(lib.hd_sample_loop(h, topo.ptr, z.data_ptr(), _ptr(ctx), -1, T, 0, None, None, nb, self.seed,
-                                          sample_id_base, int(self.use_graph), stream), "hd_sample_loop")
+            z = run_loop(z, None, None, nb, self.seed, sample_id_base)
             # decode noise: draw T+1 of the same counter stream, materialised through hd_noise's raw form
             final_raw = "philox"
         self._check_mean_zero(z[:, :, :self.n_dims], node_mask)
@@ -352,8 +399,6 @@ class DiffusionQM9(_Base):
     @torch.no_grad()
     def sample(self, num_samples, device, context=None, pocket_cond=None, sample_id_base: int = 0):
         """diffusion_qm9.py:347-395: list of {'x': [n_i,3], 'h': [n_i,8], ('context': [n_i,1])} on the CPU."""
-        if pocket_cond is not None:
-            raise NotImplementedError("pocket-conditioned sampling is a 'next' row (SURVEY.md section 8f rank 3)")
         device = torch.device(device)
         sample_n = self.nodes_dist.sample(num_samples)
         n_max = max(sample_n)
@@ -363,7 +408,14 @@ class DiffusionQM9(_Base):
         if context is not None:
             context = torch.zeros([num_samples, n_max, 1]).to(device) + context
         node_mask = node_mask.to(device)
-        x, h = self.sample_from_masks(node_mask, None, context, sample_id_base=sample_id_base)
+        pocket = None
+        if pocket_cond is not None:
+            if not self.pocket:
+                raise ValueError("pocket_cond given but the model was built with cfg.pocket = False")
+            pocket = (pocket_cond[1].to(device, torch.float32),
+                      self.pocket_embed(pocket_cond[0].to(device).long()).to(torch.float32),
+                      pocket_cond[2].to(device).bool(), pocket_cond[3].to(device).bool())
+        x, h = self.sample_from_masks(node_mask, None, context, sample_id_base=sample_id_base, pocket=pocket)
         x, h = x.cpu(), h.cpu()
         xs = [x[i, :sample_n[i]].clone() for i in range(num_samples)]
         hs = [h[i, :sample_n[i]].clone() for i in range(num_samples)]
@@ -374,14 +426,28 @@ class DiffusionQM9(_Base):
 
     def sample_batches(self, batch_size, num_batches, device, context_range=None, protein_data_all=None,
                        sample_id_base: int = 0):
-        """diffusion_qm9.py:397-436 (protein branch not supported)."""
+        """diffusion_qm9.py:397-436, incl. the protein branch (`protein_data_all`: list of dicts with
+        'residue_type', 'coord', 'pocket_name', 'ligand_name')."""
+        protein_cond_all = None
         if protein_data_all is not None:
-            raise NotImplementedError("pocket-conditioned sampling is a 'next' row (SURVEY.md section 8f rank 3)")
+            protein_cond_all = pocket_tensors(protein_data_all)
         results, test_names = [], []
         for i in range(num_batches):
-            ctx = None if context_range is None else context_range[i % len(context_range)]
-            results.extend(self.sample(batch_size, device, context=ctx, pocket_cond=None,
-                                       sample_id_base=sample_id_base + i * batch_size))
+            lo, hi = i * batch_size, (i + 1) * batch_size
+            base = sample_id_base + lo
+            if protein_cond_all is not None:
+                n_prot = len(protein_cond_all[0])
+                cond = [x[lo % n_prot: (hi - 1) % n_prot + 1] for x in protein_cond_all]
+                # the reference indexes the names modulo len(protein_cond_all) == 4 (diffusion_qm9.py:428); kept as is
+                names = [protein_data_all[k]['pocket_name'] + '/' + protein_data_all[k]['ligand_name']
+                         for k in range(lo % len(protein_cond_all), hi % len(protein_cond_all))]
+                results.extend(self.sample(batch_size, device, context=None, pocket_cond=cond, sample_id_base=base))
+                test_names.extend(names)
+            elif context_range is not None:
+                results.extend(self.sample(batch_size, device, context=context_range[i % len(context_range)],
+                                           pocket_cond=None, sample_id_base=base))
+            else:
+                results.extend(self.sample(batch_size, device, context=None, pocket_cond=None, sample_id_base=base))
         return results, test_names
 
 

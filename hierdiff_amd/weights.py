@@ -123,10 +123,14 @@ def synthetic_gamma_state_dict(seed: int = 0) -> "OrderedDict[str, np.ndarray]":
 
 def synthetic_state_dict(in_node_nf: int, context_node_nf: int, hidden_nf: int, n_layers: int,
                          inv_sublayers: int = 2, attention: bool = True, seed: int = 0,
-                         coord_gain: float = 0.001) -> "OrderedDict[str, np.ndarray]":
+                         coord_gain: float = 0.001, pocket: bool = False) -> "OrderedDict[str, np.ndarray]":
     """Full DiffusionQM9 state_dict: `dynamics.*`, `gamma.*` and the `buffer` placeholder
-    (endiffusion/train_module/diffusion_qm9.py:95,72,105)."""
+    (endiffusion/train_module/diffusion_qm9.py:95,72,105); with `pocket` also the residue embedding
+    `pocket_embed.weight` [21, in_node_nf - 1] (:55-56, N(0,1) like nn.Embedding)."""
     sd: "OrderedDict[str, np.ndarray]" = OrderedDict()
+    if pocket:
+        sd["pocket_embed.weight"] = _rng_for("pocket_embed.weight", seed).standard_normal(
+            (21, in_node_nf - 1)).astype(np.float32)
     for k, v in synthetic_gamma_state_dict(seed).items():
         sd["gamma." + k] = v
     for k, v in synthetic_dynamics_state_dict(in_node_nf, context_node_nf, hidden_nf, n_layers,

@@ -65,9 +65,9 @@ def import_reference():
     return DiffusionQM9
 
 
-def make_cfg(hidden_nf, n_layers, context_node_nf=0, normalization_factor=10, inv_sublayers=2):
+def make_cfg(hidden_nf, n_layers, context_node_nf=0, normalization_factor=10, inv_sublayers=2, pocket=False):
     return AttrDict(
-        pocket=False, node_coarse_type="prop", loss_type="vlb", hcontinous=True,
+        pocket=pocket, node_coarse_type="prop", loss_type="vlb", hcontinous=True,
         noise_schedule="learned", timesteps=1000, norm_values=[1.0, 1.0, 1.0],
         norm_biases=[None, 0.0, 0.0], parametrization="eps", include_charges=True, dataset="qm9",
         data_augmentation=False,
@@ -81,11 +81,11 @@ def make_cfg(hidden_nf, n_layers, context_node_nf=0, normalization_factor=10, in
     )
 
 
-def build_reference(DiffusionQM9, hidden_nf, n_layers, context_node_nf=0, seed=0, coord_gain=0.001):
-    cfg = make_cfg(hidden_nf, n_layers, context_node_nf)
+def build_reference(DiffusionQM9, hidden_nf, n_layers, context_node_nf=0, seed=0, coord_gain=0.001, pocket=False):
+    cfg = make_cfg(hidden_nf, n_layers, context_node_nf, pocket=pocket)
     with contextlib.redirect_stdout(io.StringIO()):
         model = DiffusionQM9(cfg)
-    sd_np = synthetic_state_dict(9, context_node_nf, hidden_nf, n_layers, 2, True, seed, coord_gain)
+    sd_np = synthetic_state_dict(9, context_node_nf, hidden_nf, n_layers, 2, True, seed, coord_gain, pocket=pocket)
     model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd_np.items()})
     model.eval()
     ocfg = orc.DynCfg(in_node_nf=9, context_node_nf=context_node_nf, hidden_nf=hidden_nf,
@@ -307,6 +307,66 @@ def fixture_chain(DiffusionQM9, name, hidden_nf, n_layers, seed, coord_gain, T, 
          weight_seed=seed, coord_gain=coord_gain)
 
 
+def fixture_pocket(DiffusionQM9, name, hidden_nf, n_layers, seed, coord_gain, T, n_list, p_list):
+    """F8: pocket-conditioned DiffusionQM9.sample (diffusion_qm9.py:362-382): fixed residue nodes appended every
+    step, block-diagonal edge mask, T patched small, N pinned, noise recorded."""
+    model, sd, ocfg = build_reference(DiffusionQM9, hidden_nf, n_layers, 0, seed, coord_gain, pocket=True)
+    model.T = T
+    model.nodes_dist.sample = lambda n: list(n_list)
+    B, N, P = len(n_list), max(n_list), max(p_list)
+    rng = np.random.Generator(np.random.PCG64(seed + 21))
+    p_feat = torch.zeros(B, P, dtype=torch.long)
+    p_pos = torch.zeros(B, P, 3)
+    p_nm = torch.zeros(B, P, 1, dtype=torch.bool)
+    p_em = torch.zeros(B, P, P, dtype=torch.bool)
+    for b, pn in enumerate(p_list):
+        p_feat[b, :pn] = torch.from_numpy(rng.integers(1, 21, size=pn))
+        p_pos[b, :pn] = torch.from_numpy((rng.standard_normal((pn, 3)) * 2.0).astype(np.float32))
+        p_nm[b, :pn] = True
+        p_em[b, :pn, :pn] = ~torch.eye(pn, dtype=torch.bool)
+    raws = [(torch.from_numpy(rng.standard_normal((B, N, 3)).astype(np.float32)),
+             torch.from_numpy(rng.standard_normal((B, N, 8)).astype(np.float32))) for _ in range(T + 2)]
+    queue = [r for pair in raws for r in pair]
+    orig_randn = torch.randn
+
+    def fake_randn(size, device=None, **kw):
+        r = queue.pop(0)
+        assert tuple(r.shape) == tuple(size), (r.shape, size)
+        return r.clone()
+
+    seen = []
+    hook = model.gamma.register_forward_hook(
+        lambda m, a, o: seen.append((float(a[0][0, 0]), float(o[0, 0]), bool((o == o[0:1]).all()))))
+    torch.randn = fake_randn
+    try:
+        with torch.no_grad():
+            res = model.sample(B, "cpu", pocket_cond=[p_feat, p_pos, p_nm, p_em])
+    finally:
+        torch.randn = orig_randn
+        hook.remove()
+    assert not queue
+    assert all(eq for _, _, eq in seen)
+    gamma_grid = np.full(T + 1, np.nan, np.float32)
+    for tau, g, _ in seen:
+        gamma_grid[int(round(tau * T))] = g
+    nm, em = orc.canonical_masks(n_list)
+    with torch.no_grad():
+        emb = model.pocket_embed(p_feat)
+    x_got, h_got = orc.sample_chain(sd, ocfg, T, nm, em, None, raws, pocket=(p_pos, emb, p_nm, p_em))
+    x_ref = np.zeros((B, N, 3), np.float32)
+    h_ref = np.zeros((B, N, 8), np.float32)
+    for b, r in enumerate(res):
+        x_ref[b, :n_list[b]] = r["x"].numpy()
+        h_ref[b, :n_list[b]] = r["h"].numpy()
+    nmf = nm.float().numpy()
+    check(f"{name} x", x_got.numpy() * nmf, x_ref, tol=2e-5)
+    check(f"{name} h", h_got.numpy(), h_ref, tol=2e-5)
+    save(name, raw_x=np.stack([r[0].numpy() for r in raws]), raw_h=np.stack([r[1].numpy() for r in raws]),
+         n_list=np.array(n_list), p_list=np.array(p_list), pocket_feat=p_feat.numpy(), pocket_pos=p_pos.numpy(),
+         pocket_node_mask=p_nm.numpy(), pocket_edge_mask=p_em.numpy(), x=x_ref, h=h_ref, T=T, gamma_grid=gamma_grid,
+         hidden_nf=hidden_nf, n_layers=n_layers, weight_seed=seed, coord_gain=coord_gain)
+
+
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
     torch.manual_seed(0)
@@ -334,6 +394,8 @@ def main():
     # F5: 3-step chain
     fixture_chain(DiffusionQM9, "f5_chain_h256_l3", 256, 3, 9, 1.0, 3, [8, 5, 3, 7])
     fixture_chain(DiffusionQM9, "f5_chain_h32_l2", 32, 2, 10, 1.0, 4, [6, 1, 4, 5])
+    # F8: pocket-conditioned sampling (fixed residue nodes, block-diagonal masks)
+    fixture_pocket(DiffusionQM9, "f8_pocket_h64_l2", 64, 2, 13, 1.0, 3, [7, 4, 6, 5], [9, 12, 5, 12])
 
 
 if __name__ == "__main__":

@@ -99,3 +99,24 @@ def test_chain_matches_reference(name):
                                 gamma_grid=torch.from_numpy(fx["gamma_grid"]))
     assert_parity(x.numpy() * nm.float().numpy(), fx["x"], name + " x", 2e-5, 2e-4)
     assert_parity(h.numpy(), fx["h"], name + " h", 2e-5, 2e-4)
+
+
+def test_pocket_chain_matches_reference():
+    """F8: pocket-conditioned sampling (fixed residue nodes appended each step, block-diagonal edge mask)."""
+    fx = load("f8_pocket_h64_l2")
+    from hierdiff_amd.weights import synthetic_state_dict
+    H, L = int(fx["hidden_nf"]), int(fx["n_layers"])
+    sd_np = synthetic_state_dict(9, 0, H, L, 2, True, int(fx["weight_seed"]), float(fx["coord_gain"]), pocket=True)
+    sd = orc.as_torch_sd(sd_np)
+    cfg = orc.DynCfg(hidden_nf=H, n_layers=L)
+    n_list = [int(v) for v in fx["n_list"]]
+    nm, em = orc.canonical_masks(n_list)
+    T = int(fx["T"])
+    raws = [(torch.from_numpy(fx["raw_x"][i]), torch.from_numpy(fx["raw_h"][i])) for i in range(T + 2)]
+    emb = sd["pocket_embed.weight"][torch.from_numpy(fx["pocket_feat"]).long()]
+    with torch.no_grad():
+        x, h = orc.sample_chain(sd, cfg, T, nm, em, None, raws, gamma_grid=torch.from_numpy(fx["gamma_grid"]),
+                                pocket=(torch.from_numpy(fx["pocket_pos"]), emb, torch.from_numpy(fx["pocket_node_mask"]),
+                                        torch.from_numpy(fx["pocket_edge_mask"])))
+    assert_parity(x.numpy() * nm.float().numpy(), fx["x"], "pocket x", 2e-5, 2e-4)
+    assert_parity(h.numpy(), fx["h"], "pocket h", 2e-5, 2e-4)
