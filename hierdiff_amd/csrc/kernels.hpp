@@ -563,9 +563,11 @@ __global__ __launch_bounds__(256, HD_EDGE_WPS) void k_edge(EdgeArgs a) {
             // recomputes the final chunk's operands and refetches its rows, results unused.
             float Pn[16];
             bf16x8 phn[2], pln[2];
-            make_P(c + 1 < NCH ? c + 1 : NCH - 1, Pn);
-            if constexpr (PREC == 1) split_P(Pn, phn, pln);
-            load_rows(c + 2 < NCH ? c + 2 : NCH - 1);
+            const int cn1 = c + 1 < NCH ? c + 1 : NCH - 1, cn2 = c + 2 < NCH ? c + 2 : NCH - 1;
+            if constexpr (PREC == 0) {
+                make_P(cn1, Pn);
+                load_rows(cn2);
+            }
             const float* wb = wbuf + buf * CHF;
             const unsigned wb_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)wb + lane * 16;
             if constexpr (PREC == 0) {
@@ -590,22 +592,51 @@ __global__ __launch_bounds__(256, HD_EDGE_WPS) void k_edge(EdgeArgs a) {
                 // W2[32ct + n][32c + 16h + 8s + i] - the same k order as P[8s + i].  Units u = (k-step, ct) of
                 // three MFMAs (head*head, tail*head, head*tail) on one accumulator, two units per group.
                 constexpr int NG = NCT;                     // 2*NCT units / 2
+                constexpr int PG = 16 / NG;                 // next-chunk operand values produced per group
+                // The next chunk's operand generation (VALU) is cut into NG slices, one per MFMA group, so the
+                // matrix pipe and the VALU alternate every ~6 MFMAs inside ONE wavefront instead of relying on
+                // the phase of the co-resident wavefront.  w_r / w_d come from LDS a slice pair ahead; the AB
+                // rows of chunk c+2 replace those of chunk c+1 as soon as their last value has been consumed.
+                const float* wr_n = wrd_s + 32 * cn1 + 16 * hh;
+                const float* wd_n = wrd_s + H + 32 * cn1 + 16 * hh;
+                f32x4 wrq[2], wdq[2];
+                wrq[0] = *reinterpret_cast<const f32x4*>(wr_n);
+                wdq[0] = *reinterpret_cast<const f32x4*>(wd_n);
                 bf16x8 f0[4], f1[4];
-#if HD_EDGE_PRIO
-                __builtin_amdgcn_s_setprio(HD_EDGE_PRIO);
-#endif
                 lds_read4<bf16x8, frag_off_bf<NCT>(0, 0), frag_off_bf<NCT>(0, 1), frag_off_bf<NCT>(1, 0), frag_off_bf<NCT>(1, 1)>(f0, wb_lds);
                 static_for<0, NG>([&](auto Gc) {
                     constexpr int g = decltype(Gc)::value;
                     bf16x8(&cur)[4] = (g & 1) ? f1 : f0;
                     bf16x8(&nxt)[4] = (g & 1) ? f0 : f1;
+                    lds_wait4<0>(cur);
                     if constexpr (g + 1 < NG) {
                         constexpr int u = 2 * (g + 1);
                         lds_read4<bf16x8, frag_off_bf<NCT>(u, 0), frag_off_bf<NCT>(u, 1), frag_off_bf<NCT>(u + 1, 0),
                                   frag_off_bf<NCT>(u + 1, 1)>(nxt, wb_lds);
-                        lds_wait4<4>(cur);
-                    } else {
-                        lds_wait4<0>(cur);
+                    }
+                    // slice g of the next chunk's operands
+#pragma unroll
+                    for (int v = 0; v < PG; ++v) {
+                        constexpr int dummy_ = 0; (void)dummy_;
+                        const int idx = g * PG + v, u = idx >> 2, j = idx & 3;
+                        if (j == 0 && u + 1 < 4) {           // w_r / w_d for the following four values
+                            wrq[(u + 1) & 1] = *reinterpret_cast<const f32x4*>(wr_n + 4 * (u + 1));
+                            wdq[(u + 1) & 1] = *reinterpret_cast<const f32x4*>(wd_n + 4 * (u + 1));
+                        }
+                        float pre = pa[u][j] + pb[u][j];
+                        pre = __builtin_fmaf(radial, wrq[u & 1][j], pre);
+                        pre = __builtin_fmaf(d0, wdq[u & 1][j], pre);
+                        float y;
+                        if constexpr (ABL & 2) y = pa[u][j]; else y = silu_p<PREC>(pre);
+                        const __bf16 yh = (__bf16)y;
+                        phn[idx >> 3][idx & 7] = yh;
+                        pln[idx >> 3][idx & 7] = (__bf16)(y - (float)yh);
+                        if (j == 3) {                        // rows of chunk c+2 into the freed registers
+                            if constexpr (!(ABL & 8)) {
+                                pa[u] = *reinterpret_cast<const f32x4*>(Arow + 32 * cn2 + 4 * u);
+                                pb[u] = *reinterpret_cast<const f32x4*>(Brow + 32 * cn2 + 4 * u);
+                            }
+                        }
                     }
                     constexpr int u0 = 2 * g, u1 = 2 * g + 1;
                     constexpr int s0 = u0 / NCT, c0 = u0 % NCT, s1 = u1 / NCT, c1 = u1 % NCT;
@@ -615,6 +646,13 @@ __global__ __launch_bounds__(256, HD_EDGE_WPS) void k_edge(EdgeArgs a) {
                     acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(plc[s1], cur[2], acc[c1], 0, 0, 0);
                     acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(phc[s0], cur[1], acc[c0], 0, 0, 0);
                     acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(phc[s1], cur[3], acc[c1], 0, 0, 0);
+#ifndef HD_NO_SCHED
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, HD_SCHED_VALU, 0);
+                    }
+#endif
                 });
 #if HD_EDGE_PRIO
                 __builtin_amdgcn_s_setprio(0);
