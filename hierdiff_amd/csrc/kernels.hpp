@@ -310,20 +310,33 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm(GemmArgs g) {
         });
     }
 
+    // Epilogue through LDS: the MFMA C layout gives each lane single floats of 16 different rows (16 dword
+    // stores per accumulator, store-issue bound); transposed through the now idle staging buffers every
+    // thread instead moves whole float4s (4x fewer, 16-byte wide, 256 B contiguous per 16 lanes).
+    constexpr int LDC_S = BN + 4;
+    static_assert(BM * LDC_S * 4 <= 2 * (A_BYTES + B_BYTES), "C tile must fit the staging buffers");
+    float* Cs = reinterpret_cast<float*>(smem_g);
 #pragma unroll
-    for (int cn = 0; cn < CN; ++cn) {
-        const int col = ctile * BN + 32 * (wc * CN + cn) + m;
-        const float bv = g.bias[col];
+    for (int cn = 0; cn < CN; ++cn)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            int row = row0 + 32 * wr + (r & 3) + 8 * (r >> 2) + 4 * hh;
-            if (row < g.M) {
-                float v = acc[cn][r] + bv;
-                float* dst = g.C + (size_t)row * g.ldc + col;
-                if (EPI == EPI_BIAS_SILU) v = silu_f(v);
-                if (EPI == EPI_RESID_MASK) v = (*dst + v) * g.nmask[row];
-                *dst = v;
+        for (int r = 0; r < 16; ++r)
+            Cs[(32 * wr + (r & 3) + 8 * (r >> 2) + 4 * hh) * LDC_S + 32 * (wc * CN + cn) + m] = acc[cn][r];
+    __syncthreads();
+    constexpr int C_F4 = BM * BN / 4 / NT;
+#pragma unroll
+    for (int u = 0; u < C_F4; ++u) {
+        const int idx = tid + u * NT;
+        const int r = idx / (BN / 4), c4 = idx % (BN / 4);
+        const int row = row0 + r, col = ctile * BN + 4 * c4;
+        if (row < g.M) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(Cs + r * LDC_S + 4 * c4) + *reinterpret_cast<const f32x4*>(g.bias + col);
+            f32x4* dst = reinterpret_cast<f32x4*>(g.C + (size_t)row * g.ldc + col);
+            if (EPI == EPI_BIAS_SILU) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = silu_f(v[j]);
             }
+            if (EPI == EPI_RESID_MASK) v = (*dst + v) * g.nmask[row];
+            *dst = v;
         }
     }
 }
