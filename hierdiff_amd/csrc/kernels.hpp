@@ -548,11 +548,14 @@ __global__ __launch_bounds__(256, HD_EDGE_WPS) void k_edge(EdgeArgs a) {
                 }
         };
 
+        // accumulators start at the second layer's bias (saves the H/32 * 16 bias adds of the epilogue)
         f32x16 acc[NCT];
 #pragma unroll
-        for (int ct = 0; ct < NCT; ++ct)
+        for (int ct = 0; ct < NCT; ++ct) {
+            const float b2v = a.b2[32 * ct + n];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[ct][r] = b2v;
+        }
 
         // Software pipeline: the operands of chunk c+1 are produced (VALU) while the matrix pipe works on
         // chunk c; the AB rows are fetched two chunks ahead.
@@ -564,6 +567,8 @@ __global__ __launch_bounds__(256, HD_EDGE_WPS) void k_edge(EdgeArgs a) {
         if constexpr (PREC == 1) split_P(Pc, phc, plc);
         if (NCH > 1) load_rows(1);
 
+        // (Unrolling this loop by two with swapped operand sets, to drop the 16 register copies per chunk, was
+        // measured: +17 spilled registers and 125 vs 109 us.)
 #pragma unroll 1
         for (int c = 0; c < NCH; ++c, ++gc) {
             const int buf = (ABL & 4) ? 0 : (gc & 1);
@@ -695,25 +700,48 @@ __global__ __launch_bounds__(256, HD_EDGE_WPS) void k_edge(EdgeArgs a) {
         for (int r = 0; r < 16; ++r) dot[r] = 0.f;
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) {
-            const float b2v = a.b2[32 * ct + n];
             const float wav = a.wa[32 * ct + n];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float mv = silu_p<PREC>(acc[ct][r] + b2v);
+                float mv = silu_p<PREC>(acc[ct][r]);
                 acc[ct][r] = mv;
                 dot[r] = __builtin_fmaf(mv, wav, dot[r]);
             }
         }
+        // Row dots: transpose-reduce over the 32 lanes of a half.  Each exchange halves the number of rows a
+        // lane still carries (16 -> 8 -> 4 -> 2 -> 1), the last one is a plain butterfly: 16 shuffles instead
+        // of 80, and lanes 2r, 2r+1 end up with the complete dot of row slot r, so the sigmoid / tanh input is
+        // evaluated once per lane instead of 16 times.
+        float rowdot;
+        {
+            float v8[8], v4[4], v2[2];
+            const bool b4 = n & 16, b3 = n & 8, b2_ = n & 4, b1 = n & 2;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float d = dot[r];
-            d += __shfl_xor(d, 1);
-            d += __shfl_xor(d, 2);
-            d += __shfl_xor(d, 4);
-            d += __shfl_xor(d, 8);
-            d += __shfl_xor(d, 16);
-            dot[r] = d;
+            for (int k = 0; k < 8; ++k) {
+                const float send = b4 ? dot[k] : dot[k + 8];
+                const float keep = b4 ? dot[k + 8] : dot[k];
+                v8[k] = keep + __shfl_xor(send, 16);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float send = b3 ? v8[k] : v8[k + 4];
+                const float keep = b3 ? v8[k + 4] : v8[k];
+                v4[k] = keep + __shfl_xor(send, 8);
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const float send = b2_ ? v4[k] : v4[k + 2];
+                const float keep = b2_ ? v4[k + 2] : v4[k];
+                v2[k] = keep + __shfl_xor(send, 4);
+            }
+            {
+                const float send = b1 ? v2[0] : v2[1];
+                const float keep = b1 ? v2[1] : v2[0];
+                rowdot = keep + __shfl_xor(send, 2);
+            }
+            rowdot += __shfl_xor(rowdot, 1);
         }
+        const int my_slot = (n >> 1) & 15;                  // this lane holds the dot of row rho(my_slot)
         const int pbase = a.tile_pbase[tile];
         const int nseg = a.tile_nseg[tile];
 
@@ -722,12 +750,13 @@ __global__ __launch_bounds__(256, HD_EDGE_WPS) void k_edge(EdgeArgs a) {
             uint32_t sw[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) sw[q] = seg_s[2 * q + hh];
+            const float att_mine = a.attention ? sigmoid_f(rowdot + a.ba) : 1.0f;
             float w[16];
             int sg[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 sg[r] = (sw[r >> 2] >> (8 * (r & 3))) & 255;
-                float att = a.attention ? sigmoid_f(dot[r] + a.ba) : 1.0f;
+                const float att = __shfl(att_mine, (lane & 32) | (2 * r));
                 w[r] = (sg[r] != 255) ? att : 0.0f;
             }
             for (int s = 0; s < nseg; ++s) {
@@ -746,10 +775,7 @@ __global__ __launch_bounds__(256, HD_EDGE_WPS) void k_edge(EdgeArgs a) {
             }
         } else {
             // phi of row rho(r) is in every lane of half hh; publish per row, then lane n handles row n
-            if (n == 0) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) my_scr[(r & 3) + 8 * (r >> 2) + 4 * hh] = dot[r];
-            }
+            if ((n & 1) == 0) my_scr[(my_slot & 3) + 8 * (my_slot >> 2) + 4 * hh] = rowdot;
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             if (hh == 0) {
