@@ -48,6 +48,7 @@ struct hd_handle {
     hd_config cfg;
     int device;
     int H, fin, F, D, NS;       // NS: 32-column sub-tiles per node-GEMM workgroup tile
+    bool fused;                 // bf16x3: one k_node launch per node update instead of k_gemm x3 + k_agg
     long long n_weights;
     bool weights_set;
     float* dw;                  // packed weights
@@ -87,7 +88,7 @@ struct hd_topology {
     uint8_t *eseg, *nm_bytes;
     float* nmask;
     // workspace
-    float *hbuf, *AB, *Tb, *agg, *x0, *xcur, *part, *xpart, *eps;
+    float *hbuf, *AB, *AB2, *Tb, *agg, *x0, *xcur, *part, *xpart, *eps;
 };
 
 // ----------------------------------------------------------------------------- small helpers
@@ -156,6 +157,7 @@ extern "C" int hd_create(const hd_config* cfg, int device, hd_handle** out) {
     h->F = F;
     h->D = 3 + F;
     h->NS = (H == 32) ? 1 : 2;
+    h->fused = cfg->precision == 1;
     h->n_weights = weight_count(*cfg);
     h->weights_set = false;
     h->dw = nullptr;
@@ -254,25 +256,21 @@ static inline void bf16_split(float v, uint16_t& hi, uint16_t& lo) {
 }
 
 // bf16x3 images (same byte size as the fp32 ones: 2 B head + 2 B tail per weight).
-// node GEMM: per (col tile, 32-wide K chunk): [hi|lo][2 k-steps][WN][64 lanes][8], k = 32c + 16s + 8*(lane>>5) + i.
+// fused node kernel (k_node): [k-step s][column tile ct][hi|lo][64 lanes][8], k = 16s + 8*(lane>>5) + i, col = 32ct + (lane&31).
 template <typename Fn>
-static void pack_gemm_b_bf(std::vector<float>& dstf, size_t off, int K, int Nc, int WN, Fn W) {
+static void pack_node_b(std::vector<float>& dstf, size_t off, int K, int Nc, Fn W) {
     uint16_t* dst = reinterpret_cast<uint16_t*>(dstf.data() + off);
-    const int BN = 32 * WN, ntile = Nc / BN, nchunk = K / 32;
-    for (int ct = 0; ct < ntile; ++ct)
-        for (int c = 0; c < nchunk; ++c)
-            for (int st = 0; st < 2; ++st)
-                for (int wc = 0; wc < WN; ++wc)
-                    for (int lane = 0; lane < 64; ++lane)
-                        for (int i = 0; i < 8; ++i) {
-                            const int k = 32 * c + 16 * st + 8 * (lane >> 5) + i;
-                            const int col = ct * BN + 32 * wc + (lane & 31);
-                            uint16_t hi, lo;
-                            bf16_split(W(col, k), hi, lo);
-                            const size_t blk = (size_t)(ct * nchunk + c) * (BN * 32 * 2);
-                            dst[blk + (((size_t)(0 * 2 + st) * WN + wc) * 64 + lane) * 8 + i] = hi;
-                            dst[blk + (((size_t)(1 * 2 + st) * WN + wc) * 64 + lane) * 8 + i] = lo;
-                        }
+    const int nct = Nc / 32;
+    for (int st = 0; st < K / 16; ++st)
+        for (int ct = 0; ct < nct; ++ct)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int i = 0; i < 8; ++i) {
+                    uint16_t hi, lo;
+                    bf16_split(W(32 * ct + (lane & 31), 16 * st + 8 * (lane >> 5) + i), hi, lo);
+                    const size_t base = ((size_t)(st * nct + ct) * 2) * 512;
+                    dst[base + (size_t)lane * 8 + i] = hi;
+                    dst[base + 512 + (size_t)lane * 8 + i] = lo;
+                }
 }
 
 // edge kernel: per K chunk [hi|lo][2 k-steps][H/32 ct][64 lanes][8], k = 32c + 16*(lane>>5) + 8s + i.
@@ -350,7 +348,7 @@ extern "C" int hd_set_weights(hd_handle* h, const float* blob, long long n, int 
         auto wab = [&](int col, int k) {
             return (col < H) ? W1[(size_t)col * ld + k] : W1[(size_t)(col - H) * ld + H + k];
         };
-        if (bf) pack_gemm_b_bf(pk, w.ab_img, H, 2 * H, WN, wab);
+        if (h->fused) pack_node_b(pk, w.ab_img, H, 2 * H, wab);
         else pack_gemm_b(pk, w.ab_img, H, 2 * H, WN, wab);
         for (int k = 0; k < H; ++k) {
             pk[w.ab_bias + k] = b1[k];
@@ -371,9 +369,9 @@ extern "C" int hd_set_weights(hd_handle* h, const float* blob, long long n, int 
             auto w4 = [&](int col, int k) { return W4[(size_t)col * H + k]; };
             if (bf) pack_edge_w2_bf(pk, w.w2_img, H, W2);
             else pack_edge_w2(pk, w.w2_img, H, W2);
-            if (bf) {
-                pack_gemm_b_bf(pk, w.w3_img, 2 * H, H, WN, w3);
-                pack_gemm_b_bf(pk, w.w4_img, H, H, WN, w4);
+            if (h->fused) {
+                pack_node_b(pk, w.w3_img, 2 * H, H, w3);
+                pack_node_b(pk, w.w4_img, H, H, w4);
             } else {
                 pack_gemm_b(pk, w.w3_img, 2 * H, H, WN, w3);
                 pack_gemm_b(pk, w.w4_img, H, H, WN, w4);
@@ -421,7 +419,7 @@ extern "C" int hd_topology_destroy(hd_topology* t) {
     (void)hipDeviceSynchronize();
     hipFree(t->node_of); hipFree(t->slot_of); hipFree(t->ei); hipFree(t->ej); hipFree(t->tile_pbase);
     hipFree(t->tile_nseg); hipFree(t->pstart); hipFree(t->nvalid); hipFree(t->eseg); hipFree(t->nm_bytes);
-    hipFree(t->nmask); hipFree(t->hbuf); hipFree(t->AB); hipFree(t->Tb); hipFree(t->agg); hipFree(t->x0); hipFree(t->xcur);
+    hipFree(t->nmask); hipFree(t->hbuf); hipFree(t->AB); hipFree(t->AB2); hipFree(t->Tb); hipFree(t->agg); hipFree(t->x0); hipFree(t->xcur);
     hipFree(t->part); hipFree(t->xpart); hipFree(t->eps);
     delete t;
     return HD_OK;
@@ -503,12 +501,14 @@ extern "C" int hd_topology_create(hd_handle* h, const uint8_t* node_mask, const 
     ok(dev_upload(&t->pstart, pstart)); ok(dev_upload(&t->nvalid, nvalid)); ok(dev_upload(&t->eseg, eseg));
     ok(dev_upload(&t->nm_bytes, nm_bytes)); ok(dev_upload(&t->nmask, nmask));
     ok(dev_alloc(&t->hbuf, (size_t)M_pad * H)); ok(dev_alloc(&t->AB, (size_t)M_pad * 2 * H));
+    ok(dev_alloc(&t->AB2, h->fused ? (size_t)M_pad * 2 * H : 1));
     ok(dev_alloc(&t->Tb, (size_t)M_pad * H)); ok(dev_alloc(&t->agg, (size_t)M_pad * H)); ok(dev_alloc(&t->x0, (size_t)M_pad * 4));
     ok(dev_alloc(&t->xcur, (size_t)M_pad * 4)); ok(dev_alloc(&t->part, (size_t)std::max(1, n_parts) * H));
     ok(dev_alloc(&t->xpart, (size_t)std::max(1, n_parts) * 4)); ok(dev_alloc(&t->eps, BN * h->D));
     if (r != HD_OK) { hd_topology_destroy(t); return r; }
     // pad rows stay zero for the lifetime of the topology (kernels never write them)
     hipMemset(t->hbuf, 0, (size_t)M_pad * H * 4); hipMemset(t->AB, 0, (size_t)M_pad * 2 * H * 4);
+    if (h->fused) hipMemset(t->AB2, 0, (size_t)M_pad * 2 * H * 4);
     hipMemset(t->Tb, 0, (size_t)M_pad * H * 4); hipMemset(t->agg, 0, (size_t)M_pad * H * 4); hipMemset(t->x0, 0, (size_t)M_pad * 16);
     hipMemset(t->xcur, 0, (size_t)M_pad * 16);
     HIP_TRY(hipDeviceSynchronize());
@@ -571,20 +571,14 @@ extern "C" int hd_profile_read(hd_handle* h, double* ms3, long long* launches3) 
 
 // ----------------------------------------------------------------------------- forward
 
-template <int WM, int WN, int CN, int PREC>
-static void launch_gemm_p(int epi, bool cat, const GemmArgs& g, hipStream_t s) {
+template <int WM, int WN, int CN>
+static void launch_gemm(int epi, bool cat, const GemmArgs& g, hipStream_t s) {
     const int nrt = (g.M + 32 * WM - 1) / (32 * WM), nct = g.Nc / (32 * WN * CN);
     dim3 grid(8 * ((nrt + 7) / 8) * nct);
     dim3 block(WM * WN * 64);
-    if (cat) hipLaunchKernelGGL((k_gemm<WM, WN, CN, EPI_BIAS_SILU, true, PREC>), grid, block, 0, s, g);
-    else if (epi == EPI_BIAS) hipLaunchKernelGGL((k_gemm<WM, WN, CN, EPI_BIAS, false, PREC>), grid, block, 0, s, g);
-    else hipLaunchKernelGGL((k_gemm<WM, WN, CN, EPI_RESID_MASK, false, PREC>), grid, block, 0, s, g);
-}
-
-template <int WM, int WN, int CN>
-static void launch_gemm(int prec, int epi, bool cat, const GemmArgs& g, hipStream_t s) {
-    if (prec == 0) launch_gemm_p<WM, WN, CN, 0>(epi, cat, g, s);
-    else launch_gemm_p<WM, WN, CN, 1>(epi, cat, g, s);
+    if (cat) hipLaunchKernelGGL((k_gemm<WM, WN, CN, EPI_BIAS_SILU, true>), grid, block, 0, s, g);
+    else if (epi == EPI_BIAS) hipLaunchKernelGGL((k_gemm<WM, WN, CN, EPI_BIAS, false>), grid, block, 0, s, g);
+    else hipLaunchKernelGGL((k_gemm<WM, WN, CN, EPI_RESID_MASK, false>), grid, block, 0, s, g);
 }
 
 // Node-GEMM tile shape per hidden size: (waves M, waves N, accumulators per wave); the weight images are
@@ -592,8 +586,49 @@ static void launch_gemm(int prec, int epi, bool cat, const GemmArgs& g, hipStrea
 static void gemm(hd_handle* h, int epi, bool cat, const GemmArgs& g, hipStream_t s) {
     ProfScope ps(h, s, 1);
 
-    if (h->NS == 1) launch_gemm<4, 1, 1>(h->cfg.precision, epi, cat, g, s);        // H = 32: 128 x 32 tiles
-    else launch_gemm<2, 2, 1>(h->cfg.precision, epi, cat, g, s);                   // 64 x 64 tiles (fastest measured)
+    if (h->NS == 1) launch_gemm<4, 1, 1>(epi, cat, g, s);        // H = 32: 128 x 32 tiles
+    else launch_gemm<2, 2, 1>(epi, cat, g, s);                   // 64 x 64 tiles (fastest measured)
+}
+
+// Fused node update (bf16x3 only): min(4, H/32) wavefronts per 32-row workgroup.
+template <int H>
+static int node_lds_bytes(bool upd) { return 32 * ((upd ? 2 * H : H) + 8) * 4 + 32 * (H + 8) * 4; }
+
+template <int H, int NW>
+static void launch_node_hw(bool upd, int nab, const NodeArgs& a, hipStream_t s) {
+    const int nrt = (a.M + 31) / 32;
+    const dim3 grid(8 * ((nrt + 7) / 8)), block(64 * NW);
+    const int lds = node_lds_bytes<H>(upd);
+    if (!upd) hipLaunchKernelGGL((k_node<H, NW, false, 1>), grid, block, lds, s, a);
+    else if (nab == 1) hipLaunchKernelGGL((k_node<H, NW, true, 1>), grid, block, lds, s, a);
+    else hipLaunchKernelGGL((k_node<H, NW, true, 2>), grid, block, lds, s, a);
+}
+
+template <int H, int NW>
+static int prepare_node_hw() {
+    HIP_TRY(hipFuncSetAttribute((const void*)k_node<H, NW, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, node_lds_bytes<H>(false)));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_node<H, NW, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, node_lds_bytes<H>(true)));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_node<H, NW, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, node_lds_bytes<H>(true)));
+    return HD_OK;
+}
+
+// wavefronts per 32-row workgroup: one 32-column tile of an H-wide output each, at most 8 (two per SIMD)
+template <int H>
+static void launch_node_h(bool upd, int nab, const NodeArgs& a, hipStream_t s) {
+    launch_node_hw<H, (H / 32 < 8 ? H / 32 : 8)>(upd, nab, a, s);
+}
+
+template <int H>
+static int prepare_node_h() { return prepare_node_hw<H, (H / 32 < 8 ? H / 32 : 8)>(); }
+
+static void node_update(hd_handle* h, bool upd, int nab, const NodeArgs& a, hipStream_t s) {
+    ProfScope ps(h, s, 1);
+    switch (h->H) {
+        case 32: launch_node_h<32>(upd, nab, a, s); break;
+        case 64: launch_node_h<64>(upd, nab, a, s); break;
+        case 128: launch_node_h<128>(upd, nab, a, s); break;
+        default: launch_node_h<256>(upd, nab, a, s); break;
+    }
 }
 
 template <int H>
@@ -654,10 +689,10 @@ static int prepare_edge_h() {
 
 static int prepare_kernels(int H) {
     switch (H) {
-        case 32: return prepare_edge_h<32>();
-        case 64: return prepare_edge_h<64>();
-        case 128: return prepare_edge_h<128>();
-        default: return prepare_edge_h<256>();
+        case 32: HD_TRY(prepare_node_h<32>()); return prepare_edge_h<32>();
+        case 64: HD_TRY(prepare_node_h<64>()); return prepare_edge_h<64>();
+        case 128: HD_TRY(prepare_node_h<128>()); return prepare_edge_h<128>();
+        default: HD_TRY(prepare_node_h<256>()); return prepare_edge_h<256>();
     }
 }
 
@@ -691,24 +726,57 @@ static int forward_impl(hd_handle* h, hd_topology* t, const float* xh, const flo
             hipLaunchKernelGGL(k_node_init, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
         }
         const float range = c.coords_range / (float)c.n_layers;
+        const int S = c.inv_sublayers;
+        // fused path: AB of the layer about to run is produced by the previous node update (or, for the very
+        // first layer, by an AB-only launch); `ab_cur` is the buffer the next edge kernel reads
+        const float* ab_cur = t->AB;
+        auto node_args = [&]() {
+            NodeArgs a;
+            std::memset(&a, 0, sizeof(a));
+            a.h_in = t->hbuf; a.h_out = t->hbuf; a.part = t->part; a.pstart = t->pstart; a.nmask = t->nmask;
+            a.norm = c.normalization_factor; a.M = M;
+            return a;
+        };
+        auto set_ab = [&](NodeArgs& a, int q, const LayerW& nw, float* dst) {
+            a.ABimg[q] = W + nw.ab_img; a.ABbias[q] = W + nw.ab_bias; a.ABout[q] = dst;
+        };
+        if (h->fused) {
+            NodeArgs a = node_args();
+            set_ab(a, 0, h->gcl[0], t->AB);
+            node_update(h, false, 1, a, s);
+        }
         for (int i = 0; i < c.n_layers; ++i) {
             for (int j = 0; j <= c.inv_sublayers; ++j) {
                 const bool coord = (j == c.inv_sublayers);
                 const LayerW& w = coord ? h->coord[i] : h->gcl[(size_t)i * c.inv_sublayers + j];
-                GemmArgs g;
-                std::memset(&g, 0, sizeof(g));
-                g.A = t->hbuf; g.lda = H; g.K1 = H; g.K = H; g.Bimg = W + w.ab_img; g.bias = W + w.ab_bias;
-                g.C = t->AB; g.ldc = 2 * H; g.M = M; g.Nc = 2 * H; g.nmask = t->nmask;
-                gemm(h, EPI_BIAS, false, g, s);
+                if (!h->fused) {
+                    GemmArgs g;
+                    std::memset(&g, 0, sizeof(g));
+                    g.A = t->hbuf; g.lda = H; g.K1 = H; g.K = H; g.Bimg = W + w.ab_img; g.bias = W + w.ab_bias;
+                    g.C = t->AB; g.ldc = 2 * H; g.M = M; g.Nc = 2 * H; g.nmask = t->nmask;
+                    gemm(h, EPI_BIAS, false, g, s);
+                }
                 EdgeArgs e;
                 std::memset(&e, 0, sizeof(e));
-                e.AB = t->AB; e.wrd = W + w.wrd; e.W2img = W + w.w2_img; e.b2 = W + w.b2; e.wa = W + w.wa;
+                e.AB = ab_cur; e.wrd = W + w.wrd; e.W2img = W + w.w2_img; e.b2 = W + w.b2; e.wa = W + w.wa;
                 e.ei = t->ei; e.ej = t->ej; e.eseg = t->eseg; e.tile_pbase = t->tile_pbase; e.tile_nseg = t->tile_nseg;
                 e.xcur = t->xcur; e.x0 = t->x0; e.part = coord ? t->xpart : t->part; e.ba = w.ba;
                 e.norm_constant = c.norm_constant; e.coords_range = range; e.attention = c.attention;
                 e.use_tanh = c.tanh; e.n_tiles = t->n_tiles; e.n_wg = t->n_wg;
                 HD_TRY(edge(h, coord, e, s));
-                if (!coord) {
+                if (!coord && h->fused) {
+                    NodeArgs a = node_args();
+                    a.W3img = W + w.w3_img; a.b3 = W + w.b3; a.W4img = W + w.w4_img; a.b4 = W + w.b4;
+                    int nab = 1;
+                    if (j + 1 < S) {
+                        set_ab(a, 0, h->gcl[(size_t)i * S + j + 1], t->AB);
+                    } else {
+                        set_ab(a, 0, h->coord[i], t->AB);
+                        if (i + 1 < c.n_layers) { set_ab(a, 1, h->gcl[(size_t)(i + 1) * S], t->AB2); nab = 2; }
+                    }
+                    node_update(h, true, nab, a, s);
+                    ab_cur = t->AB;
+                } else if (!coord) {
                     GemmArgs g1;
                     std::memset(&g1, 0, sizeof(g1));
                     {
@@ -734,6 +802,7 @@ static int forward_impl(hd_handle* h, hd_topology* t, const float* xh, const flo
                     x.part = t->xpart; x.pstart = t->pstart; x.nmask = t->nmask; x.xcur = t->xcur;
                     x.norm = c.normalization_factor; x.M = M;
                     hipLaunchKernelGGL(k_xupd, dim3((M + 255) / 256), dim3(256), 0, s, x);
+                    if (h->fused) ab_cur = t->AB2;          // next block's first GCL (written by the last node update)
                 }
             }
         }

@@ -162,25 +162,20 @@ typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // WM x WN wavefronts, each owning 32 rows x (32*CN) columns (CN accumulators); workgroup tile
-// (32*WM) x (32*WN*CN).  PREC 0: exact fp32 MFMA.  PREC 1: bf16x3 (see k_edge) - activations are split into
-// bf16 head/tail by the tile loader, weights are pre-split.  Weight image per (column tile, 32-wide K chunk):
-//   fp32  : [NS][4 q][64 lanes][4 j]          k = 32c + 16*(lane>>5) + 4q + j
-//   bf16x3: [hi|lo][2 k-steps][NS][64 lanes][8 i]   k = 32c + 16s + 8*(lane>>5) + i
+// (32*WM) x (32*WN*CN).  Exact-fp32 precision mode only (the bf16x3 mode runs the fused k_node below).
+// Weight image per (column tile, 32-wide K chunk): [NS][4 q][64 lanes][4 j], k = 32c + 16*(lane>>5) + 4q + j,
 // with NS = WN*CN 32-column sub-tiles, column = tile*32*NS + 32*sub + (lane&31).
-template <int WM, int WN, int CN, int EPI, bool CAT, int PREC>
+template <int WM, int WN, int CN, int EPI, bool CAT>
 __global__ __launch_bounds__(WM * WN * 64) void k_gemm(GemmArgs g) {
     constexpr int NS = WN * CN;
     constexpr int BM = 32 * WM, BN = 32 * NS, NT = 64 * WM * WN;
     constexpr int A_F4 = BM * 8 / NT;                    // float4 of the A tile per thread
     constexpr int B_U4 = BN * 32 * 4 / 16 / NT;          // 16-byte pieces of the B image per thread
     constexpr int LDA_F = 36;                            // fp32 A row: 32 + 4 pad floats
-    constexpr int LDA_H = 40;                            // bf16 A row: 32 + 8 pad (80 B): conflict-free b128
-    constexpr int A_BYTES = PREC == 0 ? BM * LDA_F * 4 : 2 * BM * LDA_H * 2;
+    constexpr int A_BYTES = BM * LDA_F * 4;
     constexpr int B_BYTES = BN * 32 * 4;
     __shared__ __attribute__((aligned(16))) char smem_g[2 * (A_BYTES + B_BYTES)];
     auto As_f = [&](int buf) { return reinterpret_cast<float*>(smem_g + buf * (A_BYTES + B_BYTES)); };
-    auto As_h = [&](int buf) { return reinterpret_cast<__bf16*>(smem_g + buf * (A_BYTES + B_BYTES)); };
-    auto As_l = [&](int buf) { return reinterpret_cast<__bf16*>(smem_g + buf * (A_BYTES + B_BYTES)) + BM * LDA_H; };
     auto Bs = [&](int buf) { return smem_g + buf * (A_BYTES + B_BYTES) + A_BYTES; };
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -230,17 +225,7 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm(GemmArgs g) {
         for (int u = 0; u < A_F4; ++u) {
             int idx = tid + u * NT;
             int r = idx >> 3, sg = idx & 7;
-            if constexpr (PREC == 0) {
-                *reinterpret_cast<f32x4*>(As_f(buf) + r * LDA_F + 4 * sg) = ra[u];
-            } else {
-                const f32x4 v = ra[u];
-                const __bf16 h0 = (__bf16)v[0], h1 = (__bf16)v[1], h2 = (__bf16)v[2], h3 = (__bf16)v[3];
-                const bf16x4_t vh = {h0, h1, h2, h3};
-                const bf16x4_t vl = {(__bf16)(v[0] - (float)h0), (__bf16)(v[1] - (float)h1),
-                                     (__bf16)(v[2] - (float)h2), (__bf16)(v[3] - (float)h3)};
-                *reinterpret_cast<bf16x4_t*>(As_h(buf) + r * LDA_H + 4 * sg) = vh;
-                *reinterpret_cast<bf16x4_t*>(As_l(buf) + r * LDA_H + 4 * sg) = vl;
-            }
+            *reinterpret_cast<f32x4*>(As_f(buf) + r * LDA_F + 4 * sg) = ra[u];
         }
 #pragma unroll
         for (int u = 0; u < B_U4; ++u) reinterpret_cast<u32x4*>(Bs(buf))[tid + u * NT] = rb[u];
@@ -253,40 +238,19 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm(GemmArgs g) {
         for (int r = 0; r < 16; ++r) acc[cn][r] = 0.f;
 
     auto compute = [&](int buf) {
-        if constexpr (PREC == 0) {
-            const float* Bf = reinterpret_cast<const float*>(Bs(buf));
+        const float* Bf = reinterpret_cast<const float*>(Bs(buf));
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 av = *reinterpret_cast<const f32x4*>(As_f(buf) + (32 * wr + m) * LDA_F + 16 * hh + 4 * q);
-                f32x4 bv[CN];
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(As_f(buf) + (32 * wr + m) * LDA_F + 16 * hh + 4 * q);
+            f32x4 bv[CN];
+#pragma unroll
+            for (int cn = 0; cn < CN; ++cn)
+                bv[cn] = *reinterpret_cast<const f32x4*>(Bf + (((wc * CN + cn) * 4 + q) * 64 + lane) * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int cn = 0; cn < CN; ++cn)
-                    bv[cn] = *reinterpret_cast<const f32x4*>(Bf + (((wc * CN + cn) * 4 + q) * 64 + lane) * 4);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int cn = 0; cn < CN; ++cn)
-                        acc[cn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[cn][j], acc[cn], 0, 0, 0);
-            }
-        } else {
-            const __bf16* Bh = reinterpret_cast<const __bf16*>(Bs(buf));
-#pragma unroll
-            for (int st = 0; st < 2; ++st) {
-                const bf16x8_t ah = *reinterpret_cast<const bf16x8_t*>(As_h(buf) + (32 * wr + m) * LDA_H + 16 * st + 8 * hh);
-                const bf16x8_t al = *reinterpret_cast<const bf16x8_t*>(As_l(buf) + (32 * wr + m) * LDA_H + 16 * st + 8 * hh);
-                bf16x8_t bh[CN], bl[CN];
-#pragma unroll
-                for (int cn = 0; cn < CN; ++cn) {
-                    bh[cn] = *reinterpret_cast<const bf16x8_t*>(Bh + (((0 * 2 + st) * NS + wc * CN + cn) * 64 + lane) * 8);
-                    bl[cn] = *reinterpret_cast<const bf16x8_t*>(Bh + (((1 * 2 + st) * NS + wc * CN + cn) * 64 + lane) * 8);
-                }
-#pragma unroll
-                for (int cn = 0; cn < CN; ++cn) acc[cn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[cn], acc[cn], 0, 0, 0);
-#pragma unroll
-                for (int cn = 0; cn < CN; ++cn) acc[cn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[cn], acc[cn], 0, 0, 0);
-#pragma unroll
-                for (int cn = 0; cn < CN; ++cn) acc[cn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[cn], acc[cn], 0, 0, 0);
-            }
+                    acc[cn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[cn][j], acc[cn], 0, 0, 0);
         }
     };
 
@@ -341,6 +305,301 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm(GemmArgs g) {
     }
 }
 
+// ----------------------------------------------------------------------------- fused node update (bf16x3)
+// One workgroup owns 32 node rows and runs the whole row-local chain of a GCL's node model plus the first
+// edge Linear of the layer(s) that follow, so the intermediate activations never leave the CU:
+//   X   = [h | (sum of the node's partial neighbour sums) / normalization_factor]      (egnn_new.py:52-56,280-282)
+//   T   = silu(X W3^T + b3)                                                            (node_mlp.0 + SiLU, :58-66)
+//   h'  = (h + T W4^T + b4) * mask                                                     (node_mlp.2, residual, mask)
+//   AB_q = h' [W1a_q | W1b_q]^T + [b1_q | 0]   for the next NAB edge layers            (factorised edge_mlp.0 / coord_mlp.0)
+// (UPD = false: only the last line, on h as it is - used once after the embedding.)  It replaces
+// k_gemm(AB) + k_agg + k_gemm(n1) + k_gemm(n2): at M = 7,680 rows those four launches were bound by fixed costs
+// (launch, tile prologue, C stores), not by math.
+//   * A operands: the 32-row activation tile lives in LDS as bf16 head + tail, row stride K+8 elements
+//     (16 B pad => conflict-free ds_read_b128), shared by all wavefronts.
+//   * B operands: every wavefront owns its own 32-column tiles, so weights have no reuse inside a workgroup
+//     and go L2 -> registers directly (fragment-ordered image, 1 KiB coalesced per load), PF k-steps ahead.
+//   * C tiles leave through an LDS transpose as whole float4 rows.
+// Weight image (pack_node_b): [k-step s][column tile ct][head|tail][64 lanes][8 bf16],
+//   k = 16 s + 8 (lane>>5) + i,  col = 32 ct + (lane&31).
+
+struct NodeArgs {
+    const float* h_in;      // [M_pad][H]
+    float* h_out;           // [M_pad][H] (may alias h_in: a workgroup only touches its own rows)
+    const float* part;      // [P][H] partial neighbour sums of the edge kernel
+    const int* pstart;      // [M+1]
+    const float* nmask;     // [M_pad]
+    const float* W3img;     // K = 2H, N = H
+    const float* b3;
+    const float* W4img;     // K = H, N = H
+    const float* b4;
+    const float* ABimg[2];  // K = H, N = 2H
+    const float* ABbias[2]; // [2H]
+    float* ABout[2];        // [M_pad][2H]
+    float norm;
+    int M;
+};
+
+// acc[c] += A[32 x 16 KS] * B[:, column tile ct(c)]   with ct(c) = (c / CTW) * CTG + ct0 + c % CTW.
+// B fragments travel L2 -> registers in a ring of PF k-steps; `prefetch` fills the ring (it is issued before
+// the barrier / epilogue that precedes the contraction, weights do not depend on data) and `run` consumes
+// it.  sched_barrier(0) at every k-step keeps hipcc from sinking the loads next to their MFMAs (it otherwise
+// shrinks the ring to 2-3 loads in flight to save registers and exposes the L2 latency every k-step).
+template <int KS, int CTn, int CTW, int PF, int NCT>
+struct NodeMma {
+    typedef u32x4 Ring[PF][CTn][2];
+    template <int s, int slot>
+    static HD_DEVINL void load(Ring& br, const u32x4* Bl, int ct0, int CTG) {
+#pragma unroll
+        for (int c = 0; c < CTn; ++c) {
+            const int ct = (c / CTW) * CTG + ct0 + c % CTW;
+            br[slot][c][0] = Bl[((size_t)(s * NCT + ct) * 2 + 0) * 64];
+            br[slot][c][1] = Bl[((size_t)(s * NCT + ct) * 2 + 1) * 64];
+        }
+    }
+    static HD_DEVINL void prefetch(Ring& br, const u32x4* Bl, int ct0, int CTG) {
+        static_for<0, (PF < KS ? PF : KS)>([&](auto S) { load<decltype(S)::value, decltype(S)::value>(br, Bl, ct0, CTG); });
+        asm volatile("" ::: "memory");                // keeps the loads above whatever follows (barriers included)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    static HD_DEVINL void run(f32x16 (&acc)[CTn], Ring& br, const __bf16* Ah, const __bf16* Al, const u32x4* Bl,
+                              int ct0, int CTG) {
+        bf16x8_t ah = *reinterpret_cast<const bf16x8_t*>(Ah), al = *reinterpret_cast<const bf16x8_t*>(Al);
+        static_for<0, KS>([&](auto S) {
+            constexpr int s = decltype(S)::value, slot = s % PF;
+            __builtin_amdgcn_sched_barrier(0);
+            bf16x8_t ahn = ah, aln = al;
+            if constexpr (s + 1 < KS) {
+                ahn = *reinterpret_cast<const bf16x8_t*>(Ah + 16 * (s + 1));
+                aln = *reinterpret_cast<const bf16x8_t*>(Al + 16 * (s + 1));
+            }
+            __builtin_amdgcn_sched_barrier(0);         // next A fragments are in flight under this step's MFMAs
+            bf16x8_t bh[CTn], bl[CTn];
+#pragma unroll
+            for (int c = 0; c < CTn; ++c) {
+                bh[c] = __builtin_bit_cast(bf16x8_t, br[slot][c][0]);
+                bl[c] = __builtin_bit_cast(bf16x8_t, br[slot][c][1]);
+            }
+#pragma unroll
+            for (int c = 0; c < CTn; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[c], acc[c], 0, 0, 0);
+#pragma unroll
+            for (int c = 0; c < CTn; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[c], acc[c], 0, 0, 0);
+#pragma unroll
+            for (int c = 0; c < CTn; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[c], acc[c], 0, 0, 0);
+            if constexpr (s + PF < KS) load<s + PF, slot>(br, Bl, ct0, CTG);
+            ah = ahn; al = aln;
+        });
+        __builtin_amdgcn_sched_barrier(0);
+    }
+};
+
+HD_DEVINL void bf16_split_store(__bf16* dh, __bf16* dl, float v) {
+    const __bf16 hi = (__bf16)v;
+    *dh = hi;
+    *dl = (__bf16)(v - (float)hi);
+}
+
+template <int H, int NW, bool UPD, int NAB>
+__global__ __launch_bounds__(64 * NW, 1) void k_node(NodeArgs a) {
+    constexpr int NT = 64 * NW;
+    constexpr int NCT = H / 32;            // column tiles of an H-wide output
+    constexpr int CT = NCT / NW;           // ... per wavefront
+    static_assert(CT >= 1 && CT * NW == NCT, "NW must divide H/32");
+    constexpr int KX = UPD ? 2 * H : H;
+    constexpr int LDX = KX + 8, LDH = H + 8;
+    constexpr int PF12 = 4, PF3 = 3;       // k-steps of weights in flight per wavefront (deeper rings measured no faster)
+    constexpr int R0_BYTES = 32 * LDX * 4;             // head + tail of X
+    extern __shared__ __attribute__((aligned(16))) char smem_n[];
+    __bf16* Xh = reinterpret_cast<__bf16*>(smem_n);
+    __bf16* Xl = Xh + 32 * LDX;
+    __bf16* Th = reinterpret_cast<__bf16*>(smem_n + R0_BYTES);      // region 1: T, later the AB staging tile
+    __bf16* Tl = Th + 32 * LDH;
+    __bf16* Nh = reinterpret_cast<__bf16*>(smem_n);                 // h' (head, tail) re-uses region 0 ...
+    __bf16* Nl = Nh + 32 * LDH;
+    float* stage0 = reinterpret_cast<float*>(smem_n + 32 * LDH * 4); // ... followed by its fp32 staging tile [32][H]
+    constexpr int LDS1 = H + 4;
+    float* stage1 = reinterpret_cast<float*>(smem_n + R0_BYTES);    // [32][H+4]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hh = lane >> 5, n = lane & 31;
+    // XCD-aware row-tile order: block b runs on XCD b % 8; every XCD owns a contiguous range of row tiles, the
+    // same split the edge kernel uses for its edge list, so `part` / `AB` rows stay in the XCD that touches them.
+    int rt;
+    {
+        const int nrt = (a.M + 31) >> 5;
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int q = nrt >> 3, r = nrt & 7;
+        const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        const int len = q + (xcd < r ? 1 : 0);
+        if (idx >= len) return;
+        rt = start + idx;
+    }
+    const int row0 = rt * 32;
+
+    typedef NodeMma<KX / 16, CT, CT, PF12, NCT> M1;            // X W3^T      (UPD only)
+    typedef NodeMma<H / 16, CT, CT, PF12, NCT> M2;             // T W4^T      (UPD only)
+    typedef NodeMma<H / 16, 2 * CT, CT, PF3, 2 * NCT> M3;      // h' [W1a|W1b]^T
+    typename M1::Ring br1;
+    typename M2::Ring br2;
+    typename M3::Ring br3;
+    const int ct0 = wave * CT;
+    const u32x4* W3l = reinterpret_cast<const u32x4*>(a.W3img) + lane;
+    const u32x4* W4l = reinterpret_cast<const u32x4*>(a.W4img) + lane;
+    const u32x4* AB0l = reinterpret_cast<const u32x4*>(a.ABimg[0]) + lane;
+    if constexpr (UPD) M1::prefetch(br1, W3l, ct0, 0);
+
+    // ---- phase 0: X -> LDS (bf16 head/tail).  NT/32 threads per row, each moving every (NT/32)-th float4 of
+    // the row, so a thread needs one pstart pair and all its loads are independent of each other.
+    {
+        constexpr int Q = H / 4;                     // float4 per H-wide row
+        constexpr int TPR = NT / 32;                 // threads per row
+        constexpr int NP = Q / TPR;                  // pieces per thread and source
+        static_assert(Q % TPR == 0, "row pieces must divide evenly");
+        const int r = tid / TPR, cq = tid % TPR;
+        const int row = row0 + r;
+        auto put = [&](int col, f32x4 v) {
+            const __bf16 h0 = (__bf16)v[0], h1 = (__bf16)v[1], h2 = (__bf16)v[2], h3 = (__bf16)v[3];
+            const bf16x4_t vh = {h0, h1, h2, h3};
+            const bf16x4_t vl = {(__bf16)(v[0] - (float)h0), (__bf16)(v[1] - (float)h1),
+                                 (__bf16)(v[2] - (float)h2), (__bf16)(v[3] - (float)h3)};
+            *reinterpret_cast<bf16x4_t*>(Xh + r * LDX + col) = vh;
+            *reinterpret_cast<bf16x4_t*>(Xl + r * LDX + col) = vl;
+        };
+        int p0 = 0, p1 = 0;
+        if constexpr (UPD) {
+            if (row < a.M) { p0 = a.pstart[row]; p1 = a.pstart[row + 1]; }
+        }
+        f32x4 hv[NP];
+#pragma unroll
+        for (int u = 0; u < NP; ++u)
+            hv[u] = *reinterpret_cast<const f32x4*>(a.h_in + (size_t)row * H + 4 * (cq + u * TPR));   // pad rows are zero
+        if constexpr (UPD) {
+            // the first two partial sums (the common case: a node's edges span two tiles) are fetched together
+            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+            const bool has0 = p0 < p1, has1 = p0 + 1 < p1;
+            const float* s0 = a.part + (size_t)(has0 ? p0 : 0) * H;
+            const float* s1 = a.part + (size_t)(has1 ? p0 + 1 : 0) * H;
+            f32x4 g0[NP], g1[NP];
+#pragma unroll
+            for (int u = 0; u < NP; ++u) {
+                g0[u] = *reinterpret_cast<const f32x4*>(s0 + 4 * (cq + u * TPR));
+                g1[u] = *reinterpret_cast<const f32x4*>(s1 + 4 * (cq + u * TPR));
+            }
+#pragma unroll
+            for (int u = 0; u < NP; ++u) put(4 * (cq + u * TPR), hv[u]);
+#pragma unroll
+            for (int u = 0; u < NP; ++u) {
+                f32x4 v = z4;
+                if (has0) v += g0[u];
+                if (has1) v += g1[u];
+                for (int p = p0 + 2; p < p1; ++p) v += *reinterpret_cast<const f32x4*>(a.part + (size_t)p * H + 4 * (cq + u * TPR));
+                put(H + 4 * (cq + u * TPR), v / a.norm);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < NP; ++u) put(4 * (cq + u * TPR), hv[u]);
+        }
+    }
+
+    if constexpr (UPD) {
+        // ---- phase 1: T = silu(X W3^T + b3)
+        {
+            f32x16 acc[CT];
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                const float b = a.b3[32 * (ct0 + c) + n];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[c][r] = b;
+            }
+            __syncthreads();                                         // X complete
+            M2::prefetch(br2, W4l, ct0, 0);
+            M1::run(acc, br1, Xh + n * LDX + 8 * hh, Xl + n * LDX + 8 * hh, W3l, ct0, 0);
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int R = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    bf16_split_store(Th + R * LDH + 32 * (ct0 + c) + n, Tl + R * LDH + 32 * (ct0 + c) + n, silu_p<1>(acc[c][r]));
+                }
+        }
+        __syncthreads();
+        // ---- phase 2: h' = (h + T W4^T + b4) * mask
+        {
+            f32x16 acc[CT];
+            float hres[CT][16], mk[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mk[r] = a.nmask[row0 + (r & 3) + 8 * (r >> 2) + 4 * hh];
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                const float b = a.b4[32 * (ct0 + c) + n];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    acc[c][r] = b;
+                    hres[c][r] = a.h_in[(size_t)(row0 + (r & 3) + 8 * (r >> 2) + 4 * hh) * H + 32 * (ct0 + c) + n];
+                }
+            }
+            M3::prefetch(br3, AB0l, ct0, NCT);
+            M2::run(acc, br2, Th + n * LDH + 8 * hh, Tl + n * LDH + 8 * hh, W4l, ct0, 0);
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int R = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    const float v = (hres[c][r] + acc[c][r]) * mk[r];
+                    bf16_split_store(Nh + R * LDH + 32 * (ct0 + c) + n, Nl + R * LDH + 32 * (ct0 + c) + n, v);
+                    stage0[R * H + 32 * (ct0 + c) + n] = v;
+                }
+        }
+        __syncthreads();
+        {
+            constexpr int Q = H / 4, NP = 32 * Q / NT;
+#pragma unroll
+            for (int u = 0; u < NP; ++u) {
+                const int idx = tid + u * NT, r = idx / Q, c4 = idx % Q;
+                if (row0 + r < a.M)
+                    *reinterpret_cast<f32x4*>(a.h_out + (size_t)(row0 + r) * H + 4 * c4) = *reinterpret_cast<const f32x4*>(stage0 + r * H + 4 * c4);
+            }
+        }
+    }
+
+    // ---- phase 3: AB_q = h' [W1a | W1b]^T + bias, two H-wide halves per wavefront, staged through region 1
+#pragma unroll
+    for (int q = 0; q < NAB; ++q) {
+        f32x16 acc[2 * CT];
+#pragma unroll
+        for (int c = 0; c < 2 * CT; ++c) {
+            const float b = a.ABbias[q][(c / CT) * H + 32 * (ct0 + c % CT) + n];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][r] = b;
+        }
+        const u32x4* ABl = reinterpret_cast<const u32x4*>(a.ABimg[q]) + lane;
+        if (q > 0 || !UPD) {
+            M3::prefetch(br3, ABl, ct0, NCT);
+            if (!UPD) __syncthreads();                               // h tile complete
+        }
+        M3::run(acc, br3, Nh + n * LDH + 8 * hh, Nl + n * LDH + 8 * hh, ABl, ct0, NCT);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            if (half || q) __syncthreads();                 // previous staging tile fully stored
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    stage1[((r & 3) + 8 * (r >> 2) + 4 * hh) * LDS1 + 32 * (ct0 + c) + n] = acc[half * CT + c][r];
+            __syncthreads();
+            constexpr int Q = H / 4, NP = 32 * Q / NT;
+#pragma unroll
+            for (int u = 0; u < NP; ++u) {
+                const int idx = tid + u * NT, r = idx / Q, c4 = idx % Q;
+                if (row0 + r < a.M)
+                    *reinterpret_cast<f32x4*>(a.ABout[q] + (size_t)(row0 + r) * 2 * H + half * H + 4 * c4) =
+                        *reinterpret_cast<const f32x4*>(stage1 + r * LDS1 + 4 * c4);
+            }
+        }
+    }
+}
+
 // ----------------------------------------------------------------------------- edge kernel
 // One wavefront = one tile of 32 edge rows x H output columns (NCT accumulators of 32x32).
 //   P[e][k]   = silu(A_i[k] + B_j[k] + r_e*w_r[k] + d0_e*w_d[k])      (A operand, built in registers)
@@ -377,23 +636,8 @@ struct EdgeArgs {
 // ah*bh + al*bh + ah*bl with fp32 accumulation on v_mfma_f32_32x32x16_bf16: 3 matrix instructions at
 // 16x the fp32 rate, per-product error ~1e-5 (the dropped al*bl term), i.e. ~1e-6 on a 256-term dot.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-#ifndef HD_GEMM_ABL
-#define HD_GEMM_ABL 0
-#endif
-#ifndef HD_EDGE_PRIO
-#define HD_EDGE_PRIO 0
-#endif
 #ifndef HD_EDGE_PERSIST
 #define HD_EDGE_PERSIST 0
-#endif
-#ifndef HD_EDGE_GRP
-#define HD_EDGE_GRP 2
-#endif
-#ifndef HD_SCHED_VALU
-#define HD_SCHED_VALU 4
-#endif
-#ifndef HD_EDGE_WPS
-#define HD_EDGE_WPS 2
 #endif
 
 // Four LDS fragment reads / a counted wait that releases them (see k_edge).  The reads are inline asm so
@@ -429,7 +673,7 @@ constexpr unsigned frag_off_f32(int u) { return (unsigned)(u * 64 * 16); }
 // L2), keeps the W2 chunk stream running across tiles and fetches the next tile's row metadata while the
 // current tile's epilogue runs.
 template <int H, bool COORD, int PREC, int ABL = 0>
-__global__ __launch_bounds__(256, HD_EDGE_WPS) void k_edge(EdgeArgs a) {
+__global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
     constexpr int NCT = H / 32;          // 32-column tiles
     constexpr int NCH = H / 32;          // 32-wide K chunks
     constexpr int CHF = 32 * H;          // floats per W2 chunk image
@@ -664,17 +908,12 @@ __global__ __launch_bounds__(256, HD_EDGE_WPS) void k_edge(EdgeArgs a) {
                     acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(plc[s1], cur[2], acc[c1], 0, 0, 0);
                     acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(phc[s0], cur[1], acc[c0], 0, 0, 0);
                     acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(phc[s1], cur[3], acc[c1], 0, 0, 0);
-#ifndef HD_NO_SCHED
 #pragma unroll
-                    for (int k = 0; k < 6; ++k) {
+                    for (int k = 0; k < 6; ++k) {            // interleave: 1 MFMA, then up to 4 VALU
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x002, HD_SCHED_VALU, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
                     }
-#endif
                 });
-#if HD_EDGE_PRIO
-                __builtin_amdgcn_s_setprio(0);
-#endif
 #pragma unroll
                 for (int st = 0; st < 2; ++st) { phc[st] = phn[st]; plc[st] = pln[st]; }
             }

@@ -14,11 +14,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // MODE 2: MODE 1 + B fragments read from LDS (compiler-placed)
 // MODE 3: MODE 1 + asm-pinned double-buffered LDS reads
 // MODE 4: MODE 3 + ~180 VALU per 48 MFMA (SiLU-like)
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
 template <int MODE, int WPS>
 __global__ __launch_bounds__(256, WPS) void k(float* out, const float* in, int iters) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63;
-    for (int i = threadIdx.x; i < 8192; i += 256) smem[i] = in[i & 1023];
+    for (int i = threadIdx.x; i < 16384; i += 256) smem[i] = in[i & 1023];
     __syncthreads();
     f32x16 acc[8];
     for (int c = 0; c < 8; ++c) for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
@@ -27,7 +31,32 @@ __global__ __launch_bounds__(256, WPS) void k(float* out, const float* in, int i
     float v[16];
     for (int i = 0; i < 16; ++i) v[i] = in[lane + i];
     const __bf16* wb = reinterpret_cast<const __bf16*>(smem);
+    (void)wb;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const float* big = in;                        // "AB" rows: 16 MB region
+    const int rowA = (blockIdx.x * 7 + (lane & 31) * 0) & 8191, rowB = (blockIdx.x * 29 + (lane & 31)) & 8191;
+    typedef float f32x4_ __attribute__((ext_vector_type(4)));
+    f32x4_ pa[4], pb[4];
+    for (int u = 0; u < 4; ++u) { pa[u] = f32x4_{0, 0, 0, 0}; pb[u] = pa[u]; }
     for (int it = 0; it < iters; ++it) {
+        if constexpr (MODE >= 5) {
+            __syncthreads();
+            const float* src = in + ((it + 1) & 7) * 8192;
+            float* dst = smem + ((it + 1) & 1) * 8192;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int piece = wave * 8 + u; glds16(src + piece * 256 + lane * 4, dst + piece * 256); }
+            wb = reinterpret_cast<const __bf16*>(smem + (it & 1) * 8192);
+        }
+        if constexpr (MODE >= 6) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] += pa[i >> 2][i & 3] + pb[i >> 2][i & 3];
+            const int c = (it + 2) & 7;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                pa[u] = *reinterpret_cast<const f32x4_*>(big + (size_t)rowA * 512 + 32 * c + 16 * (lane >> 5) + 4 * u);
+                pb[u] = *reinterpret_cast<const f32x4_*>(big + (size_t)rowB * 512 + 256 + 32 * c + 16 * (lane >> 5) + 4 * u);
+            }
+        }
         if constexpr (MODE == 0) {
 #pragma unroll
             for (int rep = 0; rep < 6; ++rep)
@@ -76,7 +105,7 @@ __global__ __launch_bounds__(256, WPS) void k(float* out, const float* in, int i
                 acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, cur[1], acc[c0], 0, 0, 0);
                 acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, cur[3], acc[c1], 0, 0, 0);
             }
-            if constexpr (MODE == 4) {
+            if constexpr (MODE >= 4) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     float x = v[i] + 0.001f * (float)it;
@@ -115,10 +144,10 @@ void run(const char* name, float* out, const float* in, int grid, int iters) {
 
 int main() {
     float *in, *out;
-    CK(hipMalloc(&in, 1 << 20)); CK(hipMalloc(&out, 1 << 22));
-    std::vector<float> h(1 << 18);
+    CK(hipMalloc(&in, 32 << 20)); CK(hipMalloc(&out, 1 << 22));
+    std::vector<float> h(8 << 20);
     for (size_t i = 0; i < h.size(); ++i) h[i] = (float)((i * 2654435761u) % 1000) / 500.f - 1.f;
-    CK(hipMemcpy(in, h.data(), 1 << 20, hipMemcpyHostToDevice));
+    CK(hipMemcpy(in, h.data(), 32 << 20, hipMemcpyHostToDevice));
     const int iters = 400;
     run<0, 2>("0 pure MFMA, 2 waves/SIMD", out, in, 512, iters);
     run<0, 1>("0 pure MFMA, 1 wave/SIMD", out, in, 256, iters);
@@ -129,5 +158,15 @@ int main() {
     run<3, 1>("3 + LDS frags (asm pipelined), 1 w/SIMD", out, in, 256, iters);
     run<4, 2>("4 + VALU silu/split, 2 w/SIMD", out, in, 512, iters);
     run<4, 1>("4 + VALU silu/split, 1 w/SIMD", out, in, 256, iters);
+    run<5, 2>("5 + per-chunk barrier + glds stream, 2 w/SIMD", out, in, 512, iters);
+    run<6, 2>("6 + row gathers 2 chunks ahead, 2 w/SIMD", out, in, 512, iters);
+    run<5, 2>("5 (grid 1740: 3.4 rounds of short WGs, iters=8)", out, in, 1740, 8);
+    run<6, 2>("6 (grid 1740, iters=8)", out, in, 1740, 8);
+    run<5, 2>("5 (grid 870, iters=16)", out, in, 870, 16);
+    run<5, 2>("5 (grid 512, iters=27)", out, in, 512, 27);
+    run<5, 2>("5 (grid 512, iters=54)", out, in, 512, 54);
+    run<4, 2>("4 (grid 1740, iters=8)", out, in, 1740, 8);
+    run<3, 2>("3 (grid 1740, iters=8)", out, in, 1740, 8);
+    run<0, 2>("0 (grid 1740, iters=8)", out, in, 1740, 8);
     return 0;
 }
