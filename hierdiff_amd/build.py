@@ -39,7 +39,7 @@ def build(force: bool = False, save_temps: bool = False, verbose: bool = True) -
     if not force and not needs_build():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-std=c++17", "-fPIC", "-shared",
            "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result", "-o", LIB + ".tmp"] + SOURCES
     if save_temps:
         tmpdir = os.path.join(PKG, "build")

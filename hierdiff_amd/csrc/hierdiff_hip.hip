@@ -342,19 +342,24 @@ extern "C" int hd_set_weights(hd_handle* h, const float* blob, long long n, int 
         std::copy(Wo, Wo + (size_t)fin * H, pk.begin() + h->outW);
         std::copy(bo, bo + fin, pk.begin() + h->out_b);
     }
+    // bf16x3 mode runs the edge model in a scaled domain (see silu2_scaled in kernels.hpp): everything feeding a
+    // SiLU / sigmoid of the edge kernel carries c = -log2(e), its consumers carry 1/c.  One rounding per weight.
+    const double cs = bf ? -1.4426950408889634074 : 1.0, cs_inv = 1.0 / cs;
+    auto sc = [&](float v) { return (float)((double)v * cs); };
+    auto sc_inv = [&](float v) { return (float)((double)v * cs_inv); };
     auto pack_first = [&](LayerW& w, const float* W1, const float* b1) {
         // W1 [H][2H+2]: columns [h_row(H) | h_col(H) | radial_cur | radial_init] (egnn_new.py:39,93,144)
         const int ld = 2 * H + 2;
         auto wab = [&](int col, int k) {
-            return (col < H) ? W1[(size_t)col * ld + k] : W1[(size_t)(col - H) * ld + H + k];
+            return sc((col < H) ? W1[(size_t)col * ld + k] : W1[(size_t)(col - H) * ld + H + k]);
         };
         if (h->fused) pack_node_b(pk, w.ab_img, H, 2 * H, wab);
         else pack_gemm_b(pk, w.ab_img, H, 2 * H, WN, wab);
         for (int k = 0; k < H; ++k) {
-            pk[w.ab_bias + k] = b1[k];
+            pk[w.ab_bias + k] = sc(b1[k]);
             pk[w.ab_bias + H + k] = 0.0f;
-            pk[w.wrd + k] = W1[(size_t)k * ld + 2 * H];
-            pk[w.wrd + H + k] = W1[(size_t)k * ld + 2 * H + 1];
+            pk[w.wrd + k] = sc(W1[(size_t)k * ld + 2 * H]);
+            pk[w.wrd + H + k] = sc(W1[(size_t)k * ld + 2 * H + 1]);
         }
     };
     for (int i = 0; i < L; ++i) {
@@ -365,7 +370,8 @@ extern "C" int hd_set_weights(hd_handle* h, const float* blob, long long n, int 
             const float* W3 = next((size_t)H * 2 * H);       const float* b3 = next(H);
             const float* W4 = next((size_t)H * H);           const float* b4 = next(H);
             pack_first(w, W1, b1);
-            auto w3 = [&](int col, int k) { return W3[(size_t)col * 2 * H + k]; };
+            // node_mlp.0: columns k >= H multiply the neighbour sums, which arrive scaled by c
+            auto w3 = [&](int col, int k) { const float v = W3[(size_t)col * 2 * H + k]; return k >= H ? sc_inv(v) : v; };
             auto w4 = [&](int col, int k) { return W4[(size_t)col * H + k]; };
             if (bf) pack_edge_w2_bf(pk, w.w2_img, H, W2);
             else pack_edge_w2(pk, w.w2_img, H, W2);
@@ -376,13 +382,13 @@ extern "C" int hd_set_weights(hd_handle* h, const float* blob, long long n, int 
                 pack_gemm_b(pk, w.w3_img, 2 * H, H, WN, w3);
                 pack_gemm_b(pk, w.w4_img, H, H, WN, w4);
             }
-            std::copy(b2, b2 + H, pk.begin() + w.b2);
+            for (int k = 0; k < H; ++k) pk[w.b2 + k] = sc(b2[k]);
             std::copy(b3, b3 + H, pk.begin() + w.b3);
             std::copy(b4, b4 + H, pk.begin() + w.b4);
             if (c.attention) {
                 const float* wa = next(H); const float* ba = next(1);
                 std::copy(wa, wa + H, pk.begin() + w.wa);
-                w.ba = ba[0];
+                w.ba = sc(ba[0]);
             } else {
                 w.ba = 0.0f;
             }
@@ -394,8 +400,7 @@ extern "C" int hd_set_weights(hd_handle* h, const float* blob, long long n, int 
         pack_first(w, W5, b5);
         if (bf) pack_edge_w2_bf(pk, w.w2_img, H, W6);
         else pack_edge_w2(pk, w.w2_img, H, W6);
-        std::copy(b6, b6 + H, pk.begin() + w.b2);
-        std::copy(w7, w7 + H, pk.begin() + w.wa);
+        for (int k = 0; k < H; ++k) { pk[w.b2 + k] = sc(b6[k]); pk[w.wa + k] = sc_inv(w7[k]); }
         w.ba = 0.0f;
     }
     if (p - src != n) return fail(HD_E_INVALID, "hd_set_weights: internal layout mismatch");
@@ -632,7 +637,18 @@ static void node_update(hd_handle* h, bool upd, int nab, const NodeArgs& a, hipS
 }
 
 template <int H>
-static int edge_lds_bytes() { return (2 * 32 * H + 2 * H + 4 * 136) * 4; }
+static int edge_lds_bytes() { return (2 * 32 * H + 2 * H + 4 * 136) * 4; }   // dynamic part (w_r/w_d/b2/wa are static)
+
+static long long* g_trace = nullptr;
+static int g_trace_wg = 0;
+// debug only (HD_ABLATE=16): cycle stamps of the last traced edge launch, 32 values per workgroup
+extern "C" int hd_debug_edge_trace(long long* out, int max_wg) {
+    if (!g_trace) return 0;
+    const int n = std::min(max_wg, g_trace_wg);
+    hipDeviceSynchronize();
+    hipMemcpy(out, g_trace, sizeof(long long) * 32 * n, hipMemcpyDeviceToHost);
+    return n;
+}
 
 template <int H>
 static int launch_edge_h(int prec, bool coord, const EdgeArgs& a, hipStream_t s) {
@@ -642,25 +658,32 @@ static int launch_edge_h(int prec, bool coord, const EdgeArgs& a, hipStream_t s)
         static int abl = -1;
         if (abl < 0) { const char* e = getenv("HD_ABLATE"); abl = e ? atoi(e) : 0; }
         if (abl && prec == 1 && !coord) {
-            static bool attr = false;
-            if (!attr) {
-                hipFuncSetAttribute((const void*)k_edge<256, false, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-                hipFuncSetAttribute((const void*)k_edge<256, false, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-                hipFuncSetAttribute((const void*)k_edge<256, false, 1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-                hipFuncSetAttribute((const void*)k_edge<256, false, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-                hipFuncSetAttribute((const void*)k_edge<256, false, 1, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-                hipFuncSetAttribute((const void*)k_edge<256, false, 1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-                hipFuncSetAttribute((const void*)k_edge<256, false, 1, 15>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-                attr = true;
-            }
+            auto run = [&](auto Abl) {
+                constexpr int ABL = decltype(Abl)::value;
+                static bool attr = false;
+                if (!attr) {
+                    hipFuncSetAttribute((const void*)k_edge<256, false, 1, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                    attr = true;
+                }
+                EdgeArgs b = a;
+                if constexpr (ABL & 16) {
+                    if (!g_trace) hipMalloc(reinterpret_cast<void**>(&g_trace), sizeof(long long) * 32 * 4096);
+                    if (a.n_wg > 4096) return;
+                    b.trace = g_trace; g_trace_wg = a.n_wg;
+                }
+                hipLaunchKernelGGL((k_edge<256, false, 1, ABL>), grid, block, lds, s, b);
+            };
             switch (abl) {
-                case 1: hipLaunchKernelGGL((k_edge<256, false, 1, 1>), grid, block, lds, s, a); return HD_OK;
-                case 2: hipLaunchKernelGGL((k_edge<256, false, 1, 2>), grid, block, lds, s, a); return HD_OK;
-                case 3: hipLaunchKernelGGL((k_edge<256, false, 1, 3>), grid, block, lds, s, a); return HD_OK;
-                case 4: hipLaunchKernelGGL((k_edge<256, false, 1, 4>), grid, block, lds, s, a); return HD_OK;
-                case 7: hipLaunchKernelGGL((k_edge<256, false, 1, 7>), grid, block, lds, s, a); return HD_OK;
-                case 8: hipLaunchKernelGGL((k_edge<256, false, 1, 8>), grid, block, lds, s, a); return HD_OK;
-                case 15: hipLaunchKernelGGL((k_edge<256, false, 1, 15>), grid, block, lds, s, a); return HD_OK;
+                case 1: run(std::integral_constant<int, 1>{}); return HD_OK;
+                case 2: run(std::integral_constant<int, 2>{}); return HD_OK;
+                case 4: run(std::integral_constant<int, 4>{}); return HD_OK;
+                case 8: run(std::integral_constant<int, 8>{}); return HD_OK;
+                case 15: run(std::integral_constant<int, 15>{}); return HD_OK;
+                case 16: run(std::integral_constant<int, 16>{}); return HD_OK;
+                case 18: run(std::integral_constant<int, 18>{}); return HD_OK;
+                case 20: run(std::integral_constant<int, 20>{}); return HD_OK;
+                case 24: run(std::integral_constant<int, 24>{}); return HD_OK;
+                case 30: run(std::integral_constant<int, 30>{}); return HD_OK;
                 default: break;
             }
         }

@@ -49,17 +49,32 @@ HD_DEVINL float sigmoid_f(float x) {
     return __builtin_amdgcn_rcpf(1.0f + e);
 }
 
-// SiLU of the edge kernels.  PREC 0 (exact-fp32 matrix path): the compensated form above.  PREC 1 (bf16x3
-// path, whose contraction error is ~1e-6 anyway): plain exp2(-x*log2e), 5 instructions; the exponent
-// argument is then off by <= |x|*1.7e-7, i.e. a relative error of that size on an already saturated value.
-template <int PREC>
-HD_DEVINL float silu_p(float x) {
-    if constexpr (PREC == 0) {
-        return silu_f(x);
-    } else {
-        float e = __builtin_amdgcn_exp2f(x * -1.44269502162933349609375f);
-        return x * __builtin_amdgcn_rcpf(1.0f + e);
-    }
+// plain SiLU of the bf16x3 node kernel (contraction error ~1e-6 anyway): exp2(-x*log2e), 5 instructions; the
+// exponent argument is off by <= |x|*1.7e-7, i.e. a relative error of that size on an already saturated value.
+HD_DEVINL float silu_fast(float x) {
+    float e = __builtin_amdgcn_exp2f(x * -1.44269502162933349609375f);
+    return x * __builtin_amdgcn_rcpf(1.0f + e);
+}
+
+// ---- scaled-domain activations of the bf16x3 edge kernel.  The host multiplies everything that feeds a SiLU /
+// sigmoid of the edge model by c = -log2(e) (first edge Linear incl. bias and the two distance columns, b2, the
+// attention bias), so with x' = c x
+//     silu'(x') := x' * rcp(1 + exp2(x')) = c * silu(x)          sigmoid(z) = rcp(1 + exp2(z'))
+// need no multiply by log2(e); the factor c carried by the activations is undone by 1/c folded into the
+// weights that consume them (W2: c * 1/c = 1, i.e. unchanged; coord_mlp.4; the neighbour-sum half of node_mlp.0).
+// Deliberately NOT written with v_pk_*_f32: packed fp32 runs on the matrix pipe's datapath and cannot issue while
+// an MFMA of either co-resident wavefront is in flight (scratch/mb/coissue.hip: 4 v_pk_fma per MFMA cost
+// 52 ns/slot vs 30 ns for 4 v_fma_f32, which hide completely), so the file is built with -fno-slp-vectorize.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+HD_DEVINL float silu_scaled(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x)); }
+// bf16 head / tail of a pair, each packed into one dword (element 0 in the low half)
+HD_DEVINL void bf16_split2(float y0, float y1, uint32_t& hi, uint32_t& lo) {
+    const uint32_t hp = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){y0, y1}, bf16x2_t));
+    const float l0 = y0 - __builtin_bit_cast(float, hp << 16);
+    const float l1 = y1 - __builtin_bit_cast(float, hp & 0xffff0000u);
+    hi = hp;
+    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){l0, l1}, bf16x2_t));
 }
 
 // compile-time loop: f(std::integral_constant<int, I>) for I = 0..N-1
@@ -520,7 +535,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_node(NodeArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int R = (r & 3) + 8 * (r >> 2) + 4 * hh;
-                    bf16_split_store(Th + R * LDH + 32 * (ct0 + c) + n, Tl + R * LDH + 32 * (ct0 + c) + n, silu_p<1>(acc[c][r]));
+                    bf16_split_store(Th + R * LDH + 32 * (ct0 + c) + n, Tl + R * LDH + 32 * (ct0 + c) + n, silu_fast(acc[c][r]));
                 }
         }
         __syncthreads();
@@ -628,6 +643,7 @@ struct EdgeArgs {
     float coords_range;     // per-block range
     int attention, use_tanh;
     int n_tiles, n_wg;      // n_wg = number of 128-edge workgroup-tiles
+    long long* trace;       // ABL & 16: per wave {start, loop start, loop end, end} cycle stamps
 };
 
 
@@ -658,15 +674,39 @@ HD_DEVINL void lds_wait4(V (&f)[4]) {
     asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]) : "i"(N));
 }
 
+// x[lane] + x[lane ^ 32] in every lane, on the VALU (gfx950 v_permlane32_swap: upper half of the first operand
+// <-> lower half of the second) instead of a ds_bpermute round trip.  The s_nops cover the VALU-write ->
+// permlane-read and permlane-write -> VALU-read hazards, which hipcc does not track through inline asm.
+HD_DEVINL float xhalf_sum(float x) {
+    float lo = x, hi = x;
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(lo), "+v"(hi));
+    return lo + hi;
+}
+
+// AB row gathers of the bf16x3 edge kernel: two 16-byte loads (A_i quad, B_j quad) as inline asm, released by a
+// hand-counted s_waitcnt vmcnt that names their registers.  Compiler-visible loads cannot be used next to the
+// W2 stream: hipcc treats global_load_lds as a second vmcnt event type, assumes mixed events complete out of
+// order and waits vmcnt(0) - i.e. for the stream it has just started - before the first use of a gathered row.
+// Loads (LDS-DMA included) return in issue order, so "at most N outstanding" releases everything older.
+HD_DEVINL void vm_load2(f32x4& va, f32x4& vb, const float* pa, const float* pb) {
+    asm volatile("global_load_dwordx4 %0, %2, off\n\t"
+                 "global_load_dwordx4 %1, %3, off"
+                 : "=&v"(va), "=&v"(vb) : "v"(pa), "v"(pb));
+}
+template <int N>
+HD_DEVINL void vm_wait2(f32x4& va, f32x4& vb) {
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(va), "+v"(vb) : "i"(N));
+}
+
 // byte offset (from the lane's base) of a B fragment inside a chunk image
 //   bf16x3: unit u = (k-step, column tile), hl = head (0) / tail (1);   fp32: fragment u = (q, column tile)
 template <int NCT>
 constexpr unsigned frag_off_bf(int u, int hl) { return (unsigned)((((hl * 2 + u / NCT) * NCT + u % NCT) * 64) * 16); }
 constexpr unsigned frag_off_f32(int u) { return (unsigned)(u * 64 * 16); }
 
-// ABL: ablation switches for bottleneck hunting (never set in production launches):
+// ABL: ablation switches for bottleneck hunting (never set in production launches; env HD_ABLATE, H=256 bf16x3 GCL):
 //   1 = skip the epilogue, 2 = skip operand generation (SiLU etc.), 4 = no per-chunk barrier / W2 streaming,
-//   8 = no AB row gathers
+//   8 = no AB row gathers, 16 = record per-wave cycle stamps + HW placement (hd_debug_edge_trace, scratch/edge_trace.py)
 //
 // Persistent workgroups: gridDim.x <= 2 per CU; each workgroup walks the 128-edge workgroup-tiles of its
 // XCD's contiguous share of the edge list (neighbouring tiles = same molecule = same AB rows in that XCD's
@@ -680,8 +720,11 @@ __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
     constexpr int GL_PER_WAVE = CHF / (4 * 256);   // 1 KiB pieces per wave per chunk
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* wbuf = smem;                   // [2][CHF]
-    float* wrd_s = smem + 2 * CHF;        // [2][H]
-    float* scratch = wrd_s + 2 * H;       // per wave: 32 (phi) + 96 (trans) + 8 (seg bytes)
+    // w_r / w_d live in their own LDS object: hipcc makes every compiler-visible LDS read that may alias the
+    // destination of an in-flight global_load_lds wait for vmcnt(0) - with one shared array that stalled each
+    // chunk on the W2 stream it had just started.
+    __shared__ __attribute__((aligned(16))) float wrd_s[4 * H];   // [w_r | w_d | b2 | wa], staged once per workgroup
+    float* scratch = smem + 2 * CHF + 2 * H;   // per wave: 32 (phi) + 96 (trans) + 8 (seg bytes)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -702,12 +745,15 @@ __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
         wt_count = slot < len ? (len - slot + wt_step - 1) / wt_step : 0;
     }
     if (wt_count == 0) return;
+    long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0;
+    if constexpr (ABL & 16) ts0 = __builtin_readcyclecounter();
     // HD_EDGE_PERSIST == 0 (default): the host launches one workgroup per workgroup-tile and the loop below runs
     // once.  Measured on MI355X the persistent form is no faster (118.5 vs 121.5 us) and its longer live
     // ranges cost ~25 spilled registers, so the single-pass form ships; the walk stays for experiments.
     const int n_it = HD_EDGE_PERSIST ? wt_count : 1;
 
     for (int k = tid; k < 2 * H; k += 256) wrd_s[k] = a.wrd[k];
+    for (int k = tid; k < H; k += 256) { wrd_s[2 * H + k] = a.b2[k]; wrd_s[3 * H + k] = a.wa[k]; }
     auto issue_chunk = [&](int c, int buf) {
         const float* src = a.W2img + (size_t)c * CHF;
         float* dst = wbuf + buf * CHF;
@@ -747,6 +793,8 @@ __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
         const float ex = yi[0] - yj[0], ey = yi[1] - yj[1], ez = yi[2] - yj[2];
         const float d0 = ex * ex + ey * ey + ez * ez;
         const uint32_t segb_t = segb;
+        const int pbase = tile_ok ? a.tile_pbase[tile] : 0;     // requested here, used in the epilogue
+        const int nseg = tile_ok ? a.tile_nseg[tile] : 0;
         if (hh == 0) reinterpret_cast<uint8_t*>(seg_s)[n] = (uint8_t)segb_t;
 
         const float* Arow = a.AB + (size_t)ni * (2 * H) + 16 * hh;
@@ -764,8 +812,12 @@ __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
                 pb[u] = *reinterpret_cast<const f32x4*>(Brow + 32 * c + 4 * u);
             }
         };
+        auto rows_issue = [&](int u, int c) {                  // bf16x3 mode: quad u of chunk c (see vm_load2)
+            if constexpr (ABL & 8) { pa[u] = f32x4{radial, d0, radial, d0}; pb[u] = pa[u]; }
+            else vm_load2(pa[u], pb[u], Arow + 32 * c + 4 * u, Brow + 32 * c + 4 * u);
+        };
         // first-layer activations of this lane's edge row for K chunk c (k = 32c + 16*hh + 0..15)
-        auto make_P = [&](int c, float (&P)[16]) {
+        auto make_P = [&](int c, float (&P)[16]) {             // fp32 mode
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 f32x4 wr4 = *reinterpret_cast<const f32x4*>(wrd_s + 32 * c + 16 * hh + 4 * u);
@@ -775,56 +827,88 @@ __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
                     float pre = pa[u][j] + pb[u][j];
                     pre = __builtin_fmaf(radial, wr4[j], pre);
                     pre = __builtin_fmaf(d0, wd4[j], pre);
-                    if constexpr (ABL & 2) P[4 * u + j] = pa[u][j];
-                    else P[4 * u + j] = silu_p<PREC>(pre);
+                    P[4 * u + j] = silu_f(pre);
                 }
             }
         };
-        auto split_P = [&](const float (&P)[16], bf16x8 (&ph)[2], bf16x8 (&pl)[2]) {
+        // bf16x3 mode: one pair of values (scaled domain) -> bf16 head / tail dwords
+        auto make_pair = [&](f32x2 av, f32x2 bv, f32x2 wr2, f32x2 wd2, uint32_t& hi, uint32_t& lo) {
+            float y[2];
 #pragma unroll
-            for (int st = 0; st < 2; ++st)
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const float x = P[8 * st + i];
-                    const __bf16 xh = (__bf16)x;
-                    ph[st][i] = xh;
-                    pl[st][i] = (__bf16)(x - (float)xh);
-                }
+            for (int j = 0; j < 2; ++j) {
+                float pre = av[j] + bv[j];
+                pre = __builtin_fmaf(radial, wr2[j], pre);
+                pre = __builtin_fmaf(d0, wd2[j], pre);
+                if constexpr (ABL & 2) y[j] = av[j]; else y[j] = silu_scaled(pre);
+            }
+            bf16_split2(y[0], y[1], hi, lo);
         };
+        auto make_P_bf = [&](int c, u32x4 (&ph)[2], u32x4 (&pl)[2]) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const f32x4 wr4 = *reinterpret_cast<const f32x4*>(wrd_s + 32 * c + 16 * hh + 4 * u);
+                const f32x4 wd4 = *reinterpret_cast<const f32x4*>(wrd_s + H + 32 * c + 16 * hh + 4 * u);
+#pragma unroll
+                for (int j2 = 0; j2 < 2; ++j2) {
+                    uint32_t hi, lo;
+                    make_pair(f32x2{pa[u][2 * j2], pa[u][2 * j2 + 1]}, f32x2{pb[u][2 * j2], pb[u][2 * j2 + 1]},
+                              f32x2{wr4[2 * j2], wr4[2 * j2 + 1]}, f32x2{wd4[2 * j2], wd4[2 * j2 + 1]}, hi, lo);
+                    ph[u >> 1][2 * (u & 1) + j2] = hi;
+                    pl[u >> 1][2 * (u & 1) + j2] = lo;
+                }
+            }
+        };
+
+        // Software pipeline: the operands of chunk c+1 are produced (VALU) while the matrix pipe works on
+        // chunk c; the AB rows are fetched two chunks ahead.
+        float Pc[16];
+        u32x4 phc[2], plc[2];                  // bf16x3: head / tail of the 16 operand values, 8 bf16 per k-step
+        if constexpr (PREC == 0) {
+            load_rows(0);
+            __syncthreads();               // chunk 0 of this tile landed (w_r / w_d staged on the first pass)
+            make_P(0, Pc);
+            load_rows(NCH > 1 ? 1 : 0);
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) rows_issue(u, 0);
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(pa[0]), "+v"(pa[1]), "+v"(pa[2]), "+v"(pa[3]),
+                                                "+v"(pb[0]), "+v"(pb[1]), "+v"(pb[2]), "+v"(pb[3]));
+            __syncthreads();               // chunk 0 landed in every wave's share (w_r / w_d staged on the first pass)
+            make_P_bf(0, phc, plc);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) rows_issue(u, NCH > 1 ? 1 : 0);
+        }
 
         // accumulators start at the second layer's bias (saves the H/32 * 16 bias adds of the epilogue)
         f32x16 acc[NCT];
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) {
-            const float b2v = a.b2[32 * ct + n];
+            const float b2v = wrd_s[2 * H + 32 * ct + n];
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[ct][r] = b2v;
         }
-
-        // Software pipeline: the operands of chunk c+1 are produced (VALU) while the matrix pipe works on
-        // chunk c; the AB rows are fetched two chunks ahead.
-        load_rows(0);
-        __syncthreads();                   // chunk 0 of this tile landed (w_r / w_d staged on the first pass)
-        float Pc[16];
-        bf16x8 phc[2], plc[2];
-        make_P(0, Pc);
-        if constexpr (PREC == 1) split_P(Pc, phc, plc);
-        if (NCH > 1) load_rows(1);
-
+        if constexpr (ABL & 16) ts1 = __builtin_readcyclecounter();
         // (Unrolling this loop by two with swapped operand sets, to drop the 16 register copies per chunk, was
         // measured: +17 spilled registers and 125 vs 109 us.)
 #pragma unroll 1
         for (int c = 0; c < NCH; ++c, ++gc) {
             const int buf = (ABL & 4) ? 0 : (gc & 1);
             if constexpr (!(ABL & 4)) {
-                if (c > 0) __syncthreads();    // chunk c landed (vmcnt(0)); every wave is done with the other buffer
-                if (c + 1 < NCH) issue_chunk(c + 1, buf ^ 1);
-                else if (!last_it) issue_chunk(0, buf ^ 1);        // keep the stream running into the next tile
+                // chunk c landed in LDS and every wave is done with the other buffer.  bf16x3: the only VMEM
+                // operations younger than chunk c's stream are the 8 row gathers of the previous iteration.
+                if (c > 0) {
+                    if constexpr (PREC == 0) __syncthreads();
+                    else asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+                }
+                // Unconditional (the last chunk re-requests chunk 0, unused unless a further tile follows): with the
+                // stream inside a branch hipcc has to assume "no stream in flight" at the join and waits vmcnt(0)
+                // - i.e. for the stream itself - before the first use of the gathered AB rows, every chunk.
+                issue_chunk(c + 1 < NCH ? c + 1 : 0, buf ^ 1);
             }
             // Branch-free from here to the end of the body (one scheduling region): the last iteration
             // recomputes the final chunk's operands and refetches its rows, results unused.
             float Pn[16];
-            bf16x8 phn[2], pln[2];
+            u32x4 phn[2], pln[2];
             const int cn1 = c + 1 < NCH ? c + 1 : NCH - 1, cn2 = c + 2 < NCH ? c + 2 : NCH - 1;
             if constexpr (PREC == 0) {
                 make_P(cn1, Pn);
@@ -854,7 +938,6 @@ __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
                 // W2[32ct + n][32c + 16h + 8s + i] - the same k order as P[8s + i].  Units u = (k-step, ct) of
                 // three MFMAs (head*head, tail*head, head*tail) on one accumulator, two units per group.
                 constexpr int NG = NCT;                     // 2*NCT units / 2
-                constexpr int PG = 16 / NG;                 // next-chunk operand values produced per group
                 // The next chunk's operand generation (VALU) is cut into NG slices, one per MFMA group, so the
                 // matrix pipe and the VALU alternate every ~6 MFMAs inside ONE wavefront instead of relying on
                 // the phase of the co-resident wavefront.  w_r / w_d come from LDS a slice pair ahead; the AB
@@ -876,38 +959,42 @@ __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
                         lds_read4<bf16x8, frag_off_bf<NCT>(u, 0), frag_off_bf<NCT>(u, 1), frag_off_bf<NCT>(u + 1, 0),
                                   frag_off_bf<NCT>(u + 1, 1)>(nxt, wb_lds);
                     }
-                    // slice g of the next chunk's operands
+                    // The next chunk's 8 operand pairs are produced in the FIRST half of the groups and the AB
+                    // rows of chunk c+2 are requested as soon as a quad of chunk c+1 has been consumed: the
+                    // per-chunk barrier implies vmcnt(0), so a gather issued late in the chunk would expose its
+                    // whole L2 latency there.
+                    constexpr int NGP = NG >= 2 ? NG / 2 : 1;          // groups that produce operands
+                    constexpr int PPG = 8 / NGP;                       // pairs per producing group
+                    if constexpr (g < NGP) {
 #pragma unroll
-                    for (int v = 0; v < PG; ++v) {
-                        constexpr int dummy_ = 0; (void)dummy_;
-                        const int idx = g * PG + v, u = idx >> 2, j = idx & 3;
-                        if (j == 0 && u + 1 < 4) {           // w_r / w_d for the following four values
-                            wrq[(u + 1) & 1] = *reinterpret_cast<const f32x4*>(wr_n + 4 * (u + 1));
-                            wdq[(u + 1) & 1] = *reinterpret_cast<const f32x4*>(wd_n + 4 * (u + 1));
-                        }
-                        float pre = pa[u][j] + pb[u][j];
-                        pre = __builtin_fmaf(radial, wrq[u & 1][j], pre);
-                        pre = __builtin_fmaf(d0, wdq[u & 1][j], pre);
-                        float y;
-                        if constexpr (ABL & 2) y = pa[u][j]; else y = silu_p<PREC>(pre);
-                        const __bf16 yh = (__bf16)y;
-                        phn[idx >> 3][idx & 7] = yh;
-                        pln[idx >> 3][idx & 7] = (__bf16)(y - (float)yh);
-                        if (j == 3) {                        // rows of chunk c+2 into the freed registers
-                            if constexpr (!(ABL & 8)) {
-                                pa[u] = *reinterpret_cast<const f32x4*>(Arow + 32 * cn2 + 4 * u);
-                                pb[u] = *reinterpret_cast<const f32x4*>(Brow + 32 * cn2 + 4 * u);
+                        for (int v = 0; v < PPG; ++v) {
+                            const int pi = g * PPG + v, u = pi >> 1, j2 = pi & 1;      // pair pi = values 2pi, 2pi+1
+                            // outstanding, oldest first: quads u..3 of chunk c+1, this chunk's GL_PER_WAVE stream
+                            // pieces, quads 0..u-1 of chunk c+2  =  8 + GL_PER_WAVE loads
+                            if (j2 == 0) vm_wait2<6 + GL_PER_WAVE>(pa[u], pb[u]);
+                            if (j2 == 0 && u + 1 < 4) {      // w_r / w_d for the following four values
+                                wrq[(u + 1) & 1] = *reinterpret_cast<const f32x4*>(wr_n + 4 * (u + 1));
+                                wdq[(u + 1) & 1] = *reinterpret_cast<const f32x4*>(wd_n + 4 * (u + 1));
                             }
+                            uint32_t hi, lo;
+                            make_pair(f32x2{pa[u][2 * j2], pa[u][2 * j2 + 1]}, f32x2{pb[u][2 * j2], pb[u][2 * j2 + 1]},
+                                      f32x2{wrq[u & 1][2 * j2], wrq[u & 1][2 * j2 + 1]},
+                                      f32x2{wdq[u & 1][2 * j2], wdq[u & 1][2 * j2 + 1]}, hi, lo);
+                            phn[pi >> 2][pi & 3] = hi;
+                            pln[pi >> 2][pi & 3] = lo;
+                            if (j2 == 1) rows_issue(u, cn2);     // rows of chunk c+2 into the freed registers
                         }
                     }
                     constexpr int u0 = 2 * g, u1 = 2 * g + 1;
                     constexpr int s0 = u0 / NCT, c0 = u0 % NCT, s1 = u1 / NCT, c1 = u1 % NCT;
-                    acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(phc[s0], cur[0], acc[c0], 0, 0, 0);
-                    acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(phc[s1], cur[2], acc[c1], 0, 0, 0);
-                    acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(plc[s0], cur[0], acc[c0], 0, 0, 0);
-                    acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(plc[s1], cur[2], acc[c1], 0, 0, 0);
-                    acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(phc[s0], cur[1], acc[c0], 0, 0, 0);
-                    acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(phc[s1], cur[3], acc[c1], 0, 0, 0);
+                    const bf16x8 A_h0 = __builtin_bit_cast(bf16x8, phc[s0]), A_l0 = __builtin_bit_cast(bf16x8, plc[s0]);
+                    const bf16x8 A_h1 = __builtin_bit_cast(bf16x8, phc[s1]), A_l1 = __builtin_bit_cast(bf16x8, plc[s1]);
+                    acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_h0, cur[0], acc[c0], 0, 0, 0);
+                    acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_h1, cur[2], acc[c1], 0, 0, 0);
+                    acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_l0, cur[0], acc[c0], 0, 0, 0);
+                    acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_l1, cur[2], acc[c1], 0, 0, 0);
+                    acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_h0, cur[1], acc[c0], 0, 0, 0);
+                    acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_h1, cur[3], acc[c1], 0, 0, 0);
 #pragma unroll
                     for (int k = 0; k < 6; ++k) {            // interleave: 1 MFMA, then up to 4 VALU
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -919,6 +1006,11 @@ __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
             }
         }
 
+        if constexpr (PREC == 1) {             // drain the (unused) last gathers before their registers are reused
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(pa[0]), "+v"(pa[1]), "+v"(pa[2]), "+v"(pa[3]),
+                                                "+v"(pb[0]), "+v"(pb[1]), "+v"(pb[2]), "+v"(pb[3]));
+        }
+        if constexpr (ABL & 16) ts2 = __builtin_readcyclecounter();
         // next tile's row metadata: in flight while this tile's epilogue runs
         if (!last_it) load_meta((wt_first + (it + 1) * wt_step) * 4 + wave);
 
@@ -939,14 +1031,37 @@ __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
         for (int r = 0; r < 16; ++r) dot[r] = 0.f;
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) {
-            const float wav = a.wa[32 * ct + n];
+            const float wav = wrd_s[3 * H + 32 * ct + n];
+            if constexpr (PREC == 0) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float mv = silu_p<PREC>(acc[ct][r]);
-                acc[ct][r] = mv;
-                dot[r] = __builtin_fmaf(mv, wav, dot[r]);
+                for (int r = 0; r < 16; ++r) {
+                    const float mv = silu_f(acc[ct][r]);
+                    acc[ct][r] = mv;
+                    dot[r] = __builtin_fmaf(mv, wav, dot[r]);
+                }
+            } else {
+                // stage by stage over the 16 rows of a column tile (exp x16, +1 x16, rcp x16, ...): left alone hipcc
+                // runs each value's exp -> add -> rcp -> mul chain back to back through one or two registers and
+                // the epilogue sits out the transcendental latency ~500 times.
+                float e[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) e[r] = __builtin_amdgcn_exp2f(acc[ct][r]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) e[r] = 1.0f + e[r];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) e[r] = __builtin_amdgcn_rcpf(e[r]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[ct][r] *= e[r];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dot[r] = __builtin_fmaf(acc[ct][r], wav, dot[r]);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
+        if constexpr (ABL & 16) ts3 = __builtin_readcyclecounter();
         // Row dots: transpose-reduce over the 32 lanes of a half.  Each exchange halves the number of rows a
         // lane still carries (16 -> 8 -> 4 -> 2 -> 1), the last one is a plain butterfly: 16 shuffles instead
         // of 80, and lanes 2r, 2r+1 end up with the complete dot of row slot r, so the sigmoid / tanh input is
@@ -980,16 +1095,19 @@ __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
             }
             rowdot += __shfl_xor(rowdot, 1);
         }
+        if constexpr (ABL & 16) ts4 = __builtin_readcyclecounter();
         const int my_slot = (n >> 1) & 15;                  // this lane holds the dot of row rho(my_slot)
-        const int pbase = a.tile_pbase[tile];
-        const int nseg = a.tile_nseg[tile];
 
         if (!COORD) {
             // segment byte of each of this lane's 16 rows: rows 8q+4hh .. +3 share one dword
             uint32_t sw[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) sw[q] = seg_s[2 * q + hh];
-            const float att_mine = a.attention ? sigmoid_f(rowdot + a.ba) : 1.0f;
+            float att_mine = 1.0f;
+            if (a.attention) {
+                if constexpr (PREC == 0) att_mine = sigmoid_f(rowdot + a.ba);
+                else att_mine = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(rowdot + a.ba));   // scaled domain
+            }
             float w[16];
             int sg[16];
 #pragma unroll
@@ -998,18 +1116,23 @@ __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
                 const float att = __shfl(att_mine, (lane & 32) | (2 * r));
                 w[r] = (sg[r] != 255) ? att : 0.0f;
             }
+            if constexpr (ABL & 16) ts5 = __builtin_readcyclecounter();
             for (int s = 0; s < nseg; ++s) {
                 float ws[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) ws[r] = (sg[r] == s) ? w[r] : 0.0f;
                 float* dst = a.part + (size_t)(pbase + s) * H + n;
+                float sums[NCT];
 #pragma unroll
                 for (int ct = 0; ct < NCT; ++ct) {
                     float sum = 0.f;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) sum = __builtin_fmaf(ws[r], acc[ct][r], sum);
-                    sum += __shfl_xor(sum, 32);
-                    if (hh == 0) dst[32 * ct] = sum;
+                    sums[ct] = xhalf_sum(sum);
+                }
+                if (hh == 0) {
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct) dst[32 * ct] = sums[ct];
                 }
             }
         } else {
@@ -1041,6 +1164,17 @@ __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
             }
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+        if constexpr (ABL & 16) {
+            if (lane == 0) {
+                long long* t = a.trace + ((size_t)blockIdx.x * 4 + wave) * 8;
+                // HW_ID (reg 4) / XCC_ID (reg 20) ride in the top 16 bits of the first two stamps
+                const long long hw = __builtin_amdgcn_s_getreg((16 - 1) << 11 | 4) & 0xffff;
+                const long long xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 20) & 0xf;
+                t[0] = (ts0 & 0xffffffffffffll) | (hw << 48); t[1] = (ts1 & 0xffffffffffffll) | (xcc << 48);
+                const long long m48 = 0xffffffffffffll;
+                t[2] = ts2 & m48; t[3] = __builtin_readcyclecounter() & m48; t[4] = ts3 & m48; t[5] = ts4 & m48; t[6] = ts5 & m48; t[7] = nseg;
+            }
         }
     }
 }
