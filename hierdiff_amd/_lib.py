@@ -49,6 +49,7 @@ SIGNATURES = {
     "hd_philox_normal_host": (C.c_float, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]),
     "hd_profile_enable": (C.c_int, [_VP, C.c_int]),
     "hd_profile_read": (C.c_int, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
+    "hd_debug_edge_trace": (C.c_int, [C.c_void_p, C.c_int]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -162,6 +162,12 @@ float hd_philox_normal_host(uint64_t seed, uint64_t sample_id, uint32_t draw, ui
 int hd_profile_enable(hd_handle* h, int on);
 int hd_profile_read(hd_handle* h, double* ms3, long long* launches3);
 
+/* Debug aid (no reference counterpart): per-wave cycle stamps of the most recent traced edge-kernel launch
+ * (environment HD_ABLATE with bit 16 set; H = 256, bf16x3, GCL variant).  32 int64 per workgroup =
+ * 4 waves x {start|HW_ID<<48, loop start|XCC_ID<<48, loop end, end, 3 epilogue stamps, segments}.
+ * Returns the number of workgroups copied (0 if nothing was traced). */
+int hd_debug_edge_trace(long long* out, int max_wg);
+
 #ifdef __cplusplus
 }
 #endif
