@@ -637,6 +637,9 @@ static void node_update(hd_handle* h, bool upd, int nab, const NodeArgs& a, hipS
 }
 
 template <int H>
+static int edge_p_lds_bytes() { return (3 * 32 * H + 4 * 2048 + 4 * 144) * 4; }    // k_edge_p: three chunk buffers, AB row slots, per-wave scratch
+
+template <int H>
 static int edge_lds_bytes() { return (2 * 32 * H + 2 * H + 4 * 136) * 4; }   // dynamic part (w_r/w_d/b2/wa are static)
 
 static long long* g_trace = nullptr;
@@ -688,6 +691,31 @@ static int launch_edge_h(int prec, bool coord, const EdgeArgs& a, hipStream_t s)
             }
         }
     }
+    if constexpr (H >= 256) {
+        // Experimental (HD_EDGE_PIPE=1): persistent one-wave-per-SIMD kernel with the previous tile's epilogue folded
+        // into the MFMA loop.  Correct (passes the whole GPU suite) but 124 us vs 103 us for k_edge on MI355X: a single
+        // wavefront issues at most one instruction per ~4 cycles and this stream needs ~10 per MFMA.
+        static int pipe = -1;
+        if (pipe < 0) { const char* e = getenv("HD_EDGE_PIPE"); pipe = e ? atoi(e) : 0; }
+        if (prec == 1 && pipe) {
+            const dim3 pgrid(std::min(a.n_wg, std::max(1, g_edge_grid / 2)));
+            const int plds = edge_p_lds_bytes<H>();
+            static int ptrace = -1;
+            if (ptrace < 0) { const char* e = getenv("HD_EDGE_PTRACE"); ptrace = e ? atoi(e) : 0; }
+            if (ptrace && !coord) {
+                static bool attr = false;
+                if (!attr) { hipFuncSetAttribute((const void*)k_edge_p<H, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, plds); attr = true; }
+                EdgeArgs b = a;
+                if (!g_trace) hipMalloc(reinterpret_cast<void**>(&g_trace), sizeof(long long) * 32 * 4096);
+                b.trace = g_trace; g_trace_wg = (int)pgrid.x;
+                hipLaunchKernelGGL((k_edge_p<H, false, true>), pgrid, block, plds, s, b);
+                return HD_OK;
+            }
+            if (coord) hipLaunchKernelGGL((k_edge_p<H, true>), pgrid, block, plds, s, a);
+            else hipLaunchKernelGGL((k_edge_p<H, false>), pgrid, block, plds, s, a);
+            return HD_OK;
+        }
+    }
     if (prec == 0) {
         if (coord) hipLaunchKernelGGL((k_edge<H, true, 0>), grid, block, lds, s, a);
         else hipLaunchKernelGGL((k_edge<H, false, 0>), grid, block, lds, s, a);
@@ -707,6 +735,10 @@ static int prepare_edge_h() {
     HIP_TRY(hipFuncSetAttribute((const void*)k_edge<H, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIP_TRY(hipFuncSetAttribute((const void*)k_edge<H, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIP_TRY(hipFuncSetAttribute((const void*)k_edge<H, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    if constexpr (H >= 256) {
+        HIP_TRY(hipFuncSetAttribute((const void*)k_edge_p<H, true>, hipFuncAttributeMaxDynamicSharedMemorySize, edge_p_lds_bytes<H>()));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_edge_p<H, false>, hipFuncAttributeMaxDynamicSharedMemorySize, edge_p_lds_bytes<H>()));
+    }
     return HD_OK;
 }
 

@@ -4,6 +4,7 @@ the reference and against the CPU oracle on seeded inputs.
 Tolerance: rel-L2 over the whole [B,N,3+F] output < 1e-4 and
 max-abs < 1e-4*max(1, max|ref|); masked rows bit-exact 0.  A correct fp32 kernel lands near 1e-6.
 """
+import os
 import numpy as np
 import pytest
 import torch
@@ -389,3 +390,45 @@ def test_pocket_public_api():
     from hierdiff_amd.diffusion import pocket_tensors
     with pytest.raises(ValueError):
         plain.sample(2, DEV, pocket_cond=[t[:2] for t in pocket_tensors(prot)])
+
+
+def test_experimental_pipelined_edge_kernel_subprocess():
+    """k_edge_p (HD_EDGE_PIPE=1, off by default; the switch is read once per process): golden parity on a fixture
+    with several tiles per wavefront, bit-identical repeats, and agreement with the default kernel at full size."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent('''
+        import sys, numpy as np, torch
+        sys.path.insert(0, ".")
+        from tests.test_gpu_parity import build_dynamics, DEV, load, fixture_model
+        from tests.helpers import rel_l2
+        from oracle import egnn_oracle as orc
+        from hierdiff_amd.weights import synthetic_state_dict
+        fx = load("f6_b16_n30_h256_l9")
+        sd_np, _, _ = fixture_model(fx)
+        dyn = build_dynamics(sd_np, int(fx["hidden_nf"]), int(fx["n_layers"])); dyn.precision = "bf16x3"
+        xh = torch.from_numpy(fx["xh"]).to(DEV); nm = torch.from_numpy(fx["node_mask"]).to(DEV)
+        em = torch.from_numpy(fx["edge_mask"]).to(DEV); B = xh.shape[0]
+        out = dyn._forward(torch.full((B, 1), float(fx["t_values"][0]), device=DEV), xh, nm, em, None, None)
+        print("GOLDEN", rel_l2(out.cpu().numpy(), fx["out_t0"]))
+        sd2 = synthetic_state_dict(9, 0, 256, 6, 2, True, 123, 1.0)
+        d2 = build_dynamics(sd2, 256, 6); d2.precision = "bf16x3"
+        x2, n2, e2 = orc.random_inputs([30] * 256, 8, 9)
+        t2 = torch.full((256, 1), 0.4, device=DEV)
+        o = [d2._forward(t2, x2.to(DEV), n2.to(DEV), e2.to(DEV), None, None).cpu().numpy() for _ in range(3)]
+        print("REPEAT", float(max(np.abs(o[1] - o[0]).max(), np.abs(o[2] - o[0]).max())))
+        np.save(sys.argv[1], o[0])
+    ''')
+    import tempfile
+    outs = {}
+    with tempfile.TemporaryDirectory() as td:
+        for pipe in ("1", "0"):
+            env = dict(os.environ, HD_EDGE_PIPE=pipe)
+            path = os.path.join(td, f"o{pipe}.npy")
+            r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=600,
+                               cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            assert r.returncode == 0, r.stderr[-2000:]
+            vals = {ln.split()[0]: float(ln.split()[1]) for ln in r.stdout.splitlines() if ln.split() and ln.split()[0] in ("GOLDEN", "REPEAT")}
+            assert vals["GOLDEN"] < 1e-4, vals          # same bar as every other forward test
+            assert vals["REPEAT"] == 0.0, vals          # deterministic
+            outs[pipe] = np.load(path)
+    assert rel_l2(outs["1"], outs["0"]) < 1e-5
