@@ -15,6 +15,7 @@ hooks) is out of scope.
 from __future__ import annotations
 
 import ctypes as C
+import math
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -184,6 +185,154 @@ class DiffusionQM9(_Base):
         x = x * self.norm_values[0]
         h = (h * self.norm_values[1] + self.norm_biases[1]) * node_mask
         return x, h
+
+    # ------------------------------------------------------------------ loss / NLL, forward value (reference API)
+    # diffusion_qm9.py:160-172, 206-292, 460-751.  The network calls go through the HIP dynamics (per-row t); the
+    # few element-wise terms around them are torch ops on the same device.  There is no backward pass in this
+    # library: everything runs under no_grad and the results do not require grad (training on MI355X is the
+    # "next" row 2 of SURVEY.md section 8f).
+    def subspace_dimensionality(self, node_mask):
+        return (torch.sum(node_mask.squeeze(2), dim=1) - 1) * self.n_dims
+
+    def normalize(self, x, h, node_mask):
+        x = x / self.norm_values[0]
+        delta_log_px = -self.subspace_dimensionality(node_mask) * math.log(self.norm_values[0])
+        h = (h - self.norm_biases[1]) / self.norm_values[1] * node_mask
+        return x, h, delta_log_px
+
+    def _gamma_rows(self, t, key, gammas):
+        """gamma at the [B,1] times `t`: fp64 evaluation rounded once (noise_model.evaluate_gamma) unless the caller
+        replays recorded values (`gammas[key]`)."""
+        if gammas is not None and key in gammas:
+            return torch.as_tensor(gammas[key], dtype=torch.float32, device=t.device).view(-1, 1)
+        return evaluate_gamma(self.gamma, t).to(t.device)
+
+    def compute_error(self, net_out, gamma_t, eps):
+        err = (eps - net_out) ** 2
+        err = err.reshape(err.size(0), -1).sum(-1)
+        if self.training and self.loss_type == 'l2':
+            err = err / ((self.n_dims + self.in_node_nf) * net_out.shape[1])
+        return err
+
+    def kl_prior(self, xh, node_mask, gamma_T=None):
+        B = xh.size(0)
+        if gamma_T is None:
+            gamma_T = self._gamma_rows(torch.ones((B, 1), device=xh.device), "gamma_T", None)
+        nm = node_mask.to(xh.dtype)
+        mu = self.alpha(gamma_T, xh) * xh
+        sig = torch.sqrt(torch.sigmoid(gamma_T)).view(-1)
+        sig3 = sig.view(-1, 1, 1)
+        kl_h = ((torch.log(1.0 / sig3) + 0.5 * (sig3 ** 2 + mu[:, :, self.n_dims:] ** 2) - 0.5) * nm).reshape(B, -1).sum(-1)
+        d = self.subspace_dimensionality(nm)
+        mu2 = (mu[:, :, :self.n_dims] ** 2).reshape(B, -1).sum(-1)
+        kl_x = d * torch.log(1.0 / sig) + 0.5 * (d * sig ** 2 + mu2) - 0.5 * d
+        return kl_x + kl_h
+
+    def log_constants_p_x_given_z0(self, x, node_mask, gamma_0=None):
+        n_nodes = node_mask.squeeze(2).sum(1)
+        if gamma_0 is None:
+            gamma_0 = self._gamma_rows(torch.zeros((x.size(0), 1), device=x.device), "gamma_0", None)
+        return (n_nodes - 1) * self.n_dims * (-0.5 * gamma_0.view(-1) - 0.5 * math.log(2 * math.pi))
+
+    def log_constants_p_h_given_z0(self, h, node_mask, gamma_0=None):
+        n_nodes = node_mask.squeeze(2).sum(1)
+        if gamma_0 is None:
+            gamma_0 = self._gamma_rows(torch.zeros((h.size(0), 1), device=h.device), "gamma_0", None)
+        return n_nodes * self.in_node_nf * (-0.5 * gamma_0.view(-1) - 0.5 * math.log(2 * math.pi))
+
+    def log_pxh_given_z0_without_constants(self, x, h, z_t, gamma_0, eps, net_out, node_mask, epsilon=1e-10):
+        int_nf, cont_nf = (5, 3) if self.node_coarse_type == 'prop' else (3, 0)
+        nd = self.n_dims
+        z_h_int = z_t[:, :, nd:nd + int_nf]
+        log_px = -0.5 * self.compute_error(net_out[:, :, :nd], gamma_0, eps[:, :, :nd])
+        # the reference slices the continuous-feature prediction with a stride (`[: nd+int_nf : nd+int_nf+cont_nf]`,
+        # diffusion_qm9.py:477), i.e. column 0 broadcast against the noise columns; kept for drop-in parity
+        log_ph = -0.5 * self.compute_error(net_out[:, :, :nd + int_nf:nd + int_nf + cont_nf], gamma_0,
+                                           eps[:, :, nd + int_nf:nd + int_nf + cont_nf])
+        sigma_0_int = self.sigma(gamma_0, target_tensor=z_t) * self.norm_values[2]
+        h_integer = torch.round(h[:, :, :int_nf] * self.norm_values[2] + self.norm_biases[2]).long()
+        centred = h_integer - (z_h_int * self.norm_values[2] + self.norm_biases[2])
+        cdf = lambda v: 0.5 * (1. + torch.erf(v / math.sqrt(2)))
+        log_int = torch.log(cdf((centred + 0.5) / sigma_0_int) - cdf((centred - 0.5) / sigma_0_int) + epsilon)
+        log_int = (log_int * node_mask).reshape(x.size(0), -1).sum(-1)
+        return log_px + log_ph + log_int
+
+    @torch.no_grad()
+    def compute_loss(self, x, h, node_mask, edge_mask, context, t0_always, mol_shape=None,
+                     t_int=None, eps=None, eps0=None, gammas=None):
+        """Forward value of the variational bound estimator / simple loss (diffusion_qm9.py:530-673).  `t_int`
+        [B,1], `eps`, `eps0` [B,N,3+F] replay recorded draws (otherwise torch.randint / torch.randn on x.device, in
+        the reference's order); `gammas` replays schedule values (keys gamma_s, gamma_t, gamma_0, gamma_T)."""
+        if self.pocket or (mol_shape is not None and mol_shape != x.size(1)):
+            raise NotImplementedError("loss with fixed pocket nodes is not implemented (sampling is)")
+        B, N = x.size(0), x.size(1)
+        dev = x.device
+        nm = node_mask.to(torch.float32)
+        if t_int is None:
+            t_int = torch.randint(1 if t0_always else 0, self.T + 1, size=(B, 1), device=dev).float()
+        t_int = torch.as_tensor(t_int, dtype=torch.float32, device=dev).view(B, 1)
+        s, t = (t_int - 1) / self.T, t_int / self.T
+        t_is_zero = (t_int == 0).float().view(-1)
+        gamma_s, gamma_t = self._gamma_rows(s, "gamma_s", gammas), self._gamma_rows(t, "gamma_t", gammas)
+        gamma_0 = self._gamma_rows(torch.zeros_like(t), "gamma_0", gammas)
+        gamma_T = self._gamma_rows(torch.ones_like(t), "gamma_T", gammas)
+        if eps is None:
+            eps = self.sample_combined_position_feature_noise(B, N, node_mask)
+        eps = torch.as_tensor(eps, dtype=torch.float32, device=dev)
+        xh = torch.cat([x, h], dim=2)
+        self._check_mean_zero(x, node_mask)
+        z_t = self.alpha(gamma_t, x) * xh + self.sigma(gamma_t, x) * eps
+        net_out = self.phi(z_t, t, node_mask, edge_mask, context, mol_shape=N)
+        error = self.compute_error(net_out, gamma_t, eps)
+        l2_train = self.training and self.loss_type == 'l2'
+        snr_weight = torch.ones_like(error) if l2_train else (self.SNR(gamma_s - gamma_t) - 1).view(-1)
+        loss_t_larger_than_zero = 0.5 * snr_weight * error
+        neg_log_constants = -self.log_constants_p_x_given_z0(x, nm, gamma_0) - self.log_constants_p_h_given_z0(h, nm, gamma_0)
+        if l2_train:
+            neg_log_constants = torch.zeros_like(neg_log_constants)
+        kl_prior = self.kl_prior(xh, nm, gamma_T)
+        if t0_always:
+            if eps0 is None:
+                eps0 = self.sample_combined_position_feature_noise(B, N, node_mask)
+            eps0 = torch.as_tensor(eps0, dtype=torch.float32, device=dev)
+            z_0 = self.alpha(gamma_0, x) * xh + self.sigma(gamma_0, x) * eps0
+            net0 = self.phi(z_0, torch.zeros_like(t), node_mask, edge_mask, context, mol_shape=N)
+            loss_term_0 = -self.log_pxh_given_z0_without_constants(x, h, z_0, gamma_0, eps0, net0, nm)
+            loss = kl_prior + self.T * loss_t_larger_than_zero + neg_log_constants + loss_term_0
+        else:
+            loss_term_0 = -self.log_pxh_given_z0_without_constants(x, h, z_t, gamma_t, eps, net_out, nm)
+            loss_t = loss_term_0 * t_is_zero + (1 - t_is_zero) * loss_t_larger_than_zero
+            estimator = loss_t if l2_train else (self.T + 1) * loss_t
+            loss = kl_prior + estimator + neg_log_constants
+        return loss, {'t': t_int.squeeze(), 'loss_t': loss.squeeze(), 'error': error.squeeze()}
+
+    @torch.no_grad()
+    def nll(self, x, h, node_mask=None, edge_mask=None, context=None, mol_shape=None, **replay):
+        """Loss if training (value only), NLL estimate if eval (diffusion_qm9.py:675-699)."""
+        x, h, delta_log_px = self.normalize(x, h, node_mask.to(torch.float32))
+        if self.training and self.loss_type == 'l2':
+            delta_log_px = torch.zeros_like(delta_log_px)
+        loss, _ = self.compute_loss(x, h, node_mask, edge_mask, context, t0_always=not self.training,
+                                    mol_shape=mol_shape, **replay)
+        return loss - delta_log_px
+
+    @torch.no_grad()
+    def forward(self, batch, **replay):
+        """`{"loss": mean NLL}` for a reference data batch (keys positions, atom_mask, edge_mask, node_feature and,
+        with a context model, context) - diffusion_qm9.py:701-751 without the pocket branch."""
+        if self.pocket:
+            raise NotImplementedError("loss with fixed pocket nodes is not implemented (sampling is)")
+        x, node_mask = batch['positions'], batch['atom_mask']
+        nm = node_mask.to(x.dtype)
+        bad = (x * (1 - nm)).abs().sum()
+        if self.debug_checks:
+            assert bad.item() < 1e-5, f'Error {bad.item()} too high'
+        x = x - (x.sum(1, keepdim=True) / nm.sum(1, keepdim=True)) * nm
+        context = batch['context'] if self.dynamics.context_node_nf > 0 else None
+        bs, n_nodes, _ = x.size()
+        edge_mask = batch['edge_mask'].view(bs, n_nodes * n_nodes)
+        neg_log_pxh = self.nll(x, batch["node_feature"], node_mask, edge_mask, context=context, **replay)
+        return {"loss": neg_log_pxh.mean(0)}
 
     # ------------------------------------------------------------------ HIP plumbing
     def _lib_handle(self):

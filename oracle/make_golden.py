@@ -367,6 +367,55 @@ def fixture_pocket(DiffusionQM9, name, hidden_nf, n_layers, seed, coord_gain, T,
          hidden_nf=hidden_nf, n_layers=n_layers, weight_seed=seed, coord_gain=coord_gain)
 
 
+def fixture_nll(DiffusionQM9, name, hidden_nf, n_layers, seed, coord_gain, n_list, training):
+    """F9: forward value of DiffusionQM9.compute_loss / nll (diffusion_qm9.py:530-699), eval mode (t0_always: two
+    network calls) or training mode ('vlb': one call, t may be 0).  The reference's own draws (t_int from
+    torch.randint, eps from torch.randn) are recorded and injected into the oracle, together with the schedule
+    values its fp32 GammaNetwork produced on this host."""
+    model, sd, ocfg = build_reference(DiffusionQM9, hidden_nf, n_layers, 0, seed, coord_gain)
+    model.train(training)
+    nm, em = orc.canonical_masks(n_list)
+    B, N = nm.shape[:2]
+    g = torch.Generator().manual_seed(seed + 300)
+    x = torch.randn(B, N, 3, generator=g) * nm
+    x = x - (x.sum(1, keepdim=True) / nm.sum(1, keepdim=True)) * nm
+    h_int = torch.randint(0, 5, (B, N, 5), generator=g).float()
+    h = torch.cat([h_int, torch.randn(B, N, 3, generator=g)], dim=2) * nm
+    draws = []
+    orig = model.sample_combined_position_feature_noise
+
+    def recording(**kw):
+        z = orig(**kw)
+        draws.append(z.clone())
+        return z
+    model.sample_combined_position_feature_noise = recording
+    torch.manual_seed(seed + 301)
+    real_randint = torch.randint
+    if training:                          # steer the reference's own draw so that the t == 0 (L0) branch and both ends occur
+        preset = torch.tensor([0, 1, 500, 1000, 37][:B]).view(B, 1)
+        torch.randint = lambda *a, **k: preset.clone()
+    try:
+        with torch.no_grad():
+            loss, info = model.compute_loss(x, h, nm, em.view(B, N * N), None, t0_always=not training)
+    finally:
+        torch.randint = real_randint
+    with torch.no_grad():
+        t_int = info["t"].view(B, 1)
+        gam = {"gamma_s": model.gamma((t_int - 1) / model.T), "gamma_t": model.gamma(t_int / model.T),
+               "gamma_0": model.gamma(torch.zeros(B, 1)), "gamma_T": model.gamma(torch.ones(B, 1))}
+        got, err = orc.nll_forward(sd, ocfg, model.T, x, h, nm, em, None, t_int, draws[0],
+                                   draws[1] if not training else None, training=training, gammas=gam)
+    check(f"{name} loss", got.numpy(), loss.numpy(), tol=5e-6)
+    check(f"{name} error", err.numpy(), info["error"].numpy(), tol=5e-6)
+    out = dict(x=x.numpy(), h=h.numpy(), n_list=np.array(n_list), t_int=t_int.numpy(), eps=draws[0].numpy(),
+               loss=loss.numpy(), error=info["error"].numpy(), training=int(training), T=model.T,
+               hidden_nf=hidden_nf, n_layers=n_layers, weight_seed=seed, coord_gain=coord_gain,
+               **{k: v.numpy() for k, v in gam.items()})
+    if not training:
+        out["eps0"] = draws[1].numpy()
+    save(name, **out)
+
+
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
     torch.manual_seed(0)
@@ -396,6 +445,9 @@ def main():
     fixture_chain(DiffusionQM9, "f5_chain_h32_l2", 32, 2, 10, 1.0, 4, [6, 1, 4, 5])
     # F8: pocket-conditioned sampling (fixed residue nodes, block-diagonal masks)
     fixture_pocket(DiffusionQM9, "f8_pocket_h64_l2", 64, 2, 13, 1.0, 3, [7, 4, 6, 5], [9, 12, 5, 12])
+    # F9: loss / NLL forward value (validation NLL = two network calls; training-mode value = one)
+    fixture_nll(DiffusionQM9, "f9_nll_eval_h64_l2", 64, 2, 14, 1.0, [9, 4, 7, 6, 8], training=False)
+    fixture_nll(DiffusionQM9, "f9_nll_train_h64_l2", 64, 2, 15, 1.0, [9, 4, 7, 6, 8], training=True)
 
 
 if __name__ == "__main__":

@@ -24,7 +24,7 @@ __device__ __forceinline__ void valu(float (&v)[8], f32x2 (&p)[4]) {
     }
 }
 
-template <int KIND, int NV, bool MF>
+template <int KIND, int NV, bool MF, bool AG = false>
 __global__ __launch_bounds__(256, 2) void k(float* out, const float* in, int iters) {
     const int lane = threadIdx.x & 63;
     f32x16 acc[8];
@@ -37,7 +37,8 @@ __global__ __launch_bounds__(256, 2) void k(float* out, const float* in, int ite
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-            if constexpr (MF) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[c]) : "v"(a0), "v"(b0));
+            if constexpr (MF && !AG) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[c]) : "v"(a0), "v"(b0));
+            if constexpr (MF && AG) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[c]) : "v"(a0), "v"(b0));
             valu<KIND, NV>(v, p);
         }
     }
@@ -48,14 +49,14 @@ __global__ __launch_bounds__(256, 2) void k(float* out, const float* in, int ite
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
-template <int KIND, int NV, bool MF>
+template <int KIND, int NV, bool MF, bool AG = false>
 void run(const char* name, float* out, const float* in, int grid) {
     const int iters = 4000;
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-    hipLaunchKernelGGL((k<KIND, NV, MF>), dim3(grid), dim3(256), 0, 0, out, in, iters);
+    hipLaunchKernelGGL((k<KIND, NV, MF, AG>), dim3(grid), dim3(256), 0, 0, out, in, iters);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(a));
-    hipLaunchKernelGGL((k<KIND, NV, MF>), dim3(grid), dim3(256), 0, 0, out, in, iters);
+    hipLaunchKernelGGL((k<KIND, NV, MF, AG>), dim3(grid), dim3(256), 0, 0, out, in, iters);
     CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
     float ms; CK(hipEventElapsedTime(&ms, a, b));
     // ns per (MFMA + NV VALU) slot per wave
@@ -75,6 +76,10 @@ int main() {
         printf("---- grid %d (%d wave(s) per SIMD)\n", g, g / 256);
         run<0, 0, true>("MFMA only", out, in, g);
         ROW(1, "v_fma_f32")
+        run<0, 0, true, true>("MFMA only, acc in AGPRs", out, in, g);
+        run<1, 4, true, true>("v_fma_f32 x4 + MFMA(AGPR)", out, in, g); run<1, 8, true, true>("v_fma_f32 x8 + MFMA(AGPR)", out, in, g);
+        run<1, 12, true, false>("v_fma_f32 x12 + MFMA", out, in, g); run<1, 12, true, true>("v_fma_f32 x12 + MFMA(AGPR)", out, in, g);
+        run<3, 8, true, true>("v_exp_f32 x8 + MFMA(AGPR)", out, in, g);
         ROW(2, "v_pk_fma_f32")
         ROW(5, "v_pk_mul_f32")
         ROW(3, "v_exp_f32")

@@ -466,3 +466,34 @@ def test_full_length_chain_vs_oracle(precision):
 
 
 _CACHE = {}
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+@pytest.mark.parametrize("name", ["f9_nll_eval_h64_l2", "f9_nll_train_h64_l2"])
+def test_nll_forward_golden(name, precision):
+    """DiffusionQM9.compute_loss / nll / forward(batch) value (validation NLL: two network calls with per-row t;
+    training-mode value: one call incl. the t == 0 branch) against the reference, with its draws and schedule values
+    replayed.  Tolerance: 1e-4 relative per molecule (+1e-3 absolute), the per-forward bar carried through the loss."""
+    fx = load(name)
+    sd_np, _, _ = fixture_model(fx)
+    model = build_diffusion(sd_np, int(fx["hidden_nf"]), int(fx["n_layers"]), T=int(fx["T"]), precision=precision)
+    training = bool(int(fx["training"]))
+    model.train(training)
+    nm, em = orc.canonical_masks([int(v) for v in fx["n_list"]])
+    x, h = torch.from_numpy(fx["x"]).to(DEV), torch.from_numpy(fx["h"]).to(DEV)
+    gam = {k: fx[k] for k in ("gamma_s", "gamma_t", "gamma_0", "gamma_T")}
+    replay = dict(t_int=fx["t_int"], eps=fx["eps"], gammas=gam)
+    if not training:
+        replay["eps0"] = fx["eps0"]
+    loss, info = model.compute_loss(x, h, nm.to(DEV), em.to(DEV), None, t0_always=not training, **replay)
+    np.testing.assert_allclose(loss.cpu().numpy(), fx["loss"], rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(info["error"].cpu().numpy(), fx["error"], rtol=1e-4, atol=1e-4)
+    # the batch-level entry point of the reference's training / validation step
+    B, N = x.shape[:2]
+    batch = {"positions": x, "atom_mask": nm.to(DEV), "edge_mask": em.to(DEV).view(B, N, N), "node_feature": h}
+    out = model(batch, **replay)
+    assert abs(out["loss"].item() - float(np.mean(fx["loss"]))) <= 1e-4 * abs(float(np.mean(fx["loss"]))) + 1e-3
+    # without replay the draws come from torch's generator: finite and reproducible under a seed
+    torch.manual_seed(5); a = model.nll(x, h, nm.to(DEV), em.to(DEV))
+    torch.manual_seed(5); b = model.nll(x, h, nm.to(DEV), em.to(DEV))
+    assert torch.isfinite(a).all() and torch.equal(a, b)

@@ -120,3 +120,20 @@ def test_pocket_chain_matches_reference():
                                         torch.from_numpy(fx["pocket_edge_mask"])))
     assert_parity(x.numpy() * nm.float().numpy(), fx["x"], "pocket x", 2e-5, 2e-4)
     assert_parity(h.numpy(), fx["h"], "pocket h", 2e-5, 2e-4)
+
+
+@pytest.mark.parametrize("name", ["f9_nll_eval_h64_l2", "f9_nll_train_h64_l2"])
+def test_nll_forward_matches_reference(name):
+    """Loss / NLL forward value (diffusion_qm9.py:530-699) with the reference's own draws and schedule values."""
+    fx = load(name)
+    _, sd, cfg = fixture_model(fx)
+    nm, em = orc.canonical_masks([int(v) for v in fx["n_list"]])
+    training = bool(int(fx["training"]))
+    gam = {k: torch.from_numpy(fx[k]) for k in ("gamma_s", "gamma_t", "gamma_0", "gamma_T")}
+    with torch.no_grad():
+        loss, err = orc.nll_forward(sd, cfg, int(fx["T"]), fx["x"], fx["h"], nm, em, None, fx["t_int"], fx["eps"],
+                                    None if training else fx["eps0"], training=training, gammas=gam)
+    np.testing.assert_allclose(loss.numpy(), fx["loss"], rtol=2e-6, atol=1e-4)
+    np.testing.assert_allclose(err.numpy(), fx["error"], rtol=2e-6, atol=1e-5)
+    if training:
+        assert float(fx["t_int"][0, 0]) == 0.0          # the L0 branch is part of the fixture
