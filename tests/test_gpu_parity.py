@@ -497,3 +497,53 @@ def test_nll_forward_golden(name, precision):
     torch.manual_seed(5); a = model.nll(x, h, nm.to(DEV), em.to(DEV))
     torch.manual_seed(5); b = model.nll(x, h, nm.to(DEV), em.to(DEV))
     assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
+def test_c_abi_error_codes_and_messages():
+    """Error behaviour of the boundary (include/hierdiff_hip.h): negative codes + hd_last_error(), no aborts;
+    the Python mirror turns them into HierDiffHipError / ValueError."""
+    import ctypes as C
+    from hierdiff_amd import _lib
+    lib = _lib.load()
+    last = lambda: lib.hd_last_error().decode()
+
+    def cfg(**kw):
+        base = dict(in_node_nf=9, context_node_nf=0, n_dims=3, hidden_nf=32, n_layers=1, inv_sublayers=1, attention=1,
+                    tanh=1, condition_time=1, norm_constant=0.0, normalization_factor=10.0, coords_range=30.0, precision=1)
+        base.update(kw)
+        return _lib.HdConfig(**base)
+    h = C.c_void_p()
+    assert lib.hd_create(C.byref(cfg(hidden_nf=48)), 0, C.byref(h)) == -1 and "hidden_nf" in last()
+    assert lib.hd_create(C.byref(cfg(precision=7)), 0, C.byref(h)) == -1 and "precision" in last()
+    assert lib.hd_create(C.byref(cfg(normalization_factor=0.0)), 0, C.byref(h)) == -1
+    assert lib.hd_create(C.byref(cfg()), 99, C.byref(h)) == -2 and "device" in last()
+    assert lib.hd_create(C.byref(cfg()), 0, C.byref(h)) == 0
+    n = lib.hd_weight_count(h)
+    w = torch.zeros(n, device=DEV)
+    assert lib.hd_set_weights(h, C.c_void_p(w.data_ptr()), n - 1, 1, None) == -1 and "expected" in last()
+    nm = np.ones((2, 4), dtype=np.uint8)
+    topo = C.c_void_p()
+    assert lib.hd_topology_create(h, nm.ctypes.data_as(C.c_void_p), None, 0, 4, C.byref(topo)) == -1
+    assert lib.hd_topology_create(h, nm.ctypes.data_as(C.c_void_p), None, 2, 4, C.byref(topo)) == 0
+    xh = torch.zeros(2, 4, 11, device=DEV); out = torch.zeros_like(xh); t = torch.zeros(2, device=DEV)
+    args = lambda hh, tp, tn: (hh, tp, C.c_void_p(xh.data_ptr()), C.c_void_p(t.data_ptr()), tn, None, -1,
+                               C.c_void_p(out.data_ptr()), None)
+    assert lib.hd_egnn_forward(*args(h, topo, 2)) == -4 and "weights" in last()          # state error: no weights yet
+    assert lib.hd_set_weights(h, C.c_void_p(w.data_ptr()), n, 1, None) == 0
+    assert lib.hd_egnn_forward(*args(h, topo, 3)) == -1                                   # t must have 1 or B elements
+    assert lib.hd_egnn_forward(h, topo, None, C.c_void_p(t.data_ptr()), 2, None, -1, C.c_void_p(out.data_ptr()), None) == -1
+    h2 = C.c_void_p()
+    assert lib.hd_create(C.byref(cfg()), 0, C.byref(h2)) == 0
+    assert lib.hd_set_weights(h2, C.c_void_p(w.data_ptr()), n, 1, None) == 0
+    assert lib.hd_egnn_forward(*args(h2, topo, 2)) == -1 and "another handle" in last()
+    assert lib.hd_egnn_forward(*args(h, topo, 2)) == 0                                    # and the valid call still works
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
+    assert lib.hd_sample_loop(h, topo, C.c_void_p(xh.data_ptr()), None, 4, 3, 0, None, None, 0, 1, 0, 0, None) < 0     # no schedule set
+    lib.hd_topology_destroy(topo); lib.hd_destroy(h); lib.hd_destroy(h2)
+    # Python mirror
+    from hierdiff_amd import EGNN_dynamics_QM9
+    dyn = EGNN_dynamics_QM9(9, 0, 3, hidden_nf=32, n_layers=1).to(DEV)
+    with pytest.raises((ValueError, _lib.HierDiffHipError)):
+        dyn._forward(torch.zeros(3, 1, device=DEV), xh, torch.ones(2, 4, 1, dtype=torch.bool, device=DEV),
+                     torch.ones(2, 16, dtype=torch.bool, device=DEV), None, None)
