@@ -17,8 +17,8 @@ CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libhierdiff_hip.so")
 SOURCES = [os.path.join(CSRC, "hierdiff_hip.hip")]
-DEPS = SOURCES + [os.path.join(CSRC, "kernels.hpp"),
-                  os.path.join(os.path.dirname(PKG), "include", "hierdiff_hip.h")]
+DEPS = SOURCES + [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hpp")] + [
+    os.path.join(os.path.dirname(PKG), "include", "hierdiff_hip.h")]
 
 
 def _hipcc() -> str:

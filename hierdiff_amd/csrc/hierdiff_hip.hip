@@ -342,7 +342,7 @@ extern "C" int hd_set_weights(hd_handle* h, const float* blob, long long n, int 
         std::copy(Wo, Wo + (size_t)fin * H, pk.begin() + h->outW);
         std::copy(bo, bo + fin, pk.begin() + h->out_b);
     }
-    // bf16x3 mode runs the edge model in a scaled domain (see silu2_scaled in kernels.hpp): everything feeding a
+    // bf16x3 mode runs the edge model in a scaled domain (see silu_scaled in common.hpp): everything feeding a
     // SiLU / sigmoid of the edge kernel carries c = -log2(e), its consumers carry 1/c.  One rounding per weight.
     const double cs = bf ? -1.4426950408889634074 : 1.0, cs_inv = 1.0 / cs;
     auto sc = [&](float v) { return (float)((double)v * cs); };

@@ -1,0 +1,503 @@
+// Node-side kernels: input embedding (k_node_init), fp32-mode node GEMMs (k_gemm) and the fused bf16x3 node update
+// (k_node).  Included through kernels.hpp.
+#pragma once
+#include "common.hpp"
+
+// ----------------------------------------------------------------------------- node init
+// xh*mask -> x0/xcur; [h*mask | t | context] -> embedding (en_dynamics.py:57-79, egnn_new.py:197).
+
+struct InitArgs {
+    const float* xh;        // [B*N][D]
+    const float* t;         // [1] or [B]
+    const float* ctx;       // [B*N][C] or null
+    const int* node_of;     // [M] compact -> flat
+    const float* nmask;     // [M_pad] 0/1
+    const float* embT;      // [fin][H]
+    const float* emb_b;     // [H]
+    float* h;               // [M_pad][H]
+    float* x0;              // [M_pad][4]
+    float* xcur;            // [M_pad][4]
+    int M, N, D, F, C, H, t_stride, cond_time;
+};
+
+__global__ void k_node_init(InitArgs a) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    int i = idx / a.H, c = idx - i * a.H;
+    if (i >= a.M) return;
+    int flat = a.node_of[i];
+    float m = a.nmask[i];
+    const float* row = a.xh + (size_t)flat * a.D;
+    float acc = a.emb_b[c];
+    int f = 0;
+    for (; f < a.F; ++f) acc = __builtin_fmaf(row[3 + f] * m, a.embT[f * a.H + c], acc);
+    if (a.cond_time) {
+        float tv = a.t[(flat / a.N) * a.t_stride];
+        acc = __builtin_fmaf(tv, a.embT[f * a.H + c], acc);
+        ++f;
+    }
+    for (int k = 0; k < a.C; ++k, ++f) acc = __builtin_fmaf(a.ctx[(size_t)flat * a.C + k], a.embT[f * a.H + c], acc);
+    a.h[(size_t)i * a.H + c] = acc;
+    if (c < 4) {
+        float v = (c < 3) ? row[c] * m : 0.0f;
+        a.x0[(size_t)i * 4 + c] = v;
+        a.xcur[(size_t)i * 4 + c] = v;
+    }
+}
+
+// ----------------------------------------------------------------------------- node GEMM (fp32 MFMA)
+// C[M][Nc] = epi(A[M][K] * Wt[K][Nc] + bias).  Workgroup tile (32*WM) x (32*WN), one 32x32
+// v_mfma_f32_32x32x2_f32 accumulator per wavefront, K in chunks of 32 double-buffered through LDS.
+// The K index inside a chunk is permuted (lane half h owns k = 16h..16h+15) so that both
+// operands are fetched with one ds_read_b128 per four MFMAs; weights are pre-packed in that image.
+
+enum { EPI_BIAS = 0, EPI_BIAS_SILU = 1, EPI_RESID_MASK = 2 };
+
+struct GemmArgs {
+    const float* A;       // [M_pad][lda], columns k < K1
+    const float* A2;      // CAT: [M_pad][K - K1], columns k >= K1 (the aggregated neighbour messages)
+    const float* Bimg;    // packed weight image
+    const float* bias;    // [Nc]
+    const float* nmask;   // [M_pad] (EPI_RESID_MASK)
+    float* C;             // [M_pad][ldc]
+    int lda, ldc, K1, K, M, Nc;
+};
+
+
+// WM x WN wavefronts, each owning 32 rows x (32*CN) columns (CN accumulators); workgroup tile
+// (32*WM) x (32*WN*CN).  Exact-fp32 precision mode only (the bf16x3 mode runs the fused k_node below).
+// Weight image per (column tile, 32-wide K chunk): [NS][4 q][64 lanes][4 j], k = 32c + 16*(lane>>5) + 4q + j,
+// with NS = WN*CN 32-column sub-tiles, column = tile*32*NS + 32*sub + (lane&31).
+template <int WM, int WN, int CN, int EPI, bool CAT>
+__global__ __launch_bounds__(WM * WN * 64) void k_gemm(GemmArgs g) {
+    constexpr int NS = WN * CN;
+    constexpr int BM = 32 * WM, BN = 32 * NS, NT = 64 * WM * WN;
+    constexpr int A_F4 = BM * 8 / NT;                    // float4 of the A tile per thread
+    constexpr int B_U4 = BN * 32 * 4 / 16 / NT;          // 16-byte pieces of the B image per thread
+    constexpr int LDA_F = 36;                            // fp32 A row: 32 + 4 pad floats
+    constexpr int A_BYTES = BM * LDA_F * 4;
+    constexpr int B_BYTES = BN * 32 * 4;
+    __shared__ __attribute__((aligned(16))) char smem_g[2 * (A_BYTES + B_BYTES)];
+    auto As_f = [&](int buf) { return reinterpret_cast<float*>(smem_g + buf * (A_BYTES + B_BYTES)); };
+    auto Bs = [&](int buf) { return smem_g + buf * (A_BYTES + B_BYTES) + A_BYTES; };
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave / WN, wc = wave % WN;
+    const int hh = lane >> 5, m = lane & 31;
+    // XCD-aware tile order (1-D grid of 8 * ceil(nrt/8) * nct blocks, block b runs on XCD b % 8): every XCD owns
+    // a contiguous range of row tiles and walks (row tile, column tile) with the column tile fastest, so the
+    // A rows - written by the previous kernel, i.e. resident in Infinity Cache, not in this XCD's L2 - cross
+    // the fabric once per XCD instead of once per column tile.  Speed only.
+    int rt, ctile;
+    {
+        const int nrt = (g.M + BM - 1) / BM, nct = g.Nc / BN;
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int q = nrt >> 3, r = nrt & 7;
+        const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        const int len = q + (xcd < r ? 1 : 0);
+        if (idx >= len * nct) return;
+        rt = start + idx / nct;
+        ctile = idx % nct;
+    }
+    const int row0 = rt * BM;
+    const int nchunk = g.K >> 5;
+    const u32x4* Bsrc = reinterpret_cast<const u32x4*>(g.Bimg) + (size_t)ctile * nchunk * (B_BYTES / 16);
+
+    // Global loads run three chunks ahead of the MFMAs (register ring), LDS is double-buffered: with only a
+    // few workgroups per CU the ~1-2 us L2/MALL latency per chunk is otherwise exposed nchunk times.
+    f32x4 ra3[3][A_F4];
+    u32x4 rb3[3][B_U4];
+
+    auto load_tiles = [&](int c, f32x4 (&ra)[A_F4], u32x4 (&rb)[B_U4]) {
+        const int k0 = c << 5;
+#pragma unroll
+        for (int u = 0; u < A_F4; ++u) {
+            int idx = tid + u * NT;
+            int r = idx >> 3, sg = idx & 7;
+            int row = row0 + r;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (!CAT || k0 < g.K1) v = *reinterpret_cast<const f32x4*>(g.A + (size_t)row * g.lda + k0 + 4 * sg);
+            else v = *reinterpret_cast<const f32x4*>(g.A2 + (size_t)row * (g.K - g.K1) + (k0 - g.K1) + 4 * sg);
+            ra[u] = v;
+        }
+#pragma unroll
+        for (int u = 0; u < B_U4; ++u) rb[u] = Bsrc[(size_t)c * (B_BYTES / 16) + tid + u * NT];
+    };
+    auto store_tiles = [&](int buf, const f32x4 (&ra)[A_F4], const u32x4 (&rb)[B_U4]) {
+#pragma unroll
+        for (int u = 0; u < A_F4; ++u) {
+            int idx = tid + u * NT;
+            int r = idx >> 3, sg = idx & 7;
+            *reinterpret_cast<f32x4*>(As_f(buf) + r * LDA_F + 4 * sg) = ra[u];
+        }
+#pragma unroll
+        for (int u = 0; u < B_U4; ++u) reinterpret_cast<u32x4*>(Bs(buf))[tid + u * NT] = rb[u];
+    };
+
+    f32x16 acc[CN];
+#pragma unroll
+    for (int cn = 0; cn < CN; ++cn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[cn][r] = 0.f;
+
+    auto compute = [&](int buf) {
+        const float* Bf = reinterpret_cast<const float*>(Bs(buf));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(As_f(buf) + (32 * wr + m) * LDA_F + 16 * hh + 4 * q);
+            f32x4 bv[CN];
+#pragma unroll
+            for (int cn = 0; cn < CN; ++cn)
+                bv[cn] = *reinterpret_cast<const f32x4*>(Bf + (((wc * CN + cn) * 4 + q) * 64 + lane) * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int cn = 0; cn < CN; ++cn)
+                    acc[cn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[cn][j], acc[cn], 0, 0, 0);
+        }
+    };
+
+    load_tiles(0, ra3[0], rb3[0]);
+    if (nchunk > 1) load_tiles(1, ra3[1], rb3[1]);
+    if (nchunk > 2) load_tiles(2, ra3[2], rb3[2]);
+    store_tiles(0, ra3[0], rb3[0]);
+    __syncthreads();
+    // chunk c: compute from LDS[c&1]; stage chunk c+1 (ring slot (c+1)%3) into the other LDS buffer; refill
+    // ring slot c%3 with chunk c+3.  Unrolled by 3 so the ring slots are compile-time.
+    for (int c0 = 0; c0 < nchunk; c0 += 3) {
+        static_for<0, 3>([&](auto Rc) {
+            constexpr int rslot = decltype(Rc)::value;
+            const int c = c0 + rslot;
+            if (c < nchunk) {
+                compute(c & 1);
+                if (c + 1 < nchunk) store_tiles((c + 1) & 1, ra3[(rslot + 1) % 3], rb3[(rslot + 1) % 3]);
+                if (c + 3 < nchunk) load_tiles(c + 3, ra3[rslot], rb3[rslot]);
+                __syncthreads();
+            }
+        });
+    }
+
+    // Epilogue through LDS: the MFMA C layout gives each lane single floats of 16 different rows (16 dword
+    // stores per accumulator, store-issue bound); transposed through the now idle staging buffers every
+    // thread instead moves whole float4s (4x fewer, 16-byte wide, 256 B contiguous per 16 lanes).
+    constexpr int LDC_S = BN + 4;
+    static_assert(BM * LDC_S * 4 <= 2 * (A_BYTES + B_BYTES), "C tile must fit the staging buffers");
+    float* Cs = reinterpret_cast<float*>(smem_g);
+#pragma unroll
+    for (int cn = 0; cn < CN; ++cn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            Cs[(32 * wr + (r & 3) + 8 * (r >> 2) + 4 * hh) * LDC_S + 32 * (wc * CN + cn) + m] = acc[cn][r];
+    __syncthreads();
+    constexpr int C_F4 = BM * BN / 4 / NT;
+#pragma unroll
+    for (int u = 0; u < C_F4; ++u) {
+        const int idx = tid + u * NT;
+        const int r = idx / (BN / 4), c4 = idx % (BN / 4);
+        const int row = row0 + r, col = ctile * BN + 4 * c4;
+        if (row < g.M) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(Cs + r * LDC_S + 4 * c4) + *reinterpret_cast<const f32x4*>(g.bias + col);
+            f32x4* dst = reinterpret_cast<f32x4*>(g.C + (size_t)row * g.ldc + col);
+            if (EPI == EPI_BIAS_SILU) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = silu_f(v[j]);
+            }
+            if (EPI == EPI_RESID_MASK) v = (*dst + v) * g.nmask[row];
+            *dst = v;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------- fused node update (bf16x3)
+// One workgroup owns 32 node rows and runs the whole row-local chain of a GCL's node model plus the first
+// edge Linear of the layer(s) that follow, so the intermediate activations never leave the CU:
+//   X   = [h | (sum of the node's partial neighbour sums) / normalization_factor]      (egnn_new.py:52-56,280-282)
+//   T   = silu(X W3^T + b3)                                                            (node_mlp.0 + SiLU, :58-66)
+//   h'  = (h + T W4^T + b4) * mask                                                     (node_mlp.2, residual, mask)
+//   AB_q = h' [W1a_q | W1b_q]^T + [b1_q | 0]   for the next NAB edge layers            (factorised edge_mlp.0 / coord_mlp.0)
+// (UPD = false: only the last line, on h as it is - used once after the embedding.)  It replaces
+// k_gemm(AB) + k_agg + k_gemm(n1) + k_gemm(n2): at M = 7,680 rows those four launches were bound by fixed costs
+// (launch, tile prologue, C stores), not by math.
+//   * A operands: the 32-row activation tile lives in LDS as bf16 head + tail, row stride K+8 elements
+//     (16 B pad => conflict-free ds_read_b128), shared by all wavefronts.
+//   * B operands: every wavefront owns its own 32-column tiles, so weights have no reuse inside a workgroup
+//     and go L2 -> registers directly (fragment-ordered image, 1 KiB coalesced per load), PF k-steps ahead.
+//   * C tiles leave through an LDS transpose as whole float4 rows.
+// Weight image (pack_node_b): [k-step s][column tile ct][head|tail][64 lanes][8 bf16],
+//   k = 16 s + 8 (lane>>5) + i,  col = 32 ct + (lane&31).
+
+struct NodeArgs {
+    const float* h_in;      // [M_pad][H]
+    float* h_out;           // [M_pad][H] (may alias h_in: a workgroup only touches its own rows)
+    const float* part;      // [P][H] partial neighbour sums of the edge kernel
+    const int* pstart;      // [M+1]
+    const float* nmask;     // [M_pad]
+    const float* W3img;     // K = 2H, N = H
+    const float* b3;
+    const float* W4img;     // K = H, N = H
+    const float* b4;
+    const float* ABimg[2];  // K = H, N = 2H
+    const float* ABbias[2]; // [2H]
+    float* ABout[2];        // [M_pad][2H]
+    float norm;
+    int M;
+};
+
+// acc[c] += A[32 x 16 KS] * B[:, column tile ct(c)]   with ct(c) = (c / CTW) * CTG + ct0 + c % CTW.
+// B fragments travel L2 -> registers in a ring of PF k-steps; `prefetch` fills the ring (it is issued before
+// the barrier / epilogue that precedes the contraction, weights do not depend on data) and `run` consumes
+// it.  sched_barrier(0) at every k-step keeps hipcc from sinking the loads next to their MFMAs (it otherwise
+// shrinks the ring to 2-3 loads in flight to save registers and exposes the L2 latency every k-step).
+template <int KS, int CTn, int CTW, int PF, int NCT>
+struct NodeMma {
+    typedef u32x4 Ring[PF][CTn][2];
+    template <int s, int slot>
+    static HD_DEVINL void load(Ring& br, const u32x4* Bl, int ct0, int CTG) {
+#pragma unroll
+        for (int c = 0; c < CTn; ++c) {
+            const int ct = (c / CTW) * CTG + ct0 + c % CTW;
+            br[slot][c][0] = Bl[((size_t)(s * NCT + ct) * 2 + 0) * 64];
+            br[slot][c][1] = Bl[((size_t)(s * NCT + ct) * 2 + 1) * 64];
+        }
+    }
+    static HD_DEVINL void prefetch(Ring& br, const u32x4* Bl, int ct0, int CTG) {
+        static_for<0, (PF < KS ? PF : KS)>([&](auto S) { load<decltype(S)::value, decltype(S)::value>(br, Bl, ct0, CTG); });
+        asm volatile("" ::: "memory");                // keeps the loads above whatever follows (barriers included)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    static HD_DEVINL void run(f32x16 (&acc)[CTn], Ring& br, const __bf16* Ah, const __bf16* Al, const u32x4* Bl,
+                              int ct0, int CTG) {
+        bf16x8_t ah = *reinterpret_cast<const bf16x8_t*>(Ah), al = *reinterpret_cast<const bf16x8_t*>(Al);
+        static_for<0, KS>([&](auto S) {
+            constexpr int s = decltype(S)::value, slot = s % PF;
+            __builtin_amdgcn_sched_barrier(0);
+            bf16x8_t ahn = ah, aln = al;
+            if constexpr (s + 1 < KS) {
+                ahn = *reinterpret_cast<const bf16x8_t*>(Ah + 16 * (s + 1));
+                aln = *reinterpret_cast<const bf16x8_t*>(Al + 16 * (s + 1));
+            }
+            __builtin_amdgcn_sched_barrier(0);         // next A fragments are in flight under this step's MFMAs
+            bf16x8_t bh[CTn], bl[CTn];
+#pragma unroll
+            for (int c = 0; c < CTn; ++c) {
+                bh[c] = __builtin_bit_cast(bf16x8_t, br[slot][c][0]);
+                bl[c] = __builtin_bit_cast(bf16x8_t, br[slot][c][1]);
+            }
+#pragma unroll
+            for (int c = 0; c < CTn; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[c], acc[c], 0, 0, 0);
+#pragma unroll
+            for (int c = 0; c < CTn; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[c], acc[c], 0, 0, 0);
+#pragma unroll
+            for (int c = 0; c < CTn; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[c], acc[c], 0, 0, 0);
+            if constexpr (s + PF < KS) load<s + PF, slot>(br, Bl, ct0, CTG);
+            ah = ahn; al = aln;
+        });
+        __builtin_amdgcn_sched_barrier(0);
+    }
+};
+
+HD_DEVINL void bf16_split_store(__bf16* dh, __bf16* dl, float v) {
+    const __bf16 hi = (__bf16)v;
+    *dh = hi;
+    *dl = (__bf16)(v - (float)hi);
+}
+
+template <int H, int NW, bool UPD, int NAB>
+__global__ __launch_bounds__(64 * NW, 1) void k_node(NodeArgs a) {
+    constexpr int NT = 64 * NW;
+    constexpr int NCT = H / 32;            // column tiles of an H-wide output
+    constexpr int CT = NCT / NW;           // ... per wavefront
+    static_assert(CT >= 1 && CT * NW == NCT, "NW must divide H/32");
+    constexpr int KX = UPD ? 2 * H : H;
+    constexpr int LDX = KX + 8, LDH = H + 8;
+    constexpr int PF12 = 4, PF3 = 3;       // k-steps of weights in flight per wavefront (deeper rings measured no faster)
+    constexpr int R0_BYTES = 32 * LDX * 4;             // head + tail of X
+    extern __shared__ __attribute__((aligned(16))) char smem_n[];
+    __bf16* Xh = reinterpret_cast<__bf16*>(smem_n);
+    __bf16* Xl = Xh + 32 * LDX;
+    __bf16* Th = reinterpret_cast<__bf16*>(smem_n + R0_BYTES);      // region 1: T, later the AB staging tile
+    __bf16* Tl = Th + 32 * LDH;
+    __bf16* Nh = reinterpret_cast<__bf16*>(smem_n);                 // h' (head, tail) re-uses region 0 ...
+    __bf16* Nl = Nh + 32 * LDH;
+    float* stage0 = reinterpret_cast<float*>(smem_n + 32 * LDH * 4); // ... followed by its fp32 staging tile [32][H]
+    constexpr int LDS1 = H + 4;
+    float* stage1 = reinterpret_cast<float*>(smem_n + R0_BYTES);    // [32][H+4]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hh = lane >> 5, n = lane & 31;
+    // XCD-aware row-tile order: block b runs on XCD b % 8; every XCD owns a contiguous range of row tiles, the
+    // same split the edge kernel uses for its edge list, so `part` / `AB` rows stay in the XCD that touches them.
+    int rt;
+    {
+        const int nrt = (a.M + 31) >> 5;
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int q = nrt >> 3, r = nrt & 7;
+        const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        const int len = q + (xcd < r ? 1 : 0);
+        if (idx >= len) return;
+        rt = start + idx;
+    }
+    const int row0 = rt * 32;
+
+    typedef NodeMma<KX / 16, CT, CT, PF12, NCT> M1;            // X W3^T      (UPD only)
+    typedef NodeMma<H / 16, CT, CT, PF12, NCT> M2;             // T W4^T      (UPD only)
+    typedef NodeMma<H / 16, 2 * CT, CT, PF3, 2 * NCT> M3;      // h' [W1a|W1b]^T
+    typename M1::Ring br1;
+    typename M2::Ring br2;
+    typename M3::Ring br3;
+    const int ct0 = wave * CT;
+    const u32x4* W3l = reinterpret_cast<const u32x4*>(a.W3img) + lane;
+    const u32x4* W4l = reinterpret_cast<const u32x4*>(a.W4img) + lane;
+    const u32x4* AB0l = reinterpret_cast<const u32x4*>(a.ABimg[0]) + lane;
+    if constexpr (UPD) M1::prefetch(br1, W3l, ct0, 0);
+
+    // ---- phase 0: X -> LDS (bf16 head/tail).  NT/32 threads per row, each moving every (NT/32)-th float4 of
+    // the row, so a thread needs one pstart pair and all its loads are independent of each other.
+    {
+        constexpr int Q = H / 4;                     // float4 per H-wide row
+        constexpr int TPR = NT / 32;                 // threads per row
+        constexpr int NP = Q / TPR;                  // pieces per thread and source
+        static_assert(Q % TPR == 0, "row pieces must divide evenly");
+        const int r = tid / TPR, cq = tid % TPR;
+        const int row = row0 + r;
+        auto put = [&](int col, f32x4 v) {
+            const __bf16 h0 = (__bf16)v[0], h1 = (__bf16)v[1], h2 = (__bf16)v[2], h3 = (__bf16)v[3];
+            const bf16x4_t vh = {h0, h1, h2, h3};
+            const bf16x4_t vl = {(__bf16)(v[0] - (float)h0), (__bf16)(v[1] - (float)h1),
+                                 (__bf16)(v[2] - (float)h2), (__bf16)(v[3] - (float)h3)};
+            *reinterpret_cast<bf16x4_t*>(Xh + r * LDX + col) = vh;
+            *reinterpret_cast<bf16x4_t*>(Xl + r * LDX + col) = vl;
+        };
+        int p0 = 0, p1 = 0;
+        if constexpr (UPD) {
+            if (row < a.M) { p0 = a.pstart[row]; p1 = a.pstart[row + 1]; }
+        }
+        f32x4 hv[NP];
+#pragma unroll
+        for (int u = 0; u < NP; ++u)
+            hv[u] = *reinterpret_cast<const f32x4*>(a.h_in + (size_t)row * H + 4 * (cq + u * TPR));   // pad rows are zero
+        if constexpr (UPD) {
+            // the first two partial sums (the common case: a node's edges span two tiles) are fetched together
+            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+            const bool has0 = p0 < p1, has1 = p0 + 1 < p1;
+            const float* s0 = a.part + (size_t)(has0 ? p0 : 0) * H;
+            const float* s1 = a.part + (size_t)(has1 ? p0 + 1 : 0) * H;
+            f32x4 g0[NP], g1[NP];
+#pragma unroll
+            for (int u = 0; u < NP; ++u) {
+                g0[u] = *reinterpret_cast<const f32x4*>(s0 + 4 * (cq + u * TPR));
+                g1[u] = *reinterpret_cast<const f32x4*>(s1 + 4 * (cq + u * TPR));
+            }
+#pragma unroll
+            for (int u = 0; u < NP; ++u) put(4 * (cq + u * TPR), hv[u]);
+#pragma unroll
+            for (int u = 0; u < NP; ++u) {
+                f32x4 v = z4;
+                if (has0) v += g0[u];
+                if (has1) v += g1[u];
+                for (int p = p0 + 2; p < p1; ++p) v += *reinterpret_cast<const f32x4*>(a.part + (size_t)p * H + 4 * (cq + u * TPR));
+                put(H + 4 * (cq + u * TPR), v / a.norm);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < NP; ++u) put(4 * (cq + u * TPR), hv[u]);
+        }
+    }
+
+    if constexpr (UPD) {
+        // ---- phase 1: T = silu(X W3^T + b3)
+        {
+            f32x16 acc[CT];
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                const float b = a.b3[32 * (ct0 + c) + n];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[c][r] = b;
+            }
+            __syncthreads();                                         // X complete
+            M2::prefetch(br2, W4l, ct0, 0);
+            M1::run(acc, br1, Xh + n * LDX + 8 * hh, Xl + n * LDX + 8 * hh, W3l, ct0, 0);
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int R = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    bf16_split_store(Th + R * LDH + 32 * (ct0 + c) + n, Tl + R * LDH + 32 * (ct0 + c) + n, silu_fast(acc[c][r]));
+                }
+        }
+        __syncthreads();
+        // ---- phase 2: h' = (h + T W4^T + b4) * mask
+        {
+            f32x16 acc[CT];
+            float hres[CT][16], mk[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mk[r] = a.nmask[row0 + (r & 3) + 8 * (r >> 2) + 4 * hh];
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                const float b = a.b4[32 * (ct0 + c) + n];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    acc[c][r] = b;
+                    hres[c][r] = a.h_in[(size_t)(row0 + (r & 3) + 8 * (r >> 2) + 4 * hh) * H + 32 * (ct0 + c) + n];
+                }
+            }
+            M3::prefetch(br3, AB0l, ct0, NCT);
+            M2::run(acc, br2, Th + n * LDH + 8 * hh, Tl + n * LDH + 8 * hh, W4l, ct0, 0);
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int R = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    const float v = (hres[c][r] + acc[c][r]) * mk[r];
+                    bf16_split_store(Nh + R * LDH + 32 * (ct0 + c) + n, Nl + R * LDH + 32 * (ct0 + c) + n, v);
+                    stage0[R * H + 32 * (ct0 + c) + n] = v;
+                }
+        }
+        __syncthreads();
+        {
+            constexpr int Q = H / 4, NP = 32 * Q / NT;
+#pragma unroll
+            for (int u = 0; u < NP; ++u) {
+                const int idx = tid + u * NT, r = idx / Q, c4 = idx % Q;
+                if (row0 + r < a.M)
+                    *reinterpret_cast<f32x4*>(a.h_out + (size_t)(row0 + r) * H + 4 * c4) = *reinterpret_cast<const f32x4*>(stage0 + r * H + 4 * c4);
+            }
+        }
+    }
+
+    // ---- phase 3: AB_q = h' [W1a | W1b]^T + bias, two H-wide halves per wavefront, staged through region 1
+#pragma unroll
+    for (int q = 0; q < NAB; ++q) {
+        f32x16 acc[2 * CT];
+#pragma unroll
+        for (int c = 0; c < 2 * CT; ++c) {
+            const float b = a.ABbias[q][(c / CT) * H + 32 * (ct0 + c % CT) + n];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][r] = b;
+        }
+        const u32x4* ABl = reinterpret_cast<const u32x4*>(a.ABimg[q]) + lane;
+        if (q > 0 || !UPD) {
+            M3::prefetch(br3, ABl, ct0, NCT);
+            if (!UPD) __syncthreads();                               // h tile complete
+        }
+        M3::run(acc, br3, Nh + n * LDH + 8 * hh, Nl + n * LDH + 8 * hh, ABl, ct0, NCT);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            if (half || q) __syncthreads();                 // previous staging tile fully stored
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    stage1[((r & 3) + 8 * (r >> 2) + 4 * hh) * LDS1 + 32 * (ct0 + c) + n] = acc[half * CT + c][r];
+            __syncthreads();
+            constexpr int Q = H / 4, NP = 32 * Q / NT;
+#pragma unroll
+            for (int u = 0; u < NP; ++u) {
+                const int idx = tid + u * NT, r = idx / Q, c4 = idx % Q;
+                if (row0 + r < a.M)
+                    *reinterpret_cast<f32x4*>(a.ABout[q] + (size_t)(row0 + r) * 2 * H + half * H + 4 * c4) =
+                        *reinterpret_cast<const f32x4*>(stage1 + r * LDS1 + 4 * c4);
+            }
+        }
+    }
+}

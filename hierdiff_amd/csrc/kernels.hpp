@@ -9,1942 +9,8 @@
 //   * per-node sums over neighbours are wavefront-local (shuffle reductions), written as per-tile
 //     partial sums that the consuming node kernel adds in a fixed order (bit-reproducible).
 #pragma once
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-#include <type_traits>
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-#define HD_DEVINL __device__ __forceinline__
-
-HD_DEVINL void glds16(const void* gsrc, void* lds_dst) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
-}
-
-// ----------------------------------------------------------------------------- math helpers
-
-// x * sigmoid(x).  exp(-x) = 2^(-x*log2e) with a compensated product so the exponent argument
-// keeps ~1 ulp over the whole range (v_exp_f32 and v_rcp_f32 are 1-ulp instructions).
-HD_DEVINL float silu_f(float x) {
-    const float L2E_HI = 1.44269502162933349609375f;   // float(log2 e)
-    const float L2E_LO = 1.925962991e-8f;              // log2 e - L2E_HI
-    const float LN2 = 0.693147180559945309f;
-    float nx = -x;
-    float t = nx * L2E_HI;
-    float tlo = __builtin_fmaf(nx, L2E_HI, -t) + nx * L2E_LO;
-    float e = __builtin_amdgcn_exp2f(t);
-    e = e * __builtin_fmaf(tlo, LN2, 1.0f);       // stays +inf for x << 0 (an fma(e, d, e) would give NaN)
-    return x * __builtin_amdgcn_rcpf(1.0f + e);
-}
-
-// 1 / (1 + exp(-x)) with the same compensated exponent (~2 ulp); saturates to 0 / 1.
-HD_DEVINL float sigmoid_f(float x) {
-    const float L2E_HI = 1.44269502162933349609375f, L2E_LO = 1.925962991e-8f, LN2 = 0.693147180559945309f;
-    float nx = -x;
-    float t = nx * L2E_HI;
-    float tlo = __builtin_fmaf(nx, L2E_HI, -t) + nx * L2E_LO;
-    float e = __builtin_amdgcn_exp2f(t) * __builtin_fmaf(tlo, LN2, 1.0f);
-    return __builtin_amdgcn_rcpf(1.0f + e);
-}
-
-// plain SiLU of the bf16x3 node kernel (contraction error ~1e-6 anyway): exp2(-x*log2e), 5 instructions; the
-// exponent argument is off by <= |x|*1.7e-7, i.e. a relative error of that size on an already saturated value.
-HD_DEVINL float silu_fast(float x) {
-    float e = __builtin_amdgcn_exp2f(x * -1.44269502162933349609375f);
-    return x * __builtin_amdgcn_rcpf(1.0f + e);
-}
-
-// ---- scaled-domain activations of the bf16x3 edge kernel.  The host multiplies everything that feeds a SiLU /
-// sigmoid of the edge model by c = -log2(e) (first edge Linear incl. bias and the two distance columns, b2, the
-// attention bias), so with x' = c x
-//     silu'(x') := x' * rcp(1 + exp2(x')) = c * silu(x)          sigmoid(z) = rcp(1 + exp2(z'))
-// need no multiply by log2(e); the factor c carried by the activations is undone by 1/c folded into the
-// weights that consume them (W2: c * 1/c = 1, i.e. unchanged; coord_mlp.4; the neighbour-sum half of node_mlp.0).
-// Deliberately NOT written with v_pk_*_f32: packed fp32 runs on the matrix pipe's datapath and cannot issue while
-// an MFMA of either co-resident wavefront is in flight (scratch/mb/coissue.hip: 4 v_pk_fma per MFMA cost
-// 52 ns/slot vs 30 ns for 4 v_fma_f32, which hide completely), so the file is built with -fno-slp-vectorize.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-HD_DEVINL float silu_scaled(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x)); }
-// bf16 head / tail of a pair, each packed into one dword (element 0 in the low half)
-HD_DEVINL void bf16_split2(float y0, float y1, uint32_t& hi, uint32_t& lo) {
-    const uint32_t hp = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){y0, y1}, bf16x2_t));
-    const float l0 = y0 - __builtin_bit_cast(float, hp << 16);
-    const float l1 = y1 - __builtin_bit_cast(float, hp & 0xffff0000u);
-    hi = hp;
-    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){l0, l1}, bf16x2_t));
-}
-
-// compile-time loop: f(std::integral_constant<int, I>) for I = 0..N-1
-template <int I, int N, typename F>
-HD_DEVINL void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
-
-// ----------------------------------------------------------------------------- Philox4x32-10
-
-HD_DEVINL void philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t k0, uint32_t k1) {
-    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
-    uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
-    uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
-    uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
-    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-}
-
-// normal(seed, sample, draw, index): counter = (index/2, draw, sample.lo, sample.hi), key = seed.
-// Each counter block yields two Box-Muller normals; index & 1 selects one.
-HD_DEVINL float philox_normal(uint64_t seed, uint64_t sample, uint32_t draw, uint32_t index) {
-    uint32_t c0 = index >> 1, c1 = draw, c2 = (uint32_t)sample, c3 = (uint32_t)(sample >> 32);
-    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        philox_round(c0, c1, c2, c3, k0, k1);
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    float u1 = ((float)(c0 >> 8) + 0.5f) * (1.0f / 16777216.0f);
-    float u2 = ((float)(c1 >> 8) + 0.5f) * (1.0f / 16777216.0f);
-    float rad = sqrtf(-2.0f * logf(u1));
-    float ang = 6.283185307179586f * u2;
-    return (index & 1) ? rad * sinf(ang) : rad * cosf(ang);
-}
-
-// ----------------------------------------------------------------------------- node init
-// xh*mask -> x0/xcur; [h*mask | t | context] -> embedding (en_dynamics.py:57-79, egnn_new.py:197).
-
-struct InitArgs {
-    const float* xh;        // [B*N][D]
-    const float* t;         // [1] or [B]
-    const float* ctx;       // [B*N][C] or null
-    const int* node_of;     // [M] compact -> flat
-    const float* nmask;     // [M_pad] 0/1
-    const float* embT;      // [fin][H]
-    const float* emb_b;     // [H]
-    float* h;               // [M_pad][H]
-    float* x0;              // [M_pad][4]
-    float* xcur;            // [M_pad][4]
-    int M, N, D, F, C, H, t_stride, cond_time;
-};
-
-__global__ void k_node_init(InitArgs a) {
-    int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    int i = idx / a.H, c = idx - i * a.H;
-    if (i >= a.M) return;
-    int flat = a.node_of[i];
-    float m = a.nmask[i];
-    const float* row = a.xh + (size_t)flat * a.D;
-    float acc = a.emb_b[c];
-    int f = 0;
-    for (; f < a.F; ++f) acc = __builtin_fmaf(row[3 + f] * m, a.embT[f * a.H + c], acc);
-    if (a.cond_time) {
-        float tv = a.t[(flat / a.N) * a.t_stride];
-        acc = __builtin_fmaf(tv, a.embT[f * a.H + c], acc);
-        ++f;
-    }
-    for (int k = 0; k < a.C; ++k, ++f) acc = __builtin_fmaf(a.ctx[(size_t)flat * a.C + k], a.embT[f * a.H + c], acc);
-    a.h[(size_t)i * a.H + c] = acc;
-    if (c < 4) {
-        float v = (c < 3) ? row[c] * m : 0.0f;
-        a.x0[(size_t)i * 4 + c] = v;
-        a.xcur[(size_t)i * 4 + c] = v;
-    }
-}
-
-// ----------------------------------------------------------------------------- node GEMM (fp32 MFMA)
-// C[M][Nc] = epi(A[M][K] * Wt[K][Nc] + bias).  Workgroup tile (32*WM) x (32*WN), one 32x32
-// v_mfma_f32_32x32x2_f32 accumulator per wavefront, K in chunks of 32 double-buffered through LDS.
-// The K index inside a chunk is permuted (lane half h owns k = 16h..16h+15) so that both
-// operands are fetched with one ds_read_b128 per four MFMAs; weights are pre-packed in that image.
-
-enum { EPI_BIAS = 0, EPI_BIAS_SILU = 1, EPI_RESID_MASK = 2 };
-
-struct GemmArgs {
-    const float* A;       // [M_pad][lda], columns k < K1
-    const float* A2;      // CAT: [M_pad][K - K1], columns k >= K1 (the aggregated neighbour messages)
-    const float* Bimg;    // packed weight image
-    const float* bias;    // [Nc]
-    const float* nmask;   // [M_pad] (EPI_RESID_MASK)
-    float* C;             // [M_pad][ldc]
-    int lda, ldc, K1, K, M, Nc;
-};
-
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-// WM x WN wavefronts, each owning 32 rows x (32*CN) columns (CN accumulators); workgroup tile
-// (32*WM) x (32*WN*CN).  Exact-fp32 precision mode only (the bf16x3 mode runs the fused k_node below).
-// Weight image per (column tile, 32-wide K chunk): [NS][4 q][64 lanes][4 j], k = 32c + 16*(lane>>5) + 4q + j,
-// with NS = WN*CN 32-column sub-tiles, column = tile*32*NS + 32*sub + (lane&31).
-template <int WM, int WN, int CN, int EPI, bool CAT>
-__global__ __launch_bounds__(WM * WN * 64) void k_gemm(GemmArgs g) {
-    constexpr int NS = WN * CN;
-    constexpr int BM = 32 * WM, BN = 32 * NS, NT = 64 * WM * WN;
-    constexpr int A_F4 = BM * 8 / NT;                    // float4 of the A tile per thread
-    constexpr int B_U4 = BN * 32 * 4 / 16 / NT;          // 16-byte pieces of the B image per thread
-    constexpr int LDA_F = 36;                            // fp32 A row: 32 + 4 pad floats
-    constexpr int A_BYTES = BM * LDA_F * 4;
-    constexpr int B_BYTES = BN * 32 * 4;
-    __shared__ __attribute__((aligned(16))) char smem_g[2 * (A_BYTES + B_BYTES)];
-    auto As_f = [&](int buf) { return reinterpret_cast<float*>(smem_g + buf * (A_BYTES + B_BYTES)); };
-    auto Bs = [&](int buf) { return smem_g + buf * (A_BYTES + B_BYTES) + A_BYTES; };
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave / WN, wc = wave % WN;
-    const int hh = lane >> 5, m = lane & 31;
-    // XCD-aware tile order (1-D grid of 8 * ceil(nrt/8) * nct blocks, block b runs on XCD b % 8): every XCD owns
-    // a contiguous range of row tiles and walks (row tile, column tile) with the column tile fastest, so the
-    // A rows - written by the previous kernel, i.e. resident in Infinity Cache, not in this XCD's L2 - cross
-    // the fabric once per XCD instead of once per column tile.  Speed only.
-    int rt, ctile;
-    {
-        const int nrt = (g.M + BM - 1) / BM, nct = g.Nc / BN;
-        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-        const int q = nrt >> 3, r = nrt & 7;
-        const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-        const int len = q + (xcd < r ? 1 : 0);
-        if (idx >= len * nct) return;
-        rt = start + idx / nct;
-        ctile = idx % nct;
-    }
-    const int row0 = rt * BM;
-    const int nchunk = g.K >> 5;
-    const u32x4* Bsrc = reinterpret_cast<const u32x4*>(g.Bimg) + (size_t)ctile * nchunk * (B_BYTES / 16);
-
-    // Global loads run three chunks ahead of the MFMAs (register ring), LDS is double-buffered: with only a
-    // few workgroups per CU the ~1-2 us L2/MALL latency per chunk is otherwise exposed nchunk times.
-    f32x4 ra3[3][A_F4];
-    u32x4 rb3[3][B_U4];
-
-    auto load_tiles = [&](int c, f32x4 (&ra)[A_F4], u32x4 (&rb)[B_U4]) {
-        const int k0 = c << 5;
-#pragma unroll
-        for (int u = 0; u < A_F4; ++u) {
-            int idx = tid + u * NT;
-            int r = idx >> 3, sg = idx & 7;
-            int row = row0 + r;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (!CAT || k0 < g.K1) v = *reinterpret_cast<const f32x4*>(g.A + (size_t)row * g.lda + k0 + 4 * sg);
-            else v = *reinterpret_cast<const f32x4*>(g.A2 + (size_t)row * (g.K - g.K1) + (k0 - g.K1) + 4 * sg);
-            ra[u] = v;
-        }
-#pragma unroll
-        for (int u = 0; u < B_U4; ++u) rb[u] = Bsrc[(size_t)c * (B_BYTES / 16) + tid + u * NT];
-    };
-    auto store_tiles = [&](int buf, const f32x4 (&ra)[A_F4], const u32x4 (&rb)[B_U4]) {
-#pragma unroll
-        for (int u = 0; u < A_F4; ++u) {
-            int idx = tid + u * NT;
-            int r = idx >> 3, sg = idx & 7;
-            *reinterpret_cast<f32x4*>(As_f(buf) + r * LDA_F + 4 * sg) = ra[u];
-        }
-#pragma unroll
-        for (int u = 0; u < B_U4; ++u) reinterpret_cast<u32x4*>(Bs(buf))[tid + u * NT] = rb[u];
-    };
-
-    f32x16 acc[CN];
-#pragma unroll
-    for (int cn = 0; cn < CN; ++cn)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[cn][r] = 0.f;
-
-    auto compute = [&](int buf) {
-        const float* Bf = reinterpret_cast<const float*>(Bs(buf));
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 av = *reinterpret_cast<const f32x4*>(As_f(buf) + (32 * wr + m) * LDA_F + 16 * hh + 4 * q);
-            f32x4 bv[CN];
-#pragma unroll
-            for (int cn = 0; cn < CN; ++cn)
-                bv[cn] = *reinterpret_cast<const f32x4*>(Bf + (((wc * CN + cn) * 4 + q) * 64 + lane) * 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int cn = 0; cn < CN; ++cn)
-                    acc[cn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[cn][j], acc[cn], 0, 0, 0);
-        }
-    };
-
-    load_tiles(0, ra3[0], rb3[0]);
-    if (nchunk > 1) load_tiles(1, ra3[1], rb3[1]);
-    if (nchunk > 2) load_tiles(2, ra3[2], rb3[2]);
-    store_tiles(0, ra3[0], rb3[0]);
-    __syncthreads();
-    // chunk c: compute from LDS[c&1]; stage chunk c+1 (ring slot (c+1)%3) into the other LDS buffer; refill
-    // ring slot c%3 with chunk c+3.  Unrolled by 3 so the ring slots are compile-time.
-    for (int c0 = 0; c0 < nchunk; c0 += 3) {
-        static_for<0, 3>([&](auto Rc) {
-            constexpr int rslot = decltype(Rc)::value;
-            const int c = c0 + rslot;
-            if (c < nchunk) {
-                compute(c & 1);
-                if (c + 1 < nchunk) store_tiles((c + 1) & 1, ra3[(rslot + 1) % 3], rb3[(rslot + 1) % 3]);
-                if (c + 3 < nchunk) load_tiles(c + 3, ra3[rslot], rb3[rslot]);
-                __syncthreads();
-            }
-        });
-    }
-
-    // Epilogue through LDS: the MFMA C layout gives each lane single floats of 16 different rows (16 dword
-    // stores per accumulator, store-issue bound); transposed through the now idle staging buffers every
-    // thread instead moves whole float4s (4x fewer, 16-byte wide, 256 B contiguous per 16 lanes).
-    constexpr int LDC_S = BN + 4;
-    static_assert(BM * LDC_S * 4 <= 2 * (A_BYTES + B_BYTES), "C tile must fit the staging buffers");
-    float* Cs = reinterpret_cast<float*>(smem_g);
-#pragma unroll
-    for (int cn = 0; cn < CN; ++cn)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            Cs[(32 * wr + (r & 3) + 8 * (r >> 2) + 4 * hh) * LDC_S + 32 * (wc * CN + cn) + m] = acc[cn][r];
-    __syncthreads();
-    constexpr int C_F4 = BM * BN / 4 / NT;
-#pragma unroll
-    for (int u = 0; u < C_F4; ++u) {
-        const int idx = tid + u * NT;
-        const int r = idx / (BN / 4), c4 = idx % (BN / 4);
-        const int row = row0 + r, col = ctile * BN + 4 * c4;
-        if (row < g.M) {
-            f32x4 v = *reinterpret_cast<const f32x4*>(Cs + r * LDC_S + 4 * c4) + *reinterpret_cast<const f32x4*>(g.bias + col);
-            f32x4* dst = reinterpret_cast<f32x4*>(g.C + (size_t)row * g.ldc + col);
-            if (EPI == EPI_BIAS_SILU) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = silu_f(v[j]);
-            }
-            if (EPI == EPI_RESID_MASK) v = (*dst + v) * g.nmask[row];
-            *dst = v;
-        }
-    }
-}
-
-// ----------------------------------------------------------------------------- fused node update (bf16x3)
-// One workgroup owns 32 node rows and runs the whole row-local chain of a GCL's node model plus the first
-// edge Linear of the layer(s) that follow, so the intermediate activations never leave the CU:
-//   X   = [h | (sum of the node's partial neighbour sums) / normalization_factor]      (egnn_new.py:52-56,280-282)
-//   T   = silu(X W3^T + b3)                                                            (node_mlp.0 + SiLU, :58-66)
-//   h'  = (h + T W4^T + b4) * mask                                                     (node_mlp.2, residual, mask)
-//   AB_q = h' [W1a_q | W1b_q]^T + [b1_q | 0]   for the next NAB edge layers            (factorised edge_mlp.0 / coord_mlp.0)
-// (UPD = false: only the last line, on h as it is - used once after the embedding.)  It replaces
-// k_gemm(AB) + k_agg + k_gemm(n1) + k_gemm(n2): at M = 7,680 rows those four launches were bound by fixed costs
-// (launch, tile prologue, C stores), not by math.
-//   * A operands: the 32-row activation tile lives in LDS as bf16 head + tail, row stride K+8 elements
-//     (16 B pad => conflict-free ds_read_b128), shared by all wavefronts.
-//   * B operands: every wavefront owns its own 32-column tiles, so weights have no reuse inside a workgroup
-//     and go L2 -> registers directly (fragment-ordered image, 1 KiB coalesced per load), PF k-steps ahead.
-//   * C tiles leave through an LDS transpose as whole float4 rows.
-// Weight image (pack_node_b): [k-step s][column tile ct][head|tail][64 lanes][8 bf16],
-//   k = 16 s + 8 (lane>>5) + i,  col = 32 ct + (lane&31).
-
-struct NodeArgs {
-    const float* h_in;      // [M_pad][H]
-    float* h_out;           // [M_pad][H] (may alias h_in: a workgroup only touches its own rows)
-    const float* part;      // [P][H] partial neighbour sums of the edge kernel
-    const int* pstart;      // [M+1]
-    const float* nmask;     // [M_pad]
-    const float* W3img;     // K = 2H, N = H
-    const float* b3;
-    const float* W4img;     // K = H, N = H
-    const float* b4;
-    const float* ABimg[2];  // K = H, N = 2H
-    const float* ABbias[2]; // [2H]
-    float* ABout[2];        // [M_pad][2H]
-    float norm;
-    int M;
-};
-
-// acc[c] += A[32 x 16 KS] * B[:, column tile ct(c)]   with ct(c) = (c / CTW) * CTG + ct0 + c % CTW.
-// B fragments travel L2 -> registers in a ring of PF k-steps; `prefetch` fills the ring (it is issued before
-// the barrier / epilogue that precedes the contraction, weights do not depend on data) and `run` consumes
-// it.  sched_barrier(0) at every k-step keeps hipcc from sinking the loads next to their MFMAs (it otherwise
-// shrinks the ring to 2-3 loads in flight to save registers and exposes the L2 latency every k-step).
-template <int KS, int CTn, int CTW, int PF, int NCT>
-struct NodeMma {
-    typedef u32x4 Ring[PF][CTn][2];
-    template <int s, int slot>
-    static HD_DEVINL void load(Ring& br, const u32x4* Bl, int ct0, int CTG) {
-#pragma unroll
-        for (int c = 0; c < CTn; ++c) {
-            const int ct = (c / CTW) * CTG + ct0 + c % CTW;
-            br[slot][c][0] = Bl[((size_t)(s * NCT + ct) * 2 + 0) * 64];
-            br[slot][c][1] = Bl[((size_t)(s * NCT + ct) * 2 + 1) * 64];
-        }
-    }
-    static HD_DEVINL void prefetch(Ring& br, const u32x4* Bl, int ct0, int CTG) {
-        static_for<0, (PF < KS ? PF : KS)>([&](auto S) { load<decltype(S)::value, decltype(S)::value>(br, Bl, ct0, CTG); });
-        asm volatile("" ::: "memory");                // keeps the loads above whatever follows (barriers included)
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    static HD_DEVINL void run(f32x16 (&acc)[CTn], Ring& br, const __bf16* Ah, const __bf16* Al, const u32x4* Bl,
-                              int ct0, int CTG) {
-        bf16x8_t ah = *reinterpret_cast<const bf16x8_t*>(Ah), al = *reinterpret_cast<const bf16x8_t*>(Al);
-        static_for<0, KS>([&](auto S) {
-            constexpr int s = decltype(S)::value, slot = s % PF;
-            __builtin_amdgcn_sched_barrier(0);
-            bf16x8_t ahn = ah, aln = al;
-            if constexpr (s + 1 < KS) {
-                ahn = *reinterpret_cast<const bf16x8_t*>(Ah + 16 * (s + 1));
-                aln = *reinterpret_cast<const bf16x8_t*>(Al + 16 * (s + 1));
-            }
-            __builtin_amdgcn_sched_barrier(0);         // next A fragments are in flight under this step's MFMAs
-            bf16x8_t bh[CTn], bl[CTn];
-#pragma unroll
-            for (int c = 0; c < CTn; ++c) {
-                bh[c] = __builtin_bit_cast(bf16x8_t, br[slot][c][0]);
-                bl[c] = __builtin_bit_cast(bf16x8_t, br[slot][c][1]);
-            }
-#pragma unroll
-            for (int c = 0; c < CTn; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[c], acc[c], 0, 0, 0);
-#pragma unroll
-            for (int c = 0; c < CTn; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[c], acc[c], 0, 0, 0);
-#pragma unroll
-            for (int c = 0; c < CTn; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[c], acc[c], 0, 0, 0);
-            if constexpr (s + PF < KS) load<s + PF, slot>(br, Bl, ct0, CTG);
-            ah = ahn; al = aln;
-        });
-        __builtin_amdgcn_sched_barrier(0);
-    }
-};
-
-HD_DEVINL void bf16_split_store(__bf16* dh, __bf16* dl, float v) {
-    const __bf16 hi = (__bf16)v;
-    *dh = hi;
-    *dl = (__bf16)(v - (float)hi);
-}
-
-template <int H, int NW, bool UPD, int NAB>
-__global__ __launch_bounds__(64 * NW, 1) void k_node(NodeArgs a) {
-    constexpr int NT = 64 * NW;
-    constexpr int NCT = H / 32;            // column tiles of an H-wide output
-    constexpr int CT = NCT / NW;           // ... per wavefront
-    static_assert(CT >= 1 && CT * NW == NCT, "NW must divide H/32");
-    constexpr int KX = UPD ? 2 * H : H;
-    constexpr int LDX = KX + 8, LDH = H + 8;
-    constexpr int PF12 = 4, PF3 = 3;       // k-steps of weights in flight per wavefront (deeper rings measured no faster)
-    constexpr int R0_BYTES = 32 * LDX * 4;             // head + tail of X
-    extern __shared__ __attribute__((aligned(16))) char smem_n[];
-    __bf16* Xh = reinterpret_cast<__bf16*>(smem_n);
-    __bf16* Xl = Xh + 32 * LDX;
-    __bf16* Th = reinterpret_cast<__bf16*>(smem_n + R0_BYTES);      // region 1: T, later the AB staging tile
-    __bf16* Tl = Th + 32 * LDH;
-    __bf16* Nh = reinterpret_cast<__bf16*>(smem_n);                 // h' (head, tail) re-uses region 0 ...
-    __bf16* Nl = Nh + 32 * LDH;
-    float* stage0 = reinterpret_cast<float*>(smem_n + 32 * LDH * 4); // ... followed by its fp32 staging tile [32][H]
-    constexpr int LDS1 = H + 4;
-    float* stage1 = reinterpret_cast<float*>(smem_n + R0_BYTES);    // [32][H+4]
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int hh = lane >> 5, n = lane & 31;
-    // XCD-aware row-tile order: block b runs on XCD b % 8; every XCD owns a contiguous range of row tiles, the
-    // same split the edge kernel uses for its edge list, so `part` / `AB` rows stay in the XCD that touches them.
-    int rt;
-    {
-        const int nrt = (a.M + 31) >> 5;
-        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-        const int q = nrt >> 3, r = nrt & 7;
-        const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-        const int len = q + (xcd < r ? 1 : 0);
-        if (idx >= len) return;
-        rt = start + idx;
-    }
-    const int row0 = rt * 32;
-
-    typedef NodeMma<KX / 16, CT, CT, PF12, NCT> M1;            // X W3^T      (UPD only)
-    typedef NodeMma<H / 16, CT, CT, PF12, NCT> M2;             // T W4^T      (UPD only)
-    typedef NodeMma<H / 16, 2 * CT, CT, PF3, 2 * NCT> M3;      // h' [W1a|W1b]^T
-    typename M1::Ring br1;
-    typename M2::Ring br2;
-    typename M3::Ring br3;
-    const int ct0 = wave * CT;
-    const u32x4* W3l = reinterpret_cast<const u32x4*>(a.W3img) + lane;
-    const u32x4* W4l = reinterpret_cast<const u32x4*>(a.W4img) + lane;
-    const u32x4* AB0l = reinterpret_cast<const u32x4*>(a.ABimg[0]) + lane;
-    if constexpr (UPD) M1::prefetch(br1, W3l, ct0, 0);
-
-    // ---- phase 0: X -> LDS (bf16 head/tail).  NT/32 threads per row, each moving every (NT/32)-th float4 of
-    // the row, so a thread needs one pstart pair and all its loads are independent of each other.
-    {
-        constexpr int Q = H / 4;                     // float4 per H-wide row
-        constexpr int TPR = NT / 32;                 // threads per row
-        constexpr int NP = Q / TPR;                  // pieces per thread and source
-        static_assert(Q % TPR == 0, "row pieces must divide evenly");
-        const int r = tid / TPR, cq = tid % TPR;
-        const int row = row0 + r;
-        auto put = [&](int col, f32x4 v) {
-            const __bf16 h0 = (__bf16)v[0], h1 = (__bf16)v[1], h2 = (__bf16)v[2], h3 = (__bf16)v[3];
-            const bf16x4_t vh = {h0, h1, h2, h3};
-            const bf16x4_t vl = {(__bf16)(v[0] - (float)h0), (__bf16)(v[1] - (float)h1),
-                                 (__bf16)(v[2] - (float)h2), (__bf16)(v[3] - (float)h3)};
-            *reinterpret_cast<bf16x4_t*>(Xh + r * LDX + col) = vh;
-            *reinterpret_cast<bf16x4_t*>(Xl + r * LDX + col) = vl;
-        };
-        int p0 = 0, p1 = 0;
-        if constexpr (UPD) {
-            if (row < a.M) { p0 = a.pstart[row]; p1 = a.pstart[row + 1]; }
-        }
-        f32x4 hv[NP];
-#pragma unroll
-        for (int u = 0; u < NP; ++u)
-            hv[u] = *reinterpret_cast<const f32x4*>(a.h_in + (size_t)row * H + 4 * (cq + u * TPR));   // pad rows are zero
-        if constexpr (UPD) {
-            // the first two partial sums (the common case: a node's edges span two tiles) are fetched together
-            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-            const bool has0 = p0 < p1, has1 = p0 + 1 < p1;
-            const float* s0 = a.part + (size_t)(has0 ? p0 : 0) * H;
-            const float* s1 = a.part + (size_t)(has1 ? p0 + 1 : 0) * H;
-            f32x4 g0[NP], g1[NP];
-#pragma unroll
-            for (int u = 0; u < NP; ++u) {
-                g0[u] = *reinterpret_cast<const f32x4*>(s0 + 4 * (cq + u * TPR));
-                g1[u] = *reinterpret_cast<const f32x4*>(s1 + 4 * (cq + u * TPR));
-            }
-#pragma unroll
-            for (int u = 0; u < NP; ++u) put(4 * (cq + u * TPR), hv[u]);
-#pragma unroll
-            for (int u = 0; u < NP; ++u) {
-                f32x4 v = z4;
-                if (has0) v += g0[u];
-                if (has1) v += g1[u];
-                for (int p = p0 + 2; p < p1; ++p) v += *reinterpret_cast<const f32x4*>(a.part + (size_t)p * H + 4 * (cq + u * TPR));
-                put(H + 4 * (cq + u * TPR), v / a.norm);
-            }
-        } else {
-#pragma unroll
-            for (int u = 0; u < NP; ++u) put(4 * (cq + u * TPR), hv[u]);
-        }
-    }
-
-    if constexpr (UPD) {
-        // ---- phase 1: T = silu(X W3^T + b3)
-        {
-            f32x16 acc[CT];
-#pragma unroll
-            for (int c = 0; c < CT; ++c) {
-                const float b = a.b3[32 * (ct0 + c) + n];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[c][r] = b;
-            }
-            __syncthreads();                                         // X complete
-            M2::prefetch(br2, W4l, ct0, 0);
-            M1::run(acc, br1, Xh + n * LDX + 8 * hh, Xl + n * LDX + 8 * hh, W3l, ct0, 0);
-#pragma unroll
-            for (int c = 0; c < CT; ++c)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int R = (r & 3) + 8 * (r >> 2) + 4 * hh;
-                    bf16_split_store(Th + R * LDH + 32 * (ct0 + c) + n, Tl + R * LDH + 32 * (ct0 + c) + n, silu_fast(acc[c][r]));
-                }
-        }
-        __syncthreads();
-        // ---- phase 2: h' = (h + T W4^T + b4) * mask
-        {
-            f32x16 acc[CT];
-            float hres[CT][16], mk[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mk[r] = a.nmask[row0 + (r & 3) + 8 * (r >> 2) + 4 * hh];
-#pragma unroll
-            for (int c = 0; c < CT; ++c) {
-                const float b = a.b4[32 * (ct0 + c) + n];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    acc[c][r] = b;
-                    hres[c][r] = a.h_in[(size_t)(row0 + (r & 3) + 8 * (r >> 2) + 4 * hh) * H + 32 * (ct0 + c) + n];
-                }
-            }
-            M3::prefetch(br3, AB0l, ct0, NCT);
-            M2::run(acc, br2, Th + n * LDH + 8 * hh, Tl + n * LDH + 8 * hh, W4l, ct0, 0);
-#pragma unroll
-            for (int c = 0; c < CT; ++c)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int R = (r & 3) + 8 * (r >> 2) + 4 * hh;
-                    const float v = (hres[c][r] + acc[c][r]) * mk[r];
-                    bf16_split_store(Nh + R * LDH + 32 * (ct0 + c) + n, Nl + R * LDH + 32 * (ct0 + c) + n, v);
-                    stage0[R * H + 32 * (ct0 + c) + n] = v;
-                }
-        }
-        __syncthreads();
-        {
-            constexpr int Q = H / 4, NP = 32 * Q / NT;
-#pragma unroll
-            for (int u = 0; u < NP; ++u) {
-                const int idx = tid + u * NT, r = idx / Q, c4 = idx % Q;
-                if (row0 + r < a.M)
-                    *reinterpret_cast<f32x4*>(a.h_out + (size_t)(row0 + r) * H + 4 * c4) = *reinterpret_cast<const f32x4*>(stage0 + r * H + 4 * c4);
-            }
-        }
-    }
-
-    // ---- phase 3: AB_q = h' [W1a | W1b]^T + bias, two H-wide halves per wavefront, staged through region 1
-#pragma unroll
-    for (int q = 0; q < NAB; ++q) {
-        f32x16 acc[2 * CT];
-#pragma unroll
-        for (int c = 0; c < 2 * CT; ++c) {
-            const float b = a.ABbias[q][(c / CT) * H + 32 * (ct0 + c % CT) + n];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[c][r] = b;
-        }
-        const u32x4* ABl = reinterpret_cast<const u32x4*>(a.ABimg[q]) + lane;
-        if (q > 0 || !UPD) {
-            M3::prefetch(br3, ABl, ct0, NCT);
-            if (!UPD) __syncthreads();                               // h tile complete
-        }
-        M3::run(acc, br3, Nh + n * LDH + 8 * hh, Nl + n * LDH + 8 * hh, ABl, ct0, NCT);
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            if (half || q) __syncthreads();                 // previous staging tile fully stored
-#pragma unroll
-            for (int c = 0; c < CT; ++c)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    stage1[((r & 3) + 8 * (r >> 2) + 4 * hh) * LDS1 + 32 * (ct0 + c) + n] = acc[half * CT + c][r];
-            __syncthreads();
-            constexpr int Q = H / 4, NP = 32 * Q / NT;
-#pragma unroll
-            for (int u = 0; u < NP; ++u) {
-                const int idx = tid + u * NT, r = idx / Q, c4 = idx % Q;
-                if (row0 + r < a.M)
-                    *reinterpret_cast<f32x4*>(a.ABout[q] + (size_t)(row0 + r) * 2 * H + half * H + 4 * c4) =
-                        *reinterpret_cast<const f32x4*>(stage1 + r * LDS1 + 4 * c4);
-            }
-        }
-    }
-}
-
-// ----------------------------------------------------------------------------- edge kernel
-// One wavefront = one tile of 32 edge rows x H output columns (NCT accumulators of 32x32).
-//   P[e][k]   = silu(A_i[k] + B_j[k] + r_e*w_r[k] + d0_e*w_d[k])      (A operand, built in registers)
-//   M[e][c]   = silu(sum_k P[e][k] * W2[c][k] + b2[c])                 (fp32 MFMA, W2 streamed via LDS)
-//   GCL  : att_e = sigmoid(wa.M[e] + ba);  partial[i] += M[e]*att_e    (egnn_new.py:35-56)
-//   COORD: phi_e = w7.M[e]; trans = u_ij * tanh(phi_e) * range         (egnn_new.py:91-104)
-// Rows of a tile are consecutive entries of the edge list (sorted by receiving node i); a tile may
-// hold several receiving nodes ("segments") and a node's edges may span tiles ("parts").
-
-struct EdgeArgs {
-    const float* AB;        // [M_pad][2H]: cols <H: W1a.h+b1 ; cols >=H: W1b.h
-    const float* wrd;       // [2][H]: w_r (current radial column), w_d (initial distance column)
-    const float* W2img;     // [H/32 chunks][32*H] packed
-    const float* b2;        // [H]
-    const float* wa;        // [H]  (att_mlp.0.weight, or coord_mlp.4.weight)
-    const int* ei;          // [E_pad] receiving node (compact)
-    const int* ej;          // [E_pad] sending node
-    const uint8_t* eseg;    // [E_pad] segment index inside the tile, 255 = padding row
-    const int* tile_pbase;  // [n_tiles] first part id of the tile
-    const int* tile_nseg;   // [n_tiles]
-    const float* xcur;      // [M_pad][4] coordinates at block start
-    const float* x0;        // [M_pad][4] coordinates at network input
-    float* part;            // GCL: [P][H];  COORD: [P][4]
-    float ba;               // att bias
-    float norm_constant;
-    float coords_range;     // per-block range
-    int attention, use_tanh;
-    int n_tiles, n_wg;      // n_wg = number of 128-edge workgroup-tiles
-    long long* trace;       // ABL & 16: per wave {start, loop start, loop end, end} cycle stamps
-};
-
-
-// PREC 0: exact fp32 (v_mfma_f32_32x32x2_f32).  PREC 1: "bf16x3" - both operands are split into a bf16
-// head and a bf16 tail (a = ah + al, |a - ah - al| <= 2^-18 |a|) and the product is formed as
-// ah*bh + al*bh + ah*bl with fp32 accumulation on v_mfma_f32_32x32x16_bf16: 3 matrix instructions at
-// 16x the fp32 rate, per-product error ~1e-5 (the dropped al*bl term), i.e. ~1e-6 on a 256-term dot.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-#ifndef HD_EDGE_PERSIST
-#define HD_EDGE_PERSIST 0
-#endif
-
-// Four LDS fragment reads / a counted wait that releases them (see k_edge).  The reads are inline asm so
-// they stay where they are written (hipcc otherwise sinks every LDS read next to its MFMA to save registers,
-// exposing the LDS latency once per fragment); the wait lists the registers as read-write, so their
-// consumers cannot be scheduled above it and the compiler cannot touch them between read and wait.
-template <typename V, unsigned O0, unsigned O1, unsigned O2, unsigned O3>
-HD_DEVINL void lds_read4(V (&f)[4], unsigned addr) {
-    asm volatile("ds_read_b128 %0, %4 offset:%5\n\t"
-                 "ds_read_b128 %1, %4 offset:%6\n\t"
-                 "ds_read_b128 %2, %4 offset:%7\n\t"
-                 "ds_read_b128 %3, %4 offset:%8"
-                 : "=&v"(f[0]), "=&v"(f[1]), "=&v"(f[2]), "=&v"(f[3])
-                 : "v"(addr), "i"(O0), "i"(O1), "i"(O2), "i"(O3));
-}
-template <int N, typename V>
-HD_DEVINL void lds_wait4(V (&f)[4]) {
-    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]) : "i"(N));
-}
-
-// x[lane] + x[lane ^ 32] in every lane, on the VALU (gfx950 v_permlane32_swap: upper half of the first operand
-// <-> lower half of the second) instead of a ds_bpermute round trip.  The s_nops cover the VALU-write ->
-// permlane-read and permlane-write -> VALU-read hazards, which hipcc does not track through inline asm.
-HD_DEVINL float xhalf_sum(float x) {
-    float lo = x, hi = x;
-    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(lo), "+v"(hi));
-    return lo + hi;
-}
-
-// AB row gathers of the bf16x3 edge kernel: two 16-byte loads (A_i quad, B_j quad) as inline asm, released by a
-// hand-counted s_waitcnt vmcnt that names their registers.  Compiler-visible loads cannot be used next to the
-// W2 stream: hipcc treats global_load_lds as a second vmcnt event type, assumes mixed events complete out of
-// order and waits vmcnt(0) - i.e. for the stream it has just started - before the first use of a gathered row.
-// Loads (LDS-DMA included) return in issue order, so "at most N outstanding" releases everything older.
-HD_DEVINL void vm_load2(f32x4& va, f32x4& vb, const float* pa, const float* pb) {
-    asm volatile("global_load_dwordx4 %0, %2, off\n\t"
-                 "global_load_dwordx4 %1, %3, off"
-                 : "=&v"(va), "=&v"(vb) : "v"(pa), "v"(pb));
-}
-// same with a compile-time byte offset (13-bit signed immediate): in a fully unrolled chunk loop hipcc otherwise
-// materialises every (chunk, quad) address as its own 64-bit register pair up front and spills them
-template <int OFF>
-HD_DEVINL void vm_load2o(f32x4& va, f32x4& vb, const float* pa, const float* pb) {
-    static_assert(OFF >= 0 && OFF < 4096, "immediate offset out of range");
-    asm volatile("global_load_dwordx4 %0, %2, off offset:%4\n\t"
-                 "global_load_dwordx4 %1, %3, off offset:%4"
-                 : "=&v"(va), "=&v"(vb) : "v"(pa), "v"(pb), "i"(OFF));
-}
-// AB row gathers of the pipelined kernel go global -> LDS (16 B per lane, lane-linear 1 KiB slots) and are read
-// back with ds_read_b128: an asm load with a VGPR destination is unsafe at 256 live VGPRs - hipcc spilled the
-// still-in-flight destinations to AGPRs right after the load statement (garbage, and different on every run).
-// M0 carries the wave-uniform LDS byte address of the slot and is restored (hipcc reserves it).
-HD_DEVINL void vm_glds2(const float* ga, const float* gb, unsigned lds_a, unsigned lds_b) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\t"
-                 "s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
-                 "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(ga), "v"(gb), "s"(lds_a), "s"(lds_b));
-}
-// "at most N VMEM operations outstanding", then fetch an (A quad, B quad) slot pair; lds_ready2 releases the pair
-template <int N, unsigned OA, unsigned OB>
-HD_DEVINL void lds_read2_after_vm(f32x4& qa, f32x4& qb, unsigned addr) {
-    asm volatile("s_waitcnt vmcnt(%3)\n\t"
-                 "ds_read_b128 %0, %2 offset:%4\n\t"
-                 "ds_read_b128 %1, %2 offset:%5"
-                 : "=&v"(qa), "=&v"(qb) : "v"(addr), "i"(N), "i"(OA), "i"(OB));
-}
-HD_DEVINL void lds_ready2(f32x4& qa, f32x4& qb) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qa), "+v"(qb)); }
-
-template <int N>
-HD_DEVINL void vm_wait2(f32x4& va, f32x4& vb) {
-    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(va), "+v"(vb) : "i"(N));
-}
-
-// byte offset (from the lane's base) of a B fragment inside a chunk image
-//   bf16x3: unit u = (k-step, column tile), hl = head (0) / tail (1);   fp32: fragment u = (q, column tile)
-template <int NCT>
-constexpr unsigned frag_off_bf(int u, int hl) { return (unsigned)((((hl * 2 + u / NCT) * NCT + u % NCT) * 64) * 16); }
-constexpr unsigned frag_off_f32(int u) { return (unsigned)(u * 64 * 16); }
-
-// ABL: ablation switches for bottleneck hunting (never set in production launches; env HD_ABLATE, H=256 bf16x3 GCL):
-//   1 = skip the epilogue, 2 = skip operand generation (SiLU etc.), 4 = no per-chunk barrier / W2 streaming,
-//   8 = no AB row gathers, 16 = record per-wave cycle stamps + HW placement (hd_debug_edge_trace, scratch/edge_trace.py)
-//
-// Persistent workgroups: gridDim.x <= 2 per CU; each workgroup walks the 128-edge workgroup-tiles of its
-// XCD's contiguous share of the edge list (neighbouring tiles = same molecule = same AB rows in that XCD's
-// L2), keeps the W2 chunk stream running across tiles and fetches the next tile's row metadata while the
-// current tile's epilogue runs.
-template <int H, bool COORD, int PREC, int ABL = 0>
-__global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
-    constexpr int NCT = H / 32;          // 32-column tiles
-    constexpr int NCH = H / 32;          // 32-wide K chunks
-    constexpr int CHF = 32 * H;          // floats per W2 chunk image
-    constexpr int GL_PER_WAVE = CHF / (4 * 256);   // 1 KiB pieces per wave per chunk
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* wbuf = smem;                   // [2][CHF]
-    // w_r / w_d live in their own LDS object: hipcc makes every compiler-visible LDS read that may alias the
-    // destination of an in-flight global_load_lds wait for vmcnt(0) - with one shared array that stalled each
-    // chunk on the W2 stream it had just started.
-    __shared__ __attribute__((aligned(16))) float wrd_s[4 * H];   // [w_r | w_d | b2 | wa], staged once per workgroup
-    float* scratch = smem + 2 * CHF + 2 * H;   // per wave: 32 (phi) + 96 (trans) + 8 (seg bytes)
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int hh = lane >> 5, n = lane & 31;
-    float* my_scr = scratch + wave * 136;
-    uint32_t* seg_s = reinterpret_cast<uint32_t*>(my_scr + 128);
-
-    // this workgroup's share of the workgroup-tiles
-    int wt_first, wt_count, wt_step;
-    {
-        const int bid = blockIdx.x, G = gridDim.x, nwt = a.n_wg;
-        const int xcd = bid & 7, slot = bid >> 3;
-        const int q = nwt >> 3, r = nwt & 7;
-        const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-        const int len = q + (xcd < r ? 1 : 0);
-        wt_step = (G - xcd + 7) >> 3;                     // workgroups of this launch on the same XCD
-        wt_first = start + slot;
-        wt_count = slot < len ? (len - slot + wt_step - 1) / wt_step : 0;
-    }
-    if (wt_count == 0) return;
-    long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0;
-    if constexpr (ABL & 16) ts0 = __builtin_readcyclecounter();
-    // HD_EDGE_PERSIST == 0 (default): the host launches one workgroup per workgroup-tile and the loop below runs
-    // once.  Measured on MI355X the persistent form is no faster (118.5 vs 121.5 us) and its longer live
-    // ranges cost ~25 spilled registers, so the single-pass form ships; the walk stays for experiments.
-    const int n_it = HD_EDGE_PERSIST ? wt_count : 1;
-
-    for (int k = tid; k < 2 * H; k += 256) wrd_s[k] = a.wrd[k];
-    for (int k = tid; k < H; k += 256) { wrd_s[2 * H + k] = a.b2[k]; wrd_s[3 * H + k] = a.wa[k]; }
-    auto issue_chunk = [&](int c, int buf) {
-        const float* src = a.W2img + (size_t)c * CHF;
-        float* dst = wbuf + buf * CHF;
-#pragma unroll
-        for (int u = 0; u < GL_PER_WAVE; ++u) {
-            const int piece = wave * GL_PER_WAVE + u;           // 1 KiB pieces
-            glds16(src + piece * 256 + lane * 4, dst + piece * 256);
-        }
-    };
-    issue_chunk(0, 0);
-
-    // per-row metadata of a tile (lanes n and n+32 both describe row n)
-    int ni = 0, nj = 0;
-    uint32_t segb = 255;
-    auto load_meta = [&](int tile) {
-        ni = 0; nj = 0; segb = 255;
-        if (tile < a.n_tiles) {
-            const int e = tile * 32 + n;
-            ni = a.ei[e]; nj = a.ej[e]; segb = a.eseg[e];
-        }
-    };
-    load_meta(wt_first * 4 + wave);
-
-    int gc = 0;                                            // global chunk counter: buffer = gc & 1
-#pragma unroll 1
-    for (int it = 0; it < n_it; ++it) {
-        const int tile = (wt_first + it * wt_step) * 4 + wave;
-        const bool tile_ok = tile < a.n_tiles;
-        const bool last_it = it + 1 == n_it;
-
-        f32x4 xi = *reinterpret_cast<const f32x4*>(a.xcur + (size_t)ni * 4);
-        f32x4 xj = *reinterpret_cast<const f32x4*>(a.xcur + (size_t)nj * 4);
-        f32x4 yi = *reinterpret_cast<const f32x4*>(a.x0 + (size_t)ni * 4);
-        f32x4 yj = *reinterpret_cast<const f32x4*>(a.x0 + (size_t)nj * 4);
-        const float dx = xi[0] - xj[0], dy = xi[1] - xj[1], dz = xi[2] - xj[2];
-        const float radial = dx * dx + dy * dy + dz * dz;
-        const float ex = yi[0] - yj[0], ey = yi[1] - yj[1], ez = yi[2] - yj[2];
-        const float d0 = ex * ex + ey * ey + ez * ez;
-        const uint32_t segb_t = segb;
-        const int pbase = tile_ok ? a.tile_pbase[tile] : 0;     // requested here, used in the epilogue
-        const int nseg = tile_ok ? a.tile_nseg[tile] : 0;
-        if (hh == 0) reinterpret_cast<uint8_t*>(seg_s)[n] = (uint8_t)segb_t;
-
-        const float* Arow = a.AB + (size_t)ni * (2 * H) + 16 * hh;
-        const float* Brow = a.AB + (size_t)nj * (2 * H) + H + 16 * hh;
-        f32x4 pa[4], pb[4];
-        auto load_rows = [&](int c) {
-            if constexpr (ABL & 8) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { pa[u] = f32x4{radial, d0, radial, d0}; pb[u] = pa[u]; }
-                return;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                pa[u] = *reinterpret_cast<const f32x4*>(Arow + 32 * c + 4 * u);
-                pb[u] = *reinterpret_cast<const f32x4*>(Brow + 32 * c + 4 * u);
-            }
-        };
-        auto rows_issue = [&](int u, int c) {                  // bf16x3 mode: quad u of chunk c (see vm_load2)
-            if constexpr (ABL & 8) { pa[u] = f32x4{radial, d0, radial, d0}; pb[u] = pa[u]; }
-            else vm_load2(pa[u], pb[u], Arow + 32 * c + 4 * u, Brow + 32 * c + 4 * u);
-        };
-        // first-layer activations of this lane's edge row for K chunk c (k = 32c + 16*hh + 0..15)
-        auto make_P = [&](int c, float (&P)[16]) {             // fp32 mode
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                f32x4 wr4 = *reinterpret_cast<const f32x4*>(wrd_s + 32 * c + 16 * hh + 4 * u);
-                f32x4 wd4 = *reinterpret_cast<const f32x4*>(wrd_s + H + 32 * c + 16 * hh + 4 * u);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float pre = pa[u][j] + pb[u][j];
-                    pre = __builtin_fmaf(radial, wr4[j], pre);
-                    pre = __builtin_fmaf(d0, wd4[j], pre);
-                    P[4 * u + j] = silu_f(pre);
-                }
-            }
-        };
-        // bf16x3 mode: one pair of values (scaled domain) -> bf16 head / tail dwords
-        auto make_pair = [&](f32x2 av, f32x2 bv, f32x2 wr2, f32x2 wd2, uint32_t& hi, uint32_t& lo) {
-            float y[2];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                float pre = av[j] + bv[j];
-                pre = __builtin_fmaf(radial, wr2[j], pre);
-                pre = __builtin_fmaf(d0, wd2[j], pre);
-                if constexpr (ABL & 2) y[j] = av[j]; else y[j] = silu_scaled(pre);
-            }
-            bf16_split2(y[0], y[1], hi, lo);
-        };
-        auto make_P_bf = [&](int c, u32x4 (&ph)[2], u32x4 (&pl)[2]) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const f32x4 wr4 = *reinterpret_cast<const f32x4*>(wrd_s + 32 * c + 16 * hh + 4 * u);
-                const f32x4 wd4 = *reinterpret_cast<const f32x4*>(wrd_s + H + 32 * c + 16 * hh + 4 * u);
-#pragma unroll
-                for (int j2 = 0; j2 < 2; ++j2) {
-                    uint32_t hi, lo;
-                    make_pair(f32x2{pa[u][2 * j2], pa[u][2 * j2 + 1]}, f32x2{pb[u][2 * j2], pb[u][2 * j2 + 1]},
-                              f32x2{wr4[2 * j2], wr4[2 * j2 + 1]}, f32x2{wd4[2 * j2], wd4[2 * j2 + 1]}, hi, lo);
-                    ph[u >> 1][2 * (u & 1) + j2] = hi;
-                    pl[u >> 1][2 * (u & 1) + j2] = lo;
-                }
-            }
-        };
-
-        // Software pipeline: the operands of chunk c+1 are produced (VALU) while the matrix pipe works on
-        // chunk c; the AB rows are fetched two chunks ahead.
-        float Pc[16];
-        u32x4 phc[2], plc[2];                  // bf16x3: head / tail of the 16 operand values, 8 bf16 per k-step
-        if constexpr (PREC == 0) {
-            load_rows(0);
-            __syncthreads();               // chunk 0 of this tile landed (w_r / w_d staged on the first pass)
-            make_P(0, Pc);
-            load_rows(NCH > 1 ? 1 : 0);
-        } else {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) rows_issue(u, 0);
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(pa[0]), "+v"(pa[1]), "+v"(pa[2]), "+v"(pa[3]),
-                                                "+v"(pb[0]), "+v"(pb[1]), "+v"(pb[2]), "+v"(pb[3]));
-            __syncthreads();               // chunk 0 landed in every wave's share (w_r / w_d staged on the first pass)
-            make_P_bf(0, phc, plc);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) rows_issue(u, NCH > 1 ? 1 : 0);
-        }
-
-        // accumulators start at the second layer's bias (saves the H/32 * 16 bias adds of the epilogue)
-        f32x16 acc[NCT];
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) {
-            const float b2v = wrd_s[2 * H + 32 * ct + n];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[ct][r] = b2v;
-        }
-        if constexpr (ABL & 16) ts1 = __builtin_readcyclecounter();
-        // (Unrolling this loop by two with swapped operand sets, to drop the 16 register copies per chunk, was
-        // measured: +17 spilled registers and 125 vs 109 us.)
-#pragma unroll 1
-        for (int c = 0; c < NCH; ++c, ++gc) {
-            const int buf = (ABL & 4) ? 0 : (gc & 1);
-            if constexpr (!(ABL & 4)) {
-                // chunk c landed in LDS and every wave is done with the other buffer.  bf16x3: the only VMEM
-                // operations younger than chunk c's stream are the 8 row gathers of the previous iteration.
-                if (c > 0) {
-                    if constexpr (PREC == 0) __syncthreads();
-                    else asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
-                }
-                // Unconditional (the last chunk re-requests chunk 0, unused unless a further tile follows): with the
-                // stream inside a branch hipcc has to assume "no stream in flight" at the join and waits vmcnt(0)
-                // - i.e. for the stream itself - before the first use of the gathered AB rows, every chunk.
-                issue_chunk(c + 1 < NCH ? c + 1 : 0, buf ^ 1);
-            }
-            // Branch-free from here to the end of the body (one scheduling region): the last iteration
-            // recomputes the final chunk's operands and refetches its rows, results unused.
-            float Pn[16];
-            u32x4 phn[2], pln[2];
-            const int cn1 = c + 1 < NCH ? c + 1 : NCH - 1, cn2 = c + 2 < NCH ? c + 2 : NCH - 1;
-            if constexpr (PREC == 0) {
-                make_P(cn1, Pn);
-                load_rows(cn2);
-            }
-            const float* wb = wbuf + buf * CHF;
-            const unsigned wb_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)wb + lane * 16;
-            if constexpr (PREC == 0) {
-                // chunk image: [4 q][NCT][64 lanes][4 floats]: fragment (q, ct) holds k = 32c + 16h + 4q + j, j = 0..3,
-                // of column 32ct + n (64-cycle fp32 MFMAs hide the LDS latency without explicit prefetch).
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    f32x4 bv[NCT];
-#pragma unroll
-                    for (int ct = 0; ct < NCT; ++ct)
-                        bv[ct] = *reinterpret_cast<const f32x4*>(wb + ((q * NCT + ct) * 64 + lane) * 4);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-#pragma unroll
-                        for (int ct = 0; ct < NCT; ++ct)
-                            acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(Pc[4 * q + j], bv[ct][j], acc[ct], 0, 0, 0);
-                }
-#pragma unroll
-                for (int i = 0; i < 16; ++i) Pc[i] = Pn[i];
-            } else {
-                // chunk image: [hi|lo][2 k-steps][NCT][64 lanes][8 bf16]; lane (h, n), element i of step s is
-                // W2[32ct + n][32c + 16h + 8s + i] - the same k order as P[8s + i].  Units u = (k-step, ct) of
-                // three MFMAs (head*head, tail*head, head*tail) on one accumulator, two units per group.
-                constexpr int NG = NCT;                     // 2*NCT units / 2
-                // The next chunk's operand generation (VALU) is cut into NG slices, one per MFMA group, so the
-                // matrix pipe and the VALU alternate every ~6 MFMAs inside ONE wavefront instead of relying on
-                // the phase of the co-resident wavefront.  w_r / w_d come from LDS a slice pair ahead; the AB
-                // rows of chunk c+2 replace those of chunk c+1 as soon as their last value has been consumed.
-                const float* wr_n = wrd_s + 32 * cn1 + 16 * hh;
-                const float* wd_n = wrd_s + H + 32 * cn1 + 16 * hh;
-                f32x4 wrq[2], wdq[2];
-                wrq[0] = *reinterpret_cast<const f32x4*>(wr_n);
-                wdq[0] = *reinterpret_cast<const f32x4*>(wd_n);
-                bf16x8 f0[4], f1[4];
-                lds_read4<bf16x8, frag_off_bf<NCT>(0, 0), frag_off_bf<NCT>(0, 1), frag_off_bf<NCT>(1, 0), frag_off_bf<NCT>(1, 1)>(f0, wb_lds);
-                static_for<0, NG>([&](auto Gc) {
-                    constexpr int g = decltype(Gc)::value;
-                    bf16x8(&cur)[4] = (g & 1) ? f1 : f0;
-                    bf16x8(&nxt)[4] = (g & 1) ? f0 : f1;
-                    lds_wait4<0>(cur);
-                    if constexpr (g + 1 < NG) {
-                        constexpr int u = 2 * (g + 1);
-                        lds_read4<bf16x8, frag_off_bf<NCT>(u, 0), frag_off_bf<NCT>(u, 1), frag_off_bf<NCT>(u + 1, 0),
-                                  frag_off_bf<NCT>(u + 1, 1)>(nxt, wb_lds);
-                    }
-                    // The next chunk's 8 operand pairs are produced in the FIRST half of the groups and the AB
-                    // rows of chunk c+2 are requested as soon as a quad of chunk c+1 has been consumed: the
-                    // per-chunk barrier implies vmcnt(0), so a gather issued late in the chunk would expose its
-                    // whole L2 latency there.
-                    constexpr int NGP = NG >= 2 ? NG / 2 : 1;          // groups that produce operands
-                    constexpr int PPG = 8 / NGP;                       // pairs per producing group
-                    if constexpr (g < NGP) {
-#pragma unroll
-                        for (int v = 0; v < PPG; ++v) {
-                            const int pi = g * PPG + v, u = pi >> 1, j2 = pi & 1;      // pair pi = values 2pi, 2pi+1
-                            // outstanding, oldest first: quads u..3 of chunk c+1, this chunk's GL_PER_WAVE stream
-                            // pieces, quads 0..u-1 of chunk c+2  =  8 + GL_PER_WAVE loads
-                            if (j2 == 0) vm_wait2<6 + GL_PER_WAVE>(pa[u], pb[u]);
-                            if (j2 == 0 && u + 1 < 4) {      // w_r / w_d for the following four values
-                                wrq[(u + 1) & 1] = *reinterpret_cast<const f32x4*>(wr_n + 4 * (u + 1));
-                                wdq[(u + 1) & 1] = *reinterpret_cast<const f32x4*>(wd_n + 4 * (u + 1));
-                            }
-                            uint32_t hi, lo;
-                            make_pair(f32x2{pa[u][2 * j2], pa[u][2 * j2 + 1]}, f32x2{pb[u][2 * j2], pb[u][2 * j2 + 1]},
-                                      f32x2{wrq[u & 1][2 * j2], wrq[u & 1][2 * j2 + 1]},
-                                      f32x2{wdq[u & 1][2 * j2], wdq[u & 1][2 * j2 + 1]}, hi, lo);
-                            phn[pi >> 2][pi & 3] = hi;
-                            pln[pi >> 2][pi & 3] = lo;
-                            if (j2 == 1) rows_issue(u, cn2);     // rows of chunk c+2 into the freed registers
-                        }
-                    }
-                    constexpr int u0 = 2 * g, u1 = 2 * g + 1;
-                    constexpr int s0 = u0 / NCT, c0 = u0 % NCT, s1 = u1 / NCT, c1 = u1 % NCT;
-                    const bf16x8 A_h0 = __builtin_bit_cast(bf16x8, phc[s0]), A_l0 = __builtin_bit_cast(bf16x8, plc[s0]);
-                    const bf16x8 A_h1 = __builtin_bit_cast(bf16x8, phc[s1]), A_l1 = __builtin_bit_cast(bf16x8, plc[s1]);
-                    acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_h0, cur[0], acc[c0], 0, 0, 0);
-                    acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_h1, cur[2], acc[c1], 0, 0, 0);
-                    acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_l0, cur[0], acc[c0], 0, 0, 0);
-                    acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_l1, cur[2], acc[c1], 0, 0, 0);
-                    acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_h0, cur[1], acc[c0], 0, 0, 0);
-                    acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_h1, cur[3], acc[c1], 0, 0, 0);
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) {            // interleave: 1 MFMA, then up to 4 VALU
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-                    }
-                });
-#pragma unroll
-                for (int st = 0; st < 2; ++st) { phc[st] = phn[st]; plc[st] = pln[st]; }
-            }
-        }
-
-        if constexpr (PREC == 1) {             // drain the (unused) last gathers before their registers are reused
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(pa[0]), "+v"(pa[1]), "+v"(pa[2]), "+v"(pa[3]),
-                                                "+v"(pb[0]), "+v"(pb[1]), "+v"(pb[2]), "+v"(pb[3]));
-        }
-        if constexpr (ABL & 16) ts2 = __builtin_readcyclecounter();
-        // next tile's row metadata: in flight while this tile's epilogue runs
-        if (!last_it) load_meta((wt_first + (it + 1) * wt_step) * 4 + wave);
-
-        if (!tile_ok) continue;
-        if constexpr (ABL & 1) {
-            float sacc = 0.f;
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) sacc += acc[ct][r];
-            if (sacc == 123.456f) a.part[lane] = sacc;
-            continue;
-        }
-
-        // ---- epilogue.  acc[ct][r] = row rho(r) = (r&3) + 8*(r>>2) + 4*hh, column 32*ct + n.
-        float dot[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dot[r] = 0.f;
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) {
-            const float wav = wrd_s[3 * H + 32 * ct + n];
-            if constexpr (PREC == 0) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float mv = silu_f(acc[ct][r]);
-                    acc[ct][r] = mv;
-                    dot[r] = __builtin_fmaf(mv, wav, dot[r]);
-                }
-            } else {
-                // stage by stage over the 16 rows of a column tile (exp x16, +1 x16, rcp x16, ...): left alone hipcc
-                // runs each value's exp -> add -> rcp -> mul chain back to back through one or two registers and
-                // the epilogue sits out the transcendental latency ~500 times.
-                float e[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) e[r] = __builtin_amdgcn_exp2f(acc[ct][r]);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) e[r] = 1.0f + e[r];
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) e[r] = __builtin_amdgcn_rcpf(e[r]);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[ct][r] *= e[r];
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) dot[r] = __builtin_fmaf(acc[ct][r], wav, dot[r]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        if constexpr (ABL & 16) ts3 = __builtin_readcyclecounter();
-        // Row dots: transpose-reduce over the 32 lanes of a half.  Each exchange halves the number of rows a
-        // lane still carries (16 -> 8 -> 4 -> 2 -> 1), the last one is a plain butterfly: 16 shuffles instead
-        // of 80, and lanes 2r, 2r+1 end up with the complete dot of row slot r, so the sigmoid / tanh input is
-        // evaluated once per lane instead of 16 times.
-        float rowdot;
-        {
-            float v8[8], v4[4], v2[2];
-            const bool b4 = n & 16, b3 = n & 8, b2_ = n & 4, b1 = n & 2;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float send = b4 ? dot[k] : dot[k + 8];
-                const float keep = b4 ? dot[k + 8] : dot[k];
-                v8[k] = keep + __shfl_xor(send, 16);
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float send = b3 ? v8[k] : v8[k + 4];
-                const float keep = b3 ? v8[k + 4] : v8[k];
-                v4[k] = keep + __shfl_xor(send, 8);
-            }
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const float send = b2_ ? v4[k] : v4[k + 2];
-                const float keep = b2_ ? v4[k + 2] : v4[k];
-                v2[k] = keep + __shfl_xor(send, 4);
-            }
-            {
-                const float send = b1 ? v2[0] : v2[1];
-                const float keep = b1 ? v2[1] : v2[0];
-                rowdot = keep + __shfl_xor(send, 2);
-            }
-            rowdot += __shfl_xor(rowdot, 1);
-        }
-        if constexpr (ABL & 16) ts4 = __builtin_readcyclecounter();
-        const int my_slot = (n >> 1) & 15;                  // this lane holds the dot of row rho(my_slot)
-
-        if (!COORD) {
-            // segment byte of each of this lane's 16 rows: rows 8q+4hh .. +3 share one dword
-            uint32_t sw[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) sw[q] = seg_s[2 * q + hh];
-            float att_mine = 1.0f;
-            if (a.attention) {
-                if constexpr (PREC == 0) att_mine = sigmoid_f(rowdot + a.ba);
-                else att_mine = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(rowdot + a.ba));   // scaled domain
-            }
-            float w[16];
-            int sg[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                sg[r] = (sw[r >> 2] >> (8 * (r & 3))) & 255;
-                const float att = __shfl(att_mine, (lane & 32) | (2 * r));
-                w[r] = (sg[r] != 255) ? att : 0.0f;
-            }
-            if constexpr (ABL & 16) ts5 = __builtin_readcyclecounter();
-            for (int s = 0; s < nseg; ++s) {
-                float ws[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) ws[r] = (sg[r] == s) ? w[r] : 0.0f;
-                float* dst = a.part + (size_t)(pbase + s) * H + n;
-                float sums[NCT];
-#pragma unroll
-                for (int ct = 0; ct < NCT; ++ct) {
-                    float sum = 0.f;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) sum = __builtin_fmaf(ws[r], acc[ct][r], sum);
-                    sums[ct] = xhalf_sum(sum);
-                }
-                if (hh == 0) {
-#pragma unroll
-                    for (int ct = 0; ct < NCT; ++ct) dst[32 * ct] = sums[ct];
-                }
-            }
-        } else {
-            // phi of row rho(r) is in every lane of half hh; publish per row, then lane n handles row n
-            if ((n & 1) == 0) my_scr[(my_slot & 3) + 8 * (my_slot >> 2) + 4 * hh] = rowdot;
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            if (hh == 0) {
-                float phi = my_scr[n];
-                float nrm = sqrtf(radial + 1e-8f) + a.norm_constant;
-                float sc = a.use_tanh ? tanhf(phi) * a.coords_range : phi;
-                float valid = (segb_t != 255) ? 1.0f : 0.0f;
-                float* tr = my_scr + 32;
-                tr[n * 3 + 0] = (dx / nrm) * sc * valid;
-                tr[n * 3 + 1] = (dy / nrm) * sc * valid;
-                tr[n * 3 + 2] = (dz / nrm) * sc * valid;
-            }
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            if (lane < nseg) {
-                const uint8_t* sb = reinterpret_cast<const uint8_t*>(seg_s);
-                const float* tr = my_scr + 32;
-                float sx = 0.f, sy = 0.f, sz = 0.f;
-                for (int rr = 0; rr < 32; ++rr) {
-                    if (sb[rr] == lane) { sx += tr[rr * 3]; sy += tr[rr * 3 + 1]; sz += tr[rr * 3 + 2]; }
-                }
-                f32x4 o = {sx, sy, sz, 0.f};
-                *reinterpret_cast<f32x4*>(a.part + (size_t)(pbase + lane) * 4) = o;
-            }
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        }
-        if constexpr (ABL & 16) {
-            if (lane == 0) {
-                long long* t = a.trace + ((size_t)blockIdx.x * 4 + wave) * 8;
-                // HW_ID (reg 4) / XCC_ID (reg 20) ride in the top 16 bits of the first two stamps
-                const long long hw = __builtin_amdgcn_s_getreg((16 - 1) << 11 | 4) & 0xffff;
-                const long long xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 20) & 0xf;
-                t[0] = (ts0 & 0xffffffffffffll) | (hw << 48); t[1] = (ts1 & 0xffffffffffffll) | (xcc << 48);
-                const long long m48 = 0xffffffffffffll;
-                t[2] = ts2 & m48; t[3] = __builtin_readcyclecounter() & m48; t[4] = ts3 & m48; t[5] = ts4 & m48; t[6] = ts5 & m48; t[7] = nseg;
-            }
-        }
-    }
-}
-
-// ----------------------------------------------------------------------------- pipelined edge kernel (bf16x3, H >= 256)
-// EXPERIMENTAL, off by default (HD_EDGE_PIPE=1 selects it).  Measured on MI355X at B=256, N=30: 124 us (GCL) / 135 us
-// (coord) against 103 us for k_edge.  Per-chunk stamps (scratch/edge_ptrace.py): 3.3-3.5 k cycles per 48-MFMA chunk
-// (MFMA floor 1.5 k) and 7.7 k for stage B: with one wavefront per SIMD every instruction costs an issue slot of ~4
-// cycles (~500 instructions per chunk) and every latency is exposed, while two co-resident wavefronts of k_edge
-// share the SIMD's issue ports.  Kept as the starting point for a hand-scheduled version.
-// Same arithmetic as k_edge<H, COORD, 1>, arranged for ONE wavefront per SIMD (512 registers) and persistent
-// workgroups, because on gfx950 VALU work only overlaps matrix work when both sit in the same wavefront's
-// instruction stream (scratch/mb/phased.hip: an MFMA-streaming wavefront and a VALU-streaming one on the same
-// SIMD serialise; scratch/mb/coissue.hip: ~5 plain VALU issues per MFMA are free inside one wavefront):
-//   * a wavefront walks its tiles; while the MFMAs of tile t run, its VALU slots carry (a) the operand generation
-//     of tile t's next chunk as before and (b) stage A of tile t-1's epilogue - SiLU + attention/coordinate dot of
-//     column tile c during K chunk c (two accumulator sets, 256 registers);
-//   * stage B of tile t-1 (row-dot reduction, sigmoid / tanh, per-node sums, stores) runs between the chunk loops;
-//   * the next tile's metadata, coordinates, first AB rows and first operand chunk are fetched / built inside the
-//     last chunks of tile t, so a tile has no prologue of its own;
-//   * the W2 stream runs two chunks ahead through three LDS buffers (one workgroup per CU) and never stops
-//     between tiles.
-// vmcnt bookkeeping (loads return in issue order; G = stream pieces per wave and chunk): the stream for chunk
-// g is issued at the top of chunk g-2, every chunk issues 8 AB row gathers after it, so at the top of chunk g
-// "at most 16 + G outstanding" retires the stream of chunk g, and before the first use of a gathered quad
-// "at most 4 + G outstanding" retires the quad fetched one group ahead.  Compiler-visible loads (next tile's metadata) only ever
-// make these waits stricter.
-
-template <int H, bool COORD, bool TRACE = false>
-__global__ __launch_bounds__(256, 1) void k_edge_p(EdgeArgs a) {
-    long long tst[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // TRACE: cycle stamps of the second tile
-
-    constexpr int NCT = H / 32, NCH = H / 32, CHF = 32 * H, GLW = CHF / (4 * 256), NBUF = 3;
-    static_assert(NCH >= 8, "the cross-tile prefetch schedule needs at least 8 K chunks");
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* wbuf = smem;                                           // [NBUF][CHF]
-    __shared__ __attribute__((aligned(16))) float wrd_s[4 * H];   // [w_r | w_d | b2 | wa]
-    float* rows_all = smem + NBUF * CHF;                          // per wave: 8 slots x 1 KiB of gathered AB rows
-    float* scratch = rows_all + 4 * 2048;                         // per wave: 32 phi + 96 trans + 2 x 8 seg words
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int hh = lane >> 5, n = lane & 31;
-    float* my_scr = scratch + wave * 144;
-    uint32_t* seg_s = reinterpret_cast<uint32_t*>(my_scr + 128);  // [2][8]
-    const unsigned rows_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)(rows_all + wave * 2048);
-    const unsigned rows_lane = rows_lds + lane * 16;             // this lane's 16 bytes inside a slot
-
-    int wt_first, wt_count, wt_step;
-    {
-        const int bid = blockIdx.x, G = gridDim.x, nwt = a.n_wg;
-        const int xcd = bid & 7, slot = bid >> 3;
-        const int q = nwt >> 3, r = nwt & 7;
-        const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-        const int len = q + (xcd < r ? 1 : 0);
-        wt_step = (G - xcd + 7) >> 3;
-        wt_first = start + slot;
-        wt_count = slot < len ? (len - slot + wt_step - 1) / wt_step : 0;
-    }
-    if (wt_count == 0) return;
-
-    for (int k = tid; k < 2 * H; k += 256) wrd_s[k] = a.wrd[k];
-    for (int k = tid; k < H; k += 256) { wrd_s[2 * H + k] = a.b2[k]; wrd_s[3 * H + k] = a.wa[k]; }
-    auto issue_chunk = [&](int c, int buf) {
-        const float* src = a.W2img + (size_t)c * CHF + wave * (GLW * 256);
-        // opaque here: in the fully unrolled chunk loop hipcc otherwise hoists all NCH x GLW source addresses (a
-        // 64-bit VGPR pair each) out of the tile loop and spills them
-        asm volatile("" : "+s"(src));
-        float* dst = wbuf + buf * CHF + wave * (GLW * 256);
-#pragma unroll
-        for (int u = 0; u < GLW; ++u) glds16(src + u * 256 + lane * 4, dst + u * 256);
-    };
-    issue_chunk(0, 0);
-    issue_chunk(1, 1);
-
-    // ---- per-tile state: geometry of this lane's edge row, row pointers, segment bookkeeping
-    struct Tile {                            // 64 bytes, no padding (a padded tail is copied through scratch memory)
-        const float* Arow;
-        const float* Brow;
-        int ni, nj, pbase, nseg, ok;
-        uint32_t segb;
-        float radial, d0, ux, uy, uz, spare; // u = (x_i - x_j) / (|x_i - x_j| + norm_constant) * valid   (COORD)
-    };
-    // No branches anywhere in the tile body (a branch splits it into basic blocks and hipcc then sinks the operand
-    // generation of the chunk before the branch into the chunk after it).  Every tile index a wave can reach is
-    // inside the padded edge tables: padding rows carry eseg = 255 and padding tiles nseg = 0.
-    auto tile_meta = [&](Tile& t, int tile) {
-        t.spare = 0.f;
-        t.ok = tile < a.n_tiles;
-        const int e = tile * 32 + n;
-        t.ni = a.ei[e]; t.nj = a.ej[e]; t.segb = a.eseg[e];
-        t.pbase = a.tile_pbase[tile]; t.nseg = a.tile_nseg[tile];
-        t.Arow = a.AB + (size_t)t.ni * (2 * H) + 16 * hh;
-        t.Brow = a.AB + (size_t)t.nj * (2 * H) + H + 16 * hh;
-    };
-    auto tile_geom = [&](Tile& t) {
-        const f32x4 xi = *reinterpret_cast<const f32x4*>(a.xcur + (size_t)t.ni * 4);
-        const f32x4 xj = *reinterpret_cast<const f32x4*>(a.xcur + (size_t)t.nj * 4);
-        const f32x4 yi = *reinterpret_cast<const f32x4*>(a.x0 + (size_t)t.ni * 4);
-        const f32x4 yj = *reinterpret_cast<const f32x4*>(a.x0 + (size_t)t.nj * 4);
-        const float dx = xi[0] - xj[0], dy = xi[1] - xj[1], dz = xi[2] - xj[2];
-        t.radial = dx * dx + dy * dy + dz * dz;
-        const float ex = yi[0] - yj[0], ey = yi[1] - yj[1], ez = yi[2] - yj[2];
-        t.d0 = ex * ex + ey * ey + ez * ez;
-        if constexpr (COORD) {
-            const float inv = ((t.segb != 255) ? 1.0f : 0.0f) / (sqrtf(t.radial + 1e-8f) + a.norm_constant);
-            t.ux = dx * inv; t.uy = dy * inv; t.uz = dz * inv;
-        } else {
-            t.ux = t.uy = t.uz = 0.f;
-        }
-    };
-
-    // gathered AB rows of the chunk to be built next: quad U = (A_i[4], B_j[4]) in LDS slots 2U, 2U+1 of this wave
-    auto rows_issue = [&](auto U, auto C, const Tile& t) {
-        constexpr int u = decltype(U)::value, c = decltype(C)::value;
-        vm_glds2(t.Arow + 32 * c + 4 * u, t.Brow + 32 * c + 4 * u, rows_lds + (2 * u) * 1024, rows_lds + (2 * u + 1) * 1024);
-    };
-    f32x4 qa[2], qb[2];                         // quad being consumed / quad fetched one group ahead
-    auto make_pair = [&](const Tile& t, f32x2 av, f32x2 bv, f32x2 wr2, f32x2 wd2, uint32_t& hi, uint32_t& lo) {
-        float y[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            float pre = av[j] + bv[j];
-            pre = __builtin_fmaf(t.radial, wr2[j], pre);
-            pre = __builtin_fmaf(t.d0, wd2[j], pre);
-            y[j] = silu_scaled(pre);
-        }
-        bf16_split2(y[0], y[1], hi, lo);
-    };
-
-    // ---- first tile: the only exposed prologue
-    Tile cur, nxt;
-    tile_meta(cur, wt_first * 4 + wave);
-    tile_geom(cur);
-    u32x4 P[2][2][2];                           // [chunk parity][head|tail][k-step]: operands of the current / next chunk
-    static_for<0, 4>([&](auto U) { rows_issue(U, std::integral_constant<int, 0>{}, cur); });
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                            // w_r / w_d / b2 / wa staged; chunks 0 and 1 landed everywhere
-    static_for<0, 4>([&](auto U) {
-        constexpr int u = decltype(U)::value;
-        lds_read2_after_vm<0, (2 * u) * 1024, (2 * u + 1) * 1024>(qa[0], qb[0], rows_lane);
-        lds_ready2(qa[0], qb[0]);
-        const f32x4 wr4 = *reinterpret_cast<const f32x4*>(wrd_s + 16 * hh + 4 * u);
-        const f32x4 wd4 = *reinterpret_cast<const f32x4*>(wrd_s + H + 16 * hh + 4 * u);
-#pragma unroll
-        for (int j2 = 0; j2 < 2; ++j2) {
-            uint32_t hi, lo;
-            make_pair(cur, f32x2{qa[0][2 * j2], qa[0][2 * j2 + 1]}, f32x2{qb[0][2 * j2], qb[0][2 * j2 + 1]},
-                      f32x2{wr4[2 * j2], wr4[2 * j2 + 1]}, f32x2{wd4[2 * j2], wd4[2 * j2 + 1]}, hi, lo);
-            P[0][0][u >> 1][2 * (u & 1) + j2] = hi;
-            P[0][1][u >> 1][2 * (u & 1) + j2] = lo;
-        }
-        rows_issue(U, std::integral_constant<int, 1>{}, cur);      // the slot pair is free again
-    });
-    // quad 0 of chunk 1: younger operations are its quads 1..3
-    lds_read2_after_vm<6, 0, 1024>(qa[0], qb[0], rows_lane);
-
-    // previous tile (stage A / B operate on it); starts out as an all-zero dummy
-    f32x16 accp[NCT];
-    float dot[16];
-#pragma unroll
-    for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) accp[ct][r] = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) dot[r] = 0.f;
-    Tile prv = cur;
-    int prv_tile = -1, prv_par = 0;
-
-    // stage A of the epilogue for rows r0 .. r0+3 of column tile ct of the previous tile
-    auto stage_a = [&](auto Ct, auto R0) {
-        constexpr int ct = decltype(Ct)::value, r0 = decltype(R0)::value;
-        const float wav = wrd_s[3 * H + 32 * ct + n];
-        float e[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) e[j] = __builtin_amdgcn_exp2f(accp[ct][r0 + j]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) e[j] = 1.0f + e[j];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) e[j] = __builtin_amdgcn_rcpf(e[j]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) accp[ct][r0 + j] *= e[j];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) dot[r0 + j] = __builtin_fmaf(accp[ct][r0 + j], wav, dot[r0 + j]);
-    };
-
-    // stage B: row dots -> attention / coordinate head -> per-node sums of the previous tile.  Always executed
-    // (nseg_b = 0 when there is nothing to store): inside a conditional block hipcc sinks ALL of stage A into it.
-    auto stage_b = [&](int nseg_b) {
-        float rowdot;
-        {
-            float v8[8], v4[4], v2[2];
-            const bool b4 = n & 16, b3 = n & 8, b2_ = n & 4, b1 = n & 2;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float send = b4 ? dot[k] : dot[k + 8];
-                const float keep = b4 ? dot[k + 8] : dot[k];
-                v8[k] = keep + __shfl_xor(send, 16);
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float send = b3 ? v8[k] : v8[k + 4];
-                const float keep = b3 ? v8[k + 4] : v8[k];
-                v4[k] = keep + __shfl_xor(send, 8);
-            }
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const float send = b2_ ? v4[k] : v4[k + 2];
-                const float keep = b2_ ? v4[k + 2] : v4[k];
-                v2[k] = keep + __shfl_xor(send, 4);
-            }
-            {
-                const float send = b1 ? v2[0] : v2[1];
-                const float keep = b1 ? v2[1] : v2[0];
-                rowdot = keep + __shfl_xor(send, 2);
-            }
-            rowdot += __shfl_xor(rowdot, 1);
-        }
-        const int my_slot = (n >> 1) & 15;
-        const uint32_t* segw = seg_s + 8 * prv_par;
-        if constexpr (!COORD) {
-            uint32_t sw[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) sw[q] = segw[2 * q + hh];
-            float att_mine = 1.0f;
-            if (a.attention) att_mine = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(rowdot + a.ba));
-            float w[16];
-            int sg[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                sg[r] = (sw[r >> 2] >> (8 * (r & 3))) & 255;
-                const float att = __shfl(att_mine, (lane & 32) | (2 * r));
-                w[r] = (sg[r] != 255) ? att : 0.0f;
-            }
-            for (int s = 0; s < nseg_b; ++s) {
-                float ws[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) ws[r] = (sg[r] == s) ? w[r] : 0.0f;
-                float* dst = a.part + (size_t)(prv.pbase + s) * H + n;
-                float sums[NCT];
-#pragma unroll
-                for (int ct = 0; ct < NCT; ++ct) {
-                    float sum = 0.f;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) sum = __builtin_fmaf(ws[r], accp[ct][r], sum);
-                    sums[ct] = xhalf_sum(sum);
-                }
-                if (hh == 0) {
-#pragma unroll
-                    for (int ct = 0; ct < NCT; ++ct) dst[32 * ct] = sums[ct];
-                }
-            }
-        } else {
-            if ((n & 1) == 0) my_scr[(my_slot & 3) + 8 * (my_slot >> 2) + 4 * hh] = rowdot;
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            if (hh == 0) {
-                const float phi = my_scr[n];
-                const float sc = a.use_tanh ? tanhf(phi) * a.coords_range : phi;
-                float* tr = my_scr + 32;
-                tr[n * 3 + 0] = prv.ux * sc;
-                tr[n * 3 + 1] = prv.uy * sc;
-                tr[n * 3 + 2] = prv.uz * sc;
-            }
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            if (lane < nseg_b) {
-                const uint8_t* sb = reinterpret_cast<const uint8_t*>(segw);
-                const float* tr = my_scr + 32;
-                float sx = 0.f, sy = 0.f, sz = 0.f;
-                for (int rr = 0; rr < 32; ++rr) {
-                    if (sb[rr] == lane) { sx += tr[rr * 3]; sy += tr[rr * 3 + 1]; sz += tr[rr * 3 + 2]; }
-                }
-                f32x4 o = {sx, sy, sz, 0.f};
-                *reinterpret_cast<f32x4*>(a.part + (size_t)(prv.pbase + lane) * 4) = o;
-            }
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        }
-    };
-
-    int buf = 0;                                // LDS buffer of the current chunk (stream position mod NBUF)
-#pragma unroll 1
-    for (int it = 0; it < wt_count; ++it) {
-        const bool last_it = it + 1 == wt_count;
-        const int par = it & 1;
-        if (hh == 0) reinterpret_cast<uint8_t*>(seg_s + 8 * par)[n] = (uint8_t)cur.segb;
-        nxt = cur;                              // placeholder when no tile follows (its results are never used)
-
-        f32x16 acc[NCT];
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) {
-            const float b2v = wrd_s[2 * H + 32 * ct + n];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[ct][r] = b2v;
-        }
-
-        static_for<0, NCH>([&](auto Cc) {
-            constexpr int c = decltype(Cc)::value;
-            constexpr int cp = c & 1;                              // operand set of this chunk; the other one is being built
-            constexpr int c1 = (c + 1) % NCH, c2 = (c + 2) % NCH;  // chunk built during this one / chunk whose rows are requested
-            constexpr bool n1 = c + 1 >= NCH, n2 = c + 2 >= NCH;   // ... do they belong to the next tile?
-            // chunk landed everywhere; everyone is done with the buffer the stream is about to overwrite
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (TRACE) { if (it == 1) tst[c] = __builtin_readcyclecounter(); }
-            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "i"(16 + GLW) : "memory");
-            {
-                int nb = buf + 2; if (nb >= NBUF) nb -= NBUF;
-                issue_chunk(c2, nb);
-            }
-            // the tile after this one (the current tile again when none follows: fetched, never used)
-            if constexpr (c == NCH - 5) tile_meta(nxt, (wt_first + (last_it ? it : it + 1) * wt_step) * 4 + wave);
-            if constexpr (c == NCH - 3) tile_geom(nxt);
-            const Tile& t1 = n1 ? nxt : cur;
-            const Tile& t2 = n2 ? nxt : cur;
-
-            const float* wb = wbuf + buf * CHF;
-            const unsigned wb_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)wb + lane * 16;
-            const float* wr_n = wrd_s + 32 * c1 + 16 * hh;
-            const float* wd_n = wrd_s + H + 32 * c1 + 16 * hh;
-            f32x4 wrq[2], wdq[2];
-            wrq[0] = *reinterpret_cast<const f32x4*>(wr_n);
-            wdq[0] = *reinterpret_cast<const f32x4*>(wd_n);
-            bf16x8 f0[4], f1[4];
-            lds_read4<bf16x8, frag_off_bf<NCT>(0, 0), frag_off_bf<NCT>(0, 1), frag_off_bf<NCT>(1, 0), frag_off_bf<NCT>(1, 1)>(f0, wb_lds);
-            constexpr int NG = NCT;
-            static_for<0, NG>([&](auto Gc) {
-                constexpr int g = decltype(Gc)::value;
-                bf16x8(&fc)[4] = (g & 1) ? f1 : f0;
-                bf16x8(&fn)[4] = (g & 1) ? f0 : f1;
-                lds_wait4<0>(fc);
-                if constexpr (g + 1 < NG) {
-                    constexpr int u = 2 * (g + 1);
-                    lds_read4<bf16x8, frag_off_bf<NCT>(u, 0), frag_off_bf<NCT>(u, 1), frag_off_bf<NCT>(u + 1, 0),
-                              frag_off_bf<NCT>(u + 1, 1)>(fn, wb_lds);
-                }
-                constexpr int NGP = NG / 2;
-                static_assert(NGP == 4, "one AB quad per producing group");
-                if constexpr (g < NGP) {
-                    // group g builds the two operand pairs of quad g of chunk c1; the quad was fetched from LDS one
-                    // group earlier (lgkmcnt(0) above covers it) and quad g+1 is fetched now.  Operations younger
-                    // than quad g+1's gather: its quads g+2..3, this chunk's stream pieces, the quads 0..g-1 of
-                    // chunk c2 issued so far  =  4 + GLW.
-                    constexpr int u = g;
-                    lds_ready2(qa[u & 1], qb[u & 1]);
-                    if constexpr (u + 1 < 4) {
-                        lds_read2_after_vm<4 + GLW, (2 * (u + 1)) * 1024, (2 * (u + 1) + 1) * 1024>(qa[(u + 1) & 1], qb[(u + 1) & 1], rows_lane);
-                        wrq[(u + 1) & 1] = *reinterpret_cast<const f32x4*>(wr_n + 4 * (u + 1));
-                        wdq[(u + 1) & 1] = *reinterpret_cast<const f32x4*>(wd_n + 4 * (u + 1));
-                    }
-#pragma unroll
-                    for (int j2 = 0; j2 < 2; ++j2) {
-                        const int pi = 2 * u + j2;
-                        uint32_t hi, lo;
-                        make_pair(t1, f32x2{qa[u & 1][2 * j2], qa[u & 1][2 * j2 + 1]}, f32x2{qb[u & 1][2 * j2], qb[u & 1][2 * j2 + 1]},
-                                  f32x2{wrq[u & 1][2 * j2], wrq[u & 1][2 * j2 + 1]},
-                                  f32x2{wdq[u & 1][2 * j2], wdq[u & 1][2 * j2 + 1]}, hi, lo);
-                        P[cp ^ 1][0][pi >> 2][pi & 3] = hi;
-                        P[cp ^ 1][1][pi >> 2][pi & 3] = lo;
-                    }
-                    rows_issue(std::integral_constant<int, u>{}, std::integral_constant<int, c2>{}, t2);   // slot pair free again
-                } else {
-                    // quad 0 of the chunk after next has been in flight since group 0: fetch it for the next chunk's
-                    // group 0 (younger operations: its quads 1..3)
-                    if constexpr (g == NG - 1) lds_read2_after_vm<6, 0, 1024>(qa[0], qb[0], rows_lane);
-                    // stage A of the previous tile's epilogue: column tile c, four rows per group
-                    stage_a(std::integral_constant<int, c>{}, std::integral_constant<int, 4 * (g - NGP)>{});
-                }
-                constexpr int u0 = 2 * g, u1 = 2 * g + 1;
-                constexpr int s0 = u0 / NCT, c0 = u0 % NCT, s1 = u1 / NCT, cc1 = u1 % NCT;
-                const bf16x8 A_h0 = __builtin_bit_cast(bf16x8, P[cp][0][s0]), A_l0 = __builtin_bit_cast(bf16x8, P[cp][1][s0]);
-                const bf16x8 A_h1 = __builtin_bit_cast(bf16x8, P[cp][0][s1]), A_l1 = __builtin_bit_cast(bf16x8, P[cp][1][s1]);
-                acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_h0, fc[0], acc[c0], 0, 0, 0);
-                acc[cc1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_h1, fc[2], acc[cc1], 0, 0, 0);
-                acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_l0, fc[0], acc[c0], 0, 0, 0);
-                acc[cc1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_l1, fc[2], acc[cc1], 0, 0, 0);
-                acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_h0, fc[1], acc[c0], 0, 0, 0);
-                acc[cc1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_h1, fc[3], acc[cc1], 0, 0, 0);
-#pragma unroll
-                for (int k = 0; k < 6; ++k) {                // interleave: 1 MFMA, then up to 5 VALU
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
-                }
-                // the tile body is one straight-line block: without a fence per group hipcc piles the VALU work of
-                // several chunks into a few of them and leaves the others as bare MFMA runs
-                __builtin_amdgcn_sched_barrier(0);
-            });
-            ++buf; if (buf >= NBUF) buf -= NBUF;
-        });
-
-        // tile `it` is accumulated; finish the one before it, then rotate
-        if constexpr (TRACE) { if (it == 1) tst[8] = __builtin_readcyclecounter(); }
-        stage_b((prv_tile >= 0 && prv.ok) ? prv.nseg : 0);
-        if constexpr (TRACE) { if (it == 1) tst[9] = __builtin_readcyclecounter(); }
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) accp[ct] = acc[ct];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dot[r] = 0.f;
-        prv = cur; prv_tile = it; prv_par = par;
-        cur = nxt;
-        if constexpr (TRACE) { if (it == 1) tst[10] = __builtin_readcyclecounter(); }
-    }
-    if constexpr (TRACE) {
-        if (lane == 0) {
-            long long* t = a.trace + ((size_t)blockIdx.x * 4 + wave) * 12;
-            for (int k = 0; k < 11; ++k) t[k] = tst[k];
-            t[11] = wt_count;
-        }
-    }
-    // drain the stream and the unused last gathers, then finish the last tile without overlap
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    lds_ready2(qa[0], qb[0]);
-    static_for<0, NCT>([&](auto Ct) {
-        static_for<0, 4>([&](auto Q) { stage_a(Ct, std::integral_constant<int, 4 * decltype(Q)::value>{}); });
-    });
-    stage_b(prv.ok ? prv.nseg : 0);
-}
-
-// ----------------------------------------------------------------------------- coordinate update
-// x_i <- (x_i + sum_parts / normalization_factor) * mask_i   (egnn_new.py:100-110)
-
-struct XupdArgs {
-    const float* part;    // [P][4]
-    const int* pstart;    // [M+1]
-    const float* nmask;
-    float* xcur;          // [M_pad][4]
-    float norm;
-    int M;
-};
-
-__global__ void k_xupd(XupdArgs a) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.M) return;
-    float sx = 0.f, sy = 0.f, sz = 0.f;
-    for (int p = a.pstart[i]; p < a.pstart[i + 1]; ++p) {
-        f32x4 v = *reinterpret_cast<const f32x4*>(a.part + (size_t)p * 4);
-        sx += v[0]; sy += v[1]; sz += v[2];
-    }
-    float m = a.nmask[i];
-    f32x4 x = *reinterpret_cast<const f32x4*>(a.xcur + (size_t)i * 4);
-    x[0] = (x[0] + sx / a.norm) * m;
-    x[1] = (x[1] + sy / a.norm) * m;
-    x[2] = (x[2] + sz / a.norm) * m;
-    *reinterpret_cast<f32x4*>(a.xcur + (size_t)i * 4) = x;
-}
-
-// agg_i = (sum of node i's partial neighbour sums, fixed order) / normalization_factor   (egnn_new.py:52-56,280-282)
-struct AggArgs {
-    const float* part;    // [P][H]
-    const int* pstart;    // [M+1]
-    float* agg;           // [M_pad][H]
-    float norm;
-    int M, H;
-};
-
-__global__ void k_agg(AggArgs a) {
-    const int q = a.H >> 2;                                   // float4 per row
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const int i = idx / q, c4 = idx - i * q;
-    if (i >= a.M) return;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    for (int p = a.pstart[i]; p < a.pstart[i + 1]; ++p) v += *reinterpret_cast<const f32x4*>(a.part + (size_t)p * a.H + 4 * c4);
-    *reinterpret_cast<f32x4*>(a.agg + (size_t)i * a.H + 4 * c4) = v / a.norm;
-}
-
-// ----------------------------------------------------------------------------- output stage
-// per node: embedding_out (only the F kept columns), vel = (x_final - x_in)*mask, NaN detection
-// (egnn_new.py:202-204, en_dynamics.py:83-111).  One wavefront per node.
-
-struct Post1Args {
-    const float* h;       // [M_pad][H]
-    const float* outW;    // [fin][H]
-    const float* out_b;   // [fin]
-    const float* x0;
-    const float* xcur;
-    const int* node_of;
-    const float* nmask;
-    float* out;           // [B*N][D]
-    int* nanflag;
-    int M, N, D, F, H, mol_shape;
-};
-
-__global__ void k_post1(Post1Args a) {
-    const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (i >= a.M) return;
-    const int flat = a.node_of[i];
-    const float m = a.nmask[i];
-    float* orow = a.out + (size_t)flat * a.D;
-    for (int f = 0; f < a.F; ++f) {
-        float s = 0.f;
-        for (int c = lane; c < a.H; c += 64) s = __builtin_fmaf(a.h[(size_t)i * a.H + c], a.outW[f * a.H + c], s);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        if (lane == 0) orow[3 + f] = (s + a.out_b[f]) * m;
-    }
-    if (lane < 3) {
-        const int nloc = flat % a.N;
-        float v = 0.f;
-        if (a.mol_shape < 0 || nloc < a.mol_shape) v = (a.xcur[(size_t)i * 4 + lane] - a.x0[(size_t)i * 4 + lane]) * m;
-        orow[lane] = v;
-        if (v != v) atomicOr(a.nanflag, 1);
-    }
-}
-
-// per molecule: NaN reset, centre-of-gravity removal over all N nodes, zero rows of inactive
-// nodes (en_dynamics.py:109-116, models/utils.py:43-57).  One wavefront per molecule.
-
-struct Post2Args {
-    const int* slot_of;   // [B*N] compact id or -1
-    const float* nmask;   // [M_pad]
-    const int* nvalid;    // [B] count of node_mask
-    float* out;           // [B*N][D]
-    const int* nanflag;
-    long long* nan_events;
-    int B, N, D;
-};
-
-__global__ void k_post2(Post2Args a) {
-    const int lane = threadIdx.x & 63;
-    const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (b >= a.B) return;
-    const bool nan = (*a.nanflag) != 0;
-    if (nan && b == 0 && lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(a.nan_events), 1ULL);
-    float sx = 0.f, sy = 0.f, sz = 0.f;
-    for (int nn = lane; nn < a.N; nn += 64) {
-        const int flat = b * a.N + nn;
-        float* orow = a.out + (size_t)flat * a.D;
-        if (a.slot_of[flat] < 0) {
-            for (int d = 0; d < a.D; ++d) orow[d] = 0.f;
-        } else if (nan) {
-            orow[0] = 0.f; orow[1] = 0.f; orow[2] = 0.f;
-        } else {
-            sx += orow[0]; sy += orow[1]; sz += orow[2];
-        }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { sx += __shfl_xor(sx, o); sy += __shfl_xor(sy, o); sz += __shfl_xor(sz, o); }
-    const int cnt = a.nvalid[b];
-    if (cnt == 0) return;
-    const float mx = sx / (float)cnt, my = sy / (float)cnt, mz = sz / (float)cnt;
-    for (int nn = lane; nn < a.N; nn += 64) {
-        const int flat = b * a.N + nn;
-        const int s = a.slot_of[flat];
-        if (s < 0) continue;
-        const float m = a.nmask[s];
-        float* orow = a.out + (size_t)flat * a.D;
-        orow[0] -= mx * m; orow[1] -= my * m; orow[2] -= mz * m;
-    }
-}
-
-// ----------------------------------------------------------------------------- sampling maths
-// One wavefront per molecule; all reductions are over <= N nodes.
-
-struct NoiseSrc {
-    const float* raw_x;   // [rows][mol][3] or null -> Philox
-    const float* raw_h;   // [rows][mol][F]
-    int rows;             // 1 = shared row (fix_noise)
-    uint64_t seed, sample_base;
-    uint32_t draw;
-    int share;            // Philox: all rows use sample_base
-};
-
-HD_DEVINL float raw_noise(const NoiseSrc& s, int b, int nn, int c, int mol, int F) {
-    if (s.raw_x) {
-        const int rb = (s.rows == 1) ? 0 : b;
-        return (c < 3) ? s.raw_x[((size_t)rb * mol + nn) * 3 + c] : s.raw_h[((size_t)rb * mol + nn) * F + (c - 3)];
-    }
-    const uint64_t sid = s.sample_base + (s.share ? 0 : (uint64_t)b);
-    return philox_normal(s.seed, sid, s.draw, (uint32_t)(nn * (3 + F) + c));
-}
-
-struct StepArgs {
-    const float* zt;      // [B][N][D]
-    const float* eps;     // [B][N][D]
-    const float* coef;    // [rows][4]
-    const uint8_t* nm;    // [B*N] node mask bytes
-    float* zs;            // [B][out_stride][D]
-    NoiseSrc noise;
-    const uint32_t* draw_ptr;   // optional device-side draw counter (graph replay); overrides noise.draw
-    const int* step_ptr;        // optional device-side step index into coef (graph replay)
-    uint32_t draw0;             // draw index of the first replayed step (raw-noise offset base)
-    int coef_rows, B, N, D, F, mol, out_stride;
-};
-
-// sample_p_zs_given_zt after the network call (diffusion_qm9.py:326-345) + sample_normal.
-__global__ void k_post_step(StepArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (b >= a.B) return;
-    NoiseSrc ns = a.noise;
-    if (a.draw_ptr) {
-        ns.draw = *a.draw_ptr;
-        if (ns.raw_x) {
-            const size_t k = (size_t)(ns.draw - a.draw0) * ns.rows * a.mol;
-            ns.raw_x += k * 3;
-            ns.raw_h += k * a.F;
-        }
-    }
-    const float* cf = a.coef + (a.step_ptr ? (size_t)(*a.step_ptr) * 4 : (size_t)((a.coef_rows == 1) ? 0 : b) * 4);
-    const float alpha_ts = cf[0], sigma2_ts = cf[1], sigma_t = cf[2], sigma = cf[3];
-    const float ceps = (sigma2_ts / alpha_ts) / sigma_t;
-    const int mol = a.mol, D = a.D;
-    // pass 1: masked sums of eps_x and of raw x-noise, node count
-    float ex = 0.f, ey = 0.f, ez = 0.f, nx = 0.f, ny = 0.f, nz = 0.f, cnt = 0.f;
-    for (int nn = lane; nn < mol; nn += 64) {
-        const float m = a.nm[b * a.N + nn] ? 1.f : 0.f;
-        const float* er = a.eps + ((size_t)b * a.N + nn) * D;
-        ex += er[0]; ey += er[1]; ez += er[2];
-        nx += raw_noise(ns, b, nn, 0, mol, a.F) * m;
-        ny += raw_noise(ns, b, nn, 1, mol, a.F) * m;
-        nz += raw_noise(ns, b, nn, 2, mol, a.F) * m;
-        cnt += m;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        ex += __shfl_xor(ex, o); ey += __shfl_xor(ey, o); ez += __shfl_xor(ez, o);
-        nx += __shfl_xor(nx, o); ny += __shfl_xor(ny, o); nz += __shfl_xor(nz, o);
-        cnt += __shfl_xor(cnt, o);
-    }
-    const float emx = ex / cnt, emy = ey / cnt, emz = ez / cnt;
-    const float nmx = nx / cnt, nmy = ny / cnt, nmz = nz / cnt;
-    // pass 2: zs before the final re-centring; accumulate its x sum
-    float sx = 0.f, sy = 0.f, sz = 0.f;
-    for (int nn = lane; nn < mol; nn += 64) {
-        const float m = a.nm[b * a.N + nn] ? 1.f : 0.f;
-        const float* zr = a.zt + ((size_t)b * a.N + nn) * D;
-        const float* er = a.eps + ((size_t)b * a.N + nn) * D;
-        float* o = a.zs + ((size_t)b * a.out_stride + nn) * D;
-        const float em[3] = {emx, emy, emz}, nmn[3] = {nmx, nmy, nmz};
-        float v[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            float e = er[c] - em[c] * m;
-            float nz_ = raw_noise(ns, b, nn, c, mol, a.F) * m - nmn[c] * m;
-            float mu = zr[c] / alpha_ts - ceps * e;
-            v[c] = mu + sigma * nz_;
-        }
-        sx += v[0]; sy += v[1]; sz += v[2];
-        o[0] = v[0]; o[1] = v[1]; o[2] = v[2];
-        for (int c = 3; c < D; ++c) {
-            float mu = zr[c] / alpha_ts - ceps * er[c];
-            o[c] = mu + sigma * (raw_noise(ns, b, nn, c, mol, a.F) * m);
-        }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { sx += __shfl_xor(sx, o); sy += __shfl_xor(sy, o); sz += __shfl_xor(sz, o); }
-    const float mx = sx / cnt, my = sy / cnt, mz = sz / cnt;
-    for (int nn = lane; nn < mol; nn += 64) {
-        const float m = a.nm[b * a.N + nn] ? 1.f : 0.f;
-        float* o = a.zs + ((size_t)b * a.out_stride + nn) * D;
-        o[0] -= mx * m; o[1] -= my * m; o[2] -= mz * m;
-    }
-}
-
-// sample_p_xh_given_z0 after the network call + unnormalize with unit norm values
-// (diffusion_qm9.py:302-310,174-179): x = (1/alpha_0 * (z0 - sigma_0*eps) + sigma_x*noise)[:3],
-// h = z0[3:] * mask.
-struct DecodeArgs {
-    const float* z0;
-    const float* eps;
-    const uint8_t* nm;
-    float* x;             // [B][N][3]
-    float* hfeat;         // [B][N][F]
-    NoiseSrc noise;
-    float sigma_0, alpha_0, sigma_x;
-    int B, N, D, F;
-};
-
-__global__ void k_final_decode(DecodeArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (b >= a.B) return;
-    float nx = 0.f, ny = 0.f, nz = 0.f, cnt = 0.f;
-    for (int nn = lane; nn < a.N; nn += 64) {
-        const float m = a.nm[b * a.N + nn] ? 1.f : 0.f;
-        nx += raw_noise(a.noise, b, nn, 0, a.N, a.F) * m;
-        ny += raw_noise(a.noise, b, nn, 1, a.N, a.F) * m;
-        nz += raw_noise(a.noise, b, nn, 2, a.N, a.F) * m;
-        cnt += m;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        nx += __shfl_xor(nx, o); ny += __shfl_xor(ny, o); nz += __shfl_xor(nz, o); cnt += __shfl_xor(cnt, o);
-    }
-    const float nmn[3] = {nx / cnt, ny / cnt, nz / cnt};
-    const float inv_a = 1.0f / a.alpha_0;
-    for (int nn = lane; nn < a.N; nn += 64) {
-        const float m = a.nm[b * a.N + nn] ? 1.f : 0.f;
-        const size_t r = (size_t)b * a.N + nn;
-        const float* zr = a.z0 + r * a.D;
-        const float* er = a.eps + r * a.D;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            float nz_ = raw_noise(a.noise, b, nn, c, a.N, a.F) * m - nmn[c] * m;
-            a.x[r * 3 + c] = inv_a * (zr[c] - a.sigma_0 * er[c]) + a.sigma_x * nz_;
-        }
-        for (int f = 0; f < a.F; ++f) a.hfeat[r * a.F + f] = zr[3 + f] * m;
-    }
-}
-
-// sample_combined_position_feature_noise (diffusion_qm9.py:445-456).
-struct NoiseArgs {
-    const uint8_t* nm;
-    float* z;             // [B][N][D]
-    NoiseSrc noise;
-    int B, N, D, F;
-};
-
-__global__ void k_noise(NoiseArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (b >= a.B) return;
-    float nx = 0.f, ny = 0.f, nz = 0.f, cnt = 0.f;
-    for (int nn = lane; nn < a.N; nn += 64) {
-        const float m = a.nm[b * a.N + nn] ? 1.f : 0.f;
-        nx += raw_noise(a.noise, b, nn, 0, a.N, a.F) * m;
-        ny += raw_noise(a.noise, b, nn, 1, a.N, a.F) * m;
-        nz += raw_noise(a.noise, b, nn, 2, a.N, a.F) * m;
-        cnt += m;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        nx += __shfl_xor(nx, o); ny += __shfl_xor(ny, o); nz += __shfl_xor(nz, o); cnt += __shfl_xor(cnt, o);
-    }
-    const float nmn[3] = {nx / cnt, ny / cnt, nz / cnt};
-    for (int nn = lane; nn < a.N; nn += 64) {
-        const float m = a.nm[b * a.N + nn] ? 1.f : 0.f;
-        float* o = a.z + ((size_t)b * a.N + nn) * a.D;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) o[c] = raw_noise(a.noise, b, nn, c, a.N, a.F) * m - nmn[c] * m;
-        for (int c = 3; c < a.D; ++c) o[c] = raw_noise(a.noise, b, nn, c, a.N, a.F) * m;
-    }
-}
-
-// graph-replay helper: advances the device-side step / draw counters after each captured step
-__global__ void k_advance(int* step, uint32_t* draw, float* t_cur, const float* tau) {
-    int s = *step - 1;
-    *step = s;
-    *draw = *draw + 1;
-    *t_cur = tau[s + 1 >= 0 ? s + 1 : 0];
-}
+#include "common.hpp"
+#include "k_node.hpp"
+#include "k_edge.hpp"
+#include "k_edge_pipelined.hpp"
+#include "k_sampling.hpp"
