@@ -768,16 +768,17 @@ static int forward_impl(hd_handle* h, hd_topology* t, const float* xh, const flo
     const int H = h->H, M = t->M;
     const float* W = h->dw;
     h->prof_now = h->prof != 0 && (h->prof_fwd++ % h->prof_stride) == 0;
-    HIP_TRY(hipMemsetAsync(h->d_nanflag, 0, sizeof(int), s));
+    if (M == 0) HIP_TRY(hipMemsetAsync(h->d_nanflag, 0, sizeof(int), s));      // otherwise k_node_init resets it
     if (M > 0) {
         {
             ProfScope ps(h, s, 2);
             InitArgs a;
             a.xh = xh; a.t = tt; a.ctx = context; a.node_of = t->node_of; a.nmask = t->nmask;
             a.embT = W + h->embT; a.emb_b = W + h->emb_b; a.h = t->hbuf; a.x0 = t->x0; a.xcur = t->xcur;
+            a.nanflag = h->d_nanflag;
             a.M = M; a.N = t->N; a.D = h->D; a.F = h->F; a.C = c.context_node_nf; a.H = H;
             a.t_stride = (t_numel == 1) ? 0 : 1; a.cond_time = c.condition_time;
-            const long long total = (long long)M * H;
+            const long long total = (long long)M * (H / 4);
             hipLaunchKernelGGL(k_node_init, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
         }
         const float range = c.coords_range / (float)c.n_layers;
@@ -924,7 +925,7 @@ static int step_impl(hd_handle* h, hd_topology* t, const float* zt, const float*
     a.zt = zt; a.eps = eps; a.coef = coef; a.nm = t->nm_bytes; a.zs = zs; a.noise = ns; a.draw_ptr = draw_ptr;
     a.step_ptr = step_ptr; a.draw0 = draw0; a.coef_rows = coef_rows; a.B = t->B; a.N = t->N; a.D = h->D; a.F = h->F;
     a.mol = mol; a.out_stride = out_stride;
-    hipLaunchKernelGGL(k_post_step, dim3((t->B + 3) / 4), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_post_step, dim3(t->B), dim3(256), (size_t)a.mol * a.D * sizeof(float), s, a);
     HIP_TRY(hipGetLastError());
     return HD_OK;
 }

@@ -17,30 +17,36 @@ struct InitArgs {
     float* h;               // [M_pad][H]
     float* x0;              // [M_pad][4]
     float* xcur;            // [M_pad][4]
+    int* nanflag;           // reset here (first kernel of a forward), raised by k_post1, consumed by k_post2
     int M, N, D, F, C, H, t_stride, cond_time;
 };
 
+// One thread per (node, 4 consecutive output columns): the node's feature row is read once per thread instead of
+// once per output element, weights and the result move as float4.
 __global__ void k_node_init(InitArgs a) {
-    int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    int i = idx / a.H, c = idx - i * a.H;
+    const int q = a.H >> 2;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx == 0) *a.nanflag = 0;
+    const int i = idx / q, c = 4 * (idx - i * q);
     if (i >= a.M) return;
-    int flat = a.node_of[i];
-    float m = a.nmask[i];
+    const int flat = a.node_of[i];
+    const float m = a.nmask[i];
     const float* row = a.xh + (size_t)flat * a.D;
-    float acc = a.emb_b[c];
+    f32x4 acc = *reinterpret_cast<const f32x4*>(a.emb_b + c);
+    auto fma4 = [&](float v, int f) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(a.embT + (size_t)f * a.H + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_fmaf(v, w[j], acc[j]);
+    };
     int f = 0;
-    for (; f < a.F; ++f) acc = __builtin_fmaf(row[3 + f] * m, a.embT[f * a.H + c], acc);
-    if (a.cond_time) {
-        float tv = a.t[(flat / a.N) * a.t_stride];
-        acc = __builtin_fmaf(tv, a.embT[f * a.H + c], acc);
-        ++f;
-    }
-    for (int k = 0; k < a.C; ++k, ++f) acc = __builtin_fmaf(a.ctx[(size_t)flat * a.C + k], a.embT[f * a.H + c], acc);
-    a.h[(size_t)i * a.H + c] = acc;
-    if (c < 4) {
-        float v = (c < 3) ? row[c] * m : 0.0f;
-        a.x0[(size_t)i * 4 + c] = v;
-        a.xcur[(size_t)i * 4 + c] = v;
+    for (; f < a.F; ++f) fma4(row[3 + f] * m, f);
+    if (a.cond_time) { fma4(a.t[(flat / a.N) * a.t_stride], f); ++f; }
+    for (int k = 0; k < a.C; ++k, ++f) fma4(a.ctx[(size_t)flat * a.C + k], f);
+    *reinterpret_cast<f32x4*>(a.h + (size_t)i * a.H + c) = acc;
+    if (c == 0) {
+        const f32x4 v = {row[0] * m, row[1] * m, row[2] * m, 0.0f};
+        *reinterpret_cast<f32x4*>(a.x0 + (size_t)i * 4) = v;
+        *reinterpret_cast<f32x4*>(a.xcur + (size_t)i * 4) = v;
     }
 }
 

@@ -67,6 +67,9 @@ struct Post1Args {
     int M, N, D, F, H, mol_shape;
 };
 
+// One wavefront per node.  The node's h row is read once (float4 per lane); up to 8 outputs at a time are
+// reduced over the 64 lanes with a transpose-reduce (each exchange halves the values a lane still carries:
+// 4 + 2 + 1 shuffles, then a 3-step butterfly) instead of 8 x 6 butterflies.
 __global__ void k_post1(Post1Args a) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -74,12 +77,33 @@ __global__ void k_post1(Post1Args a) {
     const int flat = a.node_of[i];
     const float m = a.nmask[i];
     float* orow = a.out + (size_t)flat * a.D;
-    for (int f = 0; f < a.F; ++f) {
-        float s = 0.f;
-        for (int c = lane; c < a.H; c += 64) s = __builtin_fmaf(a.h[(size_t)i * a.H + c], a.outW[f * a.H + c], s);
+    const int q = a.H >> 2;
+    for (int f0 = 0; f0 < a.F; f0 += 8) {
+        float p[8];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        if (lane == 0) orow[3 + f] = (s + a.out_b[f]) * m;
+        for (int k = 0; k < 8; ++k) p[k] = 0.f;
+        for (int c4 = lane; c4 < q; c4 += 64) {
+            const f32x4 hv = *reinterpret_cast<const f32x4*>(a.h + (size_t)i * a.H + 4 * c4);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (f0 + k < a.F) {
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(a.outW + (size_t)(f0 + k) * a.H + 4 * c4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) p[k] = __builtin_fmaf(hv[j], w[j], p[k]);
+                }
+            }
+        }
+        const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8;
+        float v4[4], v2[2], v1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v4[k] = (b5 ? p[k + 4] : p[k]) + __shfl_xor(b5 ? p[k] : p[k + 4], 32);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) v2[k] = (b4 ? v4[k + 2] : v4[k]) + __shfl_xor(b4 ? v4[k] : v4[k + 2], 16);
+        v1 = (b3 ? v2[1] : v2[0]) + __shfl_xor(b3 ? v2[0] : v2[1], 8);
+        v1 += __shfl_xor(v1, 4); v1 += __shfl_xor(v1, 2); v1 += __shfl_xor(v1, 1);
+        // lanes with bits (b5, b4, b3) hold output f0 + 4 b5 + 2 b4 + b3
+        const int f = f0 + (b5 ? 4 : 0) + (b4 ? 2 : 0) + (b3 ? 1 : 0);
+        if ((lane & 7) == 0 && f < a.F) orow[3 + f] = (v1 + a.out_b[f]) * m;
     }
     if (lane < 3) {
         const int nloc = flat % a.N;
@@ -170,11 +194,24 @@ struct StepArgs {
     int coef_rows, B, N, D, F, mol, out_stride;
 };
 
+// sum of `v` over the workgroup (4 wavefronts), result in every thread; `red` is 4 floats of LDS scratch
+HD_DEVINL float block_sum4(float v, float* red, int tid) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();                               // previous use of `red` is over
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 // sample_p_zs_given_zt after the network call (diffusion_qm9.py:326-345) + sample_normal.
-__global__ void k_post_step(StepArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (b >= a.B) return;
+// One workgroup (256 threads) per molecule, one thread per (node, component): every raw normal (Philox + Box-Muller
+// is ~150 instructions) is produced once and kept in LDS for the second pass; dynamic LDS = mol * D floats.
+__global__ __launch_bounds__(256) void k_post_step(StepArgs a) {
+    extern __shared__ float nz_s[];                // [mol * D] masked raw normals, later the un-centred z_s
+    __shared__ float red[4];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x;
     NoiseSrc ns = a.noise;
     if (a.draw_ptr) {
         ns.draw = *a.draw_ptr;
@@ -187,56 +224,58 @@ __global__ void k_post_step(StepArgs a) {
     const float* cf = a.coef + (a.step_ptr ? (size_t)(*a.step_ptr) * 4 : (size_t)((a.coef_rows == 1) ? 0 : b) * 4);
     const float alpha_ts = cf[0], sigma2_ts = cf[1], sigma_t = cf[2], sigma = cf[3];
     const float ceps = (sigma2_ts / alpha_ts) / sigma_t;
-    const int mol = a.mol, D = a.D;
-    // pass 1: masked sums of eps_x and of raw x-noise, node count
-    float ex = 0.f, ey = 0.f, ez = 0.f, nx = 0.f, ny = 0.f, nz = 0.f, cnt = 0.f;
-    for (int nn = lane; nn < mol; nn += 64) {
+    const int mol = a.mol, D = a.D, total = mol * D;
+    // pass 1: raw normals (masked) into LDS; masked sums of eps_x and of the x-noise per component, node count
+    float se[3] = {0.f, 0.f, 0.f}, sn[3] = {0.f, 0.f, 0.f}, cnt = 0.f;
+    for (int e = tid; e < total; e += 256) {
+        const int nn = e / D, c = e - nn * D;
         const float m = a.nm[b * a.N + nn] ? 1.f : 0.f;
-        const float* er = a.eps + ((size_t)b * a.N + nn) * D;
-        ex += er[0]; ey += er[1]; ez += er[2];
-        nx += raw_noise(ns, b, nn, 0, mol, a.F) * m;
-        ny += raw_noise(ns, b, nn, 1, mol, a.F) * m;
-        nz += raw_noise(ns, b, nn, 2, mol, a.F) * m;
-        cnt += m;
-    }
+        const float z = raw_noise(ns, b, nn, c, mol, a.F) * m;
+        nz_s[e] = z;
+        if (c < 3) {
+            const float ev = a.eps[((size_t)b * a.N + nn) * D + c];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        ex += __shfl_xor(ex, o); ey += __shfl_xor(ey, o); ez += __shfl_xor(ez, o);
-        nx += __shfl_xor(nx, o); ny += __shfl_xor(ny, o); nz += __shfl_xor(nz, o);
-        cnt += __shfl_xor(cnt, o);
-    }
-    const float emx = ex / cnt, emy = ey / cnt, emz = ez / cnt;
-    const float nmx = nx / cnt, nmy = ny / cnt, nmz = nz / cnt;
-    // pass 2: zs before the final re-centring; accumulate its x sum
-    float sx = 0.f, sy = 0.f, sz = 0.f;
-    for (int nn = lane; nn < mol; nn += 64) {
-        const float m = a.nm[b * a.N + nn] ? 1.f : 0.f;
-        const float* zr = a.zt + ((size_t)b * a.N + nn) * D;
-        const float* er = a.eps + ((size_t)b * a.N + nn) * D;
-        float* o = a.zs + ((size_t)b * a.out_stride + nn) * D;
-        const float em[3] = {emx, emy, emz}, nmn[3] = {nmx, nmy, nmz};
-        float v[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            float e = er[c] - em[c] * m;
-            float nz_ = raw_noise(ns, b, nn, c, mol, a.F) * m - nmn[c] * m;
-            float mu = zr[c] / alpha_ts - ceps * e;
-            v[c] = mu + sigma * nz_;
-        }
-        sx += v[0]; sy += v[1]; sz += v[2];
-        o[0] = v[0]; o[1] = v[1]; o[2] = v[2];
-        for (int c = 3; c < D; ++c) {
-            float mu = zr[c] / alpha_ts - ceps * er[c];
-            o[c] = mu + sigma * (raw_noise(ns, b, nn, c, mol, a.F) * m);
+            for (int k = 0; k < 3; ++k) { if (c == k) { se[k] += ev; sn[k] += z; } }
+            if (c == 0) cnt += m;
         }
     }
+    float em[3], nmn[3];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { sx += __shfl_xor(sx, o); sy += __shfl_xor(sy, o); sz += __shfl_xor(sz, o); }
-    const float mx = sx / cnt, my = sy / cnt, mz = sz / cnt;
-    for (int nn = lane; nn < mol; nn += 64) {
+    for (int k = 0; k < 3; ++k) { em[k] = block_sum4(se[k], red, tid); nmn[k] = block_sum4(sn[k], red, tid); }
+    cnt = block_sum4(cnt, red, tid);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { em[k] /= cnt; nmn[k] /= cnt; }
+    // pass 2: z_s before the final re-centring (kept in LDS); its x sums
+    float sv[3] = {0.f, 0.f, 0.f};
+    for (int e = tid; e < total; e += 256) {
+        const int nn = e / D, c = e - nn * D;
         const float m = a.nm[b * a.N + nn] ? 1.f : 0.f;
-        float* o = a.zs + ((size_t)b * a.out_stride + nn) * D;
-        o[0] -= mx * m; o[1] -= my * m; o[2] -= mz * m;
+        const float zt = a.zt[((size_t)b * a.N + nn) * D + c];
+        float ev = a.eps[((size_t)b * a.N + nn) * D + c];
+        float z = nz_s[e];
+        if (c < 3) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { if (c == k) { ev -= em[k] * m; z -= nmn[k] * m; } }
+        }
+        const float v = (zt / alpha_ts - ceps * ev) + sigma * z;
+        nz_s[e] = v;
+        if (c < 3) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { if (c == k) sv[k] += v; }
+        }
+    }
+    float mean[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) mean[k] = block_sum4(sv[k], red, tid) / cnt;
+    for (int e = tid; e < total; e += 256) {
+        const int nn = e / D, c = e - nn * D;
+        float v = nz_s[e];
+        if (c < 3) {
+            const float m = a.nm[b * a.N + nn] ? 1.f : 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { if (c == k) v -= mean[k] * m; }
+        }
+        a.zs[((size_t)b * a.out_stride + nn) * D + c] = v;
     }
 }
 
