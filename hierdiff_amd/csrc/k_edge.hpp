@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
         }
         if constexpr (ABL & 16) ts1 = __builtin_readcyclecounter();
         // (Unrolling this loop by two with swapped operand sets, to drop the 16 register copies per chunk, was
-        // measured: +17 spilled registers and 125 vs 109 us.)
+        // measured twice: 9-17 spilled registers, 125 vs 109 us and later 110-116 vs 103-106 us; fp32 285 vs 278.)
 #pragma unroll 1
         for (int c = 0; c < NCH; ++c, ++gc) {
             const int buf = (ABL & 4) ? 0 : (gc & 1);
