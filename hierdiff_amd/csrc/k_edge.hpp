@@ -208,6 +208,16 @@ __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
         f32x4 yj = *reinterpret_cast<const f32x4*>(a.x0 + (size_t)nj * 4);
         const float dx = xi[0] - xj[0], dy = xi[1] - xj[1], dz = xi[2] - xj[2];
         const float radial = dx * dx + dy * dy + dz * dz;
+        // coordinate head: unit direction of the edge (egnn_new.py:96-99), zero for padding rows,
+        // parked in the wave-private LDS scratch (the slots the epilogue scales in place), not in registers: the
+        // kernel sits at the 256-register limit of two waves per SIMD
+        if constexpr (COORD) {
+            if (hh == 0) {
+                const float inv = ((segb != 255) ? 1.0f : 0.0f) / (sqrtf(radial + 1e-8f) + a.norm_constant);
+                float* tr = my_scr + 32;
+                tr[n * 3 + 0] = dx * inv; tr[n * 3 + 1] = dy * inv; tr[n * 3 + 2] = dz * inv;
+            }
+        }
         const float ex = yi[0] - yj[0], ey = yi[1] - yj[1], ez = yi[2] - yj[2];
         const float d0 = ex * ex + ey * ey + ez * ez;
         const uint32_t segb_t = segb;
@@ -560,13 +570,11 @@ __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             if (hh == 0) {
                 float phi = my_scr[n];
-                float nrm = sqrtf(radial + 1e-8f) + a.norm_constant;
                 float sc = a.use_tanh ? tanhf(phi) * a.coords_range : phi;
-                float valid = (segb_t != 255) ? 1.0f : 0.0f;
                 float* tr = my_scr + 32;
-                tr[n * 3 + 0] = (dx / nrm) * sc * valid;
-                tr[n * 3 + 1] = (dy / nrm) * sc * valid;
-                tr[n * 3 + 2] = (dz / nrm) * sc * valid;
+                tr[n * 3 + 0] *= sc;
+                tr[n * 3 + 1] *= sc;
+                tr[n * 3 + 2] *= sc;
             }
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
