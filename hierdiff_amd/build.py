@@ -35,19 +35,76 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in DEPS)
 
 
+RESOURCES = os.path.join(LIBDIR, "kernel_resources.json")
+
+
+def _parse_resource_remarks(text: str) -> dict:
+    """hipcc -Rpass-analysis=kernel-resource-usage -> {mangled kernel: {VGPRs, AGPRs, ScratchSize, VGPRs Spill, ...}}."""
+    import re
+    out, cur = {}, None
+    for line in text.splitlines():
+        m = re.search(r"remark: Function Name: (\S+)", line)
+        if m:
+            cur = out.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark:\s+([A-Za-z][A-Za-z /\[\]]*?)(?: \[[^\]]*\])?: (\S+) \[-Rpass", line)
+        if m and cur is not None:
+            key = m.group(1).strip()
+            try:
+                cur[key] = int(m.group(2))
+            except ValueError:
+                cur[key] = m.group(2)
+    return out
+
+
+def _production(name: str) -> bool:
+    """Everything except the ablated / traced edge-kernel instantiations (HD_ABLATE, HD_EDGE_PTRACE debug aids)."""
+    import re
+    m = re.match(r"_Z6k_edgeILi\d+ELb[01]ELi[01]ELi(\d+)EE", name)
+    if m:
+        return m.group(1) == "0"
+    return not name.startswith("_Z8k_edge_pILi256ELb0ELb1")
+
+
+def audit(resources: dict) -> list:
+    """Kernels hide loads from the compiler (inline-asm loads released by hand-counted s_waitcnt): a register spill
+    next to one of them would save a destination before its data has landed.  No production kernel may spill."""
+    bad = []
+    for name, r in resources.items():
+        if not name.startswith("_Z") or not _production(name):
+            continue
+        if r.get("ScratchSize", 0) or r.get("VGPRs Spill", 0):          # SGPR spills go to VGPR lanes, not to memory
+            bad.append(f"{name}: scratch {r.get('ScratchSize')} B/lane, VGPR spills {r.get('VGPRs Spill')}")
+    return bad
+
+
 def build(force: bool = False, save_temps: bool = False, verbose: bool = True) -> str:
-    if not force and not needs_build():
+    if not force and not needs_build() and os.path.exists(RESOURCES):
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-std=c++17", "-fPIC", "-shared",
-           "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result", "-o", LIB + ".tmp"] + SOURCES
+           "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",
+           "-Rpass-analysis=kernel-resource-usage", "-o", LIB + ".tmp"] + SOURCES
     if save_temps:
         tmpdir = os.path.join(PKG, "build")
         os.makedirs(tmpdir, exist_ok=True)
-        cmd += ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]
+        cmd += ["-save-temps=obj"]
     if verbose:
         print(" ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True, cwd=CSRC)
+    proc = subprocess.run(cmd, cwd=CSRC, stderr=subprocess.PIPE, text=True)
+    other = [ln for ln in proc.stderr.splitlines() if "-Rpass-analysis=kernel-resource-usage" not in ln
+             and not ln.startswith("In file included from")]
+    if other and (verbose or proc.returncode):
+        print("\n".join(other), file=sys.stderr, flush=True)
+    if proc.returncode:
+        raise subprocess.CalledProcessError(proc.returncode, cmd)
+    resources = _parse_resource_remarks(proc.stderr)
+    import json
+    with open(RESOURCES, "w") as fh:
+        json.dump(resources, fh, indent=1, sort_keys=True)
+    bad = audit(resources)
+    if bad:
+        raise RuntimeError("register spills in production kernels (unsafe next to inline-asm loads):\n  " + "\n  ".join(bad))
     os.replace(LIB + ".tmp", LIB)
     return LIB
 

@@ -147,3 +147,20 @@ def test_sample_results_wire_format(tmp_path):
     m = DiffusionQM9(default_config(hidden_nf=32, n_layers=1))
     m.load_state_dict(sd)
     assert np.array_equal(m.state_dict()["dynamics.egnn.embedding.weight"].numpy(), syn["dynamics.egnn.embedding.weight"])
+
+
+def test_no_register_spills_in_production_kernels():
+    """The edge kernels hide loads from hipcc (inline-asm loads released by hand-counted waits); a VGPR spill next to
+    one would save a destination before its data has landed.  The build records hipcc's resource remarks and refuses
+    to produce a library whose production kernels spill; this re-checks the recorded figures."""
+    import json
+    from hierdiff_amd import build
+    build.build(verbose=False)
+    with open(build.RESOURCES) as fh:
+        res = json.load(fh)
+    assert build.audit(res) == []
+    prod = {k: v for k, v in res.items() if build._production(k)}
+    edge = [v for k, v in prod.items() if k.startswith("_Z6k_edgeILi256")]
+    assert len(edge) == 4 and all(v["Occupancy"] >= 2 and v["ScratchSize"] == 0 for v in edge)
+    node = [v for k, v in prod.items() if k.startswith("_Z6k_nodeILi256")]
+    assert len(node) == 3 and all(v["ScratchSize"] == 0 for v in node)
