@@ -11,7 +11,7 @@
 #include <string>
 #include <vector>
 
-static int g_edge_grid = 512;      // persistent edge-kernel grid: 2 workgroups per CU (set in hd_create)
+static int g_edge_grid = 512;      // 2 x CUs (set in hd_create); the experimental persistent k_edge_p launches half of it
 
 // ----------------------------------------------------------------------------- errors
 
@@ -656,7 +656,7 @@ extern "C" int hd_debug_edge_trace(long long* out, int max_wg) {
 template <int H>
 static int launch_edge_h(int prec, bool coord, const EdgeArgs& a, hipStream_t s) {
     const int lds = edge_lds_bytes<H>();
-    const dim3 grid(HD_EDGE_PERSIST ? std::min(a.n_wg, g_edge_grid) : a.n_wg), block(256);
+    const dim3 grid(a.n_wg), block(256);
     if constexpr (H == 256) {
         static int abl = -1;
         if (abl < 0) { const char* e = getenv("HD_ABLATE"); abl = e ? atoi(e) : 0; }

@@ -39,9 +39,6 @@ struct EdgeArgs {
 // head and a bf16 tail (a = ah + al, |a - ah - al| <= 2^-18 |a|) and the product is formed as
 // ah*bh + al*bh + ah*bl with fp32 accumulation on v_mfma_f32_32x32x16_bf16: 3 matrix instructions at
 // 16x the fp32 rate, per-product error ~1e-5 (the dropped al*bl term), i.e. ~1e-6 on a 256-term dot.
-#ifndef HD_EDGE_PERSIST
-#define HD_EDGE_PERSIST 0
-#endif
 
 // Four LDS fragment reads / a counted wait that releases them (see k_edge).  The reads are inline asm so
 // they stay where they are written (hipcc otherwise sinks every LDS read next to its MFMA to save registers,
@@ -126,10 +123,8 @@ constexpr unsigned frag_off_f32(int u) { return (unsigned)(u * 64 * 16); }
 //   1 = skip the epilogue, 2 = skip operand generation (SiLU etc.), 4 = no per-chunk barrier / W2 streaming,
 //   8 = no AB row gathers, 16 = record per-wave cycle stamps + HW placement (hd_debug_edge_trace, scratch/edge_trace.py)
 //
-// Persistent workgroups: gridDim.x <= 2 per CU; each workgroup walks the 128-edge workgroup-tiles of its
-// XCD's contiguous share of the edge list (neighbouring tiles = same molecule = same AB rows in that XCD's
-// L2), keeps the W2 chunk stream running across tiles and fetches the next tile's row metadata while the
-// current tile's epilogue runs.
+// One workgroup = one 128-edge workgroup-tile (4 wavefronts x 32 edges).  (A persistent form that walks several
+// tiles per workgroup was measured no faster and spilled; the pipelined one-wave-per-SIMD form is k_edge_p.)
 template <int H, bool COORD, int PREC, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
     constexpr int NCT = H / 32;          // 32-column tiles
@@ -150,25 +145,20 @@ __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
     float* my_scr = scratch + wave * 136;
     uint32_t* seg_s = reinterpret_cast<uint32_t*>(my_scr + 128);
 
-    // this workgroup's share of the workgroup-tiles
-    int wt_first, wt_count, wt_step;
+    // XCD-aware placement: block b runs on XCD b % 8 and takes the (b / 8)-th workgroup-tile of that XCD's contiguous
+    // share of the edge list (neighbouring tiles = same molecule = same AB rows in that XCD's L2)
+    int wt;
     {
-        const int bid = blockIdx.x, G = gridDim.x, nwt = a.n_wg;
+        const int bid = blockIdx.x, nwt = a.n_wg;
         const int xcd = bid & 7, slot = bid >> 3;
         const int q = nwt >> 3, r = nwt & 7;
         const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
         const int len = q + (xcd < r ? 1 : 0);
-        wt_step = (G - xcd + 7) >> 3;                     // workgroups of this launch on the same XCD
-        wt_first = start + slot;
-        wt_count = slot < len ? (len - slot + wt_step - 1) / wt_step : 0;
+        if (slot >= len) return;
+        wt = start + slot;
     }
-    if (wt_count == 0) return;
     long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0;
     if constexpr (ABL & 16) ts0 = __builtin_readcyclecounter();
-    // HD_EDGE_PERSIST == 0 (default): the host launches one workgroup per workgroup-tile and the loop below runs
-    // once.  Measured on MI355X the persistent form is no faster (118.5 vs 121.5 us) and its longer live
-    // ranges cost ~25 spilled registers, so the single-pass form ships; the walk stays for experiments.
-    const int n_it = HD_EDGE_PERSIST ? wt_count : 1;
 
     for (int k = tid; k < 2 * H; k += 256) wrd_s[k] = a.wrd[k];
     for (int k = tid; k < H; k += 256) { wrd_s[2 * H + k] = a.b2[k]; wrd_s[3 * H + k] = a.wa[k]; }
@@ -183,424 +173,412 @@ __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
     };
     issue_chunk(0, 0);
 
-    // per-row metadata of a tile (lanes n and n+32 both describe row n)
+    // per-row metadata of this wavefront's tile (lanes n and n+32 both describe row n)
+    const int tile = wt * 4 + wave;
+    const bool tile_ok = tile < a.n_tiles;
     int ni = 0, nj = 0;
     uint32_t segb = 255;
-    auto load_meta = [&](int tile) {
-        ni = 0; nj = 0; segb = 255;
-        if (tile < a.n_tiles) {
-            const int e = tile * 32 + n;
-            ni = a.ei[e]; nj = a.ej[e]; segb = a.eseg[e];
+    if (tile_ok) {
+        const int e = tile * 32 + n;
+        ni = a.ei[e]; nj = a.ej[e]; segb = a.eseg[e];
+    }
+
+    int gc = 0;                                            // chunk counter: LDS buffer = gc & 1
+    f32x4 xi = *reinterpret_cast<const f32x4*>(a.xcur + (size_t)ni * 4);
+    f32x4 xj = *reinterpret_cast<const f32x4*>(a.xcur + (size_t)nj * 4);
+    f32x4 yi = *reinterpret_cast<const f32x4*>(a.x0 + (size_t)ni * 4);
+    f32x4 yj = *reinterpret_cast<const f32x4*>(a.x0 + (size_t)nj * 4);
+    const float dx = xi[0] - xj[0], dy = xi[1] - xj[1], dz = xi[2] - xj[2];
+    const float radial = dx * dx + dy * dy + dz * dz;
+    // coordinate head: unit direction of the edge (egnn_new.py:96-99), zero for padding rows,
+    // parked in the wave-private LDS scratch (the slots the epilogue scales in place), not in registers: the
+    // kernel sits at the 256-register limit of two waves per SIMD
+    if constexpr (COORD) {
+        if (hh == 0) {
+            const float inv = ((segb != 255) ? 1.0f : 0.0f) / (sqrtf(radial + 1e-8f) + a.norm_constant);
+            float* tr = my_scr + 32;
+            tr[n * 3 + 0] = dx * inv; tr[n * 3 + 1] = dy * inv; tr[n * 3 + 2] = dz * inv;
+        }
+    }
+    const float ex = yi[0] - yj[0], ey = yi[1] - yj[1], ez = yi[2] - yj[2];
+    const float d0 = ex * ex + ey * ey + ez * ez;
+    const uint32_t segb_t = segb;
+    const int pbase = tile_ok ? a.tile_pbase[tile] : 0;     // requested here, used in the epilogue
+    const int nseg = tile_ok ? a.tile_nseg[tile] : 0;
+    if (hh == 0) reinterpret_cast<uint8_t*>(seg_s)[n] = (uint8_t)segb_t;
+
+    const float* Arow = a.AB + (size_t)ni * (2 * H) + 16 * hh;
+    const float* Brow = a.AB + (size_t)nj * (2 * H) + H + 16 * hh;
+    f32x4 pa[4], pb[4];
+    auto load_rows = [&](int c) {
+        if constexpr (ABL & 8) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { pa[u] = f32x4{radial, d0, radial, d0}; pb[u] = pa[u]; }
+            return;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            pa[u] = *reinterpret_cast<const f32x4*>(Arow + 32 * c + 4 * u);
+            pb[u] = *reinterpret_cast<const f32x4*>(Brow + 32 * c + 4 * u);
         }
     };
-    load_meta(wt_first * 4 + wave);
-
-    int gc = 0;                                            // global chunk counter: buffer = gc & 1
-#pragma unroll 1
-    for (int it = 0; it < n_it; ++it) {
-        const int tile = (wt_first + it * wt_step) * 4 + wave;
-        const bool tile_ok = tile < a.n_tiles;
-        const bool last_it = it + 1 == n_it;
-
-        f32x4 xi = *reinterpret_cast<const f32x4*>(a.xcur + (size_t)ni * 4);
-        f32x4 xj = *reinterpret_cast<const f32x4*>(a.xcur + (size_t)nj * 4);
-        f32x4 yi = *reinterpret_cast<const f32x4*>(a.x0 + (size_t)ni * 4);
-        f32x4 yj = *reinterpret_cast<const f32x4*>(a.x0 + (size_t)nj * 4);
-        const float dx = xi[0] - xj[0], dy = xi[1] - xj[1], dz = xi[2] - xj[2];
-        const float radial = dx * dx + dy * dy + dz * dz;
-        // coordinate head: unit direction of the edge (egnn_new.py:96-99), zero for padding rows,
-        // parked in the wave-private LDS scratch (the slots the epilogue scales in place), not in registers: the
-        // kernel sits at the 256-register limit of two waves per SIMD
-        if constexpr (COORD) {
-            if (hh == 0) {
-                const float inv = ((segb != 255) ? 1.0f : 0.0f) / (sqrtf(radial + 1e-8f) + a.norm_constant);
-                float* tr = my_scr + 32;
-                tr[n * 3 + 0] = dx * inv; tr[n * 3 + 1] = dy * inv; tr[n * 3 + 2] = dz * inv;
+    auto rows_issue = [&](int u, int c) {                  // bf16x3 mode: quad u of chunk c (see vm_load2)
+        if constexpr (ABL & 8) { pa[u] = f32x4{radial, d0, radial, d0}; pb[u] = pa[u]; }
+        else vm_load2(pa[u], pb[u], Arow + 32 * c + 4 * u, Brow + 32 * c + 4 * u);
+    };
+    // first-layer activations of this lane's edge row for K chunk c (k = 32c + 16*hh + 0..15)
+    auto make_P = [&](int c, float (&P)[16]) {             // fp32 mode
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            f32x4 wr4 = *reinterpret_cast<const f32x4*>(wrd_s + 32 * c + 16 * hh + 4 * u);
+            f32x4 wd4 = *reinterpret_cast<const f32x4*>(wrd_s + H + 32 * c + 16 * hh + 4 * u);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float pre = pa[u][j] + pb[u][j];
+                pre = __builtin_fmaf(radial, wr4[j], pre);
+                pre = __builtin_fmaf(d0, wd4[j], pre);
+                P[4 * u + j] = silu_f(pre);
             }
         }
-        const float ex = yi[0] - yj[0], ey = yi[1] - yj[1], ez = yi[2] - yj[2];
-        const float d0 = ex * ex + ey * ey + ez * ez;
-        const uint32_t segb_t = segb;
-        const int pbase = tile_ok ? a.tile_pbase[tile] : 0;     // requested here, used in the epilogue
-        const int nseg = tile_ok ? a.tile_nseg[tile] : 0;
-        if (hh == 0) reinterpret_cast<uint8_t*>(seg_s)[n] = (uint8_t)segb_t;
+    };
+    // bf16x3 mode: one pair of values (scaled domain) -> bf16 head / tail dwords
+    auto make_pair = [&](f32x2 av, f32x2 bv, f32x2 wr2, f32x2 wd2, uint32_t& hi, uint32_t& lo) {
+        float y[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float pre = av[j] + bv[j];
+            pre = __builtin_fmaf(radial, wr2[j], pre);
+            pre = __builtin_fmaf(d0, wd2[j], pre);
+            if constexpr (ABL & 2) y[j] = av[j]; else y[j] = silu_scaled(pre);
+        }
+        bf16_split2(y[0], y[1], hi, lo);
+    };
+    auto make_P_bf = [&](int c, u32x4 (&ph)[2], u32x4 (&pl)[2]) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const f32x4 wr4 = *reinterpret_cast<const f32x4*>(wrd_s + 32 * c + 16 * hh + 4 * u);
+            const f32x4 wd4 = *reinterpret_cast<const f32x4*>(wrd_s + H + 32 * c + 16 * hh + 4 * u);
+#pragma unroll
+            for (int j2 = 0; j2 < 2; ++j2) {
+                uint32_t hi, lo;
+                make_pair(f32x2{pa[u][2 * j2], pa[u][2 * j2 + 1]}, f32x2{pb[u][2 * j2], pb[u][2 * j2 + 1]},
+                          f32x2{wr4[2 * j2], wr4[2 * j2 + 1]}, f32x2{wd4[2 * j2], wd4[2 * j2 + 1]}, hi, lo);
+                ph[u >> 1][2 * (u & 1) + j2] = hi;
+                pl[u >> 1][2 * (u & 1) + j2] = lo;
+            }
+        }
+    };
 
-        const float* Arow = a.AB + (size_t)ni * (2 * H) + 16 * hh;
-        const float* Brow = a.AB + (size_t)nj * (2 * H) + H + 16 * hh;
-        f32x4 pa[4], pb[4];
-        auto load_rows = [&](int c) {
-            if constexpr (ABL & 8) {
+    // Software pipeline: the operands of chunk c+1 are produced (VALU) while the matrix pipe works on
+    // chunk c; the AB rows are fetched two chunks ahead.
+    float Pc[16];
+    u32x4 phc[2], plc[2];                  // bf16x3: head / tail of the 16 operand values, 8 bf16 per k-step
+    if constexpr (PREC == 0) {
+        load_rows(0);
+        __syncthreads();               // chunk 0 of this tile landed (w_r / w_d staged on the first pass)
+        make_P(0, Pc);
+        load_rows(NCH > 1 ? 1 : 0);
+    } else {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { pa[u] = f32x4{radial, d0, radial, d0}; pb[u] = pa[u]; }
-                return;
-            }
+        for (int u = 0; u < 4; ++u) rows_issue(u, 0);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(pa[0]), "+v"(pa[1]), "+v"(pa[2]), "+v"(pa[3]),
+                                            "+v"(pb[0]), "+v"(pb[1]), "+v"(pb[2]), "+v"(pb[3]));
+        __syncthreads();               // chunk 0 landed in every wave's share (w_r / w_d staged on the first pass)
+        make_P_bf(0, phc, plc);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                pa[u] = *reinterpret_cast<const f32x4*>(Arow + 32 * c + 4 * u);
-                pb[u] = *reinterpret_cast<const f32x4*>(Brow + 32 * c + 4 * u);
-            }
-        };
-        auto rows_issue = [&](int u, int c) {                  // bf16x3 mode: quad u of chunk c (see vm_load2)
-            if constexpr (ABL & 8) { pa[u] = f32x4{radial, d0, radial, d0}; pb[u] = pa[u]; }
-            else vm_load2(pa[u], pb[u], Arow + 32 * c + 4 * u, Brow + 32 * c + 4 * u);
-        };
-        // first-layer activations of this lane's edge row for K chunk c (k = 32c + 16*hh + 0..15)
-        auto make_P = [&](int c, float (&P)[16]) {             // fp32 mode
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                f32x4 wr4 = *reinterpret_cast<const f32x4*>(wrd_s + 32 * c + 16 * hh + 4 * u);
-                f32x4 wd4 = *reinterpret_cast<const f32x4*>(wrd_s + H + 32 * c + 16 * hh + 4 * u);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float pre = pa[u][j] + pb[u][j];
-                    pre = __builtin_fmaf(radial, wr4[j], pre);
-                    pre = __builtin_fmaf(d0, wd4[j], pre);
-                    P[4 * u + j] = silu_f(pre);
-                }
-            }
-        };
-        // bf16x3 mode: one pair of values (scaled domain) -> bf16 head / tail dwords
-        auto make_pair = [&](f32x2 av, f32x2 bv, f32x2 wr2, f32x2 wd2, uint32_t& hi, uint32_t& lo) {
-            float y[2];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                float pre = av[j] + bv[j];
-                pre = __builtin_fmaf(radial, wr2[j], pre);
-                pre = __builtin_fmaf(d0, wd2[j], pre);
-                if constexpr (ABL & 2) y[j] = av[j]; else y[j] = silu_scaled(pre);
-            }
-            bf16_split2(y[0], y[1], hi, lo);
-        };
-        auto make_P_bf = [&](int c, u32x4 (&ph)[2], u32x4 (&pl)[2]) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const f32x4 wr4 = *reinterpret_cast<const f32x4*>(wrd_s + 32 * c + 16 * hh + 4 * u);
-                const f32x4 wd4 = *reinterpret_cast<const f32x4*>(wrd_s + H + 32 * c + 16 * hh + 4 * u);
-#pragma unroll
-                for (int j2 = 0; j2 < 2; ++j2) {
-                    uint32_t hi, lo;
-                    make_pair(f32x2{pa[u][2 * j2], pa[u][2 * j2 + 1]}, f32x2{pb[u][2 * j2], pb[u][2 * j2 + 1]},
-                              f32x2{wr4[2 * j2], wr4[2 * j2 + 1]}, f32x2{wd4[2 * j2], wd4[2 * j2 + 1]}, hi, lo);
-                    ph[u >> 1][2 * (u & 1) + j2] = hi;
-                    pl[u >> 1][2 * (u & 1) + j2] = lo;
-                }
-            }
-        };
+        for (int u = 0; u < 4; ++u) rows_issue(u, NCH > 1 ? 1 : 0);
+    }
 
-        // Software pipeline: the operands of chunk c+1 are produced (VALU) while the matrix pipe works on
-        // chunk c; the AB rows are fetched two chunks ahead.
-        float Pc[16];
-        u32x4 phc[2], plc[2];                  // bf16x3: head / tail of the 16 operand values, 8 bf16 per k-step
+    // accumulators start at the second layer's bias (saves the H/32 * 16 bias adds of the epilogue)
+    f32x16 acc[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+        const float b2v = wrd_s[2 * H + 32 * ct + n];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ct][r] = b2v;
+    }
+    if constexpr (ABL & 16) ts1 = __builtin_readcyclecounter();
+    // (Unrolling this loop by two with swapped operand sets, to drop the 16 register copies per chunk, was
+    // measured twice: 9-17 spilled registers, 125 vs 109 us and later 110-116 vs 103-106 us; fp32 285 vs 278.)
+#pragma unroll 1
+    for (int c = 0; c < NCH; ++c, ++gc) {
+        const int buf = (ABL & 4) ? 0 : (gc & 1);
+        if constexpr (!(ABL & 4)) {
+            // chunk c landed in LDS and every wave is done with the other buffer.  bf16x3: the only VMEM
+            // operations younger than chunk c's stream are the 8 row gathers of the previous iteration.
+            if (c > 0) {
+                if constexpr (PREC == 0) __syncthreads();
+                else asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+            }
+            // Unconditional (the last chunk re-requests chunk 0, unused unless a further tile follows): with the
+            // stream inside a branch hipcc has to assume "no stream in flight" at the join and waits vmcnt(0)
+            // - i.e. for the stream itself - before the first use of the gathered AB rows, every chunk.
+            issue_chunk(c + 1 < NCH ? c + 1 : 0, buf ^ 1);
+        }
+        // Branch-free from here to the end of the body (one scheduling region): the last iteration
+        // recomputes the final chunk's operands and refetches its rows, results unused.
+        float Pn[16];
+        u32x4 phn[2], pln[2];
+        const int cn1 = c + 1 < NCH ? c + 1 : NCH - 1, cn2 = c + 2 < NCH ? c + 2 : NCH - 1;
         if constexpr (PREC == 0) {
-            load_rows(0);
-            __syncthreads();               // chunk 0 of this tile landed (w_r / w_d staged on the first pass)
-            make_P(0, Pc);
-            load_rows(NCH > 1 ? 1 : 0);
-        } else {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) rows_issue(u, 0);
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(pa[0]), "+v"(pa[1]), "+v"(pa[2]), "+v"(pa[3]),
-                                                "+v"(pb[0]), "+v"(pb[1]), "+v"(pb[2]), "+v"(pb[3]));
-            __syncthreads();               // chunk 0 landed in every wave's share (w_r / w_d staged on the first pass)
-            make_P_bf(0, phc, plc);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) rows_issue(u, NCH > 1 ? 1 : 0);
+            make_P(cn1, Pn);
+            load_rows(cn2);
         }
-
-        // accumulators start at the second layer's bias (saves the H/32 * 16 bias adds of the epilogue)
-        f32x16 acc[NCT];
+        const float* wb = wbuf + buf * CHF;
+        const unsigned wb_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)wb + lane * 16;
+        if constexpr (PREC == 0) {
+            // chunk image: [4 q][NCT][64 lanes][4 floats]: fragment (q, ct) holds k = 32c + 16h + 4q + j, j = 0..3,
+            // of column 32ct + n (64-cycle fp32 MFMAs hide the LDS latency without explicit prefetch).
 #pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) {
-            const float b2v = wrd_s[2 * H + 32 * ct + n];
+            for (int q = 0; q < 4; ++q) {
+                f32x4 bv[NCT];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[ct][r] = b2v;
-        }
-        if constexpr (ABL & 16) ts1 = __builtin_readcyclecounter();
-        // (Unrolling this loop by two with swapped operand sets, to drop the 16 register copies per chunk, was
-        // measured twice: 9-17 spilled registers, 125 vs 109 us and later 110-116 vs 103-106 us; fp32 285 vs 278.)
-#pragma unroll 1
-        for (int c = 0; c < NCH; ++c, ++gc) {
-            const int buf = (ABL & 4) ? 0 : (gc & 1);
-            if constexpr (!(ABL & 4)) {
-                // chunk c landed in LDS and every wave is done with the other buffer.  bf16x3: the only VMEM
-                // operations younger than chunk c's stream are the 8 row gathers of the previous iteration.
-                if (c > 0) {
-                    if constexpr (PREC == 0) __syncthreads();
-                    else asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
-                }
-                // Unconditional (the last chunk re-requests chunk 0, unused unless a further tile follows): with the
-                // stream inside a branch hipcc has to assume "no stream in flight" at the join and waits vmcnt(0)
-                // - i.e. for the stream itself - before the first use of the gathered AB rows, every chunk.
-                issue_chunk(c + 1 < NCH ? c + 1 : 0, buf ^ 1);
-            }
-            // Branch-free from here to the end of the body (one scheduling region): the last iteration
-            // recomputes the final chunk's operands and refetches its rows, results unused.
-            float Pn[16];
-            u32x4 phn[2], pln[2];
-            const int cn1 = c + 1 < NCH ? c + 1 : NCH - 1, cn2 = c + 2 < NCH ? c + 2 : NCH - 1;
-            if constexpr (PREC == 0) {
-                make_P(cn1, Pn);
-                load_rows(cn2);
-            }
-            const float* wb = wbuf + buf * CHF;
-            const unsigned wb_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)wb + lane * 16;
-            if constexpr (PREC == 0) {
-                // chunk image: [4 q][NCT][64 lanes][4 floats]: fragment (q, ct) holds k = 32c + 16h + 4q + j, j = 0..3,
-                // of column 32ct + n (64-cycle fp32 MFMAs hide the LDS latency without explicit prefetch).
+                for (int ct = 0; ct < NCT; ++ct)
+                    bv[ct] = *reinterpret_cast<const f32x4*>(wb + ((q * NCT + ct) * 64 + lane) * 4);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    f32x4 bv[NCT];
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int ct = 0; ct < NCT; ++ct)
-                        bv[ct] = *reinterpret_cast<const f32x4*>(wb + ((q * NCT + ct) * 64 + lane) * 4);
+                        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(Pc[4 * q + j], bv[ct][j], acc[ct], 0, 0, 0);
+            }
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-#pragma unroll
-                        for (int ct = 0; ct < NCT; ++ct)
-                            acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(Pc[4 * q + j], bv[ct][j], acc[ct], 0, 0, 0);
+            for (int i = 0; i < 16; ++i) Pc[i] = Pn[i];
+        } else {
+            // chunk image: [hi|lo][2 k-steps][NCT][64 lanes][8 bf16]; lane (h, n), element i of step s is
+            // W2[32ct + n][32c + 16h + 8s + i] - the same k order as P[8s + i].  Units u = (k-step, ct) of
+            // three MFMAs (head*head, tail*head, head*tail) on one accumulator, two units per group.
+            constexpr int NG = NCT;                     // 2*NCT units / 2
+            // The next chunk's operand generation (VALU) is cut into NG slices, one per MFMA group, so the
+            // matrix pipe and the VALU alternate every ~6 MFMAs inside ONE wavefront instead of relying on
+            // the phase of the co-resident wavefront.  w_r / w_d come from LDS a slice pair ahead; the AB
+            // rows of chunk c+2 replace those of chunk c+1 as soon as their last value has been consumed.
+            const float* wr_n = wrd_s + 32 * cn1 + 16 * hh;
+            const float* wd_n = wrd_s + H + 32 * cn1 + 16 * hh;
+            f32x4 wrq[2], wdq[2];
+            wrq[0] = *reinterpret_cast<const f32x4*>(wr_n);
+            wdq[0] = *reinterpret_cast<const f32x4*>(wd_n);
+            bf16x8 f0[4], f1[4];
+            lds_read4<bf16x8, frag_off_bf<NCT>(0, 0), frag_off_bf<NCT>(0, 1), frag_off_bf<NCT>(1, 0), frag_off_bf<NCT>(1, 1)>(f0, wb_lds);
+            static_for<0, NG>([&](auto Gc) {
+                constexpr int g = decltype(Gc)::value;
+                bf16x8(&cur)[4] = (g & 1) ? f1 : f0;
+                bf16x8(&nxt)[4] = (g & 1) ? f0 : f1;
+                lds_wait4<0>(cur);
+                if constexpr (g + 1 < NG) {
+                    constexpr int u = 2 * (g + 1);
+                    lds_read4<bf16x8, frag_off_bf<NCT>(u, 0), frag_off_bf<NCT>(u, 1), frag_off_bf<NCT>(u + 1, 0),
+                              frag_off_bf<NCT>(u + 1, 1)>(nxt, wb_lds);
                 }
+                // The next chunk's 8 operand pairs are produced in the FIRST half of the groups and the AB
+                // rows of chunk c+2 are requested as soon as a quad of chunk c+1 has been consumed: the
+                // per-chunk barrier implies vmcnt(0), so a gather issued late in the chunk would expose its
+                // whole L2 latency there.
+                constexpr int NGP = NG >= 2 ? NG / 2 : 1;          // groups that produce operands
+                constexpr int PPG = 8 / NGP;                       // pairs per producing group
+                if constexpr (g < NGP) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) Pc[i] = Pn[i];
-            } else {
-                // chunk image: [hi|lo][2 k-steps][NCT][64 lanes][8 bf16]; lane (h, n), element i of step s is
-                // W2[32ct + n][32c + 16h + 8s + i] - the same k order as P[8s + i].  Units u = (k-step, ct) of
-                // three MFMAs (head*head, tail*head, head*tail) on one accumulator, two units per group.
-                constexpr int NG = NCT;                     // 2*NCT units / 2
-                // The next chunk's operand generation (VALU) is cut into NG slices, one per MFMA group, so the
-                // matrix pipe and the VALU alternate every ~6 MFMAs inside ONE wavefront instead of relying on
-                // the phase of the co-resident wavefront.  w_r / w_d come from LDS a slice pair ahead; the AB
-                // rows of chunk c+2 replace those of chunk c+1 as soon as their last value has been consumed.
-                const float* wr_n = wrd_s + 32 * cn1 + 16 * hh;
-                const float* wd_n = wrd_s + H + 32 * cn1 + 16 * hh;
-                f32x4 wrq[2], wdq[2];
-                wrq[0] = *reinterpret_cast<const f32x4*>(wr_n);
-                wdq[0] = *reinterpret_cast<const f32x4*>(wd_n);
-                bf16x8 f0[4], f1[4];
-                lds_read4<bf16x8, frag_off_bf<NCT>(0, 0), frag_off_bf<NCT>(0, 1), frag_off_bf<NCT>(1, 0), frag_off_bf<NCT>(1, 1)>(f0, wb_lds);
-                static_for<0, NG>([&](auto Gc) {
-                    constexpr int g = decltype(Gc)::value;
-                    bf16x8(&cur)[4] = (g & 1) ? f1 : f0;
-                    bf16x8(&nxt)[4] = (g & 1) ? f0 : f1;
-                    lds_wait4<0>(cur);
-                    if constexpr (g + 1 < NG) {
-                        constexpr int u = 2 * (g + 1);
-                        lds_read4<bf16x8, frag_off_bf<NCT>(u, 0), frag_off_bf<NCT>(u, 1), frag_off_bf<NCT>(u + 1, 0),
-                                  frag_off_bf<NCT>(u + 1, 1)>(nxt, wb_lds);
-                    }
-                    // The next chunk's 8 operand pairs are produced in the FIRST half of the groups and the AB
-                    // rows of chunk c+2 are requested as soon as a quad of chunk c+1 has been consumed: the
-                    // per-chunk barrier implies vmcnt(0), so a gather issued late in the chunk would expose its
-                    // whole L2 latency there.
-                    constexpr int NGP = NG >= 2 ? NG / 2 : 1;          // groups that produce operands
-                    constexpr int PPG = 8 / NGP;                       // pairs per producing group
-                    if constexpr (g < NGP) {
-#pragma unroll
-                        for (int v = 0; v < PPG; ++v) {
-                            const int pi = g * PPG + v, u = pi >> 1, j2 = pi & 1;      // pair pi = values 2pi, 2pi+1
-                            // outstanding, oldest first: quads u..3 of chunk c+1, this chunk's GL_PER_WAVE stream
-                            // pieces, quads 0..u-1 of chunk c+2  =  8 + GL_PER_WAVE loads
-                            if (j2 == 0) vm_wait2<6 + GL_PER_WAVE>(pa[u], pb[u]);
-                            if (j2 == 0 && u + 1 < 4) {      // w_r / w_d for the following four values
-                                wrq[(u + 1) & 1] = *reinterpret_cast<const f32x4*>(wr_n + 4 * (u + 1));
-                                wdq[(u + 1) & 1] = *reinterpret_cast<const f32x4*>(wd_n + 4 * (u + 1));
-                            }
-                            uint32_t hi, lo;
-                            make_pair(f32x2{pa[u][2 * j2], pa[u][2 * j2 + 1]}, f32x2{pb[u][2 * j2], pb[u][2 * j2 + 1]},
-                                      f32x2{wrq[u & 1][2 * j2], wrq[u & 1][2 * j2 + 1]},
-                                      f32x2{wdq[u & 1][2 * j2], wdq[u & 1][2 * j2 + 1]}, hi, lo);
-                            phn[pi >> 2][pi & 3] = hi;
-                            pln[pi >> 2][pi & 3] = lo;
-                            if (j2 == 1) rows_issue(u, cn2);     // rows of chunk c+2 into the freed registers
+                    for (int v = 0; v < PPG; ++v) {
+                        const int pi = g * PPG + v, u = pi >> 1, j2 = pi & 1;      // pair pi = values 2pi, 2pi+1
+                        // outstanding, oldest first: quads u..3 of chunk c+1, this chunk's GL_PER_WAVE stream
+                        // pieces, quads 0..u-1 of chunk c+2  =  8 + GL_PER_WAVE loads
+                        if (j2 == 0) vm_wait2<6 + GL_PER_WAVE>(pa[u], pb[u]);
+                        if (j2 == 0 && u + 1 < 4) {      // w_r / w_d for the following four values
+                            wrq[(u + 1) & 1] = *reinterpret_cast<const f32x4*>(wr_n + 4 * (u + 1));
+                            wdq[(u + 1) & 1] = *reinterpret_cast<const f32x4*>(wd_n + 4 * (u + 1));
                         }
+                        uint32_t hi, lo;
+                        make_pair(f32x2{pa[u][2 * j2], pa[u][2 * j2 + 1]}, f32x2{pb[u][2 * j2], pb[u][2 * j2 + 1]},
+                                  f32x2{wrq[u & 1][2 * j2], wrq[u & 1][2 * j2 + 1]},
+                                  f32x2{wdq[u & 1][2 * j2], wdq[u & 1][2 * j2 + 1]}, hi, lo);
+                        phn[pi >> 2][pi & 3] = hi;
+                        pln[pi >> 2][pi & 3] = lo;
+                        if (j2 == 1) rows_issue(u, cn2);     // rows of chunk c+2 into the freed registers
                     }
-                    constexpr int u0 = 2 * g, u1 = 2 * g + 1;
-                    constexpr int s0 = u0 / NCT, c0 = u0 % NCT, s1 = u1 / NCT, c1 = u1 % NCT;
-                    const bf16x8 A_h0 = __builtin_bit_cast(bf16x8, phc[s0]), A_l0 = __builtin_bit_cast(bf16x8, plc[s0]);
-                    const bf16x8 A_h1 = __builtin_bit_cast(bf16x8, phc[s1]), A_l1 = __builtin_bit_cast(bf16x8, plc[s1]);
-                    acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_h0, cur[0], acc[c0], 0, 0, 0);
-                    acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_h1, cur[2], acc[c1], 0, 0, 0);
-                    acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_l0, cur[0], acc[c0], 0, 0, 0);
-                    acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_l1, cur[2], acc[c1], 0, 0, 0);
-                    acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_h0, cur[1], acc[c0], 0, 0, 0);
-                    acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_h1, cur[3], acc[c1], 0, 0, 0);
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) {            // interleave: 1 MFMA, then up to 4 VALU
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-                    }
-                });
-#pragma unroll
-                for (int st = 0; st < 2; ++st) { phc[st] = phn[st]; plc[st] = pln[st]; }
-            }
-        }
-
-        if constexpr (PREC == 1) {             // drain the (unused) last gathers before their registers are reused
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(pa[0]), "+v"(pa[1]), "+v"(pa[2]), "+v"(pa[3]),
-                                                "+v"(pb[0]), "+v"(pb[1]), "+v"(pb[2]), "+v"(pb[3]));
-        }
-        if constexpr (ABL & 16) ts2 = __builtin_readcyclecounter();
-        // next tile's row metadata: in flight while this tile's epilogue runs
-        if (!last_it) load_meta((wt_first + (it + 1) * wt_step) * 4 + wave);
-
-        if (!tile_ok) continue;
-        if constexpr (ABL & 1) {
-            float sacc = 0.f;
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) sacc += acc[ct][r];
-            if (sacc == 123.456f) a.part[lane] = sacc;
-            continue;
-        }
-
-        // ---- epilogue.  acc[ct][r] = row rho(r) = (r&3) + 8*(r>>2) + 4*hh, column 32*ct + n.
-        float dot[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dot[r] = 0.f;
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) {
-            const float wav = wrd_s[3 * H + 32 * ct + n];
-            if constexpr (PREC == 0) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float mv = silu_f(acc[ct][r]);
-                    acc[ct][r] = mv;
-                    dot[r] = __builtin_fmaf(mv, wav, dot[r]);
                 }
-            } else {
-                // stage by stage over the 16 rows of a column tile (exp x16, +1 x16, rcp x16, ...): left alone hipcc
-                // runs each value's exp -> add -> rcp -> mul chain back to back through one or two registers and
-                // the epilogue sits out the transcendental latency ~500 times.
-                float e[16];
+                constexpr int u0 = 2 * g, u1 = 2 * g + 1;
+                constexpr int s0 = u0 / NCT, c0 = u0 % NCT, s1 = u1 / NCT, c1 = u1 % NCT;
+                const bf16x8 A_h0 = __builtin_bit_cast(bf16x8, phc[s0]), A_l0 = __builtin_bit_cast(bf16x8, plc[s0]);
+                const bf16x8 A_h1 = __builtin_bit_cast(bf16x8, phc[s1]), A_l1 = __builtin_bit_cast(bf16x8, plc[s1]);
+                acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_h0, cur[0], acc[c0], 0, 0, 0);
+                acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_h1, cur[2], acc[c1], 0, 0, 0);
+                acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_l0, cur[0], acc[c0], 0, 0, 0);
+                acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_l1, cur[2], acc[c1], 0, 0, 0);
+                acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_h0, cur[1], acc[c0], 0, 0, 0);
+                acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_h1, cur[3], acc[c1], 0, 0, 0);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) e[r] = __builtin_amdgcn_exp2f(acc[ct][r]);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int k = 0; k < 6; ++k) {            // interleave: 1 MFMA, then up to 4 VALU
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                }
+            });
 #pragma unroll
-                for (int r = 0; r < 16; ++r) e[r] = 1.0f + e[r];
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) e[r] = __builtin_amdgcn_rcpf(e[r]);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[ct][r] *= e[r];
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) dot[r] = __builtin_fmaf(acc[ct][r], wav, dot[r]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            for (int st = 0; st < 2; ++st) { phc[st] = phn[st]; plc[st] = pln[st]; }
         }
-        if constexpr (ABL & 16) ts3 = __builtin_readcyclecounter();
-        // Row dots: transpose-reduce over the 32 lanes of a half.  Each exchange halves the number of rows a
-        // lane still carries (16 -> 8 -> 4 -> 2 -> 1), the last one is a plain butterfly: 16 shuffles instead
-        // of 80, and lanes 2r, 2r+1 end up with the complete dot of row slot r, so the sigmoid / tanh input is
-        // evaluated once per lane instead of 16 times.
-        float rowdot;
-        {
-            float v8[8], v4[4], v2[2];
-            const bool b4 = n & 16, b3 = n & 8, b2_ = n & 4, b1 = n & 2;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float send = b4 ? dot[k] : dot[k + 8];
-                const float keep = b4 ? dot[k + 8] : dot[k];
-                v8[k] = keep + __shfl_xor(send, 16);
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float send = b3 ? v8[k] : v8[k + 4];
-                const float keep = b3 ? v8[k + 4] : v8[k];
-                v4[k] = keep + __shfl_xor(send, 8);
-            }
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const float send = b2_ ? v4[k] : v4[k + 2];
-                const float keep = b2_ ? v4[k + 2] : v4[k];
-                v2[k] = keep + __shfl_xor(send, 4);
-            }
-            {
-                const float send = b1 ? v2[0] : v2[1];
-                const float keep = b1 ? v2[1] : v2[0];
-                rowdot = keep + __shfl_xor(send, 2);
-            }
-            rowdot += __shfl_xor(rowdot, 1);
-        }
-        if constexpr (ABL & 16) ts4 = __builtin_readcyclecounter();
-        const int my_slot = (n >> 1) & 15;                  // this lane holds the dot of row rho(my_slot)
+    }
 
-        if (!COORD) {
-            // segment byte of each of this lane's 16 rows: rows 8q+4hh .. +3 share one dword
-            uint32_t sw[4];
+    if constexpr (PREC == 1) {             // drain the (unused) last gathers before their registers are reused
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(pa[0]), "+v"(pa[1]), "+v"(pa[2]), "+v"(pa[3]),
+                                            "+v"(pb[0]), "+v"(pb[1]), "+v"(pb[2]), "+v"(pb[3]));
+    }
+    if constexpr (ABL & 16) ts2 = __builtin_readcyclecounter();
+    if (!tile_ok) return;                  // padding tile of the last workgroup: nothing to store
+    if constexpr (ABL & 1) {
+        float sacc = 0.f;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) sw[q] = seg_s[2 * q + hh];
-            float att_mine = 1.0f;
-            if (a.attention) {
-                if constexpr (PREC == 0) att_mine = sigmoid_f(rowdot + a.ba);
-                else att_mine = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(rowdot + a.ba));   // scaled domain
-            }
-            float w[16];
-            int sg[16];
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc += acc[ct][r];
+        if (sacc == 123.456f) a.part[lane] = sacc;
+        return;
+    }
+
+    // ---- epilogue.  acc[ct][r] = row rho(r) = (r&3) + 8*(r>>2) + 4*hh, column 32*ct + n.
+    float dot[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dot[r] = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+        const float wav = wrd_s[3 * H + 32 * ct + n];
+        if constexpr (PREC == 0) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                sg[r] = (sw[r >> 2] >> (8 * (r & 3))) & 255;
-                const float att = __shfl(att_mine, (lane & 32) | (2 * r));
-                w[r] = (sg[r] != 255) ? att : 0.0f;
-            }
-            if constexpr (ABL & 16) ts5 = __builtin_readcyclecounter();
-            for (int s = 0; s < nseg; ++s) {
-                float ws[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) ws[r] = (sg[r] == s) ? w[r] : 0.0f;
-                float* dst = a.part + (size_t)(pbase + s) * H + n;
-                float sums[NCT];
-#pragma unroll
-                for (int ct = 0; ct < NCT; ++ct) {
-                    float sum = 0.f;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) sum = __builtin_fmaf(ws[r], acc[ct][r], sum);
-                    sums[ct] = xhalf_sum(sum);
-                }
-                if (hh == 0) {
-#pragma unroll
-                    for (int ct = 0; ct < NCT; ++ct) dst[32 * ct] = sums[ct];
-                }
+                const float mv = silu_f(acc[ct][r]);
+                acc[ct][r] = mv;
+                dot[r] = __builtin_fmaf(mv, wav, dot[r]);
             }
         } else {
-            // phi of row rho(r) is in every lane of half hh; publish per row, then lane n handles row n
-            if ((n & 1) == 0) my_scr[(my_slot & 3) + 8 * (my_slot >> 2) + 4 * hh] = rowdot;
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            if (hh == 0) {
-                float phi = my_scr[n];
-                float sc = a.use_tanh ? tanhf(phi) * a.coords_range : phi;
-                float* tr = my_scr + 32;
-                tr[n * 3 + 0] *= sc;
-                tr[n * 3 + 1] *= sc;
-                tr[n * 3 + 2] *= sc;
-            }
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            if (lane < nseg) {
-                const uint8_t* sb = reinterpret_cast<const uint8_t*>(seg_s);
-                const float* tr = my_scr + 32;
-                float sx = 0.f, sy = 0.f, sz = 0.f;
-                for (int rr = 0; rr < 32; ++rr) {
-                    if (sb[rr] == lane) { sx += tr[rr * 3]; sy += tr[rr * 3 + 1]; sz += tr[rr * 3 + 2]; }
-                }
-                f32x4 o = {sx, sy, sz, 0.f};
-                *reinterpret_cast<f32x4*>(a.part + (size_t)(pbase + lane) * 4) = o;
-            }
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            // stage by stage over the 16 rows of a column tile (exp x16, +1 x16, rcp x16, ...): left alone hipcc
+            // runs each value's exp -> add -> rcp -> mul chain back to back through one or two registers and
+            // the epilogue sits out the transcendental latency ~500 times.
+            float e[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) e[r] = __builtin_amdgcn_exp2f(acc[ct][r]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) e[r] = 1.0f + e[r];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) e[r] = __builtin_amdgcn_rcpf(e[r]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ct][r] *= e[r];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dot[r] = __builtin_fmaf(acc[ct][r], wav, dot[r]);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if constexpr (ABL & 16) {
-            if (lane == 0) {
-                long long* t = a.trace + ((size_t)blockIdx.x * 4 + wave) * 8;
-                // HW_ID (reg 4) / XCC_ID (reg 20) ride in the top 16 bits of the first two stamps
-                const long long hw = __builtin_amdgcn_s_getreg((16 - 1) << 11 | 4) & 0xffff;
-                const long long xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 20) & 0xf;
-                t[0] = (ts0 & 0xffffffffffffll) | (hw << 48); t[1] = (ts1 & 0xffffffffffffll) | (xcc << 48);
-                const long long m48 = 0xffffffffffffll;
-                t[2] = ts2 & m48; t[3] = __builtin_readcyclecounter() & m48; t[4] = ts3 & m48; t[5] = ts4 & m48; t[6] = ts5 & m48; t[7] = nseg;
+    }
+    if constexpr (ABL & 16) ts3 = __builtin_readcyclecounter();
+    // Row dots: transpose-reduce over the 32 lanes of a half.  Each exchange halves the number of rows a
+    // lane still carries (16 -> 8 -> 4 -> 2 -> 1), the last one is a plain butterfly: 16 shuffles instead
+    // of 80, and lanes 2r, 2r+1 end up with the complete dot of row slot r, so the sigmoid / tanh input is
+    // evaluated once per lane instead of 16 times.
+    float rowdot;
+    {
+        float v8[8], v4[4], v2[2];
+        const bool b4 = n & 16, b3 = n & 8, b2_ = n & 4, b1 = n & 2;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float send = b4 ? dot[k] : dot[k + 8];
+            const float keep = b4 ? dot[k + 8] : dot[k];
+            v8[k] = keep + __shfl_xor(send, 16);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float send = b3 ? v8[k] : v8[k + 4];
+            const float keep = b3 ? v8[k + 4] : v8[k];
+            v4[k] = keep + __shfl_xor(send, 8);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const float send = b2_ ? v4[k] : v4[k + 2];
+            const float keep = b2_ ? v4[k + 2] : v4[k];
+            v2[k] = keep + __shfl_xor(send, 4);
+        }
+        {
+            const float send = b1 ? v2[0] : v2[1];
+            const float keep = b1 ? v2[1] : v2[0];
+            rowdot = keep + __shfl_xor(send, 2);
+        }
+        rowdot += __shfl_xor(rowdot, 1);
+    }
+    if constexpr (ABL & 16) ts4 = __builtin_readcyclecounter();
+    const int my_slot = (n >> 1) & 15;                  // this lane holds the dot of row rho(my_slot)
+
+    if (!COORD) {
+        // segment byte of each of this lane's 16 rows: rows 8q+4hh .. +3 share one dword
+        uint32_t sw[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sw[q] = seg_s[2 * q + hh];
+        float att_mine = 1.0f;
+        if (a.attention) {
+            if constexpr (PREC == 0) att_mine = sigmoid_f(rowdot + a.ba);
+            else att_mine = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(rowdot + a.ba));   // scaled domain
+        }
+        float w[16];
+        int sg[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            sg[r] = (sw[r >> 2] >> (8 * (r & 3))) & 255;
+            const float att = __shfl(att_mine, (lane & 32) | (2 * r));
+            w[r] = (sg[r] != 255) ? att : 0.0f;
+        }
+        if constexpr (ABL & 16) ts5 = __builtin_readcyclecounter();
+        for (int s = 0; s < nseg; ++s) {
+            float ws[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ws[r] = (sg[r] == s) ? w[r] : 0.0f;
+            float* dst = a.part + (size_t)(pbase + s) * H + n;
+            float sums[NCT];
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                float sum = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sum = __builtin_fmaf(ws[r], acc[ct][r], sum);
+                sums[ct] = xhalf_sum(sum);
             }
+            if (hh == 0) {
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) dst[32 * ct] = sums[ct];
+            }
+        }
+    } else {
+        // phi of row rho(r) is in every lane of half hh; publish per row, then lane n handles row n
+        if ((n & 1) == 0) my_scr[(my_slot & 3) + 8 * (my_slot >> 2) + 4 * hh] = rowdot;
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (hh == 0) {
+            float phi = my_scr[n];
+            float sc = a.use_tanh ? tanhf(phi) * a.coords_range : phi;
+            float* tr = my_scr + 32;
+            tr[n * 3 + 0] *= sc;
+            tr[n * 3 + 1] *= sc;
+            tr[n * 3 + 2] *= sc;
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (lane < nseg) {
+            const uint8_t* sb = reinterpret_cast<const uint8_t*>(seg_s);
+            const float* tr = my_scr + 32;
+            float sx = 0.f, sy = 0.f, sz = 0.f;
+            for (int rr = 0; rr < 32; ++rr) {
+                if (sb[rr] == lane) { sx += tr[rr * 3]; sy += tr[rr * 3 + 1]; sz += tr[rr * 3 + 2]; }
+            }
+            f32x4 o = {sx, sy, sz, 0.f};
+            *reinterpret_cast<f32x4*>(a.part + (size_t)(pbase + lane) * 4) = o;
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    if constexpr (ABL & 16) {
+        if (lane == 0) {
+            long long* t = a.trace + ((size_t)blockIdx.x * 4 + wave) * 8;
+            // HW_ID (reg 4) / XCC_ID (reg 20) ride in the top 16 bits of the first two stamps
+            const long long hw = __builtin_amdgcn_s_getreg((16 - 1) << 11 | 4) & 0xffff;
+            const long long xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 20) & 0xf;
+            t[0] = (ts0 & 0xffffffffffffll) | (hw << 48); t[1] = (ts1 & 0xffffffffffffll) | (xcc << 48);
+            const long long m48 = 0xffffffffffffll;
+            t[2] = ts2 & m48; t[3] = __builtin_readcyclecounter() & m48; t[4] = ts3 & m48; t[5] = ts4 & m48; t[6] = ts5 & m48; t[7] = nseg;
         }
     }
 }
