@@ -20,6 +20,14 @@ HD_DEVINL void glds16(const void* gsrc, void* lds_dst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
+// same with a compile-time byte offset, which the instruction applies to BOTH the global and the LDS address: a run of
+// 1 KiB pieces then needs one address / one M0 value per 4 KiB instead of one per piece
+template <int OFF>
+HD_DEVINL void glds16o(const void* gsrc, void* lds_dst) {
+    static_assert(OFF >= 0 && OFF < 4096, "12-bit immediate");
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, OFF, 0);
+}
 
 // ----------------------------------------------------------------------------- math helpers
 

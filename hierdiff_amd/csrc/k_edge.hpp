@@ -163,13 +163,13 @@ __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
     for (int k = tid; k < 2 * H; k += 256) wrd_s[k] = a.wrd[k];
     for (int k = tid; k < H; k += 256) { wrd_s[2 * H + k] = a.b2[k]; wrd_s[3 * H + k] = a.wa[k]; }
     auto issue_chunk = [&](int c, int buf) {
-        const float* src = a.W2img + (size_t)c * CHF;
-        float* dst = wbuf + buf * CHF;
-#pragma unroll
-        for (int u = 0; u < GL_PER_WAVE; ++u) {
-            const int piece = wave * GL_PER_WAVE + u;           // 1 KiB pieces
-            glds16(src + piece * 256 + lane * 4, dst + piece * 256);
-        }
+        // this wave's GL_PER_WAVE consecutive 1 KiB pieces of the chunk image; groups of four share one base
+        const float* src = a.W2img + (size_t)c * CHF + wave * (GL_PER_WAVE * 256) + lane * 4;
+        float* dst = wbuf + buf * CHF + wave * (GL_PER_WAVE * 256);
+        static_for<0, GL_PER_WAVE>([&](auto U) {
+            constexpr int u = decltype(U)::value;
+            glds16o<(u & 3) * 1024>(src + (u >> 2) * 1024, dst + (u >> 2) * 1024);
+        });
     };
     issue_chunk(0, 0);
 
