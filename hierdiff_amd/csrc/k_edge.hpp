@@ -253,6 +253,33 @@ __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
         }
         bf16_split2(y[0], y[1], hi, lo);
     };
+    // four values at a time, stage by stage (pre-activation, exp, +1, rcp, product, bf16 split): written per
+    // value hipcc schedules each exp -> add -> rcp -> mul chain back to back, which costs an s_nop after every
+    // transcendental (forwarding hazard) and a dependent-issue stall per step
+    auto make_quad = [&](f32x4 av, f32x4 bv, f32x4 wr4, f32x4 wd4, uint32_t (&hi)[2], uint32_t (&lo)[2]) {
+        float pre[4], e[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pre[j] = av[j] + bv[j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pre[j] = __builtin_fmaf(radial, wr4[j], pre[j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pre[j] = __builtin_fmaf(d0, wd4[j], pre[j]);
+        if constexpr (ABL & 2) {
+            bf16_split2(av[0], av[1], hi[0], lo[0]);
+            bf16_split2(av[2], av[3], hi[1], lo[1]);
+            return;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) e[j] = __builtin_amdgcn_exp2f(pre[j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) e[j] = 1.0f + e[j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) e[j] = __builtin_amdgcn_rcpf(e[j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pre[j] *= e[j];
+        bf16_split2(pre[0], pre[1], hi[0], lo[0]);
+        bf16_split2(pre[2], pre[3], hi[1], lo[1]);
+    };
     auto make_P_bf = [&](int c, u32x4 (&ph)[2], u32x4 (&pl)[2]) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -320,6 +347,8 @@ __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
         float Pn[16];
         u32x4 phn[2], pln[2];
         const int cn1 = c + 1 < NCH ? c + 1 : NCH - 1, cn2 = c + 2 < NCH ? c + 2 : NCH - 1;
+        const float* Arow_n2 = Arow + 32 * cn2;        // rows of chunk c+2: one address pair per chunk,
+        const float* Brow_n2 = Brow + 32 * cn2;        // the quad offset rides in the load's immediate
         if constexpr (PREC == 0) {
             make_P(cn1, Pn);
             load_rows(cn2);
@@ -376,24 +405,23 @@ __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
                 constexpr int NGP = NG >= 2 ? NG / 2 : 1;          // groups that produce operands
                 constexpr int PPG = 8 / NGP;                       // pairs per producing group
                 if constexpr (g < NGP) {
-#pragma unroll
-                    for (int v = 0; v < PPG; ++v) {
-                        const int pi = g * PPG + v, u = pi >> 1, j2 = pi & 1;      // pair pi = values 2pi, 2pi+1
+                    static_for<0, PPG / 2>([&](auto V) {
+                        constexpr int u = g * (PPG / 2) + decltype(V)::value;   // quad u = values 4u .. 4u+3 (pairs 2u, 2u+1)
                         // outstanding, oldest first: quads u..3 of chunk c+1, this chunk's GL_PER_WAVE stream
                         // pieces, quads 0..u-1 of chunk c+2  =  8 + GL_PER_WAVE loads
-                        if (j2 == 0) vm_wait2<6 + GL_PER_WAVE>(pa[u], pb[u]);
-                        if (j2 == 0 && u + 1 < 4) {      // w_r / w_d for the following four values
+                        vm_wait2<6 + GL_PER_WAVE>(pa[u], pb[u]);
+                        if constexpr (u + 1 < 4) {                       // w_r / w_d for the following four values
                             wrq[(u + 1) & 1] = *reinterpret_cast<const f32x4*>(wr_n + 4 * (u + 1));
                             wdq[(u + 1) & 1] = *reinterpret_cast<const f32x4*>(wd_n + 4 * (u + 1));
                         }
-                        uint32_t hi, lo;
-                        make_pair(f32x2{pa[u][2 * j2], pa[u][2 * j2 + 1]}, f32x2{pb[u][2 * j2], pb[u][2 * j2 + 1]},
-                                  f32x2{wrq[u & 1][2 * j2], wrq[u & 1][2 * j2 + 1]},
-                                  f32x2{wdq[u & 1][2 * j2], wdq[u & 1][2 * j2 + 1]}, hi, lo);
-                        phn[pi >> 2][pi & 3] = hi;
-                        pln[pi >> 2][pi & 3] = lo;
-                        if (j2 == 1) rows_issue(u, cn2);     // rows of chunk c+2 into the freed registers
-                    }
+                        uint32_t hi[2], lo[2];
+                        make_quad(pa[u], pb[u], wrq[u & 1], wdq[u & 1], hi, lo);
+                        phn[u >> 1][2 * (u & 1)] = hi[0]; phn[u >> 1][2 * (u & 1) + 1] = hi[1];
+                        pln[u >> 1][2 * (u & 1)] = lo[0]; pln[u >> 1][2 * (u & 1) + 1] = lo[1];
+                        // rows of chunk c+2 into the freed registers (quad offset as an immediate)
+                        if constexpr (ABL & 8) { pa[u] = f32x4{radial, d0, radial, d0}; pb[u] = pa[u]; }
+                        else vm_load2o<16 * u>(pa[u], pb[u], Arow_n2, Brow_n2);
+                    });
                 }
                 constexpr int u0 = 2 * g, u1 = 2 * g + 1;
                 constexpr int s0 = u0 / NCT, c0 = u0 % NCT, s1 = u1 / NCT, c1 = u1 % NCT;
