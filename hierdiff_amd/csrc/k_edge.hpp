@@ -66,6 +66,19 @@ HD_DEVINL float xhalf_sum(float x) {
     asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(lo), "+v"(hi));
     return lo + hi;
 }
+// four values per statement: one pair of hazard nops for four swaps
+HD_DEVINL void xhalf_sum4(float (&x)[4]) {
+    float lo[4], hi[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { lo[k] = x[k]; hi[k] = x[k]; }
+    asm("s_nop 1\n\t"
+        "v_permlane32_swap_b32 %0, %4\n\tv_permlane32_swap_b32 %1, %5\n\t"
+        "v_permlane32_swap_b32 %2, %6\n\tv_permlane32_swap_b32 %3, %7\n\t"
+        "s_nop 1"
+        : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) x[k] = lo[k] + hi[k];
+}
 
 // AB row gathers of the bf16x3 edge kernel: two 16-byte loads (A_i quad, B_j quad) as inline asm, released by a
 // hand-counted s_waitcnt vmcnt that names their registers.  Compiler-visible loads cannot be used next to the
@@ -563,7 +576,20 @@ __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
                 float sum = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sum = __builtin_fmaf(ws[r], acc[ct][r], sum);
-                sums[ct] = xhalf_sum(sum);
+                sums[ct] = sum;
+            }
+            // add the two halves of the wavefront (lane n + 32 hh holds rows 4hh.. of column n)
+            if constexpr (NCT % 4 == 0) {
+#pragma unroll
+                for (int c4 = 0; c4 < NCT; c4 += 4) {
+                    float q4[4] = {sums[c4], sums[c4 + 1], sums[c4 + 2], sums[c4 + 3]};
+                    xhalf_sum4(q4);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) sums[c4 + k] = q4[k];
+                }
+            } else {
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) sums[ct] = xhalf_sum(sums[ct]);
             }
             if (hh == 0) {
 #pragma unroll
