@@ -254,18 +254,6 @@ __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
             }
         }
     };
-    // bf16x3 mode: one pair of values (scaled domain) -> bf16 head / tail dwords
-    auto make_pair = [&](f32x2 av, f32x2 bv, f32x2 wr2, f32x2 wd2, uint32_t& hi, uint32_t& lo) {
-        float y[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            float pre = av[j] + bv[j];
-            pre = __builtin_fmaf(radial, wr2[j], pre);
-            pre = __builtin_fmaf(d0, wd2[j], pre);
-            if constexpr (ABL & 2) y[j] = av[j]; else y[j] = silu_scaled(pre);
-        }
-        bf16_split2(y[0], y[1], hi, lo);
-    };
     // four values at a time, stage by stage (pre-activation, exp, +1, rcp, product, bf16 split): written per
     // value hipcc schedules each exp -> add -> rcp -> mul chain back to back, which costs an s_nop after every
     // transcendental (forwarding hazard) and a dependent-issue stall per step
@@ -298,14 +286,10 @@ __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
         for (int u = 0; u < 4; ++u) {
             const f32x4 wr4 = *reinterpret_cast<const f32x4*>(wrd_s + 32 * c + 16 * hh + 4 * u);
             const f32x4 wd4 = *reinterpret_cast<const f32x4*>(wrd_s + H + 32 * c + 16 * hh + 4 * u);
-#pragma unroll
-            for (int j2 = 0; j2 < 2; ++j2) {
-                uint32_t hi, lo;
-                make_pair(f32x2{pa[u][2 * j2], pa[u][2 * j2 + 1]}, f32x2{pb[u][2 * j2], pb[u][2 * j2 + 1]},
-                          f32x2{wr4[2 * j2], wr4[2 * j2 + 1]}, f32x2{wd4[2 * j2], wd4[2 * j2 + 1]}, hi, lo);
-                ph[u >> 1][2 * (u & 1) + j2] = hi;
-                pl[u >> 1][2 * (u & 1) + j2] = lo;
-            }
+            uint32_t hi[2], lo[2];
+            make_quad(pa[u], pb[u], wr4, wd4, hi, lo);
+            ph[u >> 1][2 * (u & 1)] = hi[0]; ph[u >> 1][2 * (u & 1) + 1] = hi[1];
+            pl[u >> 1][2 * (u & 1)] = lo[0]; pl[u >> 1][2 * (u & 1) + 1] = lo[1];
         }
     };
 
