@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
             // Unconditional (the last chunk re-requests chunk 0, unused unless a further tile follows): with the
             // stream inside a branch hipcc has to assume "no stream in flight" at the join and waits vmcnt(0)
             // - i.e. for the stream itself - before the first use of the gathered AB rows, every chunk.
-            issue_chunk(c + 1 < NCH ? c + 1 : 0, buf ^ 1);
+            if constexpr (PREC == 0) issue_chunk(c + 1 < NCH ? c + 1 : 0, buf ^ 1);
         }
         // Branch-free from here to the end of the body (one scheduling region): the last iteration
         // recomputes the final chunk's operands and refetches its rows, results unused.
@@ -385,6 +385,9 @@ __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
             wdq[0] = *reinterpret_cast<const f32x4*>(wd_n);
             bf16x8 f0[4], f1[4];
             lds_read4<bf16x8, frag_off_bf<NCT>(0, 0), frag_off_bf<NCT>(0, 1), frag_off_bf<NCT>(1, 0), frag_off_bf<NCT>(1, 1)>(f0, wb_lds);
+            // the stream for the next chunk goes out behind the first fragment reads: its eight LDS-DMA issues cover
+            // the LDS latency the first MFMA group would otherwise wait out
+            if constexpr (!(ABL & 4)) issue_chunk(c + 1 < NCH ? c + 1 : 0, buf ^ 1);
             static_for<0, NG>([&](auto Gc) {
                 constexpr int g = decltype(Gc)::value;
                 bf16x8(&cur)[4] = (g & 1) ? f1 : f0;
