@@ -36,6 +36,7 @@ SIGNATURES = {
     "hd_set_weights": (C.c_int, [_VP, _FP, C.c_longlong, C.c_int, _VP]),
     "hd_topology_create": (C.c_int, [_VP, _U8P, _U8P, C.c_int, C.c_int, C.POINTER(_VP)]),
     "hd_topology_destroy": (C.c_int, [_VP]),
+    "hd_topology_layout": (C.c_int, [_U8P, _U8P, C.c_int, C.c_int, C.POINTER(C.c_longlong), _VP, _VP, _VP, _VP, _VP, _VP]),
     "hd_topology_info": (C.c_int, [_VP, C.POINTER(C.c_longlong)]),
     "hd_egnn_forward": (C.c_int, [_VP, _VP, _FP, _FP, C.c_int, _FP, C.c_int, _FP, _VP]),
     "hd_nan_events": (C.c_int, [_VP, _VP, C.POINTER(C.c_longlong)]),
@@ -49,9 +50,10 @@ SIGNATURES = {
     "hd_philox_normal_host": (C.c_float, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]),
     "hd_profile_enable": (C.c_int, [_VP, C.c_int]),
     "hd_profile_read": (C.c_int, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
-    "hd_debug_edge_trace": (C.c_int, [C.c_void_p, C.c_int]),
+    "hd_debug_edge_trace": (C.c_int, [_VP, C.c_void_p, C.c_int]),
 }
 
+ABI_VERSION = 2          # HD_ABI_VERSION of include/hierdiff_hip.h
 _lib: Optional[C.CDLL] = None
 
 
@@ -73,8 +75,8 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)      # AttributeError if the .so lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.hd_version() != 1:
-        raise HierDiffHipError(f"ABI version mismatch: library reports {lib.hd_version()}, binding expects 1")
+    if lib.hd_version() != ABI_VERSION:
+        raise HierDiffHipError(f"ABI version mismatch: library reports {lib.hd_version()}, binding expects {ABI_VERSION}")
     _lib = lib
     return lib
 

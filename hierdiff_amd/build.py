@@ -1,6 +1,6 @@
 """Build libhierdiff_hip.so (gfx950) in-tree with hipcc.
 
-    python -m hierdiff_amd.build [--force] [--save-temps]
+    python -m hierdiff_amd.build [--force] [--save-temps] [--debug-kernels]
 
 hipcc cross-compiles for gfx950 without a GPU, so this runs in the build container; the resulting
 .so travels to the GPU box with the repo snapshot (it is git-ignored, not gpurun-ignored).
@@ -58,12 +58,12 @@ def _parse_resource_remarks(text: str) -> dict:
 
 
 def _production(name: str) -> bool:
-    """Everything except the ablated / traced edge-kernel instantiations (HD_ABLATE, HD_EDGE_PTRACE debug aids)."""
+    """Everything except the ablated / traced edge-kernel instantiations of a --debug-kernels build."""
     import re
     m = re.match(r"_Z6k_edgeILi\d+ELb[01]ELi[01]ELi(\d+)EE", name)
     if m:
         return m.group(1) == "0"
-    return not name.startswith("_Z8k_edge_pILi256ELb0ELb1")
+    return True
 
 
 def audit(resources: dict) -> list:
@@ -78,13 +78,15 @@ def audit(resources: dict) -> list:
     return bad
 
 
-def build(force: bool = False, save_temps: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, save_temps: bool = False, verbose: bool = True, debug_kernels: bool = False) -> str:
     if not force and not needs_build() and os.path.exists(RESOURCES):
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-std=c++17", "-fPIC", "-shared",
            "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",
            "-Rpass-analysis=kernel-resource-usage", "-o", LIB + ".tmp"] + SOURCES
+    if debug_kernels:        # measurement build: HD_ABLATE variants of the edge kernel + hd_debug_edge_trace (never shipped)
+        cmd.insert(1, "-DHD_DEBUG_KERNELS")
     if save_temps:
         tmpdir = os.path.join(PKG, "build")
         os.makedirs(tmpdir, exist_ok=True)
@@ -110,5 +112,6 @@ def build(force: bool = False, save_temps: bool = False, verbose: bool = True) -
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, save_temps="--save-temps" in sys.argv)
+    build(force="--force" in sys.argv or "--debug-kernels" in sys.argv, save_temps="--save-temps" in sys.argv,
+          debug_kernels="--debug-kernels" in sys.argv)
     print(LIB)

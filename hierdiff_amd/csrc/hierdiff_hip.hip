@@ -11,8 +11,6 @@
 #include <string>
 #include <vector>
 
-static int g_edge_grid = 512;      // 2 x CUs (set in hd_create); the experimental persistent k_edge_p launches half of it
-
 // ----------------------------------------------------------------------------- errors
 
 static thread_local std::string g_err;
@@ -64,11 +62,19 @@ struct hd_handle {
     std::vector<float> tau_h, coef_h;
     float* d_tau;
     float* d_coef;
-    // graph-replay state
+    // graph-replay state (device words the captured step reads and k_advance moves on)
     int* d_step;
     uint32_t* d_draw;
     float* d_tcur;
-    hipStream_t own_stream;     // capture stream used when the caller passes the legacy NULL stream
+    unsigned long long* d_base; // global id of the batch's first sample (Philox stream selector)
+    hipStream_t own_stream;     // capture / replay stream used when the caller passes the legacy NULL stream
+    hipEvent_t ev_in, ev_out;   // order own_stream against the caller's stream without host syncs
+    unsigned long long weights_gen, sched_gen;   // bumped when the packed weights / schedule tables are re-allocated
+#ifdef HD_DEBUG_KERNELS
+    long long* d_trace;         // HD_ABLATE bit 16: cycle stamps of the last traced edge launch
+    int trace_wg;
+    int ablate;                 // HD_ABLATE value read at hd_create
+#endif
     // profiling
     int prof;                   // bitmask of kernel families bracketed with events
     int prof_stride;            // bracket every prof_stride-th forward
@@ -79,16 +85,34 @@ struct hd_handle {
     size_t pool_used;
 };
 
+// Everything a captured diffusion step has baked in: a cached graph is replayed only when all of it is unchanged.
+struct GraphKey {
+    const float *raw_x, *raw_h;
+    int has_ctx, mol_shape, noise_rows, T, s_hi;       // s_hi: injected-noise offsets are relative to the first step
+    uint64_t seed;
+    unsigned long long weights_gen, sched_gen;
+    bool operator==(const GraphKey& o) const {
+        return raw_x == o.raw_x && raw_h == o.raw_h && has_ctx == o.has_ctx && mol_shape == o.mol_shape &&
+               noise_rows == o.noise_rows && T == o.T && s_hi == o.s_hi && seed == o.seed && weights_gen == o.weights_gen &&
+               sched_gen == o.sched_gen;
+    }
+};
+
 struct hd_topology {
     hd_handle* h;
     int device;
     int B, N, M, M_pad, E, E_pad, n_tiles, n_wg, n_parts;
     // device tables
-    int *node_of, *slot_of, *ei, *ej, *tile_pbase, *tile_nseg, *pstart, *nvalid;
+    int *node_of, *slot_of, *ei, *ej, *seg_part, *tile_nseg, *pstart, *nvalid;
     uint8_t *eseg, *nm_bytes;
     float* nmask;
     // workspace
     float *hbuf, *AB, *AB2, *Tb, *agg, *x0, *xcur, *part, *xpart, *eps;
+    // hd_sample_loop with use_graph: the captured step works on library-owned copies of z / context so that the
+    // instantiated graph survives across calls (the caller's tensors move); one graph per topology
+    float *zbuf, *ctxbuf;
+    hipGraphExec_t gexec;
+    GraphKey gkey;
 };
 
 // ----------------------------------------------------------------------------- small helpers
@@ -131,7 +155,7 @@ static int dev_upload(T** p, const std::vector<T>& v) {
 
 // ----------------------------------------------------------------------------- create / destroy
 
-static int prepare_kernels(int H);
+static int prepare_kernels(hd_handle* h);
 
 extern "C" int hd_create(const hd_config* cfg, int device, hd_handle** out) {
     if (!cfg || !out) return fail(HD_E_INVALID, "hd_create: null argument");
@@ -170,22 +194,29 @@ extern "C" int hd_create(const hd_config* cfg, int device, hd_handle** out) {
     h->prof_now = false;
     h->pool_used = 0;
     h->own_stream = nullptr;
-    int r = dev_alloc(&h->d_nanflag, 1);
-    if (r == HD_OK) r = dev_alloc(&h->d_nan_events, 1);
-    if (r == HD_OK) r = dev_alloc(&h->d_step, 1);
-    if (r == HD_OK) r = dev_alloc(&h->d_draw, 1);
-    if (r == HD_OK) r = dev_alloc(&h->d_tcur, 1);
-    if (r != HD_OK) { delete h; return r; }
-    HIP_TRY(hipMemset(h->d_nanflag, 0, sizeof(int)));
-    HIP_TRY(hipMemset(h->d_nan_events, 0, sizeof(long long)));
-    r = prepare_kernels(H);
-    if (r != HD_OK) { hd_destroy(h); return r; }
-    {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
-            g_edge_grid = 2 * prop.multiProcessorCount;
-        if (const char* e = getenv("HD_EDGE_GRID")) g_edge_grid = std::max(1, atoi(e));
-    }
+    h->ev_in = h->ev_out = nullptr;
+    h->weights_gen = h->sched_gen = 0;
+    h->d_nanflag = nullptr; h->d_nan_events = nullptr; h->d_step = nullptr; h->d_draw = nullptr; h->d_tcur = nullptr;
+    h->d_base = nullptr;
+#ifdef HD_DEBUG_KERNELS
+    h->d_trace = nullptr; h->trace_wg = 0;
+    { const char* e = getenv("HD_ABLATE"); h->ablate = e ? atoi(e) : 0; }
+#endif
+    auto create_rest = [&]() -> int {        // every failure below leaves through hd_destroy (frees what exists)
+        HD_TRY(dev_alloc(&h->d_nanflag, 1));
+        HD_TRY(dev_alloc(&h->d_nan_events, 1));
+        HD_TRY(dev_alloc(&h->d_step, 1));
+        HD_TRY(dev_alloc(&h->d_draw, 1));
+        HD_TRY(dev_alloc(&h->d_tcur, 1));
+        HD_TRY(dev_alloc(&h->d_base, 1));
+        HIP_TRY(hipMemset(h->d_nanflag, 0, sizeof(int)));
+        HIP_TRY(hipMemset(h->d_nan_events, 0, sizeof(long long)));
+        HIP_TRY(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&h->ev_out, hipEventDisableTiming));
+        return prepare_kernels(h);
+    };
+    const int r = create_rest();
+    if (r != HD_OK) { const std::string keep = g_err; hd_destroy(h); g_err = keep; return r; }
     *out = h;
     return HD_OK;
 }
@@ -195,8 +226,13 @@ extern "C" int hd_destroy(hd_handle* h) {
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
     hipFree(h->dw); hipFree(h->d_nanflag); hipFree(h->d_nan_events);
-    hipFree(h->d_tau); hipFree(h->d_coef); hipFree(h->d_step); hipFree(h->d_draw); hipFree(h->d_tcur);
+    hipFree(h->d_tau); hipFree(h->d_coef); hipFree(h->d_step); hipFree(h->d_draw); hipFree(h->d_tcur); hipFree(h->d_base);
+#ifdef HD_DEBUG_KERNELS
+    hipFree(h->d_trace);
+#endif
     for (auto e : h->pool) hipEventDestroy(e);
+    if (h->ev_in) hipEventDestroy(h->ev_in);
+    if (h->ev_out) hipEventDestroy(h->ev_out);
     if (h->own_stream) hipStreamDestroy(h->own_stream);
     delete h;
     return HD_OK;
@@ -409,6 +445,7 @@ extern "C" int hd_set_weights(hd_handle* h, const float* blob, long long n, int 
         h->dw = nullptr;
         HD_TRY(dev_alloc(&h->dw, pk.size()));
         h->dw_floats = pk.size();
+        h->weights_gen++;                      // captured graphs hold the old address
     }
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     HIP_TRY(hipMemcpy(h->dw, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -422,21 +459,34 @@ extern "C" int hd_topology_destroy(hd_topology* t) {
     if (!t) return HD_OK;
     (void)hipSetDevice(t->device);
     (void)hipDeviceSynchronize();
-    hipFree(t->node_of); hipFree(t->slot_of); hipFree(t->ei); hipFree(t->ej); hipFree(t->tile_pbase);
+    if (t->gexec) hipGraphExecDestroy(t->gexec);
+    hipFree(t->node_of); hipFree(t->slot_of); hipFree(t->ei); hipFree(t->ej); hipFree(t->seg_part);
     hipFree(t->tile_nseg); hipFree(t->pstart); hipFree(t->nvalid); hipFree(t->eseg); hipFree(t->nm_bytes);
     hipFree(t->nmask); hipFree(t->hbuf); hipFree(t->AB); hipFree(t->AB2); hipFree(t->Tb); hipFree(t->agg); hipFree(t->x0); hipFree(t->xcur);
-    hipFree(t->part); hipFree(t->xpart); hipFree(t->eps);
+    hipFree(t->part); hipFree(t->xpart); hipFree(t->eps); hipFree(t->zbuf); hipFree(t->ctxbuf);
     delete t;
     return HD_OK;
 }
 
-extern "C" int hd_topology_create(hd_handle* h, const uint8_t* node_mask, const uint8_t* edge_mask, int B, int N,
-                                  hd_topology** out) {
-    if (!h || !node_mask || !out) return fail(HD_E_INVALID, "hd_topology_create: null argument");
-    *out = nullptr;
+// Edge tiles.  The unmasked edges of molecule b, sorted by receiving node, are cut into pieces at MOLECULE-relative
+// multiples of 32: full pieces own a 32-row tile, the remainder (< 32 rows) shares a "tail tile" with the remainders
+// of neighbouring molecules at 4-row-aligned offsets.  Which edges of a node are summed together (a "part" = the
+// node's rows inside one piece) therefore depends on the molecule alone, never on its position in the batch, and the
+// edge kernel's per-node sums are invariant under 4-row shifts of a piece (k_edge.hpp) - so a sample comes out
+// bit-identical whatever batch / rank / world size it is computed in.  Part ids are node-major
+// (a node's parts are contiguous, in piece order = the order the consumers add them); every (tile, segment) carries
+// its part id explicitly.
+struct TileLayout {
+    int M, M_pad, n_tiles, n_wg, n_parts;
+    long long E;
+    std::vector<int> slot_of, node_of, nvalid, ei, ej, seg_part, tile_nseg, pstart;
+    std::vector<uint8_t> eseg;
+    std::vector<float> nmask;
+};
+
+static int build_layout(const uint8_t* node_mask, const uint8_t* edge_mask, int B, int N, TileLayout& L) {
     if (B < 1 || N < 1) return fail(HD_E_INVALID, "hd_topology_create: B and N must be >= 1");
     if ((long long)B * N > (1LL << 30)) return fail(HD_E_INVALID, "hd_topology_create: B*N too large");
-    HIP_TRY(hipSetDevice(h->device));
     const size_t BN = (size_t)B * N;
     // active nodes: masked-in, or touched by an unmasked edge (general edge masks only)
     std::vector<uint8_t> active(node_mask, node_mask + BN);
@@ -447,8 +497,9 @@ extern "C" int hd_topology_create(hd_handle* h, const uint8_t* node_mask, const 
                 for (int j = 0; j < N; ++j)
                     if (edge_mask[((size_t)b * N + i) * N + j]) { active[(size_t)b * N + i] = 1; active[(size_t)b * N + j] = 1; }
     }
-    std::vector<int> slot_of(BN, -1), node_of, nvalid(B, 0);
-    std::vector<float> nmask;
+    std::vector<int>&slot_of = L.slot_of, &node_of = L.node_of, &nvalid = L.nvalid;
+    std::vector<float>& nmask = L.nmask;
+    slot_of.assign(BN, -1); node_of.clear(); nvalid.assign(B, 0); nmask.clear();
     for (size_t f = 0; f < BN; ++f) {
         if (active[f]) { slot_of[f] = (int)node_of.size(); node_of.push_back((int)f); nmask.push_back(node_mask[f] ? 1.0f : 0.0f); }
         if (node_mask[f]) nvalid[f / N]++;
@@ -456,41 +507,116 @@ extern "C" int hd_topology_create(hd_handle* h, const uint8_t* node_mask, const 
     const int M = (int)node_of.size();
     const int M_pad = std::max(128, (M + 127) / 128 * 128);
     nmask.resize(M_pad, 0.0f);
-    std::vector<int> ei, ej;
-    for (int b = 0; b < B; ++b)
+    // per-molecule edge lists (compact node ids), sorted by receiving node then sender
+    std::vector<int> mei, mej;
+    std::vector<long long> mstart(B + 1, 0);
+    for (int b = 0; b < B; ++b) {
         for (int i = 0; i < N; ++i) {
             const size_t fi = (size_t)b * N + i;
             if (!active[fi]) continue;
             for (int j = 0; j < N; ++j) {
                 const size_t fj = (size_t)b * N + j;
                 const bool on = edge_mask ? edge_mask[fi * N + j] != 0 : (node_mask[fi] && node_mask[fj] && i != j);
-                if (on) { ei.push_back(slot_of[fi]); ej.push_back(slot_of[fj]); }
+                if (on) { mei.push_back(slot_of[fi]); mej.push_back(slot_of[fj]); }
             }
         }
-    const long long E = (long long)ei.size();
-    if (E > (1LL << 30)) return fail(HD_E_INVALID, "hd_topology_create: too many edges");
-    const int E_pad = (int)((E + 127) / 128 * 128);
-    const int n_tiles = (int)((E + 31) / 32);
-    const int n_wg = E_pad / 128;
-    ei.resize(E_pad, 0); ej.resize(E_pad, 0);
-    std::vector<uint8_t> eseg(E_pad, 255);
-    std::vector<int> tile_pbase(std::max(1, E_pad / 32), 0), tile_nseg(std::max(1, E_pad / 32), 0);
-    std::vector<int> part_node;
-    for (int t = 0; t < E_pad / 32; ++t) {
-        tile_pbase[t] = (int)part_node.size();
-        int prev = -1, seg = -1;
-        for (int r = 0; r < 32; ++r) {
-            const long long e = (long long)t * 32 + r;
-            if (e >= E) break;
-            if (ei[e] != prev) { ++seg; prev = ei[e]; part_node.push_back(prev); }
-            eseg[e] = (uint8_t)seg;
-        }
-        tile_nseg[t] = seg + 1;
+        mstart[b + 1] = (long long)mei.size();
     }
-    const int n_parts = (int)part_node.size();
-    std::vector<int> pstart(M + 1, 0);
-    for (int p = 0; p < n_parts; ++p) pstart[part_node[p] + 1]++;
+    const long long E = (long long)mei.size();
+    if (E > (1LL << 30)) return fail(HD_E_INVALID, "hd_topology_create: too many edges");
+    // parts per node: the pieces (molecule-relative 32-row blocks) its edge run touches
+    std::vector<int>& pstart = L.pstart;
+    std::vector<int> first_piece(M, 0);
+    pstart.assign(M + 1, 0);
+    for (int b = 0; b < B; ++b) {
+        const long long e0 = mstart[b], e1 = mstart[b + 1];
+        for (long long e = e0; e < e1;) {
+            const int node = mei[e];
+            long long f = e;
+            while (f < e1 && mei[f] == node) ++f;
+            first_piece[node] = (int)((e - e0) / 32);
+            pstart[node + 1] = (int)((f - 1 - e0) / 32) - first_piece[node] + 1;
+            e = f;
+        }
+    }
     for (int i = 0; i < M; ++i) pstart[i + 1] += pstart[i];
+    // tiles
+    std::vector<int>&ei = L.ei, &ej = L.ej, &seg_part = L.seg_part, &tile_nseg = L.tile_nseg;
+    std::vector<uint8_t>& eseg = L.eseg;
+    ei.clear(); ej.clear(); seg_part.clear(); tile_nseg.clear(); eseg.clear();
+    auto new_tile = [&]() {
+        const int t = (int)tile_nseg.size();
+        ei.resize(ei.size() + 32, 0); ej.resize(ej.size() + 32, 0); eseg.resize(eseg.size() + 32, 255);
+        seg_part.resize(seg_part.size() + 32, 0); tile_nseg.push_back(0);
+        return t;
+    };
+    auto place = [&](int t, int off, int b, int piece, int cnt) {      // rows [32 piece, 32 piece + cnt) of molecule b
+        const long long e0 = mstart[b] + 32LL * piece;
+        int prev = -1;
+        for (int r = 0; r < cnt; ++r) {
+            const int node = mei[e0 + r];
+            if (node != prev) {
+                seg_part[(size_t)t * 32 + tile_nseg[t]] = pstart[node] + (piece - first_piece[node]);
+                tile_nseg[t]++;
+                prev = node;
+            }
+            ei[(size_t)t * 32 + off + r] = node; ej[(size_t)t * 32 + off + r] = mej[e0 + r];
+            eseg[(size_t)t * 32 + off + r] = (uint8_t)(tile_nseg[t] - 1);
+        }
+    };
+    int tail_tile = -1, tail_fill = 0;
+    for (int b = 0; b < B; ++b) {
+        const int Eb = (int)(mstart[b + 1] - mstart[b]);
+        const int nfull = Eb / 32, tail = Eb % 32;
+        for (int k = 0; k < nfull; ++k) place(new_tile(), 0, b, k, 32);
+        if (tail) {
+            if (tail_tile < 0 || tail_fill + tail > 32) { tail_tile = new_tile(); tail_fill = 0; }
+            place(tail_tile, tail_fill, b, nfull, tail);
+            tail_fill = (tail_fill + tail + 3) & ~3;
+        }
+    }
+    L.n_tiles = (int)tile_nseg.size();
+    L.n_wg = (L.n_tiles + 3) / 4;
+    while ((int)tile_nseg.size() < std::max(1, L.n_wg * 4)) new_tile();     // padding tiles of the last workgroup
+    L.M = M; L.M_pad = M_pad; L.E = E; L.n_parts = pstart[M];
+    return HD_OK;
+}
+
+// Host-only view of the tables hd_topology_create builds (no device needed; used by the CPU test tier to check the
+// batch-independence of the layout).  counts5 = {active nodes, valid edges, tiles incl. padding tiles, parts, rows};
+// any of the output arrays may be NULL (query the sizes first): ei/ej/eseg [rows], seg_part [rows],
+// tile_nseg [tiles], pstart [nodes + 1].
+extern "C" int hd_topology_layout(const uint8_t* node_mask, const uint8_t* edge_mask, int B, int N, long long* counts5,
+                                  int* ei, int* ej, uint8_t* eseg, int* seg_part, int* tile_nseg, int* pstart) {
+    if (!node_mask || !counts5) return fail(HD_E_INVALID, "hd_topology_layout: null argument");
+    TileLayout L;
+    HD_TRY(build_layout(node_mask, edge_mask, B, N, L));
+    counts5[0] = L.M; counts5[1] = L.E; counts5[2] = (long long)L.tile_nseg.size(); counts5[3] = L.n_parts;
+    counts5[4] = (long long)L.ei.size();
+    if (ei) std::copy(L.ei.begin(), L.ei.end(), ei);
+    if (ej) std::copy(L.ej.begin(), L.ej.end(), ej);
+    if (eseg) std::copy(L.eseg.begin(), L.eseg.end(), eseg);
+    if (seg_part) std::copy(L.seg_part.begin(), L.seg_part.end(), seg_part);
+    if (tile_nseg) std::copy(L.tile_nseg.begin(), L.tile_nseg.end(), tile_nseg);
+    if (pstart) std::copy(L.pstart.begin(), L.pstart.end(), pstart);
+    return HD_OK;
+}
+
+extern "C" int hd_topology_create(hd_handle* h, const uint8_t* node_mask, const uint8_t* edge_mask, int B, int N,
+                                  hd_topology** out) {
+    if (!h || !node_mask || !out) return fail(HD_E_INVALID, "hd_topology_create: null argument");
+    *out = nullptr;
+    TileLayout L;
+    HD_TRY(build_layout(node_mask, edge_mask, B, N, L));
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t BN = (size_t)B * N;
+    const int M = L.M, M_pad = L.M_pad, n_tiles = L.n_tiles, n_wg = L.n_wg, n_parts = L.n_parts;
+    const long long E = L.E;
+    const int E_pad = (int)L.ei.size();
+    std::vector<int>&slot_of = L.slot_of, &node_of = L.node_of, &nvalid = L.nvalid, &ei = L.ei, &ej = L.ej;
+    std::vector<int>&seg_part = L.seg_part, &tile_nseg = L.tile_nseg, &pstart = L.pstart;
+    std::vector<uint8_t>& eseg = L.eseg;
+    std::vector<float>& nmask = L.nmask;
     std::vector<uint8_t> nm_bytes(BN);
     for (size_t f = 0; f < BN; ++f) nm_bytes[f] = node_mask[f] ? 1 : 0;
 
@@ -499,24 +625,29 @@ extern "C" int hd_topology_create(hd_handle* h, const uint8_t* node_mask, const 
     t->h = h; t->device = h->device; t->B = B; t->N = N; t->M = M; t->M_pad = M_pad; t->E = (int)E; t->E_pad = E_pad;
     t->n_tiles = n_tiles; t->n_wg = n_wg; t->n_parts = n_parts;
     const int H = h->H;
-    int r = HD_OK;
-    auto ok = [&](int rc) { if (r == HD_OK) r = rc; };
-    ok(dev_upload(&t->node_of, node_of)); ok(dev_upload(&t->slot_of, slot_of)); ok(dev_upload(&t->ei, ei));
-    ok(dev_upload(&t->ej, ej)); ok(dev_upload(&t->tile_pbase, tile_pbase)); ok(dev_upload(&t->tile_nseg, tile_nseg));
-    ok(dev_upload(&t->pstart, pstart)); ok(dev_upload(&t->nvalid, nvalid)); ok(dev_upload(&t->eseg, eseg));
-    ok(dev_upload(&t->nm_bytes, nm_bytes)); ok(dev_upload(&t->nmask, nmask));
-    ok(dev_alloc(&t->hbuf, (size_t)M_pad * H)); ok(dev_alloc(&t->AB, (size_t)M_pad * 2 * H));
-    ok(dev_alloc(&t->AB2, h->fused ? (size_t)M_pad * 2 * H : 1));
-    ok(dev_alloc(&t->Tb, (size_t)M_pad * H)); ok(dev_alloc(&t->agg, (size_t)M_pad * H)); ok(dev_alloc(&t->x0, (size_t)M_pad * 4));
-    ok(dev_alloc(&t->xcur, (size_t)M_pad * 4)); ok(dev_alloc(&t->part, (size_t)std::max(1, n_parts) * H));
-    ok(dev_alloc(&t->xpart, (size_t)std::max(1, n_parts) * 4)); ok(dev_alloc(&t->eps, BN * h->D));
-    if (r != HD_OK) { hd_topology_destroy(t); return r; }
-    // pad rows stay zero for the lifetime of the topology (kernels never write them)
-    hipMemset(t->hbuf, 0, (size_t)M_pad * H * 4); hipMemset(t->AB, 0, (size_t)M_pad * 2 * H * 4);
-    if (h->fused) hipMemset(t->AB2, 0, (size_t)M_pad * 2 * H * 4);
-    hipMemset(t->Tb, 0, (size_t)M_pad * H * 4); hipMemset(t->agg, 0, (size_t)M_pad * H * 4); hipMemset(t->x0, 0, (size_t)M_pad * 16);
-    hipMemset(t->xcur, 0, (size_t)M_pad * 16);
-    HIP_TRY(hipDeviceSynchronize());
+    auto build = [&]() -> int {
+        HD_TRY(dev_upload(&t->node_of, node_of)); HD_TRY(dev_upload(&t->slot_of, slot_of)); HD_TRY(dev_upload(&t->ei, ei));
+        HD_TRY(dev_upload(&t->ej, ej)); HD_TRY(dev_upload(&t->seg_part, seg_part)); HD_TRY(dev_upload(&t->tile_nseg, tile_nseg));
+        HD_TRY(dev_upload(&t->pstart, pstart)); HD_TRY(dev_upload(&t->nvalid, nvalid)); HD_TRY(dev_upload(&t->eseg, eseg));
+        HD_TRY(dev_upload(&t->nm_bytes, nm_bytes)); HD_TRY(dev_upload(&t->nmask, nmask));
+        // zero-filled: pad rows stay zero for the lifetime of the topology (kernels never write them)
+        auto zalloc = [&](float** p, size_t count) -> int {
+            HD_TRY(dev_alloc(p, count));
+            HIP_TRY(hipMemset(*p, 0, std::max<size_t>(count, 1) * sizeof(float)));
+            return HD_OK;
+        };
+        HD_TRY(zalloc(&t->hbuf, (size_t)M_pad * H)); HD_TRY(zalloc(&t->AB, (size_t)M_pad * 2 * H));
+        HD_TRY(zalloc(&t->AB2, h->fused ? (size_t)M_pad * 2 * H : 1));
+        HD_TRY(zalloc(&t->Tb, (size_t)M_pad * H)); HD_TRY(zalloc(&t->agg, (size_t)M_pad * H));
+        HD_TRY(zalloc(&t->x0, (size_t)M_pad * 4)); HD_TRY(zalloc(&t->xcur, (size_t)M_pad * 4));
+        HD_TRY(zalloc(&t->part, (size_t)std::max(1, n_parts) * H)); HD_TRY(zalloc(&t->xpart, (size_t)std::max(1, n_parts) * 4));
+        HD_TRY(zalloc(&t->eps, BN * h->D)); HD_TRY(zalloc(&t->zbuf, BN * h->D));
+        HD_TRY(zalloc(&t->ctxbuf, BN * (size_t)std::max(1, h->cfg.context_node_nf)));
+        HIP_TRY(hipDeviceSynchronize());
+        return HD_OK;
+    };
+    const int r = build();
+    if (r != HD_OK) { const std::string keep = g_err; hd_topology_destroy(t); g_err = keep; return r; }
     *out = t;
     return HD_OK;
 }
@@ -637,85 +768,62 @@ static void node_update(hd_handle* h, bool upd, int nab, const NodeArgs& a, hipS
 }
 
 template <int H>
-static int edge_p_lds_bytes() { return (3 * 32 * H + 4 * 2048 + 4 * 144) * 4; }    // k_edge_p: three chunk buffers, AB row slots, per-wave scratch
-
-template <int H>
 static int edge_lds_bytes() { return (2 * 32 * H + 2 * H + 4 * 136) * 4; }   // dynamic part (w_r/w_d/b2/wa are static)
 
-static long long* g_trace = nullptr;
-static int g_trace_wg = 0;
-// debug only (HD_ABLATE=16): cycle stamps of the last traced edge launch, 32 values per workgroup
-extern "C" int hd_debug_edge_trace(long long* out, int max_wg) {
-    if (!g_trace) return 0;
-    const int n = std::min(max_wg, g_trace_wg);
+#ifdef HD_DEBUG_KERNELS
+// Measurement build only (python -m hierdiff_amd.build --debug-kernels): HD_ABLATE=<bits> selects an ablated
+// instantiation of the H=256 bf16x3 GCL edge kernel; bit 16 records per-wave cycle stamps (hd_debug_edge_trace).
+// Not compiled into the product library: the variants change results and allocate on first use.
+extern "C" int hd_debug_edge_trace(hd_handle* h, long long* out, int max_wg) {
+    if (!h || !h->d_trace) return 0;
+    const int n = std::min(max_wg, h->trace_wg);
     hipDeviceSynchronize();
-    hipMemcpy(out, g_trace, sizeof(long long) * 32 * n, hipMemcpyDeviceToHost);
+    hipMemcpy(out, h->d_trace, sizeof(long long) * 32 * n, hipMemcpyDeviceToHost);
     return n;
 }
 
-template <int H>
-static int launch_edge_h(int prec, bool coord, const EdgeArgs& a, hipStream_t s) {
-    const int lds = edge_lds_bytes<H>();
+static bool launch_edge_ablated(hd_handle* h, const EdgeArgs& a, hipStream_t s) {
+    const int lds = edge_lds_bytes<256>();
     const dim3 grid(a.n_wg), block(256);
+    auto run = [&](auto Abl) {
+        constexpr int ABL = decltype(Abl)::value;
+        hipFuncSetAttribute((const void*)k_edge<256, false, 1, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        EdgeArgs b = a;
+        if constexpr (ABL & 16) {
+            if (!h->d_trace) hipMalloc(reinterpret_cast<void**>(&h->d_trace), sizeof(long long) * 32 * 4096);
+            if (a.n_wg > 4096) return;
+            b.trace = h->d_trace; h->trace_wg = a.n_wg;
+        }
+        hipLaunchKernelGGL((k_edge<256, false, 1, ABL>), grid, block, lds, s, b);
+    };
+    switch (h->ablate) {
+        case 1: run(std::integral_constant<int, 1>{}); return true;
+        case 2: run(std::integral_constant<int, 2>{}); return true;
+        case 4: run(std::integral_constant<int, 4>{}); return true;
+        case 8: run(std::integral_constant<int, 8>{}); return true;
+        case 15: run(std::integral_constant<int, 15>{}); return true;
+        case 16: run(std::integral_constant<int, 16>{}); return true;
+        case 18: run(std::integral_constant<int, 18>{}); return true;
+        case 20: run(std::integral_constant<int, 20>{}); return true;
+        case 24: run(std::integral_constant<int, 24>{}); return true;
+        case 30: run(std::integral_constant<int, 30>{}); return true;
+        default: return false;
+    }
+}
+#else
+extern "C" int hd_debug_edge_trace(hd_handle*, long long*, int) { return 0; }      // product build: nothing is traced
+#endif
+
+template <int H>
+static int launch_edge_h(hd_handle* h, bool coord, const EdgeArgs& a, hipStream_t s) {
+    const int lds = edge_lds_bytes<H>();
+    const int prec = h->cfg.precision;
+    const dim3 grid(a.n_wg), block(256);
+#ifdef HD_DEBUG_KERNELS
     if constexpr (H == 256) {
-        static int abl = -1;
-        if (abl < 0) { const char* e = getenv("HD_ABLATE"); abl = e ? atoi(e) : 0; }
-        if (abl && prec == 1 && !coord) {
-            auto run = [&](auto Abl) {
-                constexpr int ABL = decltype(Abl)::value;
-                static bool attr = false;
-                if (!attr) {
-                    hipFuncSetAttribute((const void*)k_edge<256, false, 1, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-                    attr = true;
-                }
-                EdgeArgs b = a;
-                if constexpr (ABL & 16) {
-                    if (!g_trace) hipMalloc(reinterpret_cast<void**>(&g_trace), sizeof(long long) * 32 * 4096);
-                    if (a.n_wg > 4096) return;
-                    b.trace = g_trace; g_trace_wg = a.n_wg;
-                }
-                hipLaunchKernelGGL((k_edge<256, false, 1, ABL>), grid, block, lds, s, b);
-            };
-            switch (abl) {
-                case 1: run(std::integral_constant<int, 1>{}); return HD_OK;
-                case 2: run(std::integral_constant<int, 2>{}); return HD_OK;
-                case 4: run(std::integral_constant<int, 4>{}); return HD_OK;
-                case 8: run(std::integral_constant<int, 8>{}); return HD_OK;
-                case 15: run(std::integral_constant<int, 15>{}); return HD_OK;
-                case 16: run(std::integral_constant<int, 16>{}); return HD_OK;
-                case 18: run(std::integral_constant<int, 18>{}); return HD_OK;
-                case 20: run(std::integral_constant<int, 20>{}); return HD_OK;
-                case 24: run(std::integral_constant<int, 24>{}); return HD_OK;
-                case 30: run(std::integral_constant<int, 30>{}); return HD_OK;
-                default: break;
-            }
-        }
+        if (h->ablate && prec == 1 && !coord && launch_edge_ablated(h, a, s)) return HD_OK;
     }
-    if constexpr (H >= 256) {
-        // Experimental (HD_EDGE_PIPE=1): persistent one-wave-per-SIMD kernel with the previous tile's epilogue folded
-        // into the MFMA loop.  Correct (passes the whole GPU suite) but 124 us vs 103 us for k_edge on MI355X: a single
-        // wavefront issues at most one instruction per ~4 cycles and this stream needs ~10 per MFMA.
-        static int pipe = -1;
-        if (pipe < 0) { const char* e = getenv("HD_EDGE_PIPE"); pipe = e ? atoi(e) : 0; }
-        if (prec == 1 && pipe) {
-            const dim3 pgrid(std::min(a.n_wg, std::max(1, g_edge_grid / 2)));
-            const int plds = edge_p_lds_bytes<H>();
-            static int ptrace = -1;
-            if (ptrace < 0) { const char* e = getenv("HD_EDGE_PTRACE"); ptrace = e ? atoi(e) : 0; }
-            if (ptrace && !coord) {
-                static bool attr = false;
-                if (!attr) { hipFuncSetAttribute((const void*)k_edge_p<H, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, plds); attr = true; }
-                EdgeArgs b = a;
-                if (!g_trace) hipMalloc(reinterpret_cast<void**>(&g_trace), sizeof(long long) * 32 * 4096);
-                b.trace = g_trace; g_trace_wg = (int)pgrid.x;
-                hipLaunchKernelGGL((k_edge_p<H, false, true>), pgrid, block, plds, s, b);
-                return HD_OK;
-            }
-            if (coord) hipLaunchKernelGGL((k_edge_p<H, true>), pgrid, block, plds, s, a);
-            else hipLaunchKernelGGL((k_edge_p<H, false>), pgrid, block, plds, s, a);
-            return HD_OK;
-        }
-    }
+#endif
     if (prec == 0) {
         if (coord) hipLaunchKernelGGL((k_edge<H, true, 0>), grid, block, lds, s, a);
         else hipLaunchKernelGGL((k_edge<H, false, 0>), grid, block, lds, s, a);
@@ -726,7 +834,7 @@ static int launch_edge_h(int prec, bool coord, const EdgeArgs& a, hipStream_t s)
     return HD_OK;
 }
 
-// Raise the dynamic-LDS limit of both edge kernels for this device (done once, at hd_create: it is
+// Raise the dynamic-LDS limit of the edge kernels for this device (done once, at hd_create: it is
 // not allowed while a stream is capturing).
 template <int H>
 static int prepare_edge_h() {
@@ -735,15 +843,11 @@ static int prepare_edge_h() {
     HIP_TRY(hipFuncSetAttribute((const void*)k_edge<H, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIP_TRY(hipFuncSetAttribute((const void*)k_edge<H, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIP_TRY(hipFuncSetAttribute((const void*)k_edge<H, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    if constexpr (H >= 256) {
-        HIP_TRY(hipFuncSetAttribute((const void*)k_edge_p<H, true>, hipFuncAttributeMaxDynamicSharedMemorySize, edge_p_lds_bytes<H>()));
-        HIP_TRY(hipFuncSetAttribute((const void*)k_edge_p<H, false>, hipFuncAttributeMaxDynamicSharedMemorySize, edge_p_lds_bytes<H>()));
-    }
     return HD_OK;
 }
 
-static int prepare_kernels(int H) {
-    switch (H) {
+static int prepare_kernels(hd_handle* h) {
+    switch (h->H) {
         case 32: HD_TRY(prepare_node_h<32>()); return prepare_edge_h<32>();
         case 64: HD_TRY(prepare_node_h<64>()); return prepare_edge_h<64>();
         case 128: HD_TRY(prepare_node_h<128>()); return prepare_edge_h<128>();
@@ -755,10 +859,10 @@ static int edge(hd_handle* h, bool coord, const EdgeArgs& a, hipStream_t s) {
     if (a.n_wg == 0) return HD_OK;
     ProfScope ps(h, s, 0);
     switch (h->H) {
-        case 32: return launch_edge_h<32>(h->cfg.precision, coord, a, s);
-        case 64: return launch_edge_h<64>(h->cfg.precision, coord, a, s);
-        case 128: return launch_edge_h<128>(h->cfg.precision, coord, a, s);
-        default: return launch_edge_h<256>(h->cfg.precision, coord, a, s);
+        case 32: return launch_edge_h<32>(h, coord, a, s);
+        case 64: return launch_edge_h<64>(h, coord, a, s);
+        case 128: return launch_edge_h<128>(h, coord, a, s);
+        default: return launch_edge_h<256>(h, coord, a, s);
     }
 }
 
@@ -815,7 +919,7 @@ static int forward_impl(hd_handle* h, hd_topology* t, const float* xh, const flo
                 EdgeArgs e;
                 std::memset(&e, 0, sizeof(e));
                 e.AB = ab_cur; e.wrd = W + w.wrd; e.W2img = W + w.w2_img; e.b2 = W + w.b2; e.wa = W + w.wa;
-                e.ei = t->ei; e.ej = t->ej; e.eseg = t->eseg; e.tile_pbase = t->tile_pbase; e.tile_nseg = t->tile_nseg;
+                e.ei = t->ei; e.ej = t->ej; e.eseg = t->eseg; e.seg_part = t->seg_part; e.tile_nseg = t->tile_nseg;
                 e.xcur = t->xcur; e.x0 = t->x0; e.part = coord ? t->xpart : t->part; e.ba = w.ba;
                 e.norm_constant = c.norm_constant; e.coords_range = range; e.attention = c.attention;
                 e.use_tanh = c.tanh; e.n_tiles = t->n_tiles; e.n_wg = t->n_wg;
@@ -919,11 +1023,11 @@ static NoiseSrc make_noise(const float* raw_x, const float* raw_h, int rows, uin
 
 static int step_impl(hd_handle* h, hd_topology* t, const float* zt, const float* eps, const float* coef, int coef_rows,
                      const NoiseSrc& ns, int mol, float* zs, int out_stride, const int* step_ptr,
-                     const uint32_t* draw_ptr, uint32_t draw0, hipStream_t s) {
+                     const uint32_t* draw_ptr, uint32_t draw0, hipStream_t s, const unsigned long long* base_ptr = nullptr) {
     ProfScope ps(h, s, 2);
     StepArgs a;
     a.zt = zt; a.eps = eps; a.coef = coef; a.nm = t->nm_bytes; a.zs = zs; a.noise = ns; a.draw_ptr = draw_ptr;
-    a.step_ptr = step_ptr; a.draw0 = draw0; a.coef_rows = coef_rows; a.B = t->B; a.N = t->N; a.D = h->D; a.F = h->F;
+    a.step_ptr = step_ptr; a.base_ptr = base_ptr; a.draw0 = draw0; a.coef_rows = coef_rows; a.B = t->B; a.N = t->N; a.D = h->D; a.F = h->F;
     a.mol = mol; a.out_stride = out_stride;
     hipLaunchKernelGGL(k_post_step, dim3(t->B), dim3(256), (size_t)a.mol * a.D * sizeof(float), s, a);
     HIP_TRY(hipGetLastError());
@@ -992,6 +1096,7 @@ extern "C" int hd_set_schedule(hd_handle* h, int T, const float* tau, const floa
     HD_TRY(dev_upload(&h->d_tau, h->tau_h));
     HD_TRY(dev_upload(&h->d_coef, h->coef_h));
     h->T = T;
+    h->sched_gen++;                            // captured graphs hold the old table addresses
     return HD_OK;
 }
 
@@ -1025,46 +1130,63 @@ extern "C" int hd_sample_loop(hd_handle* h, hd_topology* topo, float* z, const f
         }
         return HD_OK;
     }
-    // hipGraph: capture one step whose step index / draw / time live in device memory, replay it.
-    const int was_prof = h->prof;
-    h->prof = 0;
-    const int s0 = s_hi - 1;
-    const uint32_t d0 = draw0;
-    HIP_TRY(hipMemcpyAsync(h->d_step, &s0, sizeof(int), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(h->d_draw, &d0, sizeof(uint32_t), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(h->d_tcur, h->d_tau + s0 + 1, sizeof(float), hipMemcpyDeviceToDevice, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
-    // The legacy NULL stream cannot be captured: everything queued on the caller's stream is complete
-    // here (sync above), so run capture + replays on an internal stream and sync it before returning.
-    if (s == nullptr) {
+    // hipGraph: one captured step whose step index / draw / time / sample base live in device memory, replayed
+    // nsteps times.  The instantiated graph is kept with the topology and reused by later calls (it works on
+    // library-owned copies of z and context, so nothing it has baked in moves between calls); it is rebuilt only when
+    // something in GraphKey changes.  No host synchronisation anywhere: the caller's stream is ordered against the
+    // replay stream with events.
+    const size_t zbytes = (size_t)topo->B * topo->N * h->D * sizeof(float);
+    const size_t cbytes = (size_t)topo->B * topo->N * h->cfg.context_node_nf * sizeof(float);
+    hipStream_t rs = s;
+    if (s == nullptr) {                                  // the legacy NULL stream cannot be captured
         if (!h->own_stream) HIP_TRY(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
-        s = h->own_stream;
+        rs = h->own_stream;
+        HIP_TRY(hipEventRecord(h->ev_in, s));
+        HIP_TRY(hipStreamWaitEvent(rs, h->ev_in, 0));
     }
-    HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-    int rc = forward_impl(h, topo, z, h->d_tcur, 1, context, mol_shape < 0 ? -1 : mol, topo->eps, s);
-    if (rc == HD_OK) {
-        NoiseSrc ns = make_noise(raw_x, raw_h, noise_rows, seed, sample_id_base, draw0, share);
-        rc = step_impl(h, topo, z, topo->eps, h->d_coef, 1, ns, mol, z, topo->N, h->d_step, h->d_draw, draw0, s);
+    GraphKey key;
+    key.raw_x = raw_x; key.raw_h = raw_h; key.has_ctx = context ? 1 : 0; key.mol_shape = mol_shape < 0 ? -1 : mol;
+    key.noise_rows = noise_rows; key.T = T; key.s_hi = raw_x ? s_hi : 0; key.seed = seed; key.weights_gen = h->weights_gen; key.sched_gen = h->sched_gen;
+    if (topo->gexec && !(topo->gkey == key)) {
+        HIP_TRY(hipStreamSynchronize(rs));               // a replay of the stale graph may still be running
+        hipGraphExecDestroy(topo->gexec);
+        topo->gexec = nullptr;
     }
-    if (rc == HD_OK) hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, s, h->d_step, h->d_draw, h->d_tcur, h->d_tau);
-    hipError_t ce = hipStreamEndCapture(s, &graph);
-    h->prof = was_prof;
-    if (rc != HD_OK) { if (graph) hipGraphDestroy(graph); return rc; }
-    if (ce != hipSuccess) return fail(HD_E_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
-    hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-    if (ie != hipSuccess) { hipGraphDestroy(graph); return fail(HD_E_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ie)); }
-    for (int k = 0; k < nsteps; ++k) {
-        hipError_t le = hipGraphLaunch(exec, s);
-        if (le != hipSuccess) {
-            hipGraphExecDestroy(exec); hipGraphDestroy(graph);
-            return fail(HD_E_HIP, std::string("hipGraphLaunch: ") + hipGetErrorString(le));
+    if (!topo->gexec) {
+        const int was_prof = h->prof;
+        h->prof = 0;
+        hipGraph_t graph = nullptr;
+        HIP_TRY(hipStreamBeginCapture(rs, hipStreamCaptureModeThreadLocal));
+        int rc = forward_impl(h, topo, topo->zbuf, h->d_tcur, 1, context ? topo->ctxbuf : nullptr, mol_shape < 0 ? -1 : mol,
+                              topo->eps, rs);
+        if (rc == HD_OK) {
+            NoiseSrc ns = make_noise(raw_x, raw_h, noise_rows, seed, 0, draw0, share);
+            rc = step_impl(h, topo, topo->zbuf, topo->eps, h->d_coef, 1, ns, mol, topo->zbuf, topo->N, h->d_step, h->d_draw,
+                           draw0, rs, h->d_base);
         }
+        if (rc == HD_OK) hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, rs, h->d_step, h->d_draw, h->d_tcur, h->d_tau);
+        const hipError_t ce = hipStreamEndCapture(rs, &graph);
+        h->prof = was_prof;
+        if (rc != HD_OK) { if (graph) hipGraphDestroy(graph); return rc; }
+        if (ce != hipSuccess) return fail(HD_E_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
+        const hipError_t ie = hipGraphInstantiate(&topo->gexec, graph, nullptr, nullptr, 0);
+        hipGraphDestroy(graph);
+        if (ie != hipSuccess) { topo->gexec = nullptr; return fail(HD_E_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ie)); }
+        topo->gkey = key;
     }
-    HIP_TRY(hipStreamSynchronize(s));
-    hipGraphExecDestroy(exec);
-    hipGraphDestroy(graph);
+    HIP_TRY(hipMemcpyAsync(topo->zbuf, z, zbytes, hipMemcpyDeviceToDevice, rs));
+    if (context) HIP_TRY(hipMemcpyAsync(topo->ctxbuf, context, cbytes, hipMemcpyDeviceToDevice, rs));
+    hipLaunchKernelGGL(k_loop_state, dim3(1), dim3(1), 0, rs, h->d_step, h->d_draw, h->d_tcur, h->d_base, h->d_tau,
+                       s_hi - 1, draw0, (unsigned long long)sample_id_base);
+    for (int k = 0; k < nsteps; ++k) {
+        const hipError_t le = hipGraphLaunch(topo->gexec, rs);
+        if (le != hipSuccess) return fail(HD_E_HIP, std::string("hipGraphLaunch: ") + hipGetErrorString(le));
+    }
+    HIP_TRY(hipMemcpyAsync(z, topo->zbuf, zbytes, hipMemcpyDeviceToDevice, rs));
+    if (rs != s) {
+        HIP_TRY(hipEventRecord(h->ev_out, rs));
+        HIP_TRY(hipStreamWaitEvent(s, h->ev_out, 0));
+    }
     return HD_OK;
 }
 

@@ -9,8 +9,11 @@
 //   M[e][c]   = silu(sum_k P[e][k] * W2[c][k] + b2[c])                 (fp32 MFMA, W2 streamed via LDS)
 //   GCL  : att_e = sigmoid(wa.M[e] + ba);  partial[i] += M[e]*att_e    (egnn_new.py:35-56)
 //   COORD: phi_e = w7.M[e]; trans = u_ij * tanh(phi_e) * range         (egnn_new.py:91-104)
-// Rows of a tile are consecutive entries of the edge list (sorted by receiving node i); a tile may
-// hold several receiving nodes ("segments") and a node's edges may span tiles ("parts").
+// Rows of a tile are entries of one molecule's edge list (sorted by receiving node i) - or the short tails of several
+// molecules at 4-row-aligned offsets; a tile may hold several receiving nodes ("segments") and a node's edges may
+// span tiles ("parts").  Where a molecule's edges are cut into tiles depends on that molecule alone, and the per-node
+// sums below are invariant under 4-row shifts of a piece inside a tile, so a sample's bits do not depend on its
+// batch neighbours (hd_topology_create).
 
 struct EdgeArgs {
     const float* AB;        // [M_pad][2H]: cols <H: W1a.h+b1 ; cols >=H: W1b.h
@@ -21,7 +24,7 @@ struct EdgeArgs {
     const int* ei;          // [E_pad] receiving node (compact)
     const int* ej;          // [E_pad] sending node
     const uint8_t* eseg;    // [E_pad] segment index inside the tile, 255 = padding row
-    const int* tile_pbase;  // [n_tiles] first part id of the tile
+    const int* seg_part;    // [n_tiles][32] part id of each segment of the tile (node-major ids, see hd_topology_create)
     const int* tile_nseg;   // [n_tiles]
     const float* xcur;      // [M_pad][4] coordinates at block start
     const float* x0;        // [M_pad][4] coordinates at network input
@@ -137,7 +140,8 @@ constexpr unsigned frag_off_f32(int u) { return (unsigned)(u * 64 * 16); }
 //   8 = no AB row gathers, 16 = record per-wave cycle stamps + HW placement (hd_debug_edge_trace, scratch/edge_trace.py)
 //
 // One workgroup = one 128-edge workgroup-tile (4 wavefronts x 32 edges).  (A persistent form that walks several
-// tiles per workgroup was measured no faster and spilled; the pipelined one-wave-per-SIMD form is k_edge_p.)
+// tiles per workgroup was measured no faster and spilled; so was the pipelined one-wave-per-SIMD form of round 1,
+// scratch/experiments/k_edge_pipelined.hpp.)
 template <int H, bool COORD, int PREC, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
     constexpr int NCT = H / 32;          // 32-column tiles
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
     const float ex = yi[0] - yj[0], ey = yi[1] - yj[1], ez = yi[2] - yj[2];
     const float d0 = ex * ex + ey * ey + ez * ez;
     const uint32_t segb_t = segb;
-    const int pbase = tile_ok ? a.tile_pbase[tile] : 0;     // requested here, used in the epilogue
+    const int pid_l = tile_ok ? a.seg_part[tile * 32 + n] : 0;   // part id of segment n; requested here, used in the epilogue
     const int nseg = tile_ok ? a.tile_nseg[tile] : 0;
     if (hh == 0) reinterpret_cast<uint8_t*>(seg_s)[n] = (uint8_t)segb_t;
 
@@ -556,7 +560,7 @@ __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
             float ws[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) ws[r] = (sg[r] == s) ? w[r] : 0.0f;
-            float* dst = a.part + (size_t)(pbase + s) * H + n;
+            float* dst = a.part + (size_t)__builtin_amdgcn_readlane(pid_l, s) * H + n;
             float sums[NCT];
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
@@ -606,7 +610,7 @@ __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
                 if (sb[rr] == lane) { sx += tr[rr * 3]; sy += tr[rr * 3 + 1]; sz += tr[rr * 3 + 2]; }
             }
             f32x4 o = {sx, sy, sz, 0.f};
-            *reinterpret_cast<f32x4*>(a.part + (size_t)(pbase + lane) * 4) = o;
+            *reinterpret_cast<f32x4*>(a.part + (size_t)pid_l * 4) = o;      // lane < nseg <= 32: pid_l is segment `lane`'s id
         }
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");

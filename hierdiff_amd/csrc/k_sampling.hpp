@@ -190,6 +190,7 @@ struct StepArgs {
     NoiseSrc noise;
     const uint32_t* draw_ptr;   // optional device-side draw counter (graph replay); overrides noise.draw
     const int* step_ptr;        // optional device-side step index into coef (graph replay)
+    const unsigned long long* base_ptr;   // optional device-side first global sample id (graph replay); overrides noise.sample_base
     uint32_t draw0;             // draw index of the first replayed step (raw-noise offset base)
     int coef_rows, B, N, D, F, mol, out_stride;
 };
@@ -213,6 +214,7 @@ __global__ __launch_bounds__(256) void k_post_step(StepArgs a) {
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
     NoiseSrc ns = a.noise;
+    if (a.base_ptr) ns.sample_base = *a.base_ptr;
     if (a.draw_ptr) {
         ns.draw = *a.draw_ptr;
         if (ns.raw_x) {
@@ -359,7 +361,13 @@ __global__ void k_noise(NoiseArgs a) {
     }
 }
 
-// graph-replay helper: advances the device-side step / draw counters after each captured step
+// graph-replay helpers: k_loop_state initialises the device-side step / draw / time / sample-base words (values ride
+// in the kernel arguments, so no host buffer has to outlive the call), k_advance moves them on after each captured step
+__global__ void k_loop_state(int* step, uint32_t* draw, float* t_cur, unsigned long long* base, const float* tau,
+                             int s0, uint32_t d0, unsigned long long b0) {
+    *step = s0; *draw = d0; *t_cur = tau[s0 + 1]; *base = b0;
+}
+
 __global__ void k_advance(int* step, uint32_t* draw, float* t_cur, const float* tau) {
     int s = *step - 1;
     *step = s;

@@ -130,10 +130,27 @@ def evaluate_gamma(gamma_module: torch.nn.Module, t: torch.Tensor) -> torch.Tens
     batch size, CPU vs GPU), and sigma2_{t|s} - itself a difference of neighbouring gammas - moves by
     ~1% between machines.  The reference inherits that irreproducibility; evaluating in fp64 and
     rounding once gives the same table everywhere and sits inside the reference's own spread."""
-    import copy
     with torch.no_grad():
-        m64 = copy.deepcopy(gamma_module).to("cpu").double()
-        return m64(t.detach().to("cpu", torch.float64)).to(torch.float32)
+        return _fp64_twin(gamma_module)(t.detach().to("cpu", torch.float64)).to(torch.float32)
+
+
+_TWINS: "dict[int, tuple]" = {}
+
+
+def _fp64_twin(gamma_module: torch.nn.Module) -> torch.nn.Module:
+    """CPU fp64 copy of a schedule module, rebuilt only when one of its tensors changed (the reference-style
+    per-step API calls evaluate_gamma twice per diffusion step)."""
+    import copy
+    import weakref
+    key = tuple((p.data_ptr(), p._version, p.device) for p in gamma_module.state_dict(keep_vars=True).values())
+    hit = _TWINS.get(id(gamma_module))
+    if hit is not None and hit[0]() is gamma_module and hit[1] == key:
+        return hit[2]
+    twin = copy.deepcopy(gamma_module).to("cpu").double()
+    if len(_TWINS) > 16:
+        _TWINS.clear()
+    _TWINS[id(gamma_module)] = (weakref.ref(gamma_module), key, twin)
+    return twin
 
 
 def decode_coefficients(gamma_0: torch.Tensor) -> torch.Tensor:

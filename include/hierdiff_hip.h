@@ -11,7 +11,8 @@
  *     (thread-local).  No exceptions or aborts cross the ABI.  Kernel faults surface at the
  *     caller's next synchronisation.
  *   - one handle per (device, stream of use); calls on one handle must be serialised by the
- *     caller; distinct handles are independent.
+ *     caller; distinct handles are independent: the library keeps no process-global mutable
+ *     state besides the thread-local hd_last_error() text.
  *   - the handle OWNS a repacked device copy of the weights; a topology OWNS its index tables
  *     and activation workspace; the caller owns every tensor it passes in.
  *
@@ -39,7 +40,7 @@
 extern "C" {
 #endif
 
-#define HD_ABI_VERSION 1
+#define HD_ABI_VERSION 2
 
 #define HD_OK 0
 #define HD_E_INVALID (-1)      /* bad argument / unsupported configuration */
@@ -67,9 +68,10 @@ typedef struct hd_config {
     float normalization_factor;
     float coords_range;          /* EGNN default 30; per-block range = coords_range / n_layers */
     int32_t precision;           /* matrix-core arithmetic of the H x H contractions:
-                                    0 = exact fp32 (v_mfma_f32_32x32x2_f32),
-                                    1 = "bf16x3": fp32 operands split into bf16 head + tail, 3 bf16 MFMAs with
-                                        fp32 accumulation (~1e-6 relative on a 256-term dot product) */
+                                    0 = exact fp32 (v_mfma_f32_32x32x2_f32) - what the reference computes in,
+                                        and the default of the Python mirror,
+                                    1 = "bf16x3" (opt-in): fp32 operands split into bf16 head + tail, 3 bf16 MFMAs
+                                        with fp32 accumulation (~1e-6 relative on a 256-term dot product) */
 } hd_config;
 
 int hd_version(void);
@@ -91,10 +93,21 @@ int hd_set_weights(hd_handle* h, const float* blob, long long n, int on_device, 
 
 /* Build index tables for one (node_mask, edge_mask) pair.  Masks are HOST byte arrays
  * (0 = false): node_mask [B*N], edge_mask [B*N*N] row-major (b, i, j) or NULL for the canonical
- * mask node_mask[i] & node_mask[j] & (i != j). */
+ * mask node_mask[i] & node_mask[j] & (i != j).  The tables are laid out per molecule, so the bits
+ * computed for a molecule do not depend on the rest of the batch (sharding a batch over ranks
+ * reproduces the single-GPU result exactly). */
 int hd_topology_create(hd_handle* h, const uint8_t* node_mask, const uint8_t* edge_mask, int B, int N,
                        hd_topology** out);
 int hd_topology_destroy(hd_topology* t);
+/* Host-only view of the edge-tile tables hd_topology_create builds for the same masks (no device needed): edges are
+ * packed in 32-row tiles per molecule - cuts at molecule-relative multiples of 32, remainders of neighbouring
+ * molecules share a tile at 4-row-aligned offsets - so the rows summed into one partial sum ("part") of a node
+ * depend on its molecule alone.  counts5 = {active nodes, valid edges, tiles, parts, rows = 32 * tiles}; the
+ * output arrays may be NULL: ei/ej [rows] receiving/sending compact node id, eseg [rows] segment of the row inside
+ * its tile (255 = padding row), seg_part [rows] part id per (tile, segment), tile_nseg [tiles], pstart [nodes+1]
+ * (a node's parts are pstart[i] .. pstart[i+1]-1, in the order consumers add them). */
+int hd_topology_layout(const uint8_t* node_mask, const uint8_t* edge_mask, int B, int N, long long* counts5,
+                       int* ei, int* ej, uint8_t* eseg, int* seg_part, int* tile_nseg, int* pstart);
 /* info[0..5] = {B, N, active nodes, valid edges, edge tiles (32 edges), aggregation parts} */
 int hd_topology_info(const hd_topology* t, long long* info6);
 
@@ -144,7 +157,9 @@ int hd_set_schedule(hd_handle* h, int T, const float* tau, const float* coef4);
  * per step one hd_egnn_forward at tau[s+1] and one hd_posterior_step.
  *   raw_x/raw_h  device [(s_hi-s_lo), noise_rows, mol, 3|F] in step order (first = s_hi-1), or NULL
  *                to use the counter-based generator with draw = T - s (draw 0 is z_T).
- *   use_graph    capture one step into a hipGraph and replay it (0 = plain launches). */
+ *   use_graph    replay each step from a captured hipGraph (0 = plain launches).  The instantiated graph is
+ *                cached with the topology and reused by later calls with the same arguments (any z / context /
+ *                sample_id_base); it is stream-ordered like every other call - no host synchronisation. */
 int hd_sample_loop(hd_handle* h, hd_topology* topo, float* z, const float* context, int mol_shape,
                    int s_hi, int s_lo, const float* raw_x, const float* raw_h, int noise_rows,
                    uint64_t seed, uint64_t sample_id_base, int use_graph, void* stream);
@@ -162,11 +177,12 @@ float hd_philox_normal_host(uint64_t seed, uint64_t sample_id, uint32_t draw, ui
 int hd_profile_enable(hd_handle* h, int on);
 int hd_profile_read(hd_handle* h, double* ms3, long long* launches3);
 
-/* Debug aid (no reference counterpart): per-wave cycle stamps of the most recent traced edge-kernel launch
- * (environment HD_ABLATE with bit 16 set; H = 256, bf16x3, GCL variant).  32 int64 per workgroup =
- * 4 waves x {start|HW_ID<<48, loop start|XCC_ID<<48, loop end, end, 3 epilogue stamps, segments}.
- * Returns the number of workgroups copied (0 if nothing was traced). */
-int hd_debug_edge_trace(long long* out, int max_wg);
+/* Debug aid (no reference counterpart), live only in a measurement build of the library
+ * (python -m hierdiff_amd.build --debug-kernels; the product build returns 0): per-wave cycle stamps of the
+ * handle's most recent traced edge-kernel launch (environment HD_ABLATE with bit 16 set at hd_create; H = 256,
+ * bf16x3, GCL variant).  32 int64 per workgroup = 4 waves x {start|HW_ID<<48, loop start|XCC_ID<<48, loop end,
+ * end, 3 epilogue stamps, segments}.  Returns the number of workgroups copied (0 if nothing was traced). */
+int hd_debug_edge_trace(hd_handle* h, long long* out, int max_wg);
 
 #ifdef __cplusplus
 }

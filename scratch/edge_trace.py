@@ -1,4 +1,5 @@
-"""Per-wave cycle stamps of one k_edge launch (HD_ABLATE with bit 16): where does a wave-tile's time go?"""
+"""Per-wave cycle stamps of one k_edge launch (HD_ABLATE with bit 16): where does a wave-tile's time go?
+Needs the measurement build of the library: python -m hierdiff_amd.build --debug-kernels (rebuild with --force afterwards)."""
 import os, sys, ctypes, numpy as np, torch
 os.environ.setdefault("HD_ABLATE", "16")
 sys.path.insert(0, '.')
@@ -18,7 +19,7 @@ torch.cuda.synchronize()
 lib = _lib.load()
 buf = np.zeros(32 * 4096, dtype=np.int64)
 lib.hd_debug_edge_trace.restype = ctypes.c_int
-n = lib.hd_debug_edge_trace(buf.ctypes.data_as(ctypes.c_void_p), 4096)
+n = lib.hd_debug_edge_trace(dyn._handle(), buf.ctypes.data_as(ctypes.c_void_p), 4096)
 raw8 = buf[: n * 32].reshape(n, 4, 8).copy()         # [wg][wave][stamp]
 raw = raw8[..., :4].copy()
 hw = (raw[..., 0] >> 48) & 0xffff; xcc = (raw[..., 1] >> 48) & 0xf
