@@ -556,18 +556,34 @@ __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
             w[r] = (sg[r] != 255) ? att : 0.0f;
         }
         if constexpr (ABL & 16) ts5 = __builtin_readcyclecounter();
+        // A NaN row (a molecule whose input carries a NaN; also padding rows, which recompute node 0's self edge) would
+        // poison the other segments of its tile through 0 * NaN in the masked sums below.  The reference keeps
+        // molecules apart (only the velocity is reset batch-wide, en_dynamics.py:109-111), so a tile that holds a NaN
+        // row dot takes a select-based form of the same sums: identical bits for finite rows, NaN stays inside its
+        // own segments.
+        const bool tile_has_nan = __builtin_amdgcn_ballot_w64(rowdot != rowdot) != 0;
         for (int s = 0; s < nseg; ++s) {
             float ws[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) ws[r] = (sg[r] == s) ? w[r] : 0.0f;
             float* dst = a.part + (size_t)__builtin_amdgcn_readlane(pid_l, s) * H + n;
             float sums[NCT];
+            if (__builtin_expect(tile_has_nan, 0)) {
 #pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) {
-                float sum = 0.f;
+                for (int ct = 0; ct < NCT; ++ct) {
+                    float sum = 0.f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) sum = __builtin_fmaf(ws[r], acc[ct][r], sum);
-                sums[ct] = sum;
+                    for (int r = 0; r < 16; ++r) sum = (sg[r] == s) ? __builtin_fmaf(ws[r], acc[ct][r], sum) : sum;
+                    sums[ct] = sum;
+                }
+            } else {
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) {
+                    float sum = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sum = __builtin_fmaf(ws[r], acc[ct][r], sum);
+                    sums[ct] = sum;
+                }
             }
             // add the two halves of the wavefront (lane n + 32 hh holds rows 4hh.. of column n)
             if constexpr (NCT % 4 == 0) {

@@ -135,6 +135,8 @@ class DiffusionQM9(_Base):
         if [float(v) for v in self.norm_values] != [1.0, 1.0, 1.0] or (self.norm_biases[1] or 0.0) != 0.0:
             raise NotImplementedError("only norm_values [1,1,1] / norm_biases [None,0,0] (ddpmgblur.yaml:10-11)")
         self.register_buffer('buffer', torch.zeros(1))
+        if _get(cfg, "noise_schedule") != 'learned':
+            self.check_issues_norm_values()
         self.data_augmentation = _get(cfg, "data_augmentation", False)
         analyze = _get(cfg, "analyze", None)
         if isinstance(analyze, dict):
@@ -154,6 +156,14 @@ class DiffusionQM9(_Base):
         self.schedule_gammas = None     # optional [T+1] gamma grid overriding the network (replay a run)
         self._sched_key = None
         self._sched = None
+
+    def check_issues_norm_values(self, num_stdevs=8):
+        """diffusion_qm9.py:117-131 (predefined schedules only)."""
+        sigma_0 = float(torch.sqrt(torch.sigmoid(self.gamma(torch.zeros((1, 1))))).reshape(-1)[0])
+        max_norm_value = max(self.norm_values[1], self.norm_values[2])
+        if sigma_0 * num_stdevs > 1. / max_norm_value:
+            raise ValueError(f'Value for normalization value {max_norm_value} probably too large with sigma_0 '
+                             f'{sigma_0:.5f} and 1 / norm_value = {1. / max_norm_value}')
 
     # ------------------------------------------------------------------ schedule algebra (reference API)
     def phi(self, x, t, node_mask, edge_mask, context, mol_shape=None):
@@ -188,9 +198,8 @@ class DiffusionQM9(_Base):
 
     # ------------------------------------------------------------------ loss / NLL, forward value (reference API)
     # diffusion_qm9.py:160-172, 206-292, 460-751.  The network calls go through the HIP dynamics (per-row t); the
-    # few element-wise terms around them are torch ops on the same device.  There is no backward pass in this
-    # library: everything runs under no_grad and the results do not require grad (training on MI355X is the
-    # "next" row 2 of SURVEY.md section 8f).
+    # few element-wise terms around them are torch ops on the same device.  These entry points return values only
+    # (no_grad).
     def subspace_dimensionality(self, node_mask):
         return (torch.sum(node_mask.squeeze(2), dim=1) - 1) * self.n_dims
 
@@ -260,13 +269,18 @@ class DiffusionQM9(_Base):
     @torch.no_grad()
     def compute_loss(self, x, h, node_mask, edge_mask, context, t0_always, mol_shape=None,
                      t_int=None, eps=None, eps0=None, gammas=None):
-        """Forward value of the variational bound estimator / simple loss (diffusion_qm9.py:530-673).  `t_int`
-        [B,1], `eps`, `eps0` [B,N,3+F] replay recorded draws (otherwise torch.randint / torch.randn on x.device, in
-        the reference's order); `gammas` replays schedule values (keys gamma_s, gamma_t, gamma_0, gamma_T)."""
-        if self.pocket or (mol_shape is not None and mol_shape != x.size(1)):
-            raise NotImplementedError("loss with fixed pocket nodes is not implemented (sampling is)")
-        B, N = x.size(0), x.size(1)
+        """Forward value of the variational bound estimator / simple loss (diffusion_qm9.py:530-673).  Nodes behind
+        `mol_shape` (pocket residues) are fixed: they enter the network un-noised and the loss covers the first
+        mol_shape nodes (:553-579).  `t_int` [B,1], `eps`, `eps0` [B,mol,3+F] replay recorded draws (otherwise
+        torch.randint / torch.randn on x.device, in the reference's order); `gammas` replays schedule values (keys
+        gamma_s, gamma_t, gamma_0, gamma_T)."""
+        B = x.size(0)
         dev = x.device
+        mol = x.size(1) if mol_shape is None else int(mol_shape)
+        x, x_fix = x[:, :mol], x[:, mol:]
+        h, h_fix = h[:, :mol], h[:, mol:]
+        node_mask_all = node_mask
+        node_mask = node_mask[:, :mol]
         nm = node_mask.to(torch.float32)
         if t_int is None:
             t_int = torch.randint(1 if t0_always else 0, self.T + 1, size=(B, 1), device=dev).float()
@@ -277,12 +291,15 @@ class DiffusionQM9(_Base):
         gamma_0 = self._gamma_rows(torch.zeros_like(t), "gamma_0", gammas)
         gamma_T = self._gamma_rows(torch.ones_like(t), "gamma_T", gammas)
         if eps is None:
-            eps = self.sample_combined_position_feature_noise(B, N, node_mask)
+            eps = self.sample_combined_position_feature_noise(B, mol, node_mask)
         eps = torch.as_tensor(eps, dtype=torch.float32, device=dev)
-        xh = torch.cat([x, h], dim=2)
+        xh = torch.cat([x, h], dim=2).to(torch.float32)
+        xh_fix = torch.cat([x_fix, h_fix], dim=2).to(torch.float32)
         self._check_mean_zero(x, node_mask)
         z_t = self.alpha(gamma_t, x) * xh + self.sigma(gamma_t, x) * eps
-        net_out = self.phi(z_t, t, node_mask, edge_mask, context, mol_shape=N)
+        self._check_mean_zero(z_t[:, :, :self.n_dims], node_mask)
+        z_t = torch.cat([z_t, xh_fix], dim=1)
+        net_out = self.phi(z_t, t, node_mask_all, edge_mask, context, mol_shape=mol)[:, :mol]
         error = self.compute_error(net_out, gamma_t, eps)
         l2_train = self.training and self.loss_type == 'l2'
         snr_weight = torch.ones_like(error) if l2_train else (self.SNR(gamma_s - gamma_t) - 1).view(-1)
@@ -293,14 +310,14 @@ class DiffusionQM9(_Base):
         kl_prior = self.kl_prior(xh, nm, gamma_T)
         if t0_always:
             if eps0 is None:
-                eps0 = self.sample_combined_position_feature_noise(B, N, node_mask)
+                eps0 = self.sample_combined_position_feature_noise(B, mol, node_mask)
             eps0 = torch.as_tensor(eps0, dtype=torch.float32, device=dev)
-            z_0 = self.alpha(gamma_0, x) * xh + self.sigma(gamma_0, x) * eps0
-            net0 = self.phi(z_0, torch.zeros_like(t), node_mask, edge_mask, context, mol_shape=N)
-            loss_term_0 = -self.log_pxh_given_z0_without_constants(x, h, z_0, gamma_0, eps0, net0, nm)
+            z_0 = torch.cat([self.alpha(gamma_0, x) * xh + self.sigma(gamma_0, x) * eps0, xh_fix], dim=1)
+            net0 = self.phi(z_0, torch.zeros_like(t), node_mask_all, edge_mask, context, mol_shape=mol)[:, :mol]
+            loss_term_0 = -self.log_pxh_given_z0_without_constants(x, h, z_0[:, :mol], gamma_0, eps0, net0, nm)
             loss = kl_prior + self.T * loss_t_larger_than_zero + neg_log_constants + loss_term_0
         else:
-            loss_term_0 = -self.log_pxh_given_z0_without_constants(x, h, z_t, gamma_t, eps, net_out, nm)
+            loss_term_0 = -self.log_pxh_given_z0_without_constants(x, h, z_t[:, :mol], gamma_t, eps, net_out, nm)
             loss_t = loss_term_0 * t_is_zero + (1 - t_is_zero) * loss_t_larger_than_zero
             estimator = loss_t if l2_train else (self.T + 1) * loss_t
             loss = kl_prior + estimator + neg_log_constants
@@ -318,20 +335,34 @@ class DiffusionQM9(_Base):
 
     @torch.no_grad()
     def forward(self, batch, **replay):
-        """`{"loss": mean NLL}` for a reference data batch (keys positions, atom_mask, edge_mask, node_feature and,
-        with a context model, context) - diffusion_qm9.py:701-751 without the pocket branch."""
+        """`{"loss": mean NLL}` for a reference data batch (keys positions, atom_mask, edge_mask, node_feature; with a
+        context model, context; with a pocket model, protein_pos, protein_feat, protein_feat_mask,
+        protein_edge_mask) - diffusion_qm9.py:701-751."""
+        x, node_mask, edge_mask, h = batch['positions'], batch['atom_mask'], batch['edge_mask'], batch["node_feature"]
+        mol_shape = None
         if self.pocket:
-            raise NotImplementedError("loss with fixed pocket nodes is not implemented (sampling is)")
-        x, node_mask = batch['positions'], batch['atom_mask']
+            mol_shape = x.shape[1]
+            x = torch.cat([x, batch["protein_pos"].to(x.dtype)], dim=1)
+            node_mask = torch.cat([node_mask, batch["protein_feat_mask"]], dim=1)
+            P = batch["protein_edge_mask"].shape[1]
+            em = torch.zeros(edge_mask.shape[0], mol_shape + P, mol_shape + P, dtype=edge_mask.dtype, device=edge_mask.device)
+            em[:, :mol_shape, :mol_shape] = edge_mask.view(-1, mol_shape, mol_shape)
+            em[:, mol_shape:, mol_shape:] = batch["protein_edge_mask"]
+            edge_mask = em
+            h = torch.cat([h, self.pocket_embed(batch["protein_feat"]).to(h.dtype)], dim=1)
         nm = node_mask.to(x.dtype)
-        bad = (x * (1 - nm)).abs().sum()
-        if self.debug_checks:
-            assert bad.item() < 1e-5, f'Error {bad.item()} too high'
-        x = x - (x.sum(1, keepdim=True) / nm.sum(1, keepdim=True)) * nm
+        if self.debug_checks:                       # models/utils.py:47-50
+            bad = (x * (1 - nm)).abs().sum().item()
+            assert bad < 1e-5, f'Error {bad} too high'
+        fix = x.size(1) if mol_shape is None else mol_shape
+        # remove_mean_with_mask(x, node_mask, fix_size=mol_shape): the mean of the first mol_shape nodes is taken off
+        # every valid node, pocket residues included (models/utils.py:51-56)
+        x = x - (x[:, :fix].sum(1, keepdim=True) / nm[:, :fix].sum(1, keepdim=True)) * nm
         context = batch['context'] if self.dynamics.context_node_nf > 0 else None
         bs, n_nodes, _ = x.size()
-        edge_mask = batch['edge_mask'].view(bs, n_nodes * n_nodes)
-        neg_log_pxh = self.nll(x, batch["node_feature"], node_mask, edge_mask, context=context, **replay)
+        edge_mask = edge_mask.reshape(bs, n_nodes * n_nodes)
+        self._check_masked(x, node_mask, "assert_correctly_masked")
+        neg_log_pxh = self.nll(x, h, node_mask, edge_mask, context=context, mol_shape=mol_shape, **replay)
         return {"loss": neg_log_pxh.mean(0)}
 
     # ------------------------------------------------------------------ HIP plumbing

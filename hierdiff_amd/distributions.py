@@ -26,6 +26,8 @@ class DistributionNodes(torch.nn.Module):
         return [self.n_nodes[i] for i in self.m.sample((n_samples,)).tolist()]
 
     def log_prob(self, batch_n_nodes: torch.Tensor) -> torch.Tensor:
+        # The reference indexes the probability vector with the node COUNTS themselves (models/distributions.py:94-101:
+        # `log_p[batch_n_nodes]`), not with their categorical index `self.keys[n]`; kept as is for drop-in parity
+        # (the sampler never calls it).
         assert batch_n_nodes.dim() == 1
-        idx = torch.tensor([self.keys[int(n)] for n in batch_n_nodes.tolist()], dtype=torch.long)
-        return torch.log(self.prob + 1e-30)[idx]
+        return torch.log(self.prob + 1e-30)[batch_n_nodes]

@@ -65,13 +65,14 @@ def import_reference():
     return DiffusionQM9
 
 
-def make_cfg(hidden_nf, n_layers, context_node_nf=0, normalization_factor=10, inv_sublayers=2, pocket=False):
+def make_cfg(hidden_nf, n_layers, context_node_nf=0, normalization_factor=10, inv_sublayers=2, pocket=False,
+             node_coarse_type="prop", noise_schedule="learned", loss_type="vlb", timesteps=1000):
     return AttrDict(
-        pocket=pocket, node_coarse_type="prop", loss_type="vlb", hcontinous=True,
-        noise_schedule="learned", timesteps=1000, norm_values=[1.0, 1.0, 1.0],
+        pocket=pocket, node_coarse_type=node_coarse_type, loss_type=loss_type, hcontinous=True,
+        noise_schedule=noise_schedule, timesteps=timesteps, norm_values=[1.0, 1.0, 1.0],
         norm_biases=[None, 0.0, 0.0], parametrization="eps", include_charges=True, dataset="qm9",
         data_augmentation=False,
-        pre_noise=AttrDict(noise_schedule="learned", timesteps=1000, precision=1e-4),
+        pre_noise=AttrDict(noise_schedule=noise_schedule, timesteps=timesteps, precision=1e-4),
         dynamics=AttrDict(in_node_nf=0, context_node_nf=context_node_nf, n_dims=3,
                           hidden_nf=hidden_nf, act_fn="silu", n_layers=n_layers, attention=True,
                           condition_time=True, tanh=True, mode="egnn_dynamics", norm_constant=0,
@@ -81,14 +82,20 @@ def make_cfg(hidden_nf, n_layers, context_node_nf=0, normalization_factor=10, in
     )
 
 
-def build_reference(DiffusionQM9, hidden_nf, n_layers, context_node_nf=0, seed=0, coord_gain=0.001, pocket=False):
-    cfg = make_cfg(hidden_nf, n_layers, context_node_nf, pocket=pocket)
+def build_reference(DiffusionQM9, hidden_nf, n_layers, context_node_nf=0, seed=0, coord_gain=0.001, pocket=False,
+                    node_coarse_type="prop", noise_schedule="learned", loss_type="vlb", timesteps=1000):
+    cfg = make_cfg(hidden_nf, n_layers, context_node_nf, pocket=pocket, node_coarse_type=node_coarse_type,
+                   noise_schedule=noise_schedule, loss_type=loss_type, timesteps=timesteps)
     with contextlib.redirect_stdout(io.StringIO()):
         model = DiffusionQM9(cfg)
-    sd_np = synthetic_state_dict(9, context_node_nf, hidden_nf, n_layers, 2, True, seed, coord_gain, pocket=pocket)
+    fin = (8 if node_coarse_type == "prop" else 3) + 1
+    sd_np = synthetic_state_dict(fin, context_node_nf, hidden_nf, n_layers, 2, True, seed, coord_gain, pocket=pocket)
+    if noise_schedule != "learned":           # the schedule is a constant table, not a set of weights
+        sd_np = {k: v for k, v in sd_np.items() if not k.startswith("gamma.")}
+        sd_np["gamma.gamma"] = model.gamma.gamma.detach().numpy().copy()
     model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd_np.items()})
     model.eval()
-    ocfg = orc.DynCfg(in_node_nf=9, context_node_nf=context_node_nf, hidden_nf=hidden_nf,
+    ocfg = orc.DynCfg(in_node_nf=fin, context_node_nf=context_node_nf, hidden_nf=hidden_nf,
                       n_layers=n_layers, normalization_factor=10.0)
     return model, orc.as_torch_sd(sd_np), ocfg
 
@@ -416,38 +423,286 @@ def fixture_nll(DiffusionQM9, name, hidden_nf, n_layers, seed, coord_gain, n_lis
     save(name, **out)
 
 
+def fixture_nodes_dist(name):
+    """F10: DistributionNodes (models/distributions.py:62-101) on the production histogram conf/analyze/GEOM.yaml:
+    key order, probabilities, draws under fixed torch seeds, log_prob."""
+    import yaml
+    sys.path.insert(0, REF)
+    from models.distributions import DistributionNodes  # type: ignore
+    with open(os.path.join(REF, "conf/analyze/GEOM.yaml")) as fh:
+        hist = yaml.load(fh, Loader=yaml.Loader)
+    d = DistributionNodes(hist)
+    out = {"keys": np.array(list(hist.keys()), np.int64), "counts": np.array(list(hist.values()), np.int64),
+           "prob": d.prob.numpy()}
+    for seed, n in ((2022, 256), (7, 64), (0, 2048)):
+        torch.manual_seed(seed)
+        out[f"draws_seed{seed}"] = np.array(d.sample(n), np.int64)
+    q = torch.tensor([0, 5, 66, 13])
+    out["log_prob_idx"] = q.numpy()
+    out["log_prob"] = d.log_prob(q).numpy()
+    save(name, **out)
+
+
+def fixture_predefined_schedules(name):
+    """F11: PredefinedNoiseSchedule lookup tables (models/noise_model.py:125-160) and lookups at off-grid times."""
+    sys.path.insert(0, REF)
+    from models.noise_model import PredefinedNoiseSchedule  # type: ignore
+    out = {}
+    t = torch.tensor([[0.0], [0.0004], [0.0006], [0.5], [0.99949], [1.0]])
+    for sched, T, prec in (("polynomial_2", 1000, 1e-4), ("cosine", 1000, 1e-4), ("polynomial_3", 500, 1e-5),
+                           ("polynomial_2", 6, 1e-4)):
+        with contextlib.redirect_stdout(io.StringIO()):
+            m = PredefinedNoiseSchedule(sched, T, prec)
+        tab = m.gamma.detach().numpy()
+        got = orc.predefined_gamma_table(sched, T, prec)
+        check(f"{name} {sched} T={T}", got, tab, tol=1e-7)
+        assert np.array_equal(got, tab), "oracle table must be bit-equal (same numpy ops)"
+        key = f"{sched}_T{T}"
+        out[key] = tab
+        out[key + "_lookup"] = m(t).detach().numpy()
+    out["lookup_t"] = t.numpy()
+    save(name, **out)
+
+
+def _run_chain(model, n_list, T, F, seed, pocket_cond=None):
+    """model.sample with N pinned and recorded randn draws; returns (res, raws)."""
+    model.nodes_dist.sample = lambda n: list(n_list)
+    B, N = len(n_list), max(n_list)
+    rng = np.random.Generator(np.random.PCG64(seed))
+    raws = [(torch.from_numpy(rng.standard_normal((B, N, 3)).astype(np.float32)),
+             torch.from_numpy(rng.standard_normal((B, N, F)).astype(np.float32))) for _ in range(T + 2)]
+    queue = [r for pair in raws for r in pair]
+    orig_randn = torch.randn
+
+    def fake_randn(size, device=None, **kw):
+        r = queue.pop(0)
+        assert tuple(r.shape) == tuple(size), (r.shape, size)
+        return r.clone()
+
+    torch.randn = fake_randn
+    try:
+        with torch.no_grad():
+            res = model.sample(B, "cpu")
+    finally:
+        torch.randn = orig_randn
+    assert not queue
+    return res, raws
+
+
+def _record_loss(model, x, h, nm, em, training, seed, preset_t=None, mol_shape=None):
+    """compute_loss with the reference's own draws recorded: returns (loss, info, draws, gammas)."""
+    B = x.shape[0]
+    draws = []
+    orig = model.sample_combined_position_feature_noise
+
+    def recording(**kw):
+        z = orig(**kw)
+        draws.append(z.clone())
+        return z
+    model.sample_combined_position_feature_noise = recording
+    torch.manual_seed(seed)
+    real_randint = torch.randint
+    if preset_t is not None:
+        preset = torch.tensor(preset_t[:B]).view(B, 1)
+        torch.randint = lambda *a, **k: preset.clone()
+    try:
+        with torch.no_grad():
+            loss, info = model.compute_loss(x, h, nm, em, None, t0_always=not training, mol_shape=mol_shape)
+    finally:
+        torch.randint = real_randint
+        model.sample_combined_position_feature_noise = orig
+    with torch.no_grad():
+        t_int = info["t"].view(B, 1)
+        gam = {"gamma_s": model.gamma((t_int - 1) / model.T).view(B, 1), "gamma_t": model.gamma(t_int / model.T).view(B, 1),
+               "gamma_0": model.gamma(torch.zeros(B, 1)).view(B, 1), "gamma_T": model.gamma(torch.ones(B, 1)).view(B, 1)}
+    return loss, info, draws, gam, t_int
+
+
+def fixture_poly2_l2(DiffusionQM9, name, hidden_nf, n_layers, seed, T, n_list):
+    """F12: noise_schedule 'polynomial_2' (PredefinedNoiseSchedule) + loss_type 'l2': a full T-step sample() chain and
+    the training-mode loss value (one network call, l2 normalisation :253-255, no constants :611-612, estimator
+    not up-weighted :660-661), incl. a t == 0 row."""
+    model, sd, ocfg = build_reference(DiffusionQM9, hidden_nf, n_layers, 0, seed, 1.0, noise_schedule="polynomial_2",
+                                      loss_type="l2", timesteps=T)
+    res, raws = _run_chain(model, n_list, T, 8, seed + 31)
+    B, N = len(n_list), max(n_list)
+    nm, em = orc.canonical_masks(n_list)
+    table = model.gamma.gamma.detach().clone()
+    x_got, h_got = orc.sample_chain(sd, ocfg, T, nm, em, None, raws, gamma_grid=table)
+    x_ref = np.zeros((B, N, 3), np.float32); h_ref = np.zeros((B, N, 8), np.float32)
+    for b, r in enumerate(res):
+        x_ref[b, :n_list[b]] = r["x"].numpy(); h_ref[b, :n_list[b]] = r["h"].numpy()
+    nmf = nm.float().numpy()
+    check(f"{name} chain x", x_got.numpy() * nmf, x_ref, tol=2e-5)
+    check(f"{name} chain h", h_got.numpy(), h_ref, tol=2e-5)
+    # training-mode l2 loss
+    model.train(True)
+    g = torch.Generator().manual_seed(seed + 300)
+    x = torch.randn(B, N, 3, generator=g) * nm
+    x = x - (x.sum(1, keepdim=True) / nm.sum(1, keepdim=True)) * nm
+    h = torch.cat([torch.randint(0, 5, (B, N, 5), generator=g).float(), torch.randn(B, N, 3, generator=g)], dim=2) * nm
+    loss, info, draws, gam, t_int = _record_loss(model, x, h, nm, em.view(B, N * N), True, seed + 301,
+                                                 preset_t=[0, 1, T // 2, T, 2])
+    got, err = orc.nll_forward(sd, ocfg, T, x, h, nm, em, None, t_int, draws[0], None, training=True, gammas=gam,
+                               loss_type="l2")
+    check(f"{name} l2 loss", got.numpy(), loss.numpy(), tol=5e-6)
+    check(f"{name} l2 error", err.numpy(), info["error"].numpy(), tol=5e-6)
+    model.train(False)
+    save(name, raw_x=np.stack([r[0].numpy() for r in raws]), raw_h=np.stack([r[1].numpy() for r in raws]),
+         n_list=np.array(n_list), x=x_ref, h=h_ref, T=T, gamma_table=table.numpy(), hidden_nf=hidden_nf,
+         n_layers=n_layers, weight_seed=seed, coord_gain=1.0, loss_x=x.numpy(), loss_h=h.numpy(),
+         t_int=t_int.numpy(), eps=draws[0].numpy(), loss=loss.numpy(), error=info["error"].numpy())
+
+
+def fixture_elem(DiffusionQM9, name, hidden_nf, n_layers, seed, T, n_list):
+    """F13: node_coarse_type 'elem' (3 node features, D = 6; diffusion_qm9.py:44-50, 470-476): one dynamics forward,
+    a T-step sample() chain and the validation NLL (two network calls)."""
+    model, sd, ocfg = build_reference(DiffusionQM9, hidden_nf, n_layers, 0, seed, 1.0, node_coarse_type="elem")
+    model.T = T
+    B, N = len(n_list), max(n_list)
+    xh, nm, em = orc.random_inputs(n_list, 3, seed=seed + 100)
+    t = torch.linspace(0.1, 0.9, B).view(B, 1)
+    with torch.no_grad():
+        ref = model.dynamics._forward(t, xh.clone(), nm, em, None, None)
+        got = orc.dynamics_forward(sd, ocfg, t, xh, nm, em, None, None, prefix="dynamics.egnn.")
+    check(f"{name} forward", got.numpy(), ref.numpy())
+    seen = []
+    hook = model.gamma.register_forward_hook(lambda m, a, o: seen.append((float(a[0][0, 0]), float(o[0, 0]))))
+    res, raws = _run_chain(model, n_list, T, 3, seed + 41)
+    hook.remove()
+    gamma_grid = np.full(T + 1, np.nan, np.float32)
+    for tau, gv in seen:
+        gamma_grid[int(round(tau * T))] = gv
+    assert not np.isnan(gamma_grid).any()
+    x_got, h_got = orc.sample_chain(sd, ocfg, T, nm, em, None, raws, gamma_grid=torch.from_numpy(gamma_grid))
+    x_ref = np.zeros((B, N, 3), np.float32); h_ref = np.zeros((B, N, 3), np.float32)
+    for b, r in enumerate(res):
+        x_ref[b, :n_list[b]] = r["x"].numpy(); h_ref[b, :n_list[b]] = r["h"].numpy()
+    nmf = nm.float().numpy()
+    check(f"{name} chain x", x_got.numpy() * nmf, x_ref, tol=2e-5)
+    check(f"{name} chain h", h_got.numpy(), h_ref, tol=2e-5)
+    model.T = 1000
+    g = torch.Generator().manual_seed(seed + 300)
+    x = torch.randn(B, N, 3, generator=g) * nm
+    x = x - (x.sum(1, keepdim=True) / nm.sum(1, keepdim=True)) * nm
+    h = torch.randint(0, 4, (B, N, 3), generator=g).float() * nm
+    loss, info, draws, gam, t_int = _record_loss(model, x, h, nm, em.view(B, N * N), False, seed + 301)
+    got, err = orc.nll_forward(sd, ocfg, 1000, x, h, nm, em, None, t_int, draws[0], draws[1], training=False, gammas=gam,
+                               node_coarse_type="elem")
+    check(f"{name} nll", got.numpy(), loss.numpy(), tol=5e-6)
+    save(name, xh=xh.numpy(), t_rows=t.numpy(), out_row_t=ref.numpy(), node_mask=nm.numpy(), edge_mask=em.numpy(),
+         raw_x=np.stack([r[0].numpy() for r in raws]), raw_h=np.stack([r[1].numpy() for r in raws]),
+         n_list=np.array(n_list), x=x_ref, h=h_ref, T=T, gamma_grid=gamma_grid, hidden_nf=hidden_nf, n_layers=n_layers,
+         weight_seed=seed, coord_gain=1.0, loss_x=x.numpy(), loss_h=h.numpy(), t_int=t_int.numpy(),
+         eps=draws[0].numpy(), eps0=draws[1].numpy(), loss=loss.numpy(), error=info["error"].numpy(),
+         **{k: v.numpy() for k, v in gam.items()})
+
+
+def fixture_pocket_loss(DiffusionQM9, name, hidden_nf, n_layers, seed, n_list, p_list):
+    """F14: DiffusionQM9.forward(batch) with cfg.pocket (diffusion_qm9.py:701-751 pocket branch -> nll -> compute_loss
+    with mol_shape < N): residues appended as fixed nodes, block-diagonal edge mask, the molecule's mean taken off
+    every valid node; validation NLL (two network calls)."""
+    model, sd, ocfg = build_reference(DiffusionQM9, hidden_nf, n_layers, 0, seed, 1.0, pocket=True)
+    B, N, P = len(n_list), max(n_list), max(p_list)
+    rng = np.random.Generator(np.random.PCG64(seed + 21))
+    nm, em = orc.canonical_masks(n_list)
+    p_feat = torch.zeros(B, P, dtype=torch.long); p_pos = torch.zeros(B, P, 3)
+    p_nm = torch.zeros(B, P, 1, dtype=torch.bool); p_em = torch.zeros(B, P, P, dtype=torch.bool)
+    for b, pn in enumerate(p_list):
+        p_feat[b, :pn] = torch.from_numpy(rng.integers(1, 21, size=pn))
+        p_pos[b, :pn] = torch.from_numpy((rng.standard_normal((pn, 3)) * 2.0).astype(np.float32))
+        p_nm[b, :pn] = True
+        p_em[b, :pn, :pn] = ~torch.eye(pn, dtype=torch.bool)
+    g = torch.Generator().manual_seed(seed + 300)
+    x = torch.randn(B, N, 3, generator=g) * nm
+    h = torch.cat([torch.randint(0, 5, (B, N, 5), generator=g).float(), torch.randn(B, N, 3, generator=g)], dim=2) * nm
+    batch = {"positions": x, "atom_mask": nm, "edge_mask": em, "node_feature": h, "protein_pos": p_pos,
+             "protein_feat": p_feat, "protein_feat_mask": p_nm, "protein_edge_mask": p_em}
+    rec = {}
+    orig_cl = model.compute_loss
+
+    def spy(x_, h_, node_mask, edge_mask, context, t0_always, mol_shape=None):
+        draws = []
+        orig = model.sample_combined_position_feature_noise
+
+        def recording(**kw):
+            z = orig(**kw)
+            draws.append(z.clone())
+            return z
+        model.sample_combined_position_feature_noise = recording
+        try:
+            loss, info = orig_cl(x_, h_, node_mask, edge_mask, context, t0_always, mol_shape=mol_shape)
+        finally:
+            model.sample_combined_position_feature_noise = orig
+        rec.update(x=x_.clone(), h=h_.clone(), node_mask=node_mask.clone(), edge_mask=edge_mask.clone(), mol=mol_shape,
+                   loss=loss.clone(), info=info, draws=draws)
+        return loss, info
+    model.compute_loss = spy
+    torch.manual_seed(seed + 301)
+    with torch.no_grad():
+        out = model(batch)
+    model.compute_loss = orig_cl
+    t_int = rec["info"]["t"].view(B, 1)
+    with torch.no_grad():
+        gam = {"gamma_s": model.gamma((t_int - 1) / model.T), "gamma_t": model.gamma(t_int / model.T),
+               "gamma_0": model.gamma(torch.zeros(B, 1)), "gamma_T": model.gamma(torch.ones(B, 1))}
+        got, err = orc.nll_forward(sd, ocfg, model.T, rec["x"], rec["h"], rec["node_mask"], rec["edge_mask"], None, t_int,
+                                   rec["draws"][0], rec["draws"][1], training=False, gammas=gam, mol_shape=rec["mol"])
+    check(f"{name} loss", got.numpy(), rec["loss"].numpy(), tol=5e-6)
+    save(name, positions=x.numpy(), node_feature=h.numpy(), n_list=np.array(n_list), p_list=np.array(p_list),
+         pocket_feat=p_feat.numpy(), pocket_pos=p_pos.numpy(), pocket_node_mask=p_nm.numpy(),
+         pocket_edge_mask=p_em.numpy(), t_int=t_int.numpy(), eps=rec["draws"][0].numpy(), eps0=rec["draws"][1].numpy(),
+         loss=rec["loss"].numpy(), mean_loss=float(out["loss"]), centred_x=rec["x"].numpy(), hidden_nf=hidden_nf,
+         n_layers=n_layers, weight_seed=seed, coord_gain=1.0, T=model.T, **{k: v.numpy() for k, v in gam.items()})
+
+
+
 def main():
+    """python oracle/make_golden.py [name-prefix ...]  - no arguments regenerates every fixture."""
+    only = sys.argv[1:]
+    want = lambda name: not only or any(name.startswith(p) for p in only)
     os.makedirs(GOLDEN, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(8)
     DiffusionQM9 = import_reference()
+
+    def run(fn, name, *a, **k):
+        if want(name):
+            if fn in (fixture_nodes_dist, fixture_predefined_schedules):
+                fn(name)
+            else:
+                fn(DiffusionQM9, name, *a, **k)
     # F1 + F2: BASELINE config 1 (B=4, N=8, L=3, H=256), with per-layer intermediates
-    fixture_forward(DiffusionQM9, "f1_cfg1_h256_l3", [8, 5, 3, 7], 256, 3, 0, 0.001,
-                    [0.5, 0.001, 1.0], with_trace=True)
+    run(fixture_forward, "f1_cfg1_h256_l3", [8, 5, 3, 7], 256, 3, 0, 0.001, [0.5, 0.001, 1.0], with_trace=True)
     # same shape with the coordinate head x1000 so tanh*coords_range is exercised
-    fixture_forward(DiffusionQM9, "f1b_cfg1_h256_l3_gain1", [8, 5, 3, 7], 256, 3, 1, 1.0, [0.5])
+    run(fixture_forward, "f1b_cfg1_h256_l3_gain1", [8, 5, 3, 7], 256, 3, 1, 1.0, [0.5])
     # F7: small-H variants for fast unit tests; includes a single-node molecule and padding
-    fixture_forward(DiffusionQM9, "f7_h32_l2", [8, 1, 3, 7, 2], 32, 2, 2, 1.0, [0.3], n_max=10,
-                    with_trace=True)
-    fixture_forward(DiffusionQM9, "f7_h64_l2", [12, 5, 9], 64, 2, 3, 1.0, [0.7])
-    fixture_forward(DiffusionQM9, "f7_h128_l1", [6, 4], 128, 1, 4, 1.0, [0.2])
+    run(fixture_forward, "f7_h32_l2", [8, 1, 3, 7, 2], 32, 2, 2, 1.0, [0.3], n_max=10, with_trace=True)
+    run(fixture_forward, "f7_h64_l2", [12, 5, 9], 64, 2, 3, 1.0, [0.7])
+    run(fixture_forward, "f7_h128_l1", [6, 4], 128, 1, 4, 1.0, [0.2])
     # F6: production shape slice, B=16, N=30, L=9
-    fixture_forward(DiffusionQM9, "f6_b16_n30_h256_l9", [30] * 12 + [17, 25, 29, 2], 256, 9, 5, 1.0, [0.5])
+    run(fixture_forward, "f6_b16_n30_h256_l9", [30] * 12 + [17, 25, 29, 2], 256, 9, 5, 1.0, [0.5])
     # production YAML depth L=6 with ragged sizes padded to 48 (BASELINE config 3 flavour)
-    fixture_forward(DiffusionQM9, "f6b_n48_h256_l6", [48, 14, 33, 9, 21, 1], 256, 6, 6, 1.0, [0.9], n_max=48)
+    run(fixture_forward, "f6b_n48_h256_l6", [48, 14, 33, 9, 21, 1], 256, 6, 6, 1.0, [0.9], n_max=48)
     # F3: conditional step
-    fixture_conditional(DiffusionQM9, "f3_cond_h256_l3", 256, 3, 7, 1.0)
-    fixture_conditional(DiffusionQM9, "f3_cond_h32_l2", 32, 2, 8, 1.0)
+    run(fixture_conditional, "f3_cond_h256_l3", 256, 3, 7, 1.0)
+    run(fixture_conditional, "f3_cond_h32_l2", 32, 2, 8, 1.0)
     # F4: schedule
-    fixture_schedule(DiffusionQM9, "f4_schedule", 0)
+    run(fixture_schedule, "f4_schedule", 0)
     # F5: 3-step chain
-    fixture_chain(DiffusionQM9, "f5_chain_h256_l3", 256, 3, 9, 1.0, 3, [8, 5, 3, 7])
-    fixture_chain(DiffusionQM9, "f5_chain_h32_l2", 32, 2, 10, 1.0, 4, [6, 1, 4, 5])
+    run(fixture_chain, "f5_chain_h256_l3", 256, 3, 9, 1.0, 3, [8, 5, 3, 7])
+    run(fixture_chain, "f5_chain_h32_l2", 32, 2, 10, 1.0, 4, [6, 1, 4, 5])
     # F8: pocket-conditioned sampling (fixed residue nodes, block-diagonal masks)
-    fixture_pocket(DiffusionQM9, "f8_pocket_h64_l2", 64, 2, 13, 1.0, 3, [7, 4, 6, 5], [9, 12, 5, 12])
+    run(fixture_pocket, "f8_pocket_h64_l2", 64, 2, 13, 1.0, 3, [7, 4, 6, 5], [9, 12, 5, 12])
     # F9: loss / NLL forward value (validation NLL = two network calls; training-mode value = one)
-    fixture_nll(DiffusionQM9, "f9_nll_eval_h64_l2", 64, 2, 14, 1.0, [9, 4, 7, 6, 8], training=False)
-    fixture_nll(DiffusionQM9, "f9_nll_train_h64_l2", 64, 2, 15, 1.0, [9, 4, 7, 6, 8], training=True)
+    run(fixture_nll, "f9_nll_eval_h64_l2", 64, 2, 14, 1.0, [9, 4, 7, 6, 8], training=False)
+    run(fixture_nll, "f9_nll_train_h64_l2", 64, 2, 15, 1.0, [9, 4, 7, 6, 8], training=True)
+    # round 2: the reference's remaining configuration branches
+    run(fixture_nodes_dist, "f10_nodes_dist")
+    run(fixture_predefined_schedules, "f11_predefined_schedules")
+    run(fixture_poly2_l2, "f12_poly2_l2_h32_l2", 32, 2, 16, 6, [7, 3, 8, 5, 6])
+    run(fixture_elem, "f13_elem_h64_l2", 64, 2, 17, 3, [6, 9, 4, 7])
+    run(fixture_pocket_loss, "f14_pocket_loss_h64_l2", 64, 2, 18, [7, 4, 6, 5], [9, 12, 5, 12])
 
 
 if __name__ == "__main__":

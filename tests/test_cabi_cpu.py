@@ -164,3 +164,59 @@ def test_no_register_spills_in_production_kernels():
     assert len(edge) == 4 and all(v["Occupancy"] >= 2 and v["ScratchSize"] == 0 for v in edge)
     node = [v for k, v in prod.items() if k.startswith("_Z6k_nodeILi256")]
     assert len(node) == 3 and all(v["ScratchSize"] == 0 for v in node)
+
+
+def test_nodes_distribution_draws_equal_reference():
+    """F10: same key order, probabilities and - under the same torch seed - the same draws as the reference's
+    DistributionNodes on conf/analyze/GEOM.yaml (models/distributions.py:62-101, diffusion_qm9.py:114-115,349)."""
+    from hierdiff_amd import DistributionNodes
+    from hierdiff_amd.geom_stats import GEOM_FRAGMENT_HISTOGRAM as H
+    from tests.helpers import load
+    fx = load("f10_nodes_dist")
+    assert list(H.keys()) == [int(k) for k in fx["keys"]] and list(H.values()) == [int(v) for v in fx["counts"]]
+    d = DistributionNodes(H)
+    assert np.array_equal(d.prob.numpy(), fx["prob"])
+    for seed in (2022, 7, 0):
+        want = fx[f"draws_seed{seed}"]
+        torch.manual_seed(seed)
+        assert d.sample(len(want)) == [int(v) for v in want], seed
+    np.testing.assert_array_equal(d.log_prob(torch.from_numpy(fx["log_prob_idx"])).numpy(), fx["log_prob"])
+
+
+def test_predefined_noise_schedules_equal_reference():
+    """F11: PredefinedNoiseSchedule 'polynomial_k' / 'cosine' tables and lookups (models/noise_model.py:125-160), and
+    a DiffusionQM9 built with such a schedule (state_dict key `gamma.gamma`, check_issues_norm_values)."""
+    from hierdiff_amd import DiffusionQM9, PredefinedNoiseSchedule, default_config
+    from hierdiff_amd.noise_model import evaluate_gamma, schedule_tables
+    from tests.helpers import load
+    fx = load("f11_predefined_schedules")
+    t = torch.from_numpy(fx["lookup_t"])
+    for sched, T, prec in (("polynomial_2", 1000, 1e-4), ("cosine", 1000, 1e-4), ("polynomial_3", 500, 1e-5),
+                           ("polynomial_2", 6, 1e-4)):
+        m = PredefinedNoiseSchedule(sched, T, prec)
+        assert np.array_equal(m.gamma.detach().numpy(), fx[f"{sched}_T{T}"]), sched
+        assert np.array_equal(m(t).detach().numpy(), fx[f"{sched}_T{T}_lookup"]), sched
+        assert np.array_equal(evaluate_gamma(m, t).numpy(), fx[f"{sched}_T{T}_lookup"]), sched
+    with pytest.raises(ValueError):
+        PredefinedNoiseSchedule("linear", 10, 1e-4)
+    cfg = default_config(hidden_nf=32, n_layers=1, timesteps=6)
+    cfg["noise_schedule"] = "polynomial_2"
+    cfg["loss_type"] = "l2"
+    cfg["pre_noise"] = dict(noise_schedule="polynomial_2", timesteps=6, precision=1e-4)
+    model = DiffusionQM9(cfg)
+    assert "gamma.gamma" in model.state_dict() and not any(k.startswith("gamma.l1") for k in model.state_dict())
+    tabs = schedule_tables(model.gamma, 6)
+    assert np.array_equal(tabs["gamma"].numpy(), fx["polynomial_2_T6"])
+    cfg2 = default_config(hidden_nf=32, n_layers=1)
+    cfg2["noise_schedule"] = "learned"
+    cfg2["loss_type"] = "l2"
+    with pytest.raises(AssertionError):          # 'A noise schedule can only be learned with a vlb objective.'
+        DiffusionQM9(cfg2)
+    cfg3 = dict(cfg)
+    cfg3["node_coarse_type"] = "atoms"
+    with pytest.raises(NotImplementedError):
+        DiffusionQM9(cfg3)
+    elem = default_config(hidden_nf=32, n_layers=1)
+    elem["node_coarse_type"] = "elem"
+    m = DiffusionQM9(elem)
+    assert m.in_node_nf == 3 and m.state_dict()["dynamics.egnn.embedding.weight"].shape == (32, 4)

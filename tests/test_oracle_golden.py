@@ -137,3 +137,95 @@ def test_nll_forward_matches_reference(name):
     np.testing.assert_allclose(err.numpy(), fx["error"], rtol=2e-6, atol=1e-5)
     if training:
         assert float(fx["t_int"][0, 0]) == 0.0          # the L0 branch is part of the fixture
+
+
+def test_predefined_schedule_tables_match_reference():
+    """F11: PredefinedNoiseSchedule tables (noise_model.py:125-160), bit-equal (same numpy arithmetic)."""
+    fx = load("f11_predefined_schedules")
+    for sched, T, prec in (("polynomial_2", 1000, 1e-4), ("cosine", 1000, 1e-4), ("polynomial_3", 500, 1e-5),
+                           ("polynomial_2", 6, 1e-4)):
+        tab = orc.predefined_gamma_table(sched, T, prec)
+        assert np.array_equal(tab, fx[f"{sched}_T{T}"]), sched
+        idx = np.round(fx["lookup_t"].astype(np.float32) * np.float32(T)).astype(np.int64)
+        assert np.array_equal(tab[idx], fx[f"{sched}_T{T}_lookup"]), sched
+
+
+def _chain_inputs(fx):
+    n_list = [int(v) for v in fx["n_list"]]
+    nm, em = orc.canonical_masks(n_list)
+    raws = [(torch.from_numpy(fx["raw_x"][i]), torch.from_numpy(fx["raw_h"][i])) for i in range(len(fx["raw_x"]))]
+    return n_list, nm, em, raws
+
+
+def test_poly2_l2_matches_reference():
+    """F12: predefined 'polynomial_2' schedule: T-step chain; training-mode l2 loss value incl. a t == 0 row."""
+    from hierdiff_amd.weights import synthetic_state_dict
+    fx = load("f12_poly2_l2_h32_l2")
+    H, L, T = int(fx["hidden_nf"]), int(fx["n_layers"]), int(fx["T"])
+    sd = orc.as_torch_sd(synthetic_state_dict(9, 0, H, L, 2, True, int(fx["weight_seed"]), 1.0))
+    cfg = orc.DynCfg(hidden_nf=H, n_layers=L)
+    table = orc.predefined_gamma_table("polynomial_2", T, 1e-4)
+    assert np.array_equal(table, fx["gamma_table"])
+    n_list, nm, em, raws = _chain_inputs(fx)
+    with torch.no_grad():
+        x, h = orc.sample_chain(sd, cfg, T, nm, em, None, raws, gamma_grid=torch.from_numpy(table))
+    assert_parity(x.numpy() * nm.float().numpy(), fx["x"], "poly2 x", 2e-5, 2e-4)
+    assert_parity(h.numpy(), fx["h"], "poly2 h", 2e-5, 2e-4)
+    g = torch.from_numpy(table)
+    ti = torch.from_numpy(fx["t_int"]).long().view(-1)
+    gam = {"gamma_s": g[(ti - 1).clamp(min=-1)], "gamma_t": g[ti], "gamma_0": g[0].expand(len(ti)), "gamma_T": g[T].expand(len(ti))}
+    with torch.no_grad():
+        loss, err = orc.nll_forward(sd, cfg, T, fx["loss_x"], fx["loss_h"], nm, em, None, fx["t_int"], fx["eps"], None,
+                                    training=True, gammas=gam, loss_type="l2")
+    np.testing.assert_allclose(loss.numpy(), fx["loss"], rtol=2e-6, atol=1e-5)
+    np.testing.assert_allclose(err.numpy(), fx["error"], rtol=2e-6, atol=1e-6)
+    assert float(fx["t_int"][0, 0]) == 0.0
+
+
+def test_elem_matches_reference():
+    """F13: node_coarse_type 'elem' (3 features): forward, chain, validation NLL."""
+    from hierdiff_amd.weights import synthetic_state_dict
+    fx = load("f13_elem_h64_l2")
+    H, L, T = int(fx["hidden_nf"]), int(fx["n_layers"]), int(fx["T"])
+    sd = orc.as_torch_sd(synthetic_state_dict(4, 0, H, L, 2, True, int(fx["weight_seed"]), 1.0))
+    cfg = orc.DynCfg(in_node_nf=4, hidden_nf=H, n_layers=L)
+    n_list, nm, em, raws = _chain_inputs(fx)
+    with torch.no_grad():
+        out = orc.dynamics_forward(sd, cfg, torch.from_numpy(fx["t_rows"]), fx["xh"], nm, em, None, None, prefix="dynamics.egnn.")
+        assert_parity(out.numpy(), fx["out_row_t"], "elem forward", 2e-6, 2e-5)
+        x, h = orc.sample_chain(sd, cfg, T, nm, em, None, raws, gamma_grid=torch.from_numpy(fx["gamma_grid"]))
+        assert_parity(x.numpy() * nm.float().numpy(), fx["x"], "elem x", 2e-5, 2e-4)
+        assert_parity(h.numpy(), fx["h"], "elem h", 2e-5, 2e-4)
+        gam = {k: torch.from_numpy(fx[k]) for k in ("gamma_s", "gamma_t", "gamma_0", "gamma_T")}
+        loss, _ = orc.nll_forward(sd, cfg, 1000, fx["loss_x"], fx["loss_h"], nm, em, None, fx["t_int"], fx["eps"], fx["eps0"],
+                                  training=False, gammas=gam, node_coarse_type="elem")
+    np.testing.assert_allclose(loss.numpy(), fx["loss"], rtol=2e-6, atol=1e-4)
+
+
+def test_pocket_loss_matches_reference():
+    """F14: validation NLL with fixed pocket nodes (compute_loss with mol_shape < N)."""
+    from hierdiff_amd.weights import synthetic_state_dict
+    fx = load("f14_pocket_loss_h64_l2")
+    H, L = int(fx["hidden_nf"]), int(fx["n_layers"])
+    sd = orc.as_torch_sd(synthetic_state_dict(9, 0, H, L, 2, True, int(fx["weight_seed"]), 1.0, pocket=True))
+    cfg = orc.DynCfg(hidden_nf=H, n_layers=L)
+    n_list = [int(v) for v in fx["n_list"]]
+    nm, em = orc.canonical_masks(n_list)
+    B, N = nm.shape[:2]
+    P = fx["pocket_pos"].shape[1]
+    emb = sd["pocket_embed.weight"][torch.from_numpy(fx["pocket_feat"]).long()]
+    nm_all = torch.cat([nm, torch.from_numpy(fx["pocket_node_mask"])], dim=1)
+    em_all = torch.zeros(B, N + P, N + P, dtype=torch.bool)
+    em_all[:, :N, :N] = em
+    em_all[:, N:, N:] = torch.from_numpy(fx["pocket_edge_mask"])
+    x = torch.cat([torch.from_numpy(fx["positions"]), torch.from_numpy(fx["pocket_pos"])], dim=1)
+    nmf = nm_all.float()
+    x = x - (x[:, :N].sum(1, keepdim=True) / nmf[:, :N].sum(1, keepdim=True)) * nmf       # models/utils.py:51-56, fix_size = N
+    np.testing.assert_allclose(x.numpy(), fx["centred_x"], rtol=0, atol=1e-6)
+    h = torch.cat([torch.from_numpy(fx["node_feature"]), emb], dim=1)
+    gam = {k: torch.from_numpy(fx[k]) for k in ("gamma_s", "gamma_t", "gamma_0", "gamma_T")}
+    with torch.no_grad():
+        loss, _ = orc.nll_forward(sd, cfg, int(fx["T"]), x, h, nm_all, em_all, None, fx["t_int"], fx["eps"], fx["eps0"],
+                                  training=False, gammas=gam, mol_shape=N)
+    np.testing.assert_allclose(loss.numpy(), fx["loss"], rtol=2e-6, atol=1e-4)
+    assert abs(float(loss.mean()) - float(fx["mean_loss"])) < 1e-3
