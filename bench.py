@@ -11,6 +11,13 @@ production model H=256, L=6 (endiffusion/conf/model/ddpmgblur.yaml).  Synthetic 
 point sets, counter-based Gaussian noise) and deterministic random-init weights: the reference ships no
 checkpoint and there is no network.
 
+The JSON line's headline (`value`, `dtype`, `roofline`) is the EXACT-fp32 path (v_mfma_f32_32x32x2_f32), the
+arithmetic the reference computes in; the faster opt-in "bf16x3" mode (fp32 operands split into bf16 head + tail,
+3 bf16 MFMAs per product) is timed in the same invocation over the same K steps and reported as the sibling block
+`"bf16x3"` with its own roofline and its measured deviation from the fp32 path.  At N=1 the line also carries
+`cpu_baseline` (the oracle timed on this host) and `configs` (BASELINE.json configs 2, 3, 5 and the reference's
+default B=2 job, timed on short chains).
+
 For N > 1 the driver launches this file under torch.distributed.run, one rank per GPU: rank 0's weights
 are broadcast once over RCCL (xGMI); batches are independent, so there is no per-step collective (weak
 scaling, 256 molecules per GPU).
@@ -32,14 +39,17 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 # /opt/skills/guides/MI355X_MICROARCH.md, dense matrix peaks: v_mfma_f32_32x32x2_f32 157.3 TFLOP/s,
-# bf16 MFMA ~2.5 PFLOP/s.  The bf16x3 path executes 3 bf16 MFMA flops per algorithmic flop.
+# bf16 MFMA ~2.5 PFLOP/s; HBM3E 8 TB/s.  The bf16x3 path executes 3 bf16 MFMA flops per algorithmic flop.
 MFMA_PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0}
+HBM_PEAK_GBPS = 8000.0
+DTYPE = {"fp32": "f32", "bf16x3": "bf16x3"}
+COUNTERS = os.path.join(REPO, "profiles", "r02_counters.json")      # scratch/round_profiles.sh + summarize_profiles.py
 
 
 def edge_flops_per_launch(n_edges: int, H: int) -> float:
     """Algorithmic FLOPs of one edge-kernel launch (one sub-MLP over all valid edges), SURVEY.md
     section 8d: per edge 2H^2 (second Linear) + 2H (attention / coordinate head dot) + 5H (factorised
-    first layer: 3 adds + 2 FMAs... counted as in the survey: f_e/(S+1) = 2H^2 + 2H + 5H)."""
+    first layer), f_e/(S+1) = 2H^2 + 2H + 5H."""
     return float(n_edges) * (2.0 * H * H + 2.0 * H + 5.0 * H)
 
 
@@ -50,62 +60,47 @@ def forward_flops(n_edges: int, n_nodes: int, H: int, L: int, S: int, fin: int) 
     return L * (n_edges * f_e + n_nodes * f_n) + n_nodes * 4.0 * fin * H
 
 
-def main() -> None:
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=256, help="molecules per GPU per step")
-    ap.add_argument("--nodes", type=int, default=30)
-    ap.add_argument("--layers", type=int, default=6)
-    ap.add_argument("--hidden", type=int, default=256)
-    ap.add_argument("--timesteps", type=int, default=1000)
-    ap.add_argument("--precision", choices=["bf16x3", "fp32"], default="bf16x3",
-                    help="matrix-core arithmetic of the H x H contractions (both meet the 1e-4 parity bar)")
-    ap.add_argument("--graph", action="store_true", help="replay each diffusion step from a captured hipGraph")
-    ap.add_argument("--no-graph", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--event-stride", type=int, default=8,
-                    help="bracket the edge-kernel launches of every k-th forward with HIP events")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-kernel-events", action="store_true",
-                    help="do not bracket edge-kernel launches with HIP events in the timed region")
-    args = ap.parse_args()
+def load_counters(precision: str, shape) -> dict:
+    """PMC figures of the edge kernel from the committed rocprofv3 passes (HBM bytes per launch, MFMA-busy and
+    VALU-issue fractions); only valid for the shape they were collected on."""
+    try:
+        with open(COUNTERS) as fh:
+            c = json.load(fh)
+    except Exception:
+        return {}
+    if tuple(c.get("shape", [])) != tuple(shape):
+        return {}
+    out = dict(c.get("edge_kernel", {}).get(precision, {}))
+    out["source"] = c.get("source", "profiles/r02_counters.json")
+    return out
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus > 1 launch with: python -m torch.distributed.run --nnodes=1 "
-                         "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist  # type: ignore
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from hierdiff_amd import DiffusionQM9, _lib, default_config
-    from hierdiff_amd.sharding import broadcast_model_weights, shard_sample_ids
+def build_model(H, L, T, dev, rank, world, context_nf=0, cls=None, seed=0):
+    from hierdiff_amd import DiffusionQM9, default_config
+    from hierdiff_amd.sharding import broadcast_model_weights
     from hierdiff_amd.weights import synthetic_state_dict
-
-    H, L, S, B, N, T = args.hidden, args.layers, 2, args.batch, args.nodes, args.timesteps
-    model = DiffusionQM9(default_config(hidden_nf=H, n_layers=L, timesteps=T))
+    cls = cls or DiffusionQM9
+    model = cls(default_config(hidden_nf=H, n_layers=L, context_node_nf=context_nf, timesteps=T))
     if rank == 0:
-        sd = synthetic_state_dict(9, 0, H, L, S, True, seed=0, coord_gain=1.0)
+        sd = synthetic_state_dict(9, context_nf, H, L, 2, True, seed=seed, coord_gain=1.0)
         model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
     model = model.to(dev)
-    model.dynamics.precision = args.precision
     if world > 1:
         broadcast_model_weights(model, src=0)          # one RCCL broadcast of the packed parameters
-    # The timed region brackets the dominant kernel's launches with HIP events (roofline.achieved), which a
-    # hipGraph replay cannot carry, so it uses plain launches unless --graph is given; at this size the
-    # two are equally fast (6.16 vs 6.18 ms/forward measured) because the GPU, not the host, is the limit.
-    model.use_graph = bool(args.graph) and not args.no_graph
-    node_mask = torch.ones(B, N, 1, dtype=torch.bool, device=dev)
+    return model
 
+
+def timed_headline(model, precision, args, dev, rank, world, dist):
+    """W untimed + exactly K timed steps of the headline workload in one precision; returns the result block."""
+    from hierdiff_amd import _lib
+    from hierdiff_amd.sharding import shard_sample_ids
+    H, L, S, B, N, T = args.hidden, args.layers, 2, args.batch, args.nodes, args.timesteps
+    model.dynamics.precision = precision
+    # The timed region brackets the dominant kernel's launches with HIP events (roofline.achieved), which a
+    # hipGraph replay cannot carry, so it uses plain launches unless --graph is given; at this size the two are
+    # equally fast because the GPU, not the host, is the limit.
+    model.use_graph = bool(args.graph)
+    node_mask = torch.ones(B, N, 1, dtype=torch.bool, device=dev)
     lib = _lib.load()
     handle = model._lib_handle()
     topo = model.dynamics.topology(node_mask, None, B, N)
@@ -116,7 +111,7 @@ def main() -> None:
         x, h = model.sample_from_masks(node_mask, None, None, sample_id_base=base)
         return x.cpu(), h.cpu()
 
-    use_events = not args.no_kernel_events
+    use_events = not args.no_kernel_events and not model.use_graph
     for w in range(args.warmup):
         one_step(w)
     torch.cuda.synchronize(dev)
@@ -147,91 +142,246 @@ def main() -> None:
             avg_s = ms[0] / cnt[0] * 1e-3
             fl = edge_flops_per_launch(info["edges"], H)
             achieved = fl / avg_s / 1e12
-            traffic = None
-            tpath = os.path.join(REPO, "profiles", "edge_kernel_traffic.json")
-            if os.path.exists(tpath) and (B, N, H) == (256, 30, 256):
-                with open(tpath) as fh:
-                    traffic = json.load(fh).get("hbm_bytes_per_launch")
-            peak = MFMA_PEAK_TFLOPS[args.precision]
-            roofline = {"bound": "mfma", "kernel": "k_edge<256> (GCL + coordinate variants)",
+            peak = MFMA_PEAK_TFLOPS[precision]
+            pmc = load_counters(precision, (B, N, H, L))
+            traffic = pmc.get("hbm_bytes_per_launch")
+            roofline = {"bound": "mfma",
+                        "kernel": f"k_edge<{H}, *, {'fp32' if precision == 'fp32' else 'bf16x3'}> (GCL + coordinate variants)",
                         "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                         "frac": round(achieved / peak, 4), "traffic": traffic,
                         "launches": int(cnt[0]), "avg_launch_us": round(avg_s * 1e6, 2),
-                        "flops_per_launch": fl}
-            if args.precision == "bf16x3":
+                        "flops_per_launch": fl, "edge_rows_per_launch": info["tiles"] * 32}
+            if traffic:
+                # bytes from the committed PMC pass over this kernel's live average duration
+                roofline["hbm_gbps"] = round(traffic / avg_s / 1e9, 1)
+                roofline["hbm_frac"] = round(traffic / avg_s / 1e9 / HBM_PEAK_GBPS, 4)
+            for k in ("mfma_busy", "valu_issue_frac", "wait_inst_frac", "source"):
+                if k in pmc:
+                    roofline["pmc_source" if k == "source" else k] = pmc[k]
+            if precision == "bf16x3":
                 # fp32 operands are split head+tail: each algorithmic flop costs 3 bf16 MFMA flops
                 roofline["executed_mfma_tflops"] = round(3 * achieved, 2)
                 roofline["executed_frac"] = round(3 * achieved / peak, 4)
                 roofline["note"] = ("fp32-accurate contraction emulated with 3 bf16 MFMAs per product (bf16x3); "
-                                    "achieved counts algorithmic flops; a pure bf16 MFMA loop on random data "
-                                    "sustains 1734 TFLOP/s on this chip (scratch/mb/mb.hip)")
+                                    "achieved counts algorithmic flops")
+    n_fwd = T + 1
+    mols = world * B * args.steps
+    fwd_fl = forward_flops(info["edges"], info["nodes"], H, L, S, 9)
+    block = {"value": round(mols / elapsed, 3), "unit": "molecules/s", "dtype": DTYPE[precision], "steps": args.steps,
+             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2),
+             "ms_per_forward": round(elapsed / args.steps / n_fwd * 1e3, 4),
+             "model_tflops": round(fwd_fl * n_fwd * args.steps * world / elapsed / 1e12, 2),
+             "launch": "hipGraph replay" if model.use_graph else "plain launches"}
+    if roofline:
+        block["roofline"] = roofline
+    return block
+
+
+def precision_gap(model, args, dev) -> dict:
+    """rel-L2 between the two precision modes on one headline-shaped forward (the fp32 path is the yardstick here; both
+    are checked against the reference-generated golden vectors in tests/)."""
+    B, N = args.batch, args.nodes
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(B, N, 3, generator=g)
+    xh = torch.cat([x - x.mean(1, keepdim=True), torch.randn(B, N, 8, generator=g)], dim=2).to(dev)
+    nm = torch.ones(B, N, 1, dtype=torch.bool, device=dev)
+    worst = 0.0
+    outs = {}
+    for tv in (0.05, 0.5, 0.95):
+        t = torch.full((B, 1), tv, device=dev)
+        for p in ("fp32", "bf16x3"):
+            model.dynamics.precision = p
+            outs[p] = model.dynamics._forward(t, xh, nm, None, None, None).double()
+        worst = max(worst, float(torch.linalg.norm(outs["bf16x3"] - outs["fp32"]) / torch.linalg.norm(outs["fp32"])))
+    return {"max_rel_l2_vs_fp32_path": float(f"{worst:.3e}"),
+            "bound_vs_reference": "<= 1.3e-5 rel-L2 per forward on every golden fixture (tests/, bar 1e-4)"}
+
+
+def other_configs(args, dev) -> dict:
+    """BASELINE.json configs 2, 3, 5, the L=9 variant of the headline and the reference's shipped job (batch_size 2),
+    each timed on a short chain (T_short posterior steps + decode, after one untimed pass), per precision.
+    mol/s figures are per-forward cost scaled to 1001 forwards; b2_latency is a real T=1000 run."""
+    from hierdiff_amd import EnVariationalDiffusion
+    from hierdiff_amd.geom_stats import GEOM_FRAGMENT_HISTOGRAM as HIST
+    Ts = args.config_timesteps
+    out = {"timesteps_timed": Ts, "note": "molecules_per_s = B / (ms_per_forward * 1001)"}
+
+    def timeit(fn, reps=2):
+        fn()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / reps
+
+    def entry(B, dt, T):
+        ms = dt / (T + 1) * 1e3
+        return {"ms_per_forward": round(ms, 4), "molecules_per_s": round(B / (ms * 1e-3 * 1001), 2)}
+
+    rng = np.random.Generator(np.random.PCG64(2022))
+    keys = np.array([k for k in HIST if k <= 48])
+    p = np.array([HIST[k] for k in keys], float)
+    n3 = rng.choice(keys, size=256, p=p / p.sum())
+    nm3 = (torch.arange(48)[None, :] < torch.tensor(n3)[:, None]).unsqueeze(-1).to(dev)
+    nm5 = torch.ones(64, 30, 1, dtype=torch.bool, device=dev)
+    em5 = torch.zeros(64, 30, 30, dtype=torch.bool)
+    em5[:, :24, :24] = True
+    em5[:, 24:, 24:] = True
+    em5 = (em5 & ~torch.eye(30, dtype=torch.bool)[None]).to(dev)
+    ctx5 = torch.full((64, 30, 1), 2.3, device=dev)
+    m9 = build_model(256, 9, Ts, dev, 0, 1)
+    m6 = build_model(256, 6, Ts, dev, 0, 1)
+    m5 = build_model(256, 6, Ts, dev, 0, 1, context_nf=1, cls=EnVariationalDiffusion)
+    m1k = build_model(256, 6, 1000, dev, 0, 1)
+    for prec in ("fp32", "bf16x3"):
+        for m in (m9, m6, m5, m1k):
+            m.dynamics.precision = prec
+        blk = {}
+        nm = torch.ones(64, 30, 1, dtype=torch.bool, device=dev)
+        blk["config2_B64_N30_L9"] = entry(64, timeit(lambda: m9.sample_from_masks(nm, None, None)), Ts)
+        nm = torch.ones(256, 30, 1, dtype=torch.bool, device=dev)
+        blk["headline_L9_B256_N30"] = entry(256, timeit(lambda: m9.sample_from_masks(nm, None, None)), Ts)
+        blk["config3_B256_geom_sizes_pad48_L6"] = dict(entry(256, timeit(lambda: m6.sample_from_masks(nm3, None, None)), Ts),
+                                                       mean_n=round(float(n3.mean()), 2))
+        blk["config5_B64_N30_context_fixnoise_mol24_L6"] = entry(
+            64, timeit(lambda: m5.sample(64, 30, nm5, em5, ctx5, fix_noise=True)), Ts)
+        nm = torch.ones(64, 30, 1, dtype=torch.bool, device=dev)
+        blk["B64_N30_L6"] = entry(64, timeit(lambda: m6.sample_from_masks(nm, None, None)), Ts)
+        # the reference's shipped job: batch_size 2 (conf/sample/default.yaml:1-2), full T = 1000, graph replay
+        nm = torch.ones(2, 30, 1, dtype=torch.bool, device=dev)
+        m1k.use_graph = True
+        dt = timeit(lambda: m1k.sample_from_masks(nm, None, None), reps=1)
+        blk["b2_latency_T1000_B2_N30_L6"] = {"s_per_batch": round(dt, 4), "ms_per_forward": round(dt / 1001 * 1e3, 4),
+                                            "molecules_per_s": round(2 / dt, 3), "launch": "hipGraph replay (cached)"}
+        out[DTYPE[prec]] = blk
+    return out
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=256, help="molecules per GPU per step")
+    ap.add_argument("--nodes", type=int, default=30)
+    ap.add_argument("--layers", type=int, default=6)
+    ap.add_argument("--hidden", type=int, default=256)
+    ap.add_argument("--timesteps", type=int, default=1000)
+    ap.add_argument("--precision", choices=["both", "fp32", "bf16x3"], default="both",
+                    help="'both' (default): headline = exact fp32, plus the bf16x3 sibling block; a single mode times "
+                         "only that mode (profiling runs)")
+    ap.add_argument("--graph", action="store_true", help="replay each diffusion step from a captured hipGraph")
+    ap.add_argument("--event-stride", type=int, default=8,
+                    help="bracket the edge-kernel launches of every k-th forward with HIP events")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the configs block (BASELINE configs 2, 3, 5, B=2)")
+    ap.add_argument("--config-timesteps", type=int, default=50)
+    ap.add_argument("--no-kernel-events", action="store_true",
+                    help="do not bracket edge-kernel launches with HIP events in the timed region")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus > 1 launch with: python -m torch.distributed.run --nnodes=1 "
+                         "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # type: ignore
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    H, L, B, N, T = args.hidden, args.layers, args.batch, args.nodes, args.timesteps
+    model = build_model(H, L, T, dev, rank, world)
+    modes = ["fp32", "bf16x3"] if args.precision == "both" else [args.precision]
+    blocks = {p: timed_headline(model, p, args, dev, rank, world, dist) for p in modes}
 
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
 
+    head = modes[0]
+    hb = blocks[head]
     n_fwd = T + 1
-    mols = world * B * args.steps
-    value = mols / elapsed
-    fwd_fl = forward_flops(info["edges"], info["nodes"], H, L, S, 9)
     out = {
         "metric": "sampled molecules/sec (1000 diffusion steps, B=256, N=30)",
-        "value": round(value, 3), "unit": "molecules/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16x3" if args.precision == "bf16x3" else "f32", "data": "synthetic",
+        "value": hb["value"], "unit": "molecules/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": hb["ms_per_step"], "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": DTYPE[head], "data": "synthetic",
         "config": {"workload": f"DiffusionQM9.sample: {T}-step reverse diffusion + decode ({n_fwd} EGNN forwards), "
                                f"B={B} per GPU, N={N} all valid, H={H}, L={L}, S=2",
                    "batch_per_gpu": B, "n_nodes": N, "hidden_nf": H, "n_layers": L, "timesteps": T,
-                   "precision": args.precision,
-                   "precision_note": ("fp32 operands split into bf16 head + tail, 3 bf16 MFMAs per product, fp32 "
-                                      "accumulate; <= 1.3e-5 rel-L2 per forward vs the reference (bar 1e-4)")
-                   if args.precision == "bf16x3" else "exact fp32 MFMA (v_mfma_f32_32x32x2_f32)",
-                   "launch": "hipGraph replay" if model.use_graph else "plain launches",
+                   "precision": head,
+                   "precision_note": "exact fp32 MFMA (v_mfma_f32_32x32x2_f32), the reference's arithmetic"
+                   if head == "fp32" else "fp32 operands split into bf16 head + tail, 3 bf16 MFMAs per product, fp32 accumulate",
+                   "launch": hb["launch"],
                    "parallelism": f"{world} independent shards, RCCL weight broadcast only"},
-        "ms_per_forward": round(elapsed / args.steps / n_fwd * 1e3, 4),
-        "model_tflops": round(fwd_fl * n_fwd * args.steps * world / elapsed / 1e12, 2),
+        "ms_per_forward": hb["ms_per_forward"], "model_tflops": hb["model_tflops"],
     }
-    if roofline:
-        out["roofline"] = roofline
+    if "roofline" in hb:
+        out["roofline"] = hb["roofline"]
+    if "bf16x3" in blocks and head != "bf16x3":
+        sib = dict(blocks["bf16x3"])
+        sib["precision_note"] = ("opt-in mode: fp32 operands split into bf16 head + tail, 3 bf16 MFMAs per product, fp32 "
+                                 "accumulate; same K steps, same workload, same process as the headline")
+        if world == 1:
+            sib.update(precision_gap(model, args, dev))
+        out["bf16x3"] = sib
+    if world == 1 and not args.no_configs:
+        out["configs"] = other_configs(args, dev)
     if not args.no_cpu_baseline and world == 1:
-        out["cpu_baseline"] = cpu_baseline(H, L, N, T)
+        out["cpu_baseline"] = cpu_baseline(H, L, B, N, T)
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
 
-def cpu_baseline(H: int, L: int, N: int, T: int) -> dict:
-    """The oracle (a structural restatement of the reference's PyTorch-CPU op sequence) timed on this
-    host: a bounded sample of EGNN forwards, extrapolated to a full sample (T+1 forwards)."""
+def cpu_baseline(H: int, L: int, B: int, N: int, T: int) -> dict:
+    """The oracle (a structural restatement of the reference's PyTorch-CPU op sequence, pinned to the reference by
+    the golden vectors) timed on this host at the headline batch: 1 warm-up + K=5 EGNN dynamics forwards at B=256
+    (BASELINE.md section 3), extrapolated to a full sample (T+1 forwards)."""
     from hierdiff_amd.weights import synthetic_state_dict
     from oracle import egnn_oracle as orc
-    threads = os.cpu_count() or 1
+    logical = os.cpu_count() or 1
     try:
-        threads = len(os.sched_getaffinity(0))
+        logical = len(os.sched_getaffinity(0))
     except Exception:
         pass
-    try:                                   # one torch thread per physical core (SMT siblings do not help)
+    phys = logical
+    try:
         import psutil
-        phys = psutil.cpu_count(logical=False)
-        if phys:
-            threads = max(1, min(threads, phys))
+        phys = psutil.cpu_count(logical=False) or logical
     except Exception:
         pass
-    Bc = 64
     sd = orc.as_torch_sd(synthetic_state_dict(9, 0, H, L, 2, True, seed=0, coord_gain=1.0))
     cfg = orc.DynCfg(hidden_nf=H, n_layers=L)
-    # torch's intra-op pool scales poorly on big dual-socket hosts (128 threads measured 3x SLOWER than 8
-    # on this op mix): probe a few pool sizes with one forward each and time the fastest.
-    cands = sorted({c for c in (8, 16, 32, threads) if c <= threads})
-    probe = {c: orc.time_cpu_forward(sd, cfg, Bc, N, 8, 1, c, time.perf_counter) for c in cands}
+    # torch's intra-op pool scales poorly on big dual-socket hosts (128 threads measured 3x SLOWER than 16 on this op
+    # mix): probe a few pool sizes with one forward each at a quarter batch and time the fastest - the conservative
+    # (strongest) CPU baseline.
+    cands = sorted({c for c in (8, 16, 32, 64, min(phys, logical)) if c <= logical})
+    probe = {c: orc.time_cpu_forward(sd, cfg, max(1, B // 4), N, 8, 1, c, time.perf_counter) for c in cands}
     threads = min(probe, key=probe.get)
-    reps = 2
-    sec = orc.time_cpu_forward(sd, cfg, Bc, N, 8, reps, threads, time.perf_counter)
-    return {"value": round(Bc / ((T + 1) * sec), 5), "unit": "molecules/s", "cores": threads, "kind": "port",
-            "sample": f"{reps} EGNN dynamics forwards (after 1 warm-up; pool size chosen from {cands} by a 1-forward probe) at B={Bc}, N={N}, H={H}, L={L}, fp32, "
-                      f"{threads} torch threads; {sec:.3f} s/forward, extrapolated x{T + 1} forwards per batch",
+    K = 5
+    sec = orc.time_cpu_forward(sd, cfg, B, N, 8, K, threads, time.perf_counter)
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as fh:
+            model = next((ln.split(":", 1)[1].strip() for ln in fh if ln.startswith("model name")), "")
+    except Exception:
+        pass
+    return {"value": round(B / ((T + 1) * sec), 5), "unit": "molecules/s", "cores": threads, "host_cores": phys,
+            "host_logical_cpus": logical, "host_cpu": model, "kind": "port",
+            "sample": f"K={K} EGNN dynamics forwards after 1 warm-up at B={B}, N={N}, H={H}, L={L}, fp32, {threads} torch "
+                      f"threads (fastest of {cands} in a 1-forward probe at B={max(1, B // 4)}: "
+                      f"{ {c: round(v, 2) for c, v in probe.items()} } s); {sec:.3f} s/forward, extrapolated x{T + 1} "
+                      "forwards per batch",
             "s_per_forward": round(sec, 4)}
 
 

@@ -227,19 +227,7 @@ __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
     const float* Arow = a.AB + (size_t)ni * (2 * H) + 16 * hh;
     const float* Brow = a.AB + (size_t)nj * (2 * H) + H + 16 * hh;
     f32x4 pa[4], pb[4];
-    auto load_rows = [&](int c) {
-        if constexpr (ABL & 8) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { pa[u] = f32x4{radial, d0, radial, d0}; pb[u] = pa[u]; }
-            return;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            pa[u] = *reinterpret_cast<const f32x4*>(Arow + 32 * c + 4 * u);
-            pb[u] = *reinterpret_cast<const f32x4*>(Brow + 32 * c + 4 * u);
-        }
-    };
-    auto rows_issue = [&](int u, int c) {                  // bf16x3 mode: quad u of chunk c (see vm_load2)
+    auto rows_issue = [&](int u, int c) {                  // quad u of chunk c (see vm_load2)
         if constexpr (ABL & 8) { pa[u] = f32x4{radial, d0, radial, d0}; pb[u] = pa[u]; }
         else vm_load2(pa[u], pb[u], Arow + 32 * c + 4 * u, Brow + 32 * c + 4 * u);
     };
@@ -301,21 +289,17 @@ __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
     // chunk c; the AB rows are fetched two chunks ahead.
     float Pc[16];
     u32x4 phc[2], plc[2];                  // bf16x3: head / tail of the 16 operand values, 8 bf16 per k-step
-    if constexpr (PREC == 0) {
-        load_rows(0);
-        __syncthreads();               // chunk 0 of this tile landed (w_r / w_d staged on the first pass)
-        make_P(0, Pc);
-        load_rows(NCH > 1 ? 1 : 0);
-    } else {
+    // Both precision modes fetch the AB rows with the hand-counted inline-asm loads (see vm_load2): a compiler-visible
+    // load next to the W2 stream makes hipcc wait vmcnt(0) - i.e. for the stream it has just started - every chunk.
 #pragma unroll
-        for (int u = 0; u < 4; ++u) rows_issue(u, 0);
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(pa[0]), "+v"(pa[1]), "+v"(pa[2]), "+v"(pa[3]),
-                                            "+v"(pb[0]), "+v"(pb[1]), "+v"(pb[2]), "+v"(pb[3]));
-        __syncthreads();               // chunk 0 landed in every wave's share (w_r / w_d staged on the first pass)
-        make_P_bf(0, phc, plc);
+    for (int u = 0; u < 4; ++u) rows_issue(u, 0);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(pa[0]), "+v"(pa[1]), "+v"(pa[2]), "+v"(pa[3]),
+                                        "+v"(pb[0]), "+v"(pb[1]), "+v"(pb[2]), "+v"(pb[3]));
+    __syncthreads();               // chunk 0 landed in every wave's share (w_r / w_d staged on the first pass)
+    if constexpr (PREC == 0) make_P(0, Pc);
+    else make_P_bf(0, phc, plc);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) rows_issue(u, NCH > 1 ? 1 : 0);
-    }
+    for (int u = 0; u < 4; ++u) rows_issue(u, NCH > 1 ? 1 : 0);
 
     // accumulators start at the second layer's bias (saves the H/32 * 16 bias adds of the epilogue)
     f32x16 acc[NCT];
@@ -332,47 +316,67 @@ __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
     for (int c = 0; c < NCH; ++c, ++gc) {
         const int buf = (ABL & 4) ? 0 : (gc & 1);
         if constexpr (!(ABL & 4)) {
-            // chunk c landed in LDS and every wave is done with the other buffer.  bf16x3: the only VMEM
-            // operations younger than chunk c's stream are the 8 row gathers of the previous iteration.
-            if (c > 0) {
-                if constexpr (PREC == 0) __syncthreads();
-                else asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
-            }
-            // Unconditional (the last chunk re-requests chunk 0, unused unless a further tile follows): with the
-            // stream inside a branch hipcc has to assume "no stream in flight" at the join and waits vmcnt(0)
-            // - i.e. for the stream itself - before the first use of the gathered AB rows, every chunk.
-            if constexpr (PREC == 0) issue_chunk(c + 1 < NCH ? c + 1 : 0, buf ^ 1);
+            // chunk c landed in LDS and every wave is done with the other buffer.  The only VMEM operations younger
+            // than chunk c's stream are the 8 row gathers of the previous iteration.
+            if (c > 0) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+            // The stream of the next chunk is issued unconditionally further down (the last chunk re-requests chunk 0,
+            // unused unless a further tile follows): with the stream inside a branch hipcc has to assume "no stream in
+            // flight" at the join and waits vmcnt(0) - i.e. for the stream itself - before the first use of the
+            // gathered AB rows, every chunk.
         }
         // Branch-free from here to the end of the body (one scheduling region): the last iteration
         // recomputes the final chunk's operands and refetches its rows, results unused.
-        float Pn[16];
         u32x4 phn[2], pln[2];
         const int cn1 = c + 1 < NCH ? c + 1 : NCH - 1, cn2 = c + 2 < NCH ? c + 2 : NCH - 1;
         const float* Arow_n2 = Arow + 32 * cn2;        // rows of chunk c+2: one address pair per chunk,
         const float* Brow_n2 = Brow + 32 * cn2;        // the quad offset rides in the load's immediate
-        if constexpr (PREC == 0) {
-            make_P(cn1, Pn);
-            load_rows(cn2);
-        }
         const float* wb = wbuf + buf * CHF;
         const unsigned wb_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)wb + lane * 16;
         if constexpr (PREC == 0) {
             // chunk image: [4 q][NCT][64 lanes][4 floats]: fragment (q, ct) holds k = 32c + 16h + 4q + j, j = 0..3,
-            // of column 32ct + n (64-cycle fp32 MFMAs hide the LDS latency without explicit prefetch).
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f32x4 bv[NCT];
-#pragma unroll
-                for (int ct = 0; ct < NCT; ++ct)
-                    bv[ct] = *reinterpret_cast<const f32x4*>(wb + ((q * NCT + ct) * 64 + lane) * 4);
+            // of column 32ct + n.  Units of 4 fragments (one q, half of the column tiles) = 16 MFMAs = 1024 matrix-pipe
+            // cycles; the next unit's fragments are fetched (inline-asm ds_read_b128, see lds_read4) while the current
+            // unit's MFMAs run, the first unit's reads are covered by the stream issue and the operand generation.
+            constexpr int HC = NCT >= 4 ? 4 : NCT;          // column tiles per unit
+            constexpr int UPQ = NCT / HC;                   // units per q
+            constexpr int NU = 4 * UPQ;
+            f32x4 f0[4], f1[4];
+            auto read_unit = [&](auto U, f32x4 (&f)[4]) {
+                constexpr int u = decltype(U)::value, q = u / UPQ, c0 = (u % UPQ) * HC;
+                lds_read4<f32x4, frag_off_f32(q * NCT + c0), frag_off_f32(q * NCT + c0 + (HC > 1 ? 1 : 0)),
+                          frag_off_f32(q * NCT + c0 + (HC > 2 ? 2 : 0)), frag_off_f32(q * NCT + c0 + (HC > 3 ? 3 : 0))>(f, wb_lds);
+            };
+            read_unit(std::integral_constant<int, 0>{}, f0);
+            if constexpr (!(ABL & 4)) issue_chunk(c + 1 < NCH ? c + 1 : 0, buf ^ 1);
+            // Operands of chunk c+1 are produced IN PLACE: once the MFMAs of k-quad q have been issued their four operand
+            // registers are dead, so quad q of the next chunk is built there (from rows requested one iteration ago) and
+            // the rows of chunk c+2 go into the freed row registers.  Outstanding VMEM at that point, oldest first:
+            // quads q..3 of chunk c+1, the GL_PER_WAVE stream pieces, quads 0..q-1 of chunk c+2.
+            static_for<0, NU>([&](auto Uc) {
+                constexpr int u = decltype(Uc)::value, q = u / UPQ, c0 = (u % UPQ) * HC;
+                f32x4(&cur)[4] = (u & 1) ? f1 : f0;
+                f32x4(&nxt)[4] = (u & 1) ? f0 : f1;
+                lds_wait4<0>(cur);
+                if constexpr (u + 1 < NU) read_unit(std::integral_constant<int, u + 1>{}, nxt);
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int ct = 0; ct < NCT; ++ct)
-                        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(Pc[4 * q + j], bv[ct][j], acc[ct], 0, 0, 0);
-            }
+                    for (int ct = 0; ct < HC; ++ct)
+                        acc[c0 + ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(Pc[4 * q + j], cur[ct][j], acc[c0 + ct], 0, 0, 0);
+                if constexpr (u % UPQ == UPQ - 1) {
+                    vm_wait2<6 + GL_PER_WAVE>(pa[q], pb[q]);
+                    const f32x4 wr4 = *reinterpret_cast<const f32x4*>(wrd_s + 32 * cn1 + 16 * hh + 4 * q);
+                    const f32x4 wd4 = *reinterpret_cast<const f32x4*>(wrd_s + H + 32 * cn1 + 16 * hh + 4 * q);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) Pc[i] = Pn[i];
+                    for (int j = 0; j < 4; ++j) {
+                        float pre = pa[q][j] + pb[q][j];
+                        pre = __builtin_fmaf(radial, wr4[j], pre);
+                        pre = __builtin_fmaf(d0, wd4[j], pre);
+                        Pc[4 * q + j] = silu_f(pre);
+                    }
+                    vm_load2o<16 * q>(pa[q], pb[q], Arow_n2, Brow_n2);
+                }
+            });
         } else {
             // chunk image: [hi|lo][2 k-steps][NCT][64 lanes][8 bf16]; lane (h, n), element i of step s is
             // W2[32ct + n][32c + 16h + 8s + i] - the same k order as P[8s + i].  Units u = (k-step, ct) of
@@ -448,7 +452,7 @@ __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
         }
     }
 
-    if constexpr (PREC == 1) {             // drain the (unused) last gathers before their registers are reused
+    {                                      // drain the (unused) last gathers before their registers are reused
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(pa[0]), "+v"(pa[1]), "+v"(pa[2]), "+v"(pa[3]),
                                             "+v"(pb[0]), "+v"(pb[1]), "+v"(pb[2]), "+v"(pb[3]));
     }
