@@ -78,15 +78,18 @@ def audit(resources: dict) -> list:
     return bad
 
 
+LIB_DEBUG = os.path.join(LIBDIR, "libhierdiff_hip_dbg.so")     # --debug-kernels build; select with HIERDIFF_LIB=<path>
+
+
 def build(force: bool = False, save_temps: bool = False, verbose: bool = True, debug_kernels: bool = False) -> str:
+    if debug_kernels:
+        return _build_debug(verbose)
     if not force and not needs_build() and os.path.exists(RESOURCES):
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-std=c++17", "-fPIC", "-shared",
            "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",
            "-Rpass-analysis=kernel-resource-usage", "-o", LIB + ".tmp"] + SOURCES
-    if debug_kernels:        # measurement build: HD_ABLATE variants of the edge kernel + hd_debug_edge_trace (never shipped)
-        cmd.insert(1, "-DHD_DEBUG_KERNELS")
     if save_temps:
         tmpdir = os.path.join(PKG, "build")
         os.makedirs(tmpdir, exist_ok=True)
@@ -111,7 +114,17 @@ def build(force: bool = False, save_temps: bool = False, verbose: bool = True, d
     return LIB
 
 
+def _build_debug(verbose: bool = True) -> str:
+    """Measurement build next to the product library: HD_ABLATE variants of the edge kernel + hd_debug_edge_trace."""
+    os.makedirs(LIBDIR, exist_ok=True)
+    cmd = [_hipcc(), "-DHD_DEBUG_KERNELS", "--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-std=c++17", "-fPIC",
+           "-shared", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result", "-o", LIB_DEBUG] + SOURCES
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, cwd=CSRC, check=True)
+    return LIB_DEBUG
+
+
 if __name__ == "__main__":
-    build(force="--force" in sys.argv or "--debug-kernels" in sys.argv, save_temps="--save-temps" in sys.argv,
-          debug_kernels="--debug-kernels" in sys.argv)
-    print(LIB)
+    print(build(force="--force" in sys.argv, save_temps="--save-temps" in sys.argv,
+                debug_kernels="--debug-kernels" in sys.argv))

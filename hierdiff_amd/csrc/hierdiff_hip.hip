@@ -104,6 +104,9 @@ struct hd_topology {
     int B, N, M, M_pad, E, E_pad, n_tiles, n_wg, n_parts;
     // device tables
     int *node_of, *slot_of, *ei, *ej, *seg_part, *tile_nseg, *pstart, *nvalid;
+    int *rptr, *rrows, *sptr, *srows;          // edge rows by receiving / sending node (training kernels)
+    std::vector<int>* node_of_host;            // kept for hd_topology_nodes
+    float *w2img, *w2timg;                     // training: device-packed images of the current layer's W2 and W2^T
     uint8_t *eseg, *nm_bytes;
     float* nmask;
     // workspace
@@ -156,6 +159,7 @@ static int dev_upload(T** p, const std::vector<T>& v) {
 // ----------------------------------------------------------------------------- create / destroy
 
 static int prepare_kernels(hd_handle* h);
+template <int H> static int prepare_edge_bwd_h();
 
 extern "C" int hd_create(const hd_config* cfg, int device, hd_handle** out) {
     if (!cfg || !out) return fail(HD_E_INVALID, "hd_create: null argument");
@@ -464,6 +468,8 @@ extern "C" int hd_topology_destroy(hd_topology* t) {
     hipFree(t->tile_nseg); hipFree(t->pstart); hipFree(t->nvalid); hipFree(t->eseg); hipFree(t->nm_bytes);
     hipFree(t->nmask); hipFree(t->hbuf); hipFree(t->AB); hipFree(t->AB2); hipFree(t->Tb); hipFree(t->agg); hipFree(t->x0); hipFree(t->xcur);
     hipFree(t->part); hipFree(t->xpart); hipFree(t->eps); hipFree(t->zbuf); hipFree(t->ctxbuf);
+    hipFree(t->rptr); hipFree(t->rrows); hipFree(t->sptr); hipFree(t->srows); hipFree(t->w2img); hipFree(t->w2timg);
+    delete t->node_of_host;
     delete t;
     return HD_OK;
 }
@@ -480,6 +486,7 @@ struct TileLayout {
     int M, M_pad, n_tiles, n_wg, n_parts;
     long long E;
     std::vector<int> slot_of, node_of, nvalid, ei, ej, seg_part, tile_nseg, pstart;
+    std::vector<int> rptr, rrows, sptr, srows;      // valid edge rows by receiving / sending node (CSR, ascending rows)
     std::vector<uint8_t> eseg;
     std::vector<float> nmask;
 };
@@ -579,6 +586,18 @@ static int build_layout(const uint8_t* node_mask, const uint8_t* edge_mask, int 
     L.n_wg = (L.n_tiles + 3) / 4;
     while ((int)tile_nseg.size() < std::max(1, L.n_wg * 4)) new_tile();     // padding tiles of the last workgroup
     L.M = M; L.M_pad = M_pad; L.E = E; L.n_parts = pstart[M];
+    // CSR views of the tiled rows (training kernels): ascending row order makes the per-node sums deterministic
+    L.rptr.assign(M + 1, 0); L.sptr.assign(M + 1, 0);
+    const size_t rows = ei.size();
+    for (size_t r = 0; r < rows; ++r)
+        if (eseg[r] != 255) { L.rptr[ei[r] + 1]++; L.sptr[ej[r] + 1]++; }
+    for (int i = 0; i < M; ++i) { L.rptr[i + 1] += L.rptr[i]; L.sptr[i + 1] += L.sptr[i]; }
+    L.rrows.assign((size_t)E, 0); L.srows.assign((size_t)E, 0);
+    {
+        std::vector<int> rp(L.rptr.begin(), L.rptr.end() - 1), sp(L.sptr.begin(), L.sptr.end() - 1);
+        for (size_t r = 0; r < rows; ++r)
+            if (eseg[r] != 255) { L.rrows[rp[ei[r]]++] = (int)r; L.srows[sp[ej[r]]++] = (int)r; }
+    }
     return HD_OK;
 }
 
@@ -630,6 +649,9 @@ extern "C" int hd_topology_create(hd_handle* h, const uint8_t* node_mask, const 
         HD_TRY(dev_upload(&t->ej, ej)); HD_TRY(dev_upload(&t->seg_part, seg_part)); HD_TRY(dev_upload(&t->tile_nseg, tile_nseg));
         HD_TRY(dev_upload(&t->pstart, pstart)); HD_TRY(dev_upload(&t->nvalid, nvalid)); HD_TRY(dev_upload(&t->eseg, eseg));
         HD_TRY(dev_upload(&t->nm_bytes, nm_bytes)); HD_TRY(dev_upload(&t->nmask, nmask));
+        HD_TRY(dev_upload(&t->rptr, L.rptr)); HD_TRY(dev_upload(&t->rrows, L.rrows));
+        HD_TRY(dev_upload(&t->sptr, L.sptr)); HD_TRY(dev_upload(&t->srows, L.srows));
+        t->node_of_host = new std::vector<int>(node_of);
         // zero-filled: pad rows stay zero for the lifetime of the topology (kernels never write them)
         auto zalloc = [&](float** p, size_t count) -> int {
             HD_TRY(dev_alloc(p, count));
@@ -643,6 +665,7 @@ extern "C" int hd_topology_create(hd_handle* h, const uint8_t* node_mask, const 
         HD_TRY(zalloc(&t->part, (size_t)std::max(1, n_parts) * H)); HD_TRY(zalloc(&t->xpart, (size_t)std::max(1, n_parts) * 4));
         HD_TRY(zalloc(&t->eps, BN * h->D)); HD_TRY(zalloc(&t->zbuf, BN * h->D));
         HD_TRY(zalloc(&t->ctxbuf, BN * (size_t)std::max(1, h->cfg.context_node_nf)));
+        HD_TRY(zalloc(&t->w2img, (size_t)H * H)); HD_TRY(zalloc(&t->w2timg, (size_t)H * H));
         HIP_TRY(hipDeviceSynchronize());
         return HD_OK;
     };
@@ -782,25 +805,29 @@ extern "C" int hd_debug_edge_trace(hd_handle* h, long long* out, int max_wg) {
     return n;
 }
 
+template <int PREC>
 static bool launch_edge_ablated(hd_handle* h, const EdgeArgs& a, hipStream_t s) {
     const int lds = edge_lds_bytes<256>();
     const dim3 grid(a.n_wg), block(256);
     auto run = [&](auto Abl) {
         constexpr int ABL = decltype(Abl)::value;
-        hipFuncSetAttribute((const void*)k_edge<256, false, 1, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipFuncSetAttribute((const void*)k_edge<256, false, PREC, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         EdgeArgs b = a;
         if constexpr (ABL & 16) {
             if (!h->d_trace) hipMalloc(reinterpret_cast<void**>(&h->d_trace), sizeof(long long) * 32 * 4096);
             if (a.n_wg > 4096) return;
             b.trace = h->d_trace; h->trace_wg = a.n_wg;
         }
-        hipLaunchKernelGGL((k_edge<256, false, 1, ABL>), grid, block, lds, s, b);
+        hipLaunchKernelGGL((k_edge<256, false, PREC, ABL>), grid, block, lds, s, b);
     };
     switch (h->ablate) {
         case 1: run(std::integral_constant<int, 1>{}); return true;
         case 2: run(std::integral_constant<int, 2>{}); return true;
         case 4: run(std::integral_constant<int, 4>{}); return true;
+        case 5: run(std::integral_constant<int, 5>{}); return true;
         case 8: run(std::integral_constant<int, 8>{}); return true;
+        case 12: run(std::integral_constant<int, 12>{}); return true;
+        case 13: run(std::integral_constant<int, 13>{}); return true;
         case 15: run(std::integral_constant<int, 15>{}); return true;
         case 16: run(std::integral_constant<int, 16>{}); return true;
         case 18: run(std::integral_constant<int, 18>{}); return true;
@@ -821,7 +848,7 @@ static int launch_edge_h(hd_handle* h, bool coord, const EdgeArgs& a, hipStream_
     const dim3 grid(a.n_wg), block(256);
 #ifdef HD_DEBUG_KERNELS
     if constexpr (H == 256) {
-        if (h->ablate && prec == 1 && !coord && launch_edge_ablated(h, a, s)) return HD_OK;
+        if (h->ablate && !coord && (prec == 1 ? launch_edge_ablated<1>(h, a, s) : launch_edge_ablated<0>(h, a, s))) return HD_OK;
     }
 #endif
     if (prec == 0) {
@@ -848,10 +875,10 @@ static int prepare_edge_h() {
 
 static int prepare_kernels(hd_handle* h) {
     switch (h->H) {
-        case 32: HD_TRY(prepare_node_h<32>()); return prepare_edge_h<32>();
-        case 64: HD_TRY(prepare_node_h<64>()); return prepare_edge_h<64>();
-        case 128: HD_TRY(prepare_node_h<128>()); return prepare_edge_h<128>();
-        default: HD_TRY(prepare_node_h<256>()); return prepare_edge_h<256>();
+        case 32: HD_TRY(prepare_node_h<32>()); HD_TRY(prepare_edge_bwd_h<32>()); return prepare_edge_h<32>();
+        case 64: HD_TRY(prepare_node_h<64>()); HD_TRY(prepare_edge_bwd_h<64>()); return prepare_edge_h<64>();
+        case 128: HD_TRY(prepare_node_h<128>()); HD_TRY(prepare_edge_bwd_h<128>()); return prepare_edge_h<128>();
+        default: HD_TRY(prepare_node_h<256>()); HD_TRY(prepare_edge_bwd_h<256>()); return prepare_edge_h<256>();
     }
 }
 
@@ -1009,6 +1036,137 @@ extern "C" int hd_nan_events(hd_handle* h, void* stream, long long* count) {
     if (!h || !count) return fail(HD_E_INVALID, "hd_nan_events: null argument");
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     HIP_TRY(hipMemcpy(count, h->d_nan_events, sizeof(long long), hipMemcpyDeviceToHost));
+    return HD_OK;
+}
+
+// ----------------------------------------------------------------------------- training primitives (fp32)
+
+extern "C" int hd_topology_nodes(const hd_topology* t, int* node_of) {
+    if (!t || !node_of) return fail(HD_E_INVALID, "hd_topology_nodes: null argument");
+    std::copy(t->node_of_host->begin(), t->node_of_host->end(), node_of);
+    return HD_OK;
+}
+
+template <int H>
+static int edge_bwd_lds_bytes() { return (32 * H + 4 * 288) * 4; }
+
+template <int H>
+static int prepare_edge_bwd_h() {
+    const int lds = edge_bwd_lds_bytes<H>();
+    HIP_TRY(hipFuncSetAttribute((const void*)k_edge_bwd<H, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_edge_bwd<H, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_edge_bwd<H, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_edge_bwd<H, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    return HD_OK;
+}
+
+template <int H>
+static void launch_edge_bwd_h(bool coord, int stage, const EdgeBwdArgs& a, int n_wg, hipStream_t s) {
+    const dim3 grid(n_wg), block(256);
+    const int lds = edge_bwd_lds_bytes<H>();
+    if (!coord && stage == 0) hipLaunchKernelGGL((k_edge_bwd<H, false, 0>), grid, block, lds, s, a);
+    else if (!coord) hipLaunchKernelGGL((k_edge_bwd<H, false, 1>), grid, block, lds, s, a);
+    else if (stage == 0) hipLaunchKernelGGL((k_edge_bwd<H, true, 0>), grid, block, lds, s, a);
+    else hipLaunchKernelGGL((k_edge_bwd<H, true, 1>), grid, block, lds, s, a);
+}
+
+static void launch_edge_bwd(hd_handle* h, bool coord, int stage, const EdgeBwdArgs& a, int n_wg, hipStream_t s) {
+    switch (h->H) {
+        case 32: launch_edge_bwd_h<32>(coord, stage, a, n_wg, s); break;
+        case 64: launch_edge_bwd_h<64>(coord, stage, a, n_wg, s); break;
+        case 128: launch_edge_bwd_h<128>(coord, stage, a, n_wg, s); break;
+        default: launch_edge_bwd_h<256>(coord, stage, a, n_wg, s); break;
+    }
+}
+
+static int check_train(hd_handle* h, hd_topology* t, const char* who) {
+    if (!h || !t) return fail(HD_E_INVALID, std::string(who) + ": null handle/topology");
+    if (t->h != h) return fail(HD_E_INVALID, std::string(who) + ": topology belongs to another handle");
+    if (h->cfg.precision != 0) return fail(HD_E_STATE, std::string(who) + ": training primitives need precision 0 (exact fp32)");
+    return HD_OK;
+}
+
+extern "C" int hd_edge_layer_forward(hd_handle* h, hd_topology* t, int coord, const float* AB, const float* x,
+                                     const float* x0, const float* wrd, const float* W2, const float* b2,
+                                     const float* wa, float ba, float* out, void* stream) {
+    HD_TRY(check_train(h, t, "hd_edge_layer_forward"));
+    if (!AB || !x || !x0 || !wrd || !W2 || !b2 || !wa || !out) return fail(HD_E_INVALID, "hd_edge_layer_forward: null tensor");
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    const hd_config& c = h->cfg;
+    const int H = h->H, M = t->M;
+    const int ow = coord ? 4 : H;
+    HIP_TRY(hipMemsetAsync(out, 0, (size_t)t->M_pad * ow * sizeof(float), s));
+    if (t->n_wg == 0 || M == 0) return HD_OK;
+    hipLaunchKernelGGL((k_pack_w2<false>), dim3((H * H + 255) / 256), dim3(256), 0, s, W2, t->w2img, H);
+    EdgeArgs e;
+    std::memset(&e, 0, sizeof(e));
+    e.AB = AB; e.wrd = wrd; e.W2img = t->w2img; e.b2 = b2; e.wa = wa;
+    e.ei = t->ei; e.ej = t->ej; e.eseg = t->eseg; e.seg_part = t->seg_part; e.tile_nseg = t->tile_nseg;
+    e.xcur = x; e.x0 = x0; e.part = coord ? t->xpart : t->part; e.ba = ba;
+    e.norm_constant = c.norm_constant; e.coords_range = c.coords_range / (float)c.n_layers; e.attention = c.attention;
+    e.use_tanh = c.tanh; e.n_tiles = t->n_tiles; e.n_wg = t->n_wg;
+    HD_TRY(edge(h, coord != 0, e, s));
+    AggArgs ag;
+    ag.part = coord ? t->xpart : t->part; ag.pstart = t->pstart; ag.agg = out; ag.norm = c.normalization_factor;
+    ag.M = M; ag.H = ow;
+    const long long total = (long long)M * (ow / 4);
+    hipLaunchKernelGGL(k_agg, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ag);
+    HIP_TRY(hipGetLastError());
+    return HD_OK;
+}
+
+extern "C" int hd_edge_layer_backward(hd_handle* h, hd_topology* t, int coord, const float* AB, const float* x,
+                                      const float* x0, const float* wrd, const float* W2, const float* b2,
+                                      const float* wa, float ba, const float* gout, float* G2, float* P, float* G1,
+                                      float* escal, float* colpart, float* bapart, float* dAB, float* dx, float* dx0,
+                                      void* stream) {
+    HD_TRY(check_train(h, t, "hd_edge_layer_backward"));
+    if (!AB || !x || !x0 || !wrd || !W2 || !b2 || !wa || !gout || !G2 || !P || !G1 || !escal || !colpart || !bapart ||
+        !dAB || !dx || !dx0)
+        return fail(HD_E_INVALID, "hd_edge_layer_backward: null tensor");
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    const hd_config& c = h->cfg;
+    const int H = h->H, M = t->M;
+    HIP_TRY(hipMemsetAsync(dAB, 0, (size_t)t->M_pad * 2 * H * sizeof(float), s));
+    HIP_TRY(hipMemsetAsync(dx, 0, (size_t)t->M_pad * 4 * sizeof(float), s));
+    HIP_TRY(hipMemsetAsync(dx0, 0, (size_t)t->M_pad * 4 * sizeof(float), s));
+    const int tiles = std::max(1, t->n_wg * 4);
+    HIP_TRY(hipMemsetAsync(escal, 0, (size_t)tiles * 32 * 8 * sizeof(float), s));
+    if (t->n_wg == 0 || M == 0) {
+        HIP_TRY(hipMemsetAsync(colpart, 0, (size_t)tiles * H * sizeof(float), s));
+        HIP_TRY(hipMemsetAsync(bapart, 0, (size_t)tiles * sizeof(float), s));
+        HIP_TRY(hipMemsetAsync(G2, 0, (size_t)tiles * 32 * H * sizeof(float), s));
+        HIP_TRY(hipMemsetAsync(P, 0, (size_t)tiles * 32 * H * sizeof(float), s));
+        HIP_TRY(hipMemsetAsync(G1, 0, (size_t)tiles * 32 * H * sizeof(float), s));
+        return HD_OK;
+    }
+    if (coord) HIP_TRY(hipMemsetAsync(bapart, 0, (size_t)tiles * sizeof(float), s));     // no attention bias in a coordinate layer
+    hipLaunchKernelGGL((k_pack_w2<false>), dim3((H * H + 255) / 256), dim3(256), 0, s, W2, t->w2img, H);
+    hipLaunchKernelGGL((k_pack_w2<true>), dim3((H * H + 255) / 256), dim3(256), 0, s, W2, t->w2timg, H);
+    EdgeBwdArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.AB = AB; a.wrd = wrd; a.b2 = b2; a.wa = wa; a.ei = t->ei; a.ej = t->ej; a.eseg = t->eseg; a.xcur = x; a.x0 = x0;
+    a.ba = ba; a.norm_constant = c.norm_constant; a.coords_range = c.coords_range / (float)c.n_layers;
+    a.inv_norm = 1.0f / c.normalization_factor; a.attention = c.attention; a.use_tanh = c.tanh; a.n_tiles = t->n_tiles;
+    a.gin = gout; a.G2 = G2; a.escal = escal; a.colpart = colpart; a.bapart = bapart; a.Pout = P; a.G1 = G1;
+    a.Wimg = t->w2img;
+    launch_edge_bwd(h, coord != 0, 0, a, t->n_wg, s);
+    a.Wimg = t->w2timg;
+    launch_edge_bwd(h, coord != 0, 1, a, t->n_wg, s);
+    CsrSumArgs cs;
+    cs.G = G1; cs.out = dAB; cs.M = M; cs.H = H; cs.ldo = 2 * H;
+    const long long total = (long long)M * (H / 4);
+    cs.ptr = t->rptr; cs.rows = t->rrows; cs.col0 = 0;
+    hipLaunchKernelGGL(k_csr_sum, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, cs);
+    cs.ptr = t->sptr; cs.rows = t->srows; cs.col0 = H;
+    hipLaunchKernelGGL(k_csr_sum, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, cs);
+    EdgeDxArgs d;
+    d.escal = escal; d.ei = t->ei; d.ej = t->ej; d.rptr = t->rptr; d.rrows = t->rrows; d.sptr = t->sptr; d.srows = t->srows;
+    d.xcur = x; d.x0 = x0; d.dx = dx; d.dx0 = dx0; d.norm_constant = c.norm_constant; d.M = M; d.coord = coord ? 1 : 0;
+    hipLaunchKernelGGL(k_edge_dx, dim3((M + 255) / 256), dim3(256), 0, s, d);
+    HIP_TRY(hipGetLastError());
     return HD_OK;
 }
 

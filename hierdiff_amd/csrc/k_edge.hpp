@@ -374,7 +374,8 @@ __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
                         pre = __builtin_fmaf(d0, wd4[j], pre);
                         Pc[4 * q + j] = silu_f(pre);
                     }
-                    vm_load2o<16 * q>(pa[q], pb[q], Arow_n2, Brow_n2);
+                    if constexpr (ABL & 8) { pa[q] = f32x4{radial, d0, radial, d0}; pb[q] = pa[q]; }
+                    else vm_load2o<16 * q>(pa[q], pb[q], Arow_n2, Brow_n2);
                 }
             });
         } else {

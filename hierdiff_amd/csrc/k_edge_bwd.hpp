@@ -1,0 +1,386 @@
+// Training kernels of the edge model (exact fp32): backward of one edge layer - gather, first edge Linear (factorised),
+// SiLU, H x H Linear on the matrix cores, SiLU, attention gate (GCL) or coordinate head (EquivariantUpdate), neighbour
+// sum - i.e. of egnn_new.py:35-56 / :91-104 as k_edge computes them.  Included through kernels.hpp.
+//
+// Per-edge activations are not kept by the forward pass; they are recomputed here tile by tile (32 edge rows per
+// wavefront, same tile tables as the forward kernel) in two stages:
+//   stage A  pre2 = W2 P + b2 (MFMA, as in the forward kernel), M = silu(pre2), gate / head, and from the incoming
+//            gradient of the neighbour sum:  G2 = dL/d(pre2)  [E_pad][H]   (+ per-tile partials of d(wa), d(ba) / d(w7),
+//            COORD: per-edge d(unit direction), d(phi))
+//   stage B  dP = G2 W2 (MFMA with the transposed weight image), pre1 recomputed from the AB rows,
+//            P = silu(pre1), G1 = dP * silu'(pre1) = dL/d(pre1)  [E_pad][H]   (+ per-edge d(radial), d(d0))
+// followed by two deterministic CSR reductions (rows by receiving node -> dA, rows by sending node -> dB) and a per-node
+// coordinate-gradient kernel.  The dense reductions over all edges (dW2 = G2^T P, db2, d(w_r), d(w_d)) are plain GEMMs on the
+// materialised [E_pad][H] operands and are left to the BLAS library by the host (hierdiff_amd/training.py).
+// These kernels favour clarity over speed (one LDS buffer, two barriers per K chunk): training is not the headline path.
+#pragma once
+#include "common.hpp"
+
+struct EdgeBwdArgs {
+    // forward inputs of the layer
+    const float* AB;        // [M_pad][2H]
+    const float* wrd;       // [2][H] w_r, w_d
+    const float* Wimg;      // stage A: chunk image of W2;  stage B: chunk image of W2^T
+    const float* b2;        // [H]
+    const float* wa;        // [H] att_mlp.0.weight / coord_mlp.4.weight
+    const int* ei;
+    const int* ej;
+    const uint8_t* eseg;
+    const float* xcur;      // [M_pad][4]
+    const float* x0;        // [M_pad][4]
+    float ba, norm_constant, coords_range, inv_norm;
+    int attention, use_tanh, n_tiles;
+    // stage A
+    const float* gin;       // GCL: d(agg) [M_pad][H];  COORD: d(xagg) [M_pad][4]
+    float* G2;              // [E_pad][H]
+    float* escal;           // [E_pad][8]: {du_x, du_y, du_z, dphi, d(radial), d(d0), radial, d0}
+    float* colpart;         // [tiles][H] per-tile partial of d(wa) / d(w7)
+    float* bapart;          // [tiles]    per-tile partial of d(ba)
+    // stage B
+    float* Pout;            // [E_pad][H]
+    float* G1;              // [E_pad][H]
+};
+
+// sigmoid and the SiLU derivative from it: silu'(x) = s (1 + x (1 - s))
+HD_DEVINL float dsilu_from_sigmoid(float x, float s) { return s * __builtin_fmaf(x, 1.0f - s, 1.0f); }
+
+// STAGE 0 = A, 1 = B.  One workgroup = four 32-row tiles (one per wavefront), grid = tiles / 4.
+template <int H, bool COORD, int STAGE>
+__global__ __launch_bounds__(256) void k_edge_bwd(EdgeBwdArgs a) {
+    constexpr int NCT = H / 32, NCH = H / 32, CHF = 32 * H;
+    extern __shared__ __attribute__((aligned(16))) float smem_b[];
+    float* wbuf = smem_b;                        // [CHF] one K chunk of the weight image
+    float* scr = smem_b + CHF;                   // per wave: 32 phi + 96 unit dir + 32 ni + 32 nj + 32 radial + 32 d0 + 32 valid
+    __shared__ __attribute__((aligned(16))) float wrd_s[4 * H];    // [w_r | w_d | b2 | wa]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hh = lane >> 5, n = lane & 31;
+    float* my = scr + wave * 288;
+    float* phi_s = my;
+    float* tr = my + 32;
+    int* rowi_s = reinterpret_cast<int*>(my + 128);
+    int* rowj_s = reinterpret_cast<int*>(my + 160);
+    float* rrad_s = my + 192;
+    float* rd0_s = my + 224;
+    float* rval_s = my + 256;
+
+    for (int k = tid; k < 2 * H; k += 256) wrd_s[k] = a.wrd[k];
+    for (int k = tid; k < H; k += 256) { wrd_s[2 * H + k] = a.b2[k]; wrd_s[3 * H + k] = a.wa[k]; }
+
+    const int tile = blockIdx.x * 4 + wave;                    // every tile of the (padded) table exists
+    const int e = tile * 32 + n;
+    const int ni = a.ei[e], nj = a.ej[e];
+    const float valid = (a.eseg[e] != 255) ? 1.0f : 0.0f;
+    const f32x4 xi = *reinterpret_cast<const f32x4*>(a.xcur + (size_t)ni * 4);
+    const f32x4 xj = *reinterpret_cast<const f32x4*>(a.xcur + (size_t)nj * 4);
+    const f32x4 yi = *reinterpret_cast<const f32x4*>(a.x0 + (size_t)ni * 4);
+    const f32x4 yj = *reinterpret_cast<const f32x4*>(a.x0 + (size_t)nj * 4);
+    const float dx = xi[0] - xj[0], dy = xi[1] - xj[1], dz = xi[2] - xj[2];
+    const float radial = dx * dx + dy * dy + dz * dz;
+    const float ex = yi[0] - yj[0], ey = yi[1] - yj[1], ez = yi[2] - yj[2];
+    const float d0 = ex * ex + ey * ey + ez * ez;
+    if (hh == 0) {
+        rowi_s[n] = ni; rowj_s[n] = nj; rrad_s[n] = radial; rd0_s[n] = d0; rval_s[n] = valid;
+        if constexpr (COORD) {
+            const float inv = valid / (sqrtf(radial + 1e-8f) + a.norm_constant);
+            tr[n * 3 + 0] = dx * inv; tr[n * 3 + 1] = dy * inv; tr[n * 3 + 2] = dz * inv;
+        }
+    }
+
+    // A operand of K chunk c for this lane's edge row (k = 32c + 16hh + 0..15)
+    const float* Arow = a.AB + (size_t)ni * (2 * H) + 16 * hh;
+    const float* Brow = a.AB + (size_t)nj * (2 * H) + H + 16 * hh;
+    const float* Grow = a.G2 + (size_t)e * H + 16 * hh;
+    auto make_P = [&](int c, float (&P)[16]) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if constexpr (STAGE == 0) {
+                const f32x4 av = *reinterpret_cast<const f32x4*>(Arow + 32 * c + 4 * u);
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(Brow + 32 * c + 4 * u);
+                const f32x4 wr4 = *reinterpret_cast<const f32x4*>(wrd_s + 32 * c + 16 * hh + 4 * u);
+                const f32x4 wd4 = *reinterpret_cast<const f32x4*>(wrd_s + H + 32 * c + 16 * hh + 4 * u);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float pre = av[j] + bv[j];                       // same operation order as the forward kernel
+                    pre = __builtin_fmaf(radial, wr4[j], pre);
+                    pre = __builtin_fmaf(d0, wd4[j], pre);
+                    P[4 * u + j] = silu_f(pre);
+                }
+            } else {
+                const f32x4 gv = *reinterpret_cast<const f32x4*>(Grow + 32 * c + 4 * u);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) P[4 * u + j] = gv[j];
+            }
+        }
+    };
+
+    __syncthreads();                                             // wrd_s staged
+    f32x16 acc[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+        const float b2v = (STAGE == 0) ? wrd_s[2 * H + 32 * ct + n] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ct][r] = b2v;
+    }
+#pragma unroll 1
+    for (int c = 0; c < NCH; ++c) {
+        __syncthreads();                                         // every wave is done with the previous chunk
+        {
+            const float* src = a.Wimg + (size_t)c * CHF;
+            for (int k = tid * 4; k < CHF; k += 256 * 4) glds16(src + k, wbuf + (k - lane * 4));   // 1 KiB per wave-instruction
+        }
+        float P[16];
+        make_P(c, P);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of the chunk have landed
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 bv[NCT];
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) bv[ct] = *reinterpret_cast<const f32x4*>(wbuf + ((q * NCT + ct) * 64 + lane) * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct)
+                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(P[4 * q + j], bv[ct][j], acc[ct], 0, 0, 0);
+        }
+    }
+
+    // acc[ct][r] = row rho(r) = (r&3) + 8*(r>>2) + 4*hh, column 32*ct + n.
+    // Row dots: transpose-reduce over the 32 lanes of a half (see k_edge); lanes 2s, 2s+1 end up with the dot of row slot s.
+    auto row_reduce = [&](const float (&dot)[16]) -> float {
+        float v8[8], v4[4], v2[2];
+        const bool b4 = n & 16, b3 = n & 8, b2_ = n & 4, b1 = n & 2;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v8[k] = (b4 ? dot[k + 8] : dot[k]) + __shfl_xor(b4 ? dot[k] : dot[k + 8], 16);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v4[k] = (b3 ? v8[k + 4] : v8[k]) + __shfl_xor(b3 ? v8[k] : v8[k + 4], 8);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) v2[k] = (b2_ ? v4[k + 2] : v4[k]) + __shfl_xor(b2_ ? v4[k] : v4[k + 2], 4);
+        float v = (b1 ? v2[1] : v2[0]) + __shfl_xor(b1 ? v2[0] : v2[1], 2);
+        return v + __shfl_xor(v, 1);
+    };
+    const int my_slot = (n >> 1) & 15;
+    const int my_rho = (my_slot & 3) + 8 * (my_slot >> 2) + 4 * hh;
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    int rho[16];
+    float vr[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { rho[r] = (r & 3) + 8 * (r >> 2) + 4 * hh; vr[r] = rval_s[rho[r]]; }
+
+    if constexpr (STAGE == 0) {
+        float colsum[NCT];
+        if constexpr (!COORD) {
+            int nir[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) nir[r] = rowi_s[rho[r]];
+            float dot[16], sd[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { dot[r] = 0.f; sd[r] = 0.f; }
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                const float wav = wrd_s[3 * H + 32 * ct + n];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float m = silu_f(acc[ct][r]);
+                    dot[r] = __builtin_fmaf(m, wav, dot[r]);
+                    const float g = vr[r] * a.gin[(size_t)nir[r] * H + 32 * ct + n] * a.inv_norm;
+                    sd[r] = __builtin_fmaf(m, g, sd[r]);
+                }
+            }
+            const float rowdot = row_reduce(dot), rowsd = row_reduce(sd);
+            float att = 1.0f, q = 0.0f;
+            if (a.attention) { att = sigmoid_f(rowdot + a.ba); q = rowsd * att * (1.0f - att); }
+            {   // d(ba) of this tile: every row's q sits in two lanes of its half
+                float qs = ((n & 1) == 0) ? q * rval_s[my_rho] : 0.0f;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) qs += __shfl_xor(qs, o);
+                if (lane == 0) a.bapart[tile] = qs;
+            }
+            float attr[16], qr[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                attr[r] = __shfl(att, (lane & 32) | (2 * r));
+                qr[r] = __shfl(q, (lane & 32) | (2 * r)) * vr[r];
+            }
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                const float wav = wrd_s[3 * H + 32 * ct + n];
+                float cs = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float x = acc[ct][r];
+                    const float s = sigmoid_f(x);
+                    const float m = x * s;
+                    const float g = vr[r] * a.gin[(size_t)nir[r] * H + 32 * ct + n] * a.inv_norm;
+                    const float dM = __builtin_fmaf(qr[r], wav, g * attr[r]);       // d(msg)*att + (d(msg).M) att(1-att) wa
+                    a.G2[((size_t)tile * 32 + rho[r]) * H + 32 * ct + n] = vr[r] * dM * dsilu_from_sigmoid(x, s);
+                    cs = __builtin_fmaf(qr[r], m, cs);
+                }
+                colsum[ct] = cs;
+            }
+        } else {
+            float dot[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dot[r] = 0.f;
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                const float wav = wrd_s[3 * H + 32 * ct + n];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dot[r] = __builtin_fmaf(silu_f(acc[ct][r]), wav, dot[r]);
+            }
+            const float rowdot = row_reduce(dot);                     // phi of row rho(my_slot)
+            if ((n & 1) == 0) phi_s[my_rho] = rowdot;
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (hh == 0) {                                              // lane n handles row n
+                const float phi = phi_s[n];
+                const float ux = tr[n * 3], uy = tr[n * 3 + 1], uz = tr[n * 3 + 2];   // zero for padding rows
+                const float* gp = a.gin + (size_t)rowi_s[n] * 4;
+                const float gx = gp[0] * a.inv_norm, gy = gp[1] * a.inv_norm, gz = gp[2] * a.inv_norm;
+                const float t = tanhf(phi);
+                const float sc = a.use_tanh ? t * a.coords_range : phi;              // trans = u * sc
+                const float dsc = gx * ux + gy * uy + gz * uz;
+                const float dphi = a.use_tanh ? dsc * a.coords_range * (1.0f - t * t) : dsc;
+                const float v = rval_s[n];
+                float* es = a.escal + ((size_t)tile * 32 + n) * 8;
+                es[0] = v * gx * sc; es[1] = v * gy * sc; es[2] = v * gz * sc; es[3] = dphi;
+                phi_s[n] = dphi;
+            }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            float dphir[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dphir[r] = phi_s[rho[r]];
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                const float wav = wrd_s[3 * H + 32 * ct + n];
+                float cs = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float x = acc[ct][r];
+                    const float s = sigmoid_f(x);
+                    a.G2[((size_t)tile * 32 + rho[r]) * H + 32 * ct + n] = dphir[r] * wav * dsilu_from_sigmoid(x, s);
+                    cs = __builtin_fmaf(dphir[r], x * s, cs);
+                }
+                colsum[ct] = cs;
+            }
+        }
+        // per-tile partial of d(wa) / d(w7): add the two halves of the wavefront
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            const float tot = colsum[ct] + __shfl_xor(colsum[ct], 32);
+            if (hh == 0) a.colpart[(size_t)tile * H + 32 * ct + n] = tot;
+        }
+    } else {
+        float drr[16], ddd[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { drr[r] = 0.f; ddd[r] = 0.f; }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rni = rowi_s[rho[r]], rnj = rowj_s[rho[r]];
+            const float rad = rrad_s[rho[r]], dd0 = rd0_s[rho[r]];
+            const size_t orow = ((size_t)tile * 32 + rho[r]) * H;
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                const int col = 32 * ct + n;
+                const float wr = wrd_s[col], wd = wrd_s[H + col];
+                float pre = a.AB[(size_t)rni * (2 * H) + col] + a.AB[(size_t)rnj * (2 * H) + H + col];
+                pre = __builtin_fmaf(rad, wr, pre);
+                pre = __builtin_fmaf(dd0, wd, pre);
+                const float s = sigmoid_f(pre);
+                const float g1 = vr[r] * acc[ct][r] * dsilu_from_sigmoid(pre, s);
+                a.Pout[orow + col] = vr[r] * pre * s;
+                a.G1[orow + col] = g1;
+                drr[r] = __builtin_fmaf(g1, wr, drr[r]);
+                ddd[r] = __builtin_fmaf(g1, wd, ddd[r]);
+            }
+        }
+        const float rowdr = row_reduce(drr), rowdd = row_reduce(ddd);
+        if ((n & 1) == 0) {
+            float* es = a.escal + ((size_t)tile * 32 + my_rho) * 8;
+            es[4] = rowdr; es[5] = rowdd; es[6] = rrad_s[my_rho]; es[7] = rd0_s[my_rho];
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------- reductions after the two stages
+
+// out[i][col0 + c] = sum over the rows listed for node i (CSR, ascending row order => deterministic) of G[row][c]
+struct CsrSumArgs {
+    const float* G;         // [E_pad][H]
+    const int* ptr;         // [M+1]
+    const int* rows;        // [E]
+    float* out;             // [M_pad][ldo]
+    int M, H, ldo, col0;
+};
+
+__global__ void k_csr_sum(CsrSumArgs a) {
+    const int q = a.H >> 2;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = idx / q, c4 = idx - i * q;
+    if (i >= a.M) return;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    for (int p = a.ptr[i]; p < a.ptr[i + 1]; ++p) v += *reinterpret_cast<const f32x4*>(a.G + (size_t)a.rows[p] * a.H + 4 * c4);
+    *reinterpret_cast<f32x4*>(a.out + (size_t)i * a.ldo + a.col0 + 4 * c4) = v;
+}
+
+// Coordinate gradients of one edge layer from the per-edge scalars: radial = |x_i - x_j|^2 (d(radial) from stage B), the
+// same for d0 on the input coordinates, and - coordinate layers - the unit direction u = diff / (sqrt(radial + 1e-8) + nc).
+struct EdgeDxArgs {
+    const float* escal;     // [E_pad][8]
+    const int* ei;
+    const int* ej;
+    const int* rptr; const int* rrows;      // rows by receiving node
+    const int* sptr; const int* srows;      // rows by sending node
+    const float* xcur; const float* x0;     // [M_pad][4]
+    float* dx; float* dx0;                  // [M_pad][4] (overwritten)
+    float norm_constant;
+    int M, coord;
+};
+
+__global__ void k_edge_dx(EdgeDxArgs a) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= a.M) return;
+    const f32x4 xk = *reinterpret_cast<const f32x4*>(a.xcur + (size_t)k * 4);
+    const f32x4 yk = *reinterpret_cast<const f32x4*>(a.x0 + (size_t)k * 4);
+    float gx = 0.f, gy = 0.f, gz = 0.f, hx = 0.f, hy = 0.f, hz = 0.f;
+    auto edge = [&](int row, int other, float sign) {
+        // diff = x_recv - x_send; this node is the receiver (sign +1) or the sender (sign -1)
+        const f32x4 xo = *reinterpret_cast<const f32x4*>(a.xcur + (size_t)other * 4);
+        const f32x4 yo = *reinterpret_cast<const f32x4*>(a.x0 + (size_t)other * 4);
+        const float* es = a.escal + (size_t)row * 8;
+        const float ddx = sign * (xk[0] - xo[0]), ddy = sign * (xk[1] - xo[1]), ddz = sign * (xk[2] - xo[2]);   // = diff
+        float cx = 2.0f * es[4] * ddx, cy = 2.0f * es[4] * ddy, cz = 2.0f * es[4] * ddz;                          // via radial
+        if (a.coord) {
+            const float rad = ddx * ddx + ddy * ddy + ddz * ddz;
+            const float sq = sqrtf(rad + 1e-8f), nrm = sq + a.norm_constant;
+            const float dot = es[0] * ddx + es[1] * ddy + es[2] * ddz;
+            const float k2 = dot / (nrm * nrm * sq);
+            cx += es[0] / nrm - k2 * ddx; cy += es[1] / nrm - k2 * ddy; cz += es[2] / nrm - k2 * ddz;
+        }
+        gx += sign * cx; gy += sign * cy; gz += sign * cz;
+        const float e0x = sign * (yk[0] - yo[0]), e0y = sign * (yk[1] - yo[1]), e0z = sign * (yk[2] - yo[2]);
+        hx += sign * 2.0f * es[5] * e0x; hy += sign * 2.0f * es[5] * e0y; hz += sign * 2.0f * es[5] * e0z;
+    };
+    for (int p = a.rptr[k]; p < a.rptr[k + 1]; ++p) { const int row = a.rrows[p]; edge(row, a.ej[row], 1.0f); }
+    for (int p = a.sptr[k]; p < a.sptr[k + 1]; ++p) { const int row = a.srows[p]; edge(row, a.ei[row], -1.0f); }
+    *reinterpret_cast<f32x4*>(a.dx + (size_t)k * 4) = f32x4{gx, gy, gz, 0.f};
+    *reinterpret_cast<f32x4*>(a.dx0 + (size_t)k * 4) = f32x4{hx, hy, hz, 0.f};
+}
+
+// W [H][H] (state_dict layout, row = output) -> chunk image of the forward fp32 edge kernel (pack_edge_w2), either of W
+// (B operand W^T: image value W[col][k]) or of W^T (TRANS: image value W[k][col]); one thread per image float.
+template <bool TRANS>
+__global__ void k_pack_w2(const float* W, float* img, int H) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= H * H) return;
+    const int NCT = H / 32;
+    const int j = idx & 3, lane = (idx >> 2) & 63;
+    const int rest = idx >> 8;                   // (c * 4 + q) * NCT + ct
+    const int ct = rest % NCT, cq = rest / NCT, q = cq & 3, c = cq >> 2;
+    const int k = 32 * c + 16 * (lane >> 5) + 4 * q + j, col = 32 * ct + (lane & 31);
+    img[idx] = TRANS ? W[(size_t)k * H + col] : W[(size_t)col * H + k];
+}

@@ -6,11 +6,14 @@ Per precision and per edge-kernel variant (GCL / coordinate): launches, average 
 bytes per launch from the FETCH_SIZE / WRITE_SIZE passes with the gfx950 correction of
 /opt/skills/guides/MI355X_MICROARCH.md (FETCH_SIZE counts 64 B per 128-B request on wide coalesced reads: doubled;
 both are in KiB), and the SQ activity fractions:
-    mfma_busy       = SQ_VALU_MFMA_BUSY_CYCLES / (4 * SQ_BUSY_CYCLES)      matrix-pipe busy cycles per SIMD-cycle the
-                                                                          chip's CUs were busy (SQ_BUSY_CYCLES counts
-                                                                          per CU; 4 SIMDs per CU)
-    valu_issue_frac = 4 * SQ_ACTIVE_INST_VALU-like share is not collected; SQ_INSTS_VALU / SQ_WAVE_CYCLES is reported
-                      as instructions per wave quad-cycle instead
+    mfma_busy       = SQ_VALU_MFMA_BUSY_CYCLES / (32 * SQ_BUSY_CYCLES)     matrix-pipe busy cycles per SIMD-cycle of the
+                      kernel: the numerator is summed over the chip's 1024 SIMDs (it equals 64 x #MFMA for
+                      v_mfma_f32_32x32x2_f32 and 32 x #MFMA for v_mfma_f32_32x32x16_bf16 - checked against the launch
+                      geometry), SQ_BUSY_CYCLES is summed over the 32 shader engines, so SQ_BUSY_CYCLES / 32 = kernel
+                      duration in shader cycles and 1024 / 32 = 32.
+    clock_ghz       = (SQ_BUSY_CYCLES / 32) / duration of the same dispatch (kernel trace of the SQ pass): the chip
+                      clocks to its power budget (fp32 kernel ~2.3 GHz, bf16x3 ~2.0 GHz under the profiler)
+    SQ_INSTS_VALU / SQ_WAVE_CYCLES is reported as VALU instructions per wave quad-cycle
     wait_inst_frac  = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES                    issue stalls (quad-cycles / quad-cycles)
     wait_any_frac   = SQ_WAIT_ANY / SQ_WAVE_CYCLES                         parked in s_waitcnt / barrier
 The edge-kernel mix of one forward is 2 GCL : 1 coordinate launch; the per-launch figures bench.py uses are that mix.
@@ -56,6 +59,14 @@ def main():
         fetch = per_kernel(os.path.join(d, f"{tag}_{prec}_pmc_FETCH_SIZE.csv"))
         write = per_kernel(os.path.join(d, f"{tag}_{prec}_pmc_WRITE_SIZE.csv"))
         sq = per_kernel(os.path.join(d, f"{tag}_{prec}_sq.csv"))
+        sqdur = {}
+        tp = os.path.join(d, f"{tag}_{prec}_sq_kernel_trace.csv")
+        if os.path.exists(tp):
+            acc = collections.defaultdict(list)
+            for r in csv.DictReader(open(tp)):
+                acc[r["Kernel_Name"].split("(")[0].replace("void ", "").strip()].append(
+                    (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e3)
+            sqdur = {k: mean(v) for k, v in acc.items()}
         names = sorted(set(stats) | set(fetch) | set(sq))
         kern = {}
         for k in names:
@@ -70,7 +81,10 @@ def main():
             if c:
                 e["sq"] = {n: round(v, 1) for n, v in c.items()}
                 if c.get("SQ_BUSY_CYCLES"):
-                    e["mfma_busy"] = round(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (4.0 * c["SQ_BUSY_CYCLES"]), 4)
+                    e["mfma_busy"] = round(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (32.0 * c["SQ_BUSY_CYCLES"]), 4)
+                    if k in sqdur:
+                        e["sq_pass_avg_us"] = round(sqdur[k], 2)
+                        e["clock_ghz"] = round(c["SQ_BUSY_CYCLES"] / 32.0 / (sqdur[k] * 1e3), 3)
                 if c.get("SQ_WAVE_CYCLES"):
                     e["wait_inst_frac"] = round(c.get("SQ_WAIT_INST_ANY", 0.0) / c["SQ_WAVE_CYCLES"], 4)
                     e["wait_any_frac"] = round(c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"], 4)
@@ -81,7 +95,7 @@ def main():
         crd = next((v for k, v in kern.items() if k.startswith(f"k_edge<256, true, {pnum}")), None)
         if gcl and crd:
             mix = {}
-            for key in ("hbm_bytes_per_launch", "mfma_busy", "wait_inst_frac", "wait_any_frac", "avg_us"):
+            for key in ("hbm_bytes_per_launch", "mfma_busy", "wait_inst_frac", "wait_any_frac", "avg_us", "clock_ghz"):
                 if key in gcl and key in crd:
                     v = (2 * gcl[key] + crd[key]) / 3.0
                     mix[key] = int(v) if key == "hbm_bytes_per_launch" else round(v, 4)
