@@ -48,8 +48,8 @@ SIGNATURES = {
     "hd_sample_loop": (C.c_int, [_VP, _VP, _FP, _FP, C.c_int, C.c_int, C.c_int, _FP, _FP, C.c_int,
                                  C.c_uint64, C.c_uint64, C.c_int, _VP]),
     "hd_topology_nodes": (C.c_int, [_VP, _VP]),
-    "hd_edge_layer_forward": (C.c_int, [_VP, _VP, C.c_int] + [_FP] * 7 + [C.c_float, _FP, _VP]),
-    "hd_edge_layer_backward": (C.c_int, [_VP, _VP, C.c_int] + [_FP] * 7 + [C.c_float] + [_FP] * 10 + [_VP]),
+    "hd_edge_layer_forward": (C.c_int, [_VP, _VP, C.c_int] + [_FP] * 9 + [_VP]),
+    "hd_edge_layer_backward": (C.c_int, [_VP, _VP, C.c_int] + [_FP] * 18 + [_VP]),
     "hd_philox_normal_host": (C.c_float, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]),
     "hd_profile_enable": (C.c_int, [_VP, C.c_int]),
     "hd_profile_read": (C.c_int, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),

@@ -834,6 +834,7 @@ static bool launch_edge_ablated(hd_handle* h, const EdgeArgs& a, hipStream_t s) 
         case 20: run(std::integral_constant<int, 20>{}); return true;
         case 24: run(std::integral_constant<int, 24>{}); return true;
         case 30: run(std::integral_constant<int, 30>{}); return true;
+        case 32: run(std::integral_constant<int, 32>{}); return true;       // epilogue at default priority
         default: return false;
     }
 }
@@ -1088,7 +1089,7 @@ static int check_train(hd_handle* h, hd_topology* t, const char* who) {
 
 extern "C" int hd_edge_layer_forward(hd_handle* h, hd_topology* t, int coord, const float* AB, const float* x,
                                      const float* x0, const float* wrd, const float* W2, const float* b2,
-                                     const float* wa, float ba, float* out, void* stream) {
+                                     const float* wa, const float* ba, float* out, void* stream) {
     HD_TRY(check_train(h, t, "hd_edge_layer_forward"));
     if (!AB || !x || !x0 || !wrd || !W2 || !b2 || !wa || !out) return fail(HD_E_INVALID, "hd_edge_layer_forward: null tensor");
     HIP_TRY(hipSetDevice(h->device));
@@ -1096,14 +1097,14 @@ extern "C" int hd_edge_layer_forward(hd_handle* h, hd_topology* t, int coord, co
     const hd_config& c = h->cfg;
     const int H = h->H, M = t->M;
     const int ow = coord ? 4 : H;
-    HIP_TRY(hipMemsetAsync(out, 0, (size_t)t->M_pad * ow * sizeof(float), s));
+    HIP_TRY(hipMemsetAsync(out, 0, (size_t)std::max(1, M) * ow * sizeof(float), s));
     if (t->n_wg == 0 || M == 0) return HD_OK;
     hipLaunchKernelGGL((k_pack_w2<false>), dim3((H * H + 255) / 256), dim3(256), 0, s, W2, t->w2img, H);
     EdgeArgs e;
     std::memset(&e, 0, sizeof(e));
     e.AB = AB; e.wrd = wrd; e.W2img = t->w2img; e.b2 = b2; e.wa = wa;
     e.ei = t->ei; e.ej = t->ej; e.eseg = t->eseg; e.seg_part = t->seg_part; e.tile_nseg = t->tile_nseg;
-    e.xcur = x; e.x0 = x0; e.part = coord ? t->xpart : t->part; e.ba = ba;
+    e.xcur = x; e.x0 = x0; e.part = coord ? t->xpart : t->part; e.ba = 0.0f; e.ba_ptr = ba;
     e.norm_constant = c.norm_constant; e.coords_range = c.coords_range / (float)c.n_layers; e.attention = c.attention;
     e.use_tanh = c.tanh; e.n_tiles = t->n_tiles; e.n_wg = t->n_wg;
     HD_TRY(edge(h, coord != 0, e, s));
@@ -1118,7 +1119,7 @@ extern "C" int hd_edge_layer_forward(hd_handle* h, hd_topology* t, int coord, co
 
 extern "C" int hd_edge_layer_backward(hd_handle* h, hd_topology* t, int coord, const float* AB, const float* x,
                                       const float* x0, const float* wrd, const float* W2, const float* b2,
-                                      const float* wa, float ba, const float* gout, float* G2, float* P, float* G1,
+                                      const float* wa, const float* ba, const float* gout, float* G2, float* P, float* G1,
                                       float* escal, float* colpart, float* bapart, float* dAB, float* dx, float* dx0,
                                       void* stream) {
     HD_TRY(check_train(h, t, "hd_edge_layer_backward"));
@@ -1129,9 +1130,9 @@ extern "C" int hd_edge_layer_backward(hd_handle* h, hd_topology* t, int coord, c
     hipStream_t s = (hipStream_t)stream;
     const hd_config& c = h->cfg;
     const int H = h->H, M = t->M;
-    HIP_TRY(hipMemsetAsync(dAB, 0, (size_t)t->M_pad * 2 * H * sizeof(float), s));
-    HIP_TRY(hipMemsetAsync(dx, 0, (size_t)t->M_pad * 4 * sizeof(float), s));
-    HIP_TRY(hipMemsetAsync(dx0, 0, (size_t)t->M_pad * 4 * sizeof(float), s));
+    HIP_TRY(hipMemsetAsync(dAB, 0, (size_t)std::max(1, M) * 2 * H * sizeof(float), s));
+    HIP_TRY(hipMemsetAsync(dx, 0, (size_t)std::max(1, M) * 4 * sizeof(float), s));
+    HIP_TRY(hipMemsetAsync(dx0, 0, (size_t)std::max(1, M) * 4 * sizeof(float), s));
     const int tiles = std::max(1, t->n_wg * 4);
     HIP_TRY(hipMemsetAsync(escal, 0, (size_t)tiles * 32 * 8 * sizeof(float), s));
     if (t->n_wg == 0 || M == 0) {
@@ -1148,7 +1149,7 @@ extern "C" int hd_edge_layer_backward(hd_handle* h, hd_topology* t, int coord, c
     EdgeBwdArgs a;
     std::memset(&a, 0, sizeof(a));
     a.AB = AB; a.wrd = wrd; a.b2 = b2; a.wa = wa; a.ei = t->ei; a.ej = t->ej; a.eseg = t->eseg; a.xcur = x; a.x0 = x0;
-    a.ba = ba; a.norm_constant = c.norm_constant; a.coords_range = c.coords_range / (float)c.n_layers;
+    a.ba_ptr = ba; a.norm_constant = c.norm_constant; a.coords_range = c.coords_range / (float)c.n_layers;
     a.inv_norm = 1.0f / c.normalization_factor; a.attention = c.attention; a.use_tanh = c.tanh; a.n_tiles = t->n_tiles;
     a.gin = gout; a.G2 = G2; a.escal = escal; a.colpart = colpart; a.bapart = bapart; a.Pout = P; a.G1 = G1;
     a.Wimg = t->w2img;

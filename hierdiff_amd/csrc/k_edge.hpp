@@ -30,6 +30,7 @@ struct EdgeArgs {
     const float* x0;        // [M_pad][4] coordinates at network input
     float* part;            // GCL: [P][H];  COORD: [P][4]
     float ba;               // att bias
+    const float* ba_ptr;    // optional device copy of the att bias (training: the parameter itself); overrides ba
     float norm_constant;
     float coords_range;     // per-block range
     int attention, use_tanh;
@@ -459,6 +460,10 @@ __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
     }
     if constexpr (ABL & 16) ts2 = __builtin_readcyclecounter();
     if (!tile_ok) return;                  // padding tile of the last workgroup: nothing to store
+    // The epilogue is VALU-only.  On this chip a VALU-only wavefront and an MFMA-streaming wavefront on one SIMD serialise
+    // unless the VALU one has the higher priority (scratch/mb/phased.hip), so the epilogue runs at raised priority: its
+    // instructions slip in beside the co-resident wavefront's MFMAs instead of waiting behind them.
+    if constexpr (ABL & 32) {} else __builtin_amdgcn_s_setprio(3);
     if constexpr (ABL & 1) {
         float sacc = 0.f;
 #pragma unroll
@@ -549,8 +554,9 @@ __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
         for (int q = 0; q < 4; ++q) sw[q] = seg_s[2 * q + hh];
         float att_mine = 1.0f;
         if (a.attention) {
-            if constexpr (PREC == 0) att_mine = sigmoid_f(rowdot + a.ba);
-            else att_mine = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(rowdot + a.ba));   // scaled domain
+            const float ba = a.ba_ptr ? *a.ba_ptr : a.ba;
+            if constexpr (PREC == 0) att_mine = sigmoid_f(rowdot + ba);
+            else att_mine = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(rowdot + ba));   // scaled domain
         }
         float w[16];
         int sg[16];

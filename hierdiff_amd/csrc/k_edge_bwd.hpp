@@ -28,7 +28,8 @@ struct EdgeBwdArgs {
     const uint8_t* eseg;
     const float* xcur;      // [M_pad][4]
     const float* x0;        // [M_pad][4]
-    float ba, norm_constant, coords_range, inv_norm;
+    const float* ba_ptr;    // device pointer to the attention bias (NULL: 0)
+    float norm_constant, coords_range, inv_norm;
     int attention, use_tanh, n_tiles;
     // stage A
     const float* gin;       // GCL: d(agg) [M_pad][H];  COORD: d(xagg) [M_pad][4]
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(256) void k_edge_bwd(EdgeBwdArgs a) {
             }
             const float rowdot = row_reduce(dot), rowsd = row_reduce(sd);
             float att = 1.0f, q = 0.0f;
-            if (a.attention) { att = sigmoid_f(rowdot + a.ba); q = rowsd * att * (1.0f - att); }
+            if (a.attention) { att = sigmoid_f(rowdot + (a.ba_ptr ? *a.ba_ptr : 0.0f)); q = rowsd * att * (1.0f - att); }
             {   // d(ba) of this tile: every row's q sits in two lanes of its half
                 float qs = ((n & 1) == 0) ? q * rval_s[my_rho] : 0.0f;
 #pragma unroll

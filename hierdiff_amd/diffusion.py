@@ -167,6 +167,12 @@ class DiffusionQM9(_Base):
 
     # ------------------------------------------------------------------ schedule algebra (reference API)
     def phi(self, x, t, node_mask, edge_mask, context, mol_shape=None):
+        """diffusion_qm9.py:135-138.  Like any torch module the network call is differentiable when autograd is recording
+        (training: hierdiff_amd.training, exact-fp32 kernels + their backward); under torch.no_grad() - sampling,
+        validation - it is the inference path (hd_egnn_forward)."""
+        if torch.is_grad_enabled():
+            from .training import dynamics_forward_train
+            return dynamics_forward_train(self.dynamics, t, x, node_mask, edge_mask, context, mol_shape)
         return self.dynamics._forward(t, x, node_mask, edge_mask, context, mol_shape)
 
     def inflate_batch_array(self, array, target):
@@ -198,8 +204,8 @@ class DiffusionQM9(_Base):
 
     # ------------------------------------------------------------------ loss / NLL, forward value (reference API)
     # diffusion_qm9.py:160-172, 206-292, 460-751.  The network calls go through the HIP dynamics (per-row t); the
-    # few element-wise terms around them are torch ops on the same device.  These entry points return values only
-    # (no_grad).
+    # few element-wise terms around them are torch ops on the same device.  Under torch.no_grad() they return values
+    # (validation NLL); with autograd recording they are differentiable (training_step): see `phi`.
     def subspace_dimensionality(self, node_mask):
         return (torch.sum(node_mask.squeeze(2), dim=1) - 1) * self.n_dims
 
@@ -214,6 +220,8 @@ class DiffusionQM9(_Base):
         replays recorded values (`gammas[key]`)."""
         if gammas is not None and key in gammas:
             return torch.as_tensor(gammas[key], dtype=torch.float32, device=t.device).view(-1, 1)
+        if torch.is_grad_enabled():        # training: the schedule network is part of the graph (fp32, like the reference)
+            return self.gamma(t).view(-1, 1)
         return evaluate_gamma(self.gamma, t).to(t.device)
 
     def compute_error(self, net_out, gamma_t, eps):
@@ -266,7 +274,6 @@ class DiffusionQM9(_Base):
         log_int = (log_int * node_mask).reshape(x.size(0), -1).sum(-1)
         return log_px + log_ph + log_int
 
-    @torch.no_grad()
     def compute_loss(self, x, h, node_mask, edge_mask, context, t0_always, mol_shape=None,
                      t_int=None, eps=None, eps0=None, gammas=None):
         """Forward value of the variational bound estimator / simple loss (diffusion_qm9.py:530-673).  Nodes behind
@@ -323,7 +330,6 @@ class DiffusionQM9(_Base):
             loss = kl_prior + estimator + neg_log_constants
         return loss, {'t': t_int.squeeze(), 'loss_t': loss.squeeze(), 'error': error.squeeze()}
 
-    @torch.no_grad()
     def nll(self, x, h, node_mask=None, edge_mask=None, context=None, mol_shape=None, **replay):
         """Loss if training (value only), NLL estimate if eval (diffusion_qm9.py:675-699)."""
         x, h, delta_log_px = self.normalize(x, h, node_mask.to(torch.float32))
@@ -333,7 +339,6 @@ class DiffusionQM9(_Base):
                                     mol_shape=mol_shape, **replay)
         return loss - delta_log_px
 
-    @torch.no_grad()
     def forward(self, batch, **replay):
         """`{"loss": mean NLL}` for a reference data batch (keys positions, atom_mask, edge_mask, node_feature; with a
         context model, context; with a pocket model, protein_pos, protein_feat, protein_feat_mask,
@@ -364,6 +369,21 @@ class DiffusionQM9(_Base):
         self._check_masked(x, node_mask, "assert_correctly_masked")
         neg_log_pxh = self.nll(x, h, node_mask, edge_mask, context=context, mol_shape=mol_shape, **replay)
         return {"loss": neg_log_pxh.mean(0)}
+
+    def training_step(self, batch, batch_idx=0):
+        """diffusion_qm9.py:774-777: differentiable mean loss of the batch (call .backward() on it, then - multi-GPU -
+        hierdiff_amd.sharding.allreduce_gradients, the DDP step of conf/trainer/default.yaml:2-3)."""
+        loss = self.forward(batch)["loss"]
+        if hasattr(self, "log") and _Base is not nn.Module:
+            self.log("train_loss", loss, on_epoch=True, prog_bar=True)
+        return loss
+
+    @torch.no_grad()
+    def validation_step(self, batch, batch_idx=0):
+        """diffusion_qm9.py:779-781 (value only)."""
+        return self.forward(batch)
+
+    test_step = validation_step
 
     # ------------------------------------------------------------------ HIP plumbing
     def _lib_handle(self):

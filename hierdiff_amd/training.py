@@ -1,0 +1,178 @@
+"""Training forward / backward of the EGNN dynamics on MI355X.
+
+Reference: `DiffusionQM9.training_step` -> `forward(batch)` -> `nll` -> `compute_loss` -> `phi`
+(endiffusion/train_module/diffusion_qm9.py:774-777, 701-751, 675-699, 530-673, 135-138) with PyTorch autograd through
+`EGNN_dynamics_QM9._forward` (models/module/en_dynamics.py:49-122) and DDP gradient averaging
+(conf/trainer/default.yaml:2-3).
+
+Split of the work, by what is hot:
+  * the EDGE model of every GCL / EquivariantUpdate (gather, factorised first Linear, SiLU, H x H Linear, SiLU, attention
+    gate or coordinate head, neighbour sum - 85 % of the FLOPs) runs in hand-written HIP both ways:
+    `hd_edge_layer_forward` (the sampler's k_edge) and `hd_edge_layer_backward` (k_edge_bwd: per-edge activations are
+    recomputed tile by tile, never stored by the forward pass), wrapped as ONE autograd Function;
+  * the node-level Linears around it (embedding, the two halves of the first edge Linear, node MLP, output layer) are
+    plain dense GEMMs on [nodes, H] matrices: torch.matmul (the BLAS library) under ordinary autograd; so are the three
+    dense reductions over the materialised per-edge gradients (dW2 = G2^T P etc.).
+Arithmetic is exact fp32 (`precision = "fp32"`), like the reference's training forward (its apex O2 mode is a
+trainer-level choice outside this path).  Multi-GPU: one process per GPU, gradients averaged with one flat all-reduce
+(`hierdiff_amd.sharding.allreduce_gradients`, RCCL under backend "nccl").
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+from .dynamics import EGNN_dynamics_QM9, Topology, _stream
+
+
+class _TrainTables:
+    """Per-topology helpers of the training path: compact node order on the device and the backward workspaces."""
+
+    def __init__(self, topo: Topology, H: int, device: torch.device):
+        lib = _lib.load()
+        info = topo.info()
+        self.M = info["nodes"]
+        self.N = topo.N
+        n_wg = (info["tiles"] + 3) // 4
+        self.tiles = max(1, 4 * n_wg)
+        self.rows = 32 * self.tiles
+        node_of = np.zeros(max(1, self.M), dtype=np.int32)
+        _lib.check(lib.hd_topology_nodes(topo.ptr, node_of.ctypes.data), "hd_topology_nodes")
+        self.index = torch.from_numpy(node_of[:self.M].astype(np.int64)).to(device)      # flat index b*N + n
+        self.H = H
+        self.device = device
+        self._ws = None
+
+    def workspace(self):
+        if self._ws is None:
+            z = lambda *s: torch.empty(s, device=self.device, dtype=torch.float32)
+            self._ws = dict(G2=z(self.rows, self.H), P=z(self.rows, self.H), G1=z(self.rows, self.H),
+                            escal=z(self.rows, 8), colpart=z(self.tiles, self.H), bapart=z(self.tiles))
+        return self._ws
+
+
+def _tables(dyn: EGNN_dynamics_QM9, topo: Topology, device) -> _TrainTables:
+    tr = getattr(topo, "_train", None)
+    if tr is None:
+        tr = _TrainTables(topo, dyn._cfg.hidden_nf, device)
+        topo._train = tr
+    return tr
+
+
+class _EdgeLayer(torch.autograd.Function):
+    """out = neighbour sum of the edge model of one GCL ([M, H]) or EquivariantUpdate ([M, 4], xyz0); see
+    include/hierdiff_hip.h `hd_edge_layer_forward` / `hd_edge_layer_backward`."""
+
+    @staticmethod
+    def forward(ctx, dyn, topo, tr, coord, AB, x4, x04, wrd, W2, b2, wa, ba):
+        lib = _lib.load()
+        AB, x4, x04, wrd, W2, b2, wa = (v.detach().contiguous() for v in (AB, x4, x04, wrd, W2, b2, wa))
+        ba_c = None if ba is None else ba.detach().contiguous()
+        out = torch.empty((max(1, tr.M), 4 if coord else tr.H), device=AB.device, dtype=torch.float32)
+        _lib.check(lib.hd_edge_layer_forward(dyn._handle(), topo.ptr, int(coord), AB.data_ptr(), x4.data_ptr(), x04.data_ptr(),
+                                             wrd.data_ptr(), W2.data_ptr(), b2.data_ptr(), wa.data_ptr(),
+                                             None if ba_c is None else ba_c.data_ptr(), out.data_ptr(), _stream(AB.device)),
+                   "hd_edge_layer_forward")
+        ctx.save_for_backward(AB, x4, x04, wrd, W2, b2, wa, *([] if ba_c is None else [ba_c]))
+        ctx.misc = (dyn, topo, tr, coord, ba_c is not None)
+        return out[:tr.M]
+
+    @staticmethod
+    def backward(ctx, gout):
+        dyn, topo, tr, coord, has_ba = ctx.misc
+        saved = ctx.saved_tensors
+        AB, x4, x04, wrd, W2, b2, wa = saved[:7]
+        ba = saved[7] if has_ba else None
+        lib = _lib.load()
+        ws = tr.workspace()
+        dev = AB.device
+        M = max(1, tr.M)
+        g = torch.zeros((M, gout.shape[1]), device=dev, dtype=torch.float32)
+        g[:tr.M] = gout
+        dAB = torch.empty((M, 2 * tr.H), device=dev, dtype=torch.float32)
+        dx = torch.empty((M, 4), device=dev, dtype=torch.float32)
+        dx0 = torch.empty((M, 4), device=dev, dtype=torch.float32)
+        _lib.check(lib.hd_edge_layer_backward(
+            dyn._handle(), topo.ptr, int(coord), AB.data_ptr(), x4.data_ptr(), x04.data_ptr(), wrd.data_ptr(), W2.data_ptr(),
+            b2.data_ptr(), wa.data_ptr(), None if ba is None else ba.data_ptr(), g.data_ptr(), ws["G2"].data_ptr(),
+            ws["P"].data_ptr(), ws["G1"].data_ptr(), ws["escal"].data_ptr(), ws["colpart"].data_ptr(), ws["bapart"].data_ptr(),
+            dAB.data_ptr(), dx.data_ptr(), dx0.data_ptr(), _stream(dev)), "hd_edge_layer_backward")
+        # dense reductions over all edge rows: plain library GEMMs on the materialised operands
+        dW2 = ws["G2"].t() @ ws["P"]                           # [H, H]: dL/dW2[c][k] = sum_e G2[e][c] P[e][k]
+        db2 = ws["G2"].sum(0)
+        dwrd = ws["escal"][:, 6:8].t() @ ws["G1"]              # [2, H]: sum_e {radial, d0}_e G1[e][:]
+        dwa = ws["colpart"].sum(0)
+        dba = ws["bapart"].sum().view(1) if has_ba else None
+        return (None, None, None, None, dAB[:tr.M], dx[:tr.M], dx0[:tr.M], dwrd, dW2, db2, dwa, dba)
+
+
+def dynamics_forward_train(dyn: EGNN_dynamics_QM9, t, xh, node_mask, edge_mask, context, mol_shape=None) -> torch.Tensor:
+    """Differentiable `EGNN_dynamics_QM9._forward` (en_dynamics.py:49-122): same value as the inference path
+    (hd_egnn_forward, fp32 mode) up to fp32 round-off of the node-level GEMMs, with gradients to every parameter of
+    `dyn.egnn` and to `xh`."""
+    if xh.device.type != "cuda":
+        raise _lib.HierDiffHipError("training runs only on an MI355X (no CPU fallback)")
+    if dyn.precision != "fp32":
+        raise _lib.HierDiffHipError('training uses the exact-fp32 kernels: set dynamics.precision = "fp32"')
+    dev = xh.device
+    B, N, D = xh.shape
+    cfg = dyn._cfg
+    H, L, S = cfg.hidden_nf, cfg.n_layers, cfg.inv_sublayers
+    Fdim = D - 3
+    topo = dyn.topology(node_mask, edge_mask, B, N)
+    tr = _tables(dyn, topo, dev)
+    idx, M = tr.index, tr.M
+    egnn = dyn.egnn
+    nm = node_mask.reshape(B * N).to(torch.float32)[idx].unsqueeze(1)          # [M, 1]
+    xh_c = xh.reshape(B * N, D).to(torch.float32)[idx] * nm
+    x_in, hfeat = xh_c[:, :3], xh_c[:, 3:]
+    cols = [hfeat]
+    if dyn.condition_time:
+        tt = t.to(dev, torch.float32).reshape(-1)
+        cols.append(tt.reshape(1, 1).expand(M, 1) if tt.numel() == 1 else tt[idx // N].unsqueeze(1))
+    if dyn.context_node_nf > 0:
+        cols.append(context.to(dev, torch.float32).reshape(B * N, dyn.context_node_nf)[idx])
+    h = F.linear(torch.cat(cols, dim=1), egnn.embedding.weight, egnn.embedding.bias)
+    x4 = F.pad(x_in, (0, 1))
+    x04 = x4
+    zero_wa = torch.zeros(H, device=dev)
+
+    def edge_layer(coord, lin0, lin2, wa, ba, xb):
+        W1 = lin0.weight
+        AB = torch.cat([F.linear(h, W1[:, :H], lin0.bias), F.linear(h, W1[:, H:2 * H])], dim=1)
+        wrd = W1[:, 2 * H:2 * H + 2].t()
+        return _EdgeLayer.apply(dyn, topo, tr, coord, AB, xb, x04, wrd, lin2.weight, lin2.bias, wa, ba)
+
+    for i in range(L):
+        blk = getattr(egnn, f"e_block_{i}")
+        xb = x4
+        for j in range(S):
+            g = getattr(blk, f"gcl_{j}")
+            if cfg.attention:
+                wa, ba = g.att_mlp[0].weight.reshape(-1), g.att_mlp[0].bias
+            else:
+                wa, ba = zero_wa, None
+            agg = edge_layer(False, g.edge_mlp[0], g.edge_mlp[2], wa, ba, xb)
+            h = (h + g.node_mlp(torch.cat([h, agg], dim=1))) * nm
+        e = blk.gcl_equiv
+        xagg = edge_layer(True, e.coord_mlp[0], e.coord_mlp[2], e.coord_mlp[4].weight.reshape(-1), None, xb)
+        x4 = (xb + xagg) * nm
+        h = h * nm
+    hout = F.linear(h, egnn.embedding_out.weight, egnn.embedding_out.bias) * nm
+    x_final = x4[:, :3]
+    if mol_shape is not None:
+        fixed = ((idx % N) >= int(mol_shape)).unsqueeze(1)
+        x_final = torch.where(fixed, x_in, x_final)
+    vel = (x_final - x_in) * nm
+    vals = torch.cat([vel, hout[:, :Fdim]], dim=1)             # context, then time columns dropped (en_dynamics.py:99-105)
+    out = torch.zeros((B * N, D), device=dev, dtype=torch.float32).index_copy(0, idx, vals).view(B, N, D)
+    vel = out[..., :3]
+    vel = torch.where(torch.isnan(vel).any(), torch.zeros_like(vel), vel)     # NaN guard without a host sync (:109-111)
+    nmf = node_mask.reshape(B, N, 1).to(torch.float32)
+    vel = vel - (vel.sum(1, keepdim=True) / nmf.sum(1, keepdim=True)) * nmf
+    return torch.cat([vel, out[..., 3:]], dim=2)

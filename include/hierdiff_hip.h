@@ -168,26 +168,26 @@ int hd_sample_loop(hd_handle* h, hd_topology* topo, float* z, const float* conte
  * One "edge layer" is the part of a GCL / EquivariantUpdate that works on edges (egnn_new.py:35-56 / :91-104 with the
  * first Linear factorised): per unmasked edge (i, j)
  *     pre1 = A_i + B_j + |x_i - x_j|^2 w_r + |x0_i - x0_j|^2 w_d,   P = SiLU(pre1),   M = SiLU(W2 P + b2),
- *     GCL:   out_i = sum_j M sigmoid(wa.M + ba) / normalization_factor                          [M_pad][H]
- *     COORD: out_i = sum_j u_ij tanh(wa.M) coords_range / normalization_factor  (xyz, 4th = 0)   [M_pad][4]
- * with AB = [A | B] [M_pad][2H] the node-level halves of the first Linear (computed by the caller, e.g. with a library
- * GEMM), x / x0 [M_pad][4] the coordinates at block start / network input, rows in the topology's compact node
- * order (hd_topology_nodes).  Weights are DEVICE pointers in state_dict layout: wrd [2][H] = the two distance columns
- * of the first Linear, W2 [H][H], b2 [H], wa [H].  The node-level Linears around an edge layer are plain GEMMs and are
+ *     GCL:   out_i = sum_j M sigmoid(wa.M + ba) / normalization_factor                          [M][H]
+ *     COORD: out_i = sum_j u_ij tanh(wa.M) coords_range / normalization_factor  (xyz, 4th = 0)   [M][4]
+ * with AB = [A | B] [M][2H] the node-level halves of the first Linear (computed by the caller, e.g. with a library
+ * GEMM), x / x0 [M][4] the coordinates at block start / network input, M = active nodes, rows in the topology's
+ * compact node order (hd_topology_nodes).  Weights are DEVICE pointers in state_dict layout: wrd [2][H] = the two
+ * distance columns of the first Linear, W2 [H][H], b2 [H], wa [H], ba [1] (NULL: no attention bias).  The node-level Linears around an edge layer are plain GEMMs and are
  * not part of this ABI (hierdiff_amd/training.py runs them through the BLAS library and autograd). */
 int hd_topology_nodes(const hd_topology* t, int* node_of /* host, `active nodes` ints: flat index b*N + n */);
 int hd_edge_layer_forward(hd_handle* h, hd_topology* topo, int coord, const float* AB, const float* x,
                           const float* x0, const float* wrd, const float* W2, const float* b2, const float* wa,
-                          float ba, float* out, void* stream);
+                          const float* ba, float* out, void* stream);
 /* Backward of hd_edge_layer_forward given gout = dL/d(out).  Per-edge activations are recomputed; the caller provides
  * workspaces G2, P, G1 [rows][H], escal [rows][8], colpart [tiles][H], bapart [tiles] (rows / tiles from
- * hd_topology_layout's counts).  Written: dAB [M_pad][2H], dx, dx0 [M_pad][4] and, for the caller's dense reductions,
+ * hd_topology_layout's counts).  Written: dAB [M][2H], dx, dx0 [M][4] and, for the caller's dense reductions,
  *     G2 = dL/d(W2 P + b2),  P,  G1 = dL/d(pre1)        =>  dW2 = G2^T P,  db2 = colsum(G2),
  *     escal[:, 6:8] = {radial, d0}                      =>  d(wrd) = escal[:, 6:8]^T G1,
  *     colpart, bapart                                   =>  d(wa) = colsum(colpart),  d(ba) = sum(bapart). */
 int hd_edge_layer_backward(hd_handle* h, hd_topology* topo, int coord, const float* AB, const float* x,
                            const float* x0, const float* wrd, const float* W2, const float* b2, const float* wa,
-                           float ba, const float* gout, float* G2, float* P, float* G1, float* escal, float* colpart,
+                           const float* ba, const float* gout, float* G2, float* P, float* G1, float* escal, float* colpart,
                            float* bapart, float* dAB, float* dx, float* dx0, void* stream);
 
 /* Host implementation of the library's normal generator (same bits as the device one up to libm
