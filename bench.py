@@ -177,6 +177,7 @@ def timed_headline(model, precision, args, dev, rank, world, dist):
     return block
 
 
+@torch.no_grad()
 def precision_gap(model, args, dev) -> dict:
     """rel-L2 between the two precision modes on one headline-shaped forward (the fp32 path is the yardstick here; both
     are checked against the reference-generated golden vectors in tests/)."""

@@ -167,12 +167,7 @@ class DiffusionQM9(_Base):
 
     # ------------------------------------------------------------------ schedule algebra (reference API)
     def phi(self, x, t, node_mask, edge_mask, context, mol_shape=None):
-        """diffusion_qm9.py:135-138.  Like any torch module the network call is differentiable when autograd is recording
-        (training: hierdiff_amd.training, exact-fp32 kernels + their backward); under torch.no_grad() - sampling,
-        validation - it is the inference path (hd_egnn_forward)."""
-        if torch.is_grad_enabled():
-            from .training import dynamics_forward_train
-            return dynamics_forward_train(self.dynamics, t, x, node_mask, edge_mask, context, mol_shape)
+        """diffusion_qm9.py:135-138.  Differentiable when autograd is recording (see EGNN_dynamics_QM9._forward)."""
         return self.dynamics._forward(t, x, node_mask, edge_mask, context, mol_shape)
 
     def inflate_batch_array(self, array, target):
@@ -430,6 +425,7 @@ class DiffusionQM9(_Base):
         zx = zx - (zx.sum(1, keepdim=True) / nm.sum(1, keepdim=True)) * nm
         return torch.cat([zx, raw_h * nm], dim=2)
 
+    @torch.no_grad()
     def sample_p_zs_given_zt(self, s, t, zt, node_mask, edge_mask, context, fix_noise=False, mol_shape=None,
                              raw_noise: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
                              gammas: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
@@ -459,6 +455,7 @@ class DiffusionQM9(_Base):
             raw_x.data_ptr(), raw_h.data_ptr(), raw_x.shape[0], mol, zs.data_ptr(), _stream(dev)), "hd_posterior_step")
         return zs
 
+    @torch.no_grad()
     def sample_p_xh_given_z0(self, z0, node_mask, edge_mask, context, fix_noise=False,
                              raw_noise: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
                              gamma_0: Optional[torch.Tensor] = None):

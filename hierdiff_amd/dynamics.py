@@ -252,9 +252,16 @@ class EGNN_dynamics_QM9(nn.Module):
 
     # ------------------------------------------------------------------ forward
     def _forward(self, t, xh, node_mask, edge_mask, context, mol_shape=None):
-        """en_dynamics.py:49-122.  Returns a new [B, N, 3+F] fp32 tensor on xh.device."""
+        """en_dynamics.py:49-122.  Returns a new [B, N, 3+F] fp32 tensor on xh.device.
+
+        Like the reference module it is differentiable when autograd is recording (training_step: the exact-fp32 edge
+        kernels and their hand-written backward, hierdiff_amd/training.py); under torch.no_grad() - sampling, validation -
+        it is the inference path (hd_egnn_forward)."""
         if xh.device.type != "cuda":
             raise HierDiffHipError("EGNN_dynamics_QM9._forward needs cuda tensors (no CPU fallback)")
+        if torch.is_grad_enabled() and (xh.requires_grad or any(p.requires_grad for p in self.egnn.parameters())):
+            from .training import dynamics_forward_train
+            return dynamics_forward_train(self, t, xh, node_mask, edge_mask, context, mol_shape)
         bs, n_nodes, dims = xh.shape
         if dims - self.n_dims != self.in_node_nf - (1 if self.condition_time else 0):
             raise ValueError(f"xh has {dims - self.n_dims} feature columns, model expects "

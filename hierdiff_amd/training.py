@@ -118,7 +118,9 @@ def dynamics_forward_train(dyn: EGNN_dynamics_QM9, t, xh, node_mask, edge_mask, 
     if xh.device.type != "cuda":
         raise _lib.HierDiffHipError("training runs only on an MI355X (no CPU fallback)")
     if dyn.precision != "fp32":
-        raise _lib.HierDiffHipError('training uses the exact-fp32 kernels: set dynamics.precision = "fp32"')
+        raise _lib.HierDiffHipError('autograd is recording and the dynamics has trainable parameters: the differentiable '
+                                    'path uses the exact-fp32 kernels - set dynamics.precision = "fp32", or wrap '
+                                    'inference calls in torch.no_grad()')
     dev = xh.device
     B, N, D = xh.shape
     cfg = dyn._cfg

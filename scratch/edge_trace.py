@@ -8,11 +8,12 @@ from oracle import egnn_oracle as orc
 from hierdiff_amd.weights import synthetic_state_dict
 from hierdiff_amd import _lib
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+PREC = sys.argv[2] if len(sys.argv) > 2 else "bf16x3"
 sd_np = synthetic_state_dict(9, 0, 256, 6, 2, True, 0, 1.0)
 xh, nm, em = orc.random_inputs([30] * B, 8, 1)
 xh, nm = xh.to(DEV), nm.to(DEV)
 t = torch.full((B, 1), 0.5, device=DEV)
-dyn = build_dynamics(sd_np, 256, 6); dyn.precision = "bf16x3"
+dyn = build_dynamics(sd_np, 256, 6); dyn.precision = PREC
 topo = dyn.topology(nm, None, B, 30); dyn.sync_weights()
 for _ in range(5): o = dyn.forward_with_topology(topo, t, xh, None, None)
 torch.cuda.synchronize()
@@ -41,3 +42,28 @@ some = list(byc.items())[:3]
 for k, bl in some:
     st = [(b, int(tr[b, 0, 0] - tr[bl[0], 0, 0]), int(tr[b, 0, 3] - tr[bl[0], 0, 0])) for b in bl]
     print("CU", k, "blocks (id, start, end):", sorted(st, key=lambda z: z[1]))
+
+# overlap of the two co-resident workgroups of a CU: for every wave, how much of its prologue / epilogue falls inside the
+# chunk loop of the wave sharing its SIMD (matched by CU key + SIMD id)
+import collections
+waves = collections.defaultdict(list)
+for b in range(n):
+    for w in range(4):
+        waves[(int(key[b]), int(simd[b, w]))].append((int(tr[b, w, 0]), int(tr[b, w, 1]), int(tr[b, w, 2]), int(tr[b, w, 3])))
+cov_p, cov_e, alone = [], [], []
+for lst in waves.values():
+    for a in lst:
+        def covered(lo, hi):
+            c = 0
+            for o in lst:
+                if o is a: continue
+                c += max(0, min(hi, o[2]) - max(lo, o[1]))
+            return c / max(1, hi - lo)
+        cov_p.append(covered(a[0], a[1])); cov_e.append(covered(a[2], a[3]))
+        tot = 0
+        for o in lst:
+            if o is a: continue
+            tot += max(0, min(a[3], o[3]) - max(a[0], o[0]))
+        alone.append(1 - min(1.0, tot / max(1, a[3] - a[0])))
+print(f"fraction of a wave's prologue covered by a SIMD-mate's chunk loop: mean {np.mean(cov_p):.2f}; epilogue: {np.mean(cov_e):.2f}; "
+      f"fraction of its lifetime alone on the SIMD: {np.mean(alone):.2f}")

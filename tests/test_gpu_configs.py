@@ -228,7 +228,6 @@ def test_nan_guard_resets_whole_batch_velocity(precision):
 
 # ----------------------------------------------------------------------------- (f) the reference's runtime asserts
 
-@torch.no_grad()          # value-only: with autograd recording these entry points take the training path
 def test_debug_checks_reproduce_reference_asserts():
     """models/utils.py:47-50 (masked entries), :65-70 (centre of gravity), :73-75 (variables masked): opt-in
     (`debug_checks = True`, they cost host syncs); off by default."""
@@ -273,7 +272,6 @@ def _raws(fx):
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
-@torch.no_grad()          # value-only: with autograd recording these entry points take the training path
 def test_poly2_schedule_chain_and_l2_loss_golden(precision):
     """F12: PredefinedNoiseSchedule 'polynomial_2' + loss_type 'l2' (noise_model.py:125-160; diffusion_qm9.py:253-255,
     598-599, 611-612, 660-661): the reference's sample() chain and its training-mode loss value.  The schedule is a
@@ -305,7 +303,6 @@ def test_poly2_schedule_chain_and_l2_loss_golden(precision):
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
-@torch.no_grad()          # value-only: with autograd recording these entry points take the training path
 def test_elem_features_golden(precision):
     """F13: node_coarse_type 'elem' (3 node features, D = 6; diffusion_qm9.py:44-50, 470-476)."""
     from hierdiff_amd import DiffusionQM9, default_config
@@ -334,7 +331,6 @@ def test_elem_features_golden(precision):
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
-@torch.no_grad()          # value-only: with autograd recording these entry points take the training path
 def test_pocket_loss_golden(precision):
     """F14: DiffusionQM9.forward(batch) with cfg.pocket (diffusion_qm9.py:701-751 -> compute_loss with mol_shape < N)."""
     from hierdiff_amd import DiffusionQM9, default_config

@@ -440,7 +440,6 @@ _CACHE = {}
 
 @pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("name", ["f9_nll_eval_h64_l2", "f9_nll_train_h64_l2"])
-@torch.no_grad()          # value-only: with autograd recording these entry points take the training path
 def test_nll_forward_golden(name, precision):
     """DiffusionQM9.compute_loss / nll / forward(batch) value (validation NLL: two network calls with per-row t;
     training-mode value: one call incl. the t == 0 branch) against the reference, with its draws and schedule values
