@@ -177,6 +177,7 @@ __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
     }
     long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0;
     if constexpr (ABL & 16) ts0 = __builtin_readcyclecounter();
+    if constexpr (ABL & 64) __builtin_amdgcn_s_setprio(3);      // experiment: prologue (VALU / memory only) at raised priority
 
     for (int k = tid; k < 2 * H; k += 256) wrd_s[k] = a.wrd[k];
     for (int k = tid; k < H; k += 256) { wrd_s[2 * H + k] = a.b2[k]; wrd_s[3 * H + k] = a.wa[k]; }
@@ -311,6 +312,8 @@ __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
         for (int r = 0; r < 16; ++r) acc[ct][r] = b2v;
     }
     if constexpr (ABL & 16) ts1 = __builtin_readcyclecounter();
+    if constexpr (ABL & 64) __builtin_amdgcn_s_setprio(0);
+    if constexpr (ABL & 128) __builtin_amdgcn_s_setprio(1);     // experiment: MFMA loop above default priority
     // (Unrolling this loop by two with swapped operand sets, to drop the 16 register copies per chunk, was
     // measured twice: 9-17 spilled registers, 125 vs 109 us and later 110-116 vs 103-106 us; fp32 285 vs 278.)
 #pragma unroll 1

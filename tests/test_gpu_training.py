@@ -149,7 +149,8 @@ def test_training_step_with_learned_schedule_and_optimizer():
     # learned schedule evaluated in fp32 on both sides: gamma differs by ~1e-4 between hosts and the SNR weight
     # exp(gamma_t - gamma_s) - 1 by ~1 %, so this end-to-end comparison is loose by construction
     assert abs(loss.item() - ref.mean().item()) <= 3e-2 * abs(ref.mean().item())
-    _compare_grads(model.dynamics.egnn.named_parameters(), sd, "dynamics.egnn.", "learned schedule: dynamics", tol=5e-2)
+    # (the gradients inherit that spread - rows are weighted by the SNR factor - so they are compared below, where both
+    # sides are fed the same schedule values)
     # the sharp check of the schedule path: d(loss)/d(gamma_s, gamma_t, gamma_0, gamma_T) with the SAME gamma values as
     # leaves on both sides (what the gamma network's own backward - plain torch autograd - is fed with)
     with torch.no_grad():
