@@ -24,6 +24,12 @@ class HdConfig(C.Structure):
     ]
 
 
+class HdEgclConfig(C.Structure):
+    _fields_ = [("hidden_nf", C.c_int32), ("edges_in_d", C.c_int32), ("context_nf", C.c_int32), ("attention", C.c_int32),
+                ("tanh", C.c_int32), ("coord_update", C.c_int32), ("edge_update", C.c_int32), ("recurrent", C.c_int32),
+                ("coords_range", C.c_float)]
+
+
 # name -> (restype, argtypes); mirrors include/hierdiff_hip.h one to one
 _VP, _FP, _U8P = C.c_void_p, C.c_void_p, C.c_void_p
 SIGNATURES = {
@@ -50,6 +56,13 @@ SIGNATURES = {
     "hd_topology_nodes": (C.c_int, [_VP, _VP]),
     "hd_edge_layer_forward": (C.c_int, [_VP, _VP, C.c_int] + [_FP] * 9 + [_VP]),
     "hd_edge_layer_backward": (C.c_int, [_VP, _VP, C.c_int] + [_FP] * 18 + [_VP]),
+    "hd_egcl_create": (C.c_int, [C.POINTER(HdEgclConfig), C.c_int, C.POINTER(_VP)]),
+    "hd_egcl_destroy": (C.c_int, [_VP]),
+    "hd_egcl_weight_count": (C.c_longlong, [_VP]),
+    "hd_egcl_set_weights": (C.c_int, [_VP, _FP, C.c_longlong, C.c_int, _VP]),
+    "hd_egcl_graph_create": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int, C.POINTER(_VP)]),
+    "hd_egcl_graph_destroy": (C.c_int, [_VP]),
+    "hd_egcl_forward": (C.c_int, [_VP, _VP] + [_FP] * 8 + [_VP]),
     "hd_philox_normal_host": (C.c_float, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]),
     "hd_profile_enable": (C.c_int, [_VP, C.c_int]),
     "hd_profile_read": (C.c_int, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),

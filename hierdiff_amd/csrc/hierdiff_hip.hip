@@ -735,7 +735,9 @@ static void launch_gemm(int epi, bool cat, const GemmArgs& g, hipStream_t s) {
     const int nrt = (g.M + 32 * WM - 1) / (32 * WM), nct = g.Nc / (32 * WN * CN);
     dim3 grid(8 * ((nrt + 7) / 8) * nct);
     dim3 block(WM * WN * 64);
-    if (cat) hipLaunchKernelGGL((k_gemm<WM, WN, CN, EPI_BIAS_SILU, true>), grid, block, 0, s, g);
+    if (cat && epi == EPI_BIAS) hipLaunchKernelGGL((k_gemm<WM, WN, CN, EPI_BIAS, true>), grid, block, 0, s, g);
+    else if (cat) hipLaunchKernelGGL((k_gemm<WM, WN, CN, EPI_BIAS_SILU, true>), grid, block, 0, s, g);
+    else if (epi == EPI_BIAS_SILU) hipLaunchKernelGGL((k_gemm<WM, WN, CN, EPI_BIAS_SILU, false>), grid, block, 0, s, g);
     else if (epi == EPI_BIAS) hipLaunchKernelGGL((k_gemm<WM, WN, CN, EPI_BIAS, false>), grid, block, 0, s, g);
     else hipLaunchKernelGGL((k_gemm<WM, WN, CN, EPI_RESID_MASK, false>), grid, block, 0, s, g);
 }
@@ -1171,6 +1173,302 @@ extern "C" int hd_edge_layer_backward(hd_handle* h, hd_topology* t, int coord, c
     d.escal = escal; d.ei = t->ei; d.ej = t->ej; d.rptr = t->rptr; d.rrows = t->rrows; d.sptr = t->sptr; d.srows = t->srows;
     d.xcur = x; d.x0 = x0; d.dx = dx; d.dx0 = dx0; d.norm_constant = c.norm_constant; d.M = M; d.coord = coord ? 1 : 0;
     hipLaunchKernelGGL(k_edge_dx, dim3((M + 255) / 256), dim3(256), 0, s, d);
+    HIP_TRY(hipGetLastError());
+    return HD_OK;
+}
+
+// ----------------------------------------------------------------------------- stage-2 layer E_GCL (forward)
+
+struct hd_egcl {
+    hd_egcl_config cfg;
+    int device, H, De, ctx, NS;
+    long long n_weights;
+    bool weights_set;
+    float* dw;
+    size_t dw_floats;
+    // float offsets into dw
+    size_t ab_img, ab_bias, w_r, w_e, w_c, w1e_img, zero_bias, w2_img, b2, wa, ba, wc1_img, bc1, wc2, we1_img, be1, w_er,
+        we2_img, be2, wn1_img, bn1, wn2_img, bn2, ones;
+};
+
+struct hd_egcl_graph {
+    hd_egcl* g;
+    int device, M, E, Mp, Ep;
+    int *row, *col, *cptr, *crows;
+    float *hin, *hres, *x4, *AB, *agg, *xagg, *Tn, *ea, *T1, *P, *M1, *C1, *geo, *trans, *ones;
+};
+
+static long long egcl_weight_count(const hd_egcl_config& c) {
+    const long long H = c.hidden_nf, De = c.edges_in_d, ctx = c.context_nf;
+    long long n = H * (2 * H + 1 + De + ctx) + H + H * H + H;                 // mes_mlp
+    if (c.edge_update) n += H * (H + 1 + De) + H + H * H + H;                 // edge_mlp
+    n += H * 2 * H + H + H * H + H;                                           // node_mlp
+    if (c.coord_update) n += H * H + H + H;                                   // coord_mlp
+    if (c.attention) n += H + 1;                                              // att_mlp
+    return n;
+}
+
+extern "C" long long hd_egcl_weight_count(const hd_egcl* g) { return g ? g->n_weights : 0; }
+
+extern "C" int hd_egcl_create(const hd_egcl_config* cfg, int device, hd_egcl** out) {
+    if (!cfg || !out) return fail(HD_E_INVALID, "hd_egcl_create: null argument");
+    *out = nullptr;
+    const int H = cfg->hidden_nf;
+    if (H != 32 && H != 64 && H != 128 && H != 256) return fail(HD_E_INVALID, "hd_egcl_create: hidden_nf must be 32, 64, 128 or 256");
+    if (cfg->edges_in_d < 0 || (cfg->edges_in_d != H && cfg->edges_in_d >= 32))
+        return fail(HD_E_INVALID, "hd_egcl_create: edges_in_d must be hidden_nf (edge features) or < 32 (scalar edge attributes)");
+    if (cfg->edge_update && cfg->edges_in_d != H) return fail(HD_E_INVALID, "hd_egcl_create: edge_update needs edges_in_d == hidden_nf");
+    if (cfg->context_nf < 0 || cfg->context_nf > H) return fail(HD_E_INVALID, "hd_egcl_create: bad context_nf");
+    if (hd_device_count() <= device || device < 0) return fail(HD_E_HIP, "hd_egcl_create: no such HIP device (is a GPU visible?)");
+    HIP_TRY(hipSetDevice(device));
+    hd_egcl* g = new hd_egcl();
+    std::memset(g, 0, sizeof(*g));
+    g->cfg = *cfg; g->device = device; g->H = H; g->De = cfg->edges_in_d; g->ctx = cfg->context_nf;
+    g->NS = (H == 32) ? 1 : 2;
+    g->n_weights = egcl_weight_count(*cfg);
+    *out = g;
+    return HD_OK;
+}
+
+extern "C" int hd_egcl_destroy(hd_egcl* g) {
+    if (!g) return HD_OK;
+    (void)hipSetDevice(g->device);
+    (void)hipDeviceSynchronize();
+    hipFree(g->dw);
+    delete g;
+    return HD_OK;
+}
+
+extern "C" int hd_egcl_set_weights(hd_egcl* g, const float* blob, long long n, int on_device, void* stream) {
+    if (!g || !blob) return fail(HD_E_INVALID, "hd_egcl_set_weights: null argument");
+    if (n != g->n_weights)
+        return fail(HD_E_INVALID, "hd_egcl_set_weights: expected " + std::to_string(g->n_weights) + " values, got " + std::to_string(n));
+    HIP_TRY(hipSetDevice(g->device));
+    std::vector<float> host;
+    const float* src = blob;
+    if (on_device) {
+        host.resize((size_t)n);
+        HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+        HIP_TRY(hipMemcpy(host.data(), blob, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+        src = host.data();
+    }
+    const hd_egcl_config& c = g->cfg;
+    const int H = g->H, De = g->De, ctx = g->ctx, WN = g->NS;
+    const bool wide = De == H;
+    size_t off = 0;
+    auto take = [&](size_t cnt) { size_t o = off; off += (cnt + 3) & ~size_t(3); return o; };
+    g->ab_img = take((size_t)H * 2 * H); g->ab_bias = take(2 * H); g->w_r = take(H); g->w_e = take((size_t)std::max(1, De) * H);
+    g->w_c = take((size_t)std::max(1, ctx) * H); g->w1e_img = take((size_t)H * H); g->zero_bias = take(2 * H);
+    g->w2_img = take((size_t)H * H); g->b2 = take(H); g->wa = take(H); g->ba = take(4);
+    g->wc1_img = take((size_t)H * H); g->bc1 = take(H); g->wc2 = take(H);
+    g->we1_img = take((size_t)2 * H * H); g->be1 = take(H); g->w_er = take(H); g->we2_img = take((size_t)H * H); g->be2 = take(H);
+    g->wn1_img = take((size_t)2 * H * H); g->bn1 = take(H); g->wn2_img = take((size_t)H * H); g->bn2 = take(H);
+    std::vector<float> pk(off, 0.0f);
+    const float* p = src;
+    auto next = [&](size_t cnt) { const float* q = p; p += cnt; return q; };
+    {   // mes_mlp.0 [H][2H + 1 + De + ctx]: columns [source(H) | target(H) | radial | edge_attr(De) | context(ctx)] (gcl.py:92-98)
+        const int ld = 2 * H + 1 + De + ctx;
+        const float* W1 = next((size_t)H * ld); const float* b1 = next(H);
+        pack_gemm_b(pk, g->ab_img, H, 2 * H, WN, [&](int col, int k) {
+            return (col < H) ? W1[(size_t)col * ld + k] : W1[(size_t)(col - H) * ld + H + k]; });
+        for (int k = 0; k < H; ++k) {
+            pk[g->ab_bias + k] = b1[k];
+            pk[g->w_r + k] = W1[(size_t)k * ld + 2 * H];
+            for (int d = 0; d < De && !wide; ++d) pk[g->w_e + (size_t)d * H + k] = W1[(size_t)k * ld + 2 * H + 1 + d];
+            for (int d = 0; d < ctx; ++d) pk[g->w_c + (size_t)d * H + k] = W1[(size_t)k * ld + 2 * H + 1 + De + d];
+        }
+        if (wide) pack_gemm_b(pk, g->w1e_img, H, H, WN, [&](int col, int k) { return W1[(size_t)col * ld + 2 * H + 1 + k]; });
+        const float* W2 = next((size_t)H * H); const float* b2 = next(H);
+        pack_gemm_b(pk, g->w2_img, H, H, WN, [&](int col, int k) { return W2[(size_t)col * H + k]; });
+        std::copy(b2, b2 + H, pk.begin() + g->b2);
+    }
+    if (c.edge_update) {   // edge_mlp.0 [H][H + 1 + De]: columns [edge_feat(H) | radial | edge_attr(De)] (gcl.py:111)
+        const int ld = H + 1 + De;
+        const float* We1 = next((size_t)H * ld); const float* be1 = next(H);
+        pack_gemm_b(pk, g->we1_img, 2 * H, H, WN, [&](int col, int k) {
+            return (k < H) ? We1[(size_t)col * ld + k] : We1[(size_t)col * ld + H + 1 + (k - H)]; });
+        for (int k = 0; k < H; ++k) { pk[g->be1 + k] = be1[k]; pk[g->w_er + k] = We1[(size_t)k * ld + H]; }
+        const float* We2 = next((size_t)H * H); const float* be2 = next(H);
+        pack_gemm_b(pk, g->we2_img, H, H, WN, [&](int col, int k) { return We2[(size_t)col * H + k]; });
+        std::copy(be2, be2 + H, pk.begin() + g->be2);
+    }
+    {   // node_mlp.0 [H][2H]: columns [h | agg] (gcl.py:123-126)
+        const float* Wn1 = next((size_t)H * 2 * H); const float* bn1 = next(H);
+        pack_gemm_b(pk, g->wn1_img, 2 * H, H, WN, [&](int col, int k) { return Wn1[(size_t)col * 2 * H + k]; });
+        std::copy(bn1, bn1 + H, pk.begin() + g->bn1);
+        const float* Wn2 = next((size_t)H * H); const float* bn2 = next(H);
+        pack_gemm_b(pk, g->wn2_img, H, H, WN, [&](int col, int k) { return Wn2[(size_t)col * H + k]; });
+        std::copy(bn2, bn2 + H, pk.begin() + g->bn2);
+    }
+    if (c.coord_update) {
+        const float* Wc1 = next((size_t)H * H); const float* bc1 = next(H); const float* wc2 = next(H);
+        pack_gemm_b(pk, g->wc1_img, H, H, WN, [&](int col, int k) { return Wc1[(size_t)col * H + k]; });
+        std::copy(bc1, bc1 + H, pk.begin() + g->bc1);
+        std::copy(wc2, wc2 + H, pk.begin() + g->wc2);
+    }
+    if (c.attention) {
+        const float* wa = next(H); const float* ba = next(1);
+        std::copy(wa, wa + H, pk.begin() + g->wa);
+        pk[g->ba] = ba[0];
+    }
+    if (p - src != n) return fail(HD_E_INVALID, "hd_egcl_set_weights: internal layout mismatch");
+    if (g->dw_floats != pk.size()) {
+        hipFree(g->dw); g->dw = nullptr;
+        HD_TRY(dev_alloc(&g->dw, pk.size()));
+        g->dw_floats = pk.size();
+    }
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    HIP_TRY(hipMemcpy(g->dw, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
+    g->weights_set = true;
+    return HD_OK;
+}
+
+extern "C" int hd_egcl_graph_destroy(hd_egcl_graph* t) {
+    if (!t) return HD_OK;
+    (void)hipSetDevice(t->device);
+    (void)hipDeviceSynchronize();
+    hipFree(t->row); hipFree(t->col); hipFree(t->cptr); hipFree(t->crows);
+    hipFree(t->hin); hipFree(t->hres); hipFree(t->x4); hipFree(t->AB); hipFree(t->agg); hipFree(t->xagg); hipFree(t->Tn);
+    hipFree(t->ea); hipFree(t->T1); hipFree(t->P); hipFree(t->M1); hipFree(t->C1); hipFree(t->geo); hipFree(t->trans); hipFree(t->ones);
+    delete t;
+    return HD_OK;
+}
+
+extern "C" int hd_egcl_graph_create(hd_egcl* g, const int* row, const int* col, int M, int E, hd_egcl_graph** out) {
+    if (!g || !out || (E > 0 && (!row || !col))) return fail(HD_E_INVALID, "hd_egcl_graph_create: null argument");
+    *out = nullptr;
+    if (M < 1 || E < 0) return fail(HD_E_INVALID, "hd_egcl_graph_create: need M >= 1, E >= 0");
+    for (int e = 0; e < E; ++e)
+        if (row[e] < 0 || row[e] >= M || col[e] < 0 || col[e] >= M) return fail(HD_E_INVALID, "hd_egcl_graph_create: edge index out of range");
+    HIP_TRY(hipSetDevice(g->device));
+    std::vector<int> vr(row, row + E), vc(col, col + E), cptr(M + 1, 0), crows((size_t)E);
+    for (int e = 0; e < E; ++e) cptr[vc[e] + 1]++;
+    for (int i = 0; i < M; ++i) cptr[i + 1] += cptr[i];
+    { std::vector<int> cur(cptr.begin(), cptr.end() - 1); for (int e = 0; e < E; ++e) crows[cur[vc[e]]++] = e; }
+    hd_egcl_graph* t = new hd_egcl_graph();
+    std::memset(t, 0, sizeof(*t));
+    t->g = g; t->device = g->device; t->M = M; t->E = E;
+    t->Mp = (M + 127) / 128 * 128; t->Ep = std::max(128, (E + 127) / 128 * 128);
+    const int H = g->H;
+    auto build = [&]() -> int {
+        HD_TRY(dev_upload(&t->row, vr)); HD_TRY(dev_upload(&t->col, vc)); HD_TRY(dev_upload(&t->cptr, cptr)); HD_TRY(dev_upload(&t->crows, crows));
+        auto zalloc = [&](float** p, size_t count) -> int {
+            HD_TRY(dev_alloc(p, count));
+            HIP_TRY(hipMemset(*p, 0, std::max<size_t>(count, 1) * sizeof(float)));
+            return HD_OK;
+        };
+        const size_t Mp = t->Mp, Ep = t->Ep;
+        HD_TRY(zalloc(&t->hin, Mp * H)); HD_TRY(zalloc(&t->hres, Mp * H)); HD_TRY(zalloc(&t->x4, Mp * 4)); HD_TRY(zalloc(&t->AB, Mp * 2 * H));
+        HD_TRY(zalloc(&t->agg, Mp * H)); HD_TRY(zalloc(&t->xagg, Mp * 4)); HD_TRY(zalloc(&t->Tn, Mp * H));
+        HD_TRY(zalloc(&t->ea, Ep * H)); HD_TRY(zalloc(&t->T1, Ep * H)); HD_TRY(zalloc(&t->P, Ep * H)); HD_TRY(zalloc(&t->M1, Ep * H));
+        HD_TRY(zalloc(&t->C1, Ep * H)); HD_TRY(zalloc(&t->geo, Ep * 4)); HD_TRY(zalloc(&t->trans, Ep * 4));
+        std::vector<float> ones(Mp, 1.0f);
+        HD_TRY(dev_upload(&t->ones, ones));
+        return HD_OK;
+    };
+    const int r = build();
+    if (r != HD_OK) { const std::string keep = g_err; hd_egcl_graph_destroy(t); g_err = keep; return r; }
+    *out = t;
+    return HD_OK;
+}
+
+static void egcl_gemm(hd_egcl* g, int epi, bool cat, const GemmArgs& a, hipStream_t s) {
+    if (g->NS == 1) launch_gemm<4, 1, 1>(epi, cat, a, s);
+    else launch_gemm<2, 2, 1>(epi, cat, a, s);
+}
+
+extern "C" int hd_egcl_forward(hd_egcl* g, hd_egcl_graph* t, const float* h, const float* x, const float* edge_attr,
+                               const float* node_mask, const float* edge_mask, float* h_out, float* x_out,
+                               float* edge_attr_out, void* stream) {
+    if (!g || !t) return fail(HD_E_INVALID, "hd_egcl_forward: null handle/graph");
+    if (t->g != g) return fail(HD_E_INVALID, "hd_egcl_forward: graph belongs to another handle");
+    if (!g->weights_set) return fail(HD_E_STATE, "hd_egcl_forward: weights not set (hd_egcl_set_weights)");
+    if (!h || !x || !h_out || !x_out) return fail(HD_E_INVALID, "hd_egcl_forward: null tensor");
+    const hd_egcl_config& c = g->cfg;
+    if (g->De > 0 && !edge_attr) return fail(HD_E_INVALID, "hd_egcl_forward: edge_attr required");
+    if (c.edge_update && !edge_attr_out) return fail(HD_E_INVALID, "hd_egcl_forward: edge_attr_out required with edge_update");
+    HIP_TRY(hipSetDevice(g->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int H = g->H, De = g->De, ctx = g->ctx, M = t->M, E = t->E;
+    const float* W = g->dw;
+    const bool wide = De == H;
+    auto blocks = [](long long total) { return dim3((unsigned)((total + 255) / 256)); };
+    auto gemm_args = [&](const float* A, int lda, int K1, int K, const float* A2, size_t img, size_t bias, float* Cc, int ldc,
+                         int rows, int Nc, const float* nmask) {
+        GemmArgs a;
+        std::memset(&a, 0, sizeof(a));
+        a.A = A; a.lda = lda; a.K1 = K1; a.K = K; a.A2 = A2; a.Bimg = W + img; a.bias = W + bias; a.C = Cc; a.ldc = ldc; a.M = rows;
+        a.Nc = Nc; a.nmask = nmask;
+        return a;
+    };
+    {   // node inputs
+        EgclNodeInArgs a;
+        a.h = h; a.x = x; a.hin = t->hin; a.hres = t->hres; a.x4 = t->x4; a.M = M; a.H = H; a.ctx = ctx;
+        hipLaunchKernelGGL(k_egcl_node_in, blocks((long long)M * H), dim3(256), 0, s, a);
+    }
+    egcl_gemm(g, EPI_BIAS, false, gemm_args(t->hin, H, H, H, nullptr, g->ab_img, g->ab_bias, t->AB, 2 * H, M, 2 * H, nullptr), s);
+    if (E > 0) {
+        if (wide) {
+            HIP_TRY(hipMemcpyAsync(t->ea, edge_attr, (size_t)E * H * sizeof(float), hipMemcpyDeviceToDevice, s));
+            egcl_gemm(g, EPI_BIAS, false, gemm_args(t->ea, H, H, H, nullptr, g->w1e_img, g->zero_bias, t->T1, H, E, H, nullptr), s);
+        }
+        {
+            EgclPreArgs a;
+            a.AB = t->AB; a.T1 = wide ? t->T1 : nullptr; a.ea = wide ? nullptr : edge_attr; a.w_e = W + g->w_e; a.w_r = W + g->w_r;
+            a.w_c = W + g->w_c; a.hin = t->hin; a.x = t->x4; a.row = t->row; a.col = t->col; a.P = t->P; a.geo = t->geo;
+            a.E = E; a.H = H; a.De = De; a.ctx = ctx;
+            hipLaunchKernelGGL(k_egcl_pre, blocks((long long)E * (H / 4)), dim3(256), 0, s, a);
+        }
+        egcl_gemm(g, EPI_BIAS_SILU, false, gemm_args(t->P, H, H, H, nullptr, g->w2_img, g->b2, t->M1, H, E, H, nullptr), s);
+        {   // edge_feat = M (* att) * edge_mask, in place
+            EgclRowArgs a;
+            std::memset(&a, 0, sizeof(a));
+            a.X = t->M1; a.w = W + g->wa; a.bias = W + g->ba; a.emask = edge_mask; a.E = E; a.H = H; a.attention = c.attention;
+            hipLaunchKernelGGL((k_egcl_row<0>), dim3((E + 3) / 4), dim3(256), 0, s, a);
+        }
+        if (c.coord_update) {
+            egcl_gemm(g, EPI_BIAS_SILU, false, gemm_args(t->M1, H, H, H, nullptr, g->wc1_img, g->bc1, t->C1, H, E, H, nullptr), s);
+            EgclRowArgs a;
+            std::memset(&a, 0, sizeof(a));
+            a.X = t->C1; a.w = W + g->wc2; a.emask = edge_mask; a.geo = t->geo; a.trans = t->trans; a.range = c.coords_range;
+            a.E = E; a.H = H; a.use_tanh = c.tanh;
+            hipLaunchKernelGGL((k_egcl_row<1>), dim3((E + 3) / 4), dim3(256), 0, s, a);
+        }
+    }
+    {   // sums over incoming edges (receiving index = col), ascending edge order
+        CsrSumArgs cs;
+        cs.ptr = t->cptr; cs.rows = t->crows; cs.M = M; cs.col0 = 0;
+        cs.G = t->M1; cs.out = t->agg; cs.H = H; cs.ldo = H;
+        hipLaunchKernelGGL(k_csr_sum, blocks((long long)M * (H / 4)), dim3(256), 0, s, cs);
+        if (c.coord_update) {
+            cs.G = t->trans; cs.out = t->xagg; cs.H = 4; cs.ldo = 4;
+            hipLaunchKernelGGL(k_csr_sum, blocks((long long)M), dim3(256), 0, s, cs);
+        }
+    }
+    // node model: h_new = (h + node_mlp([h | agg])) (* node_mask)
+    const float* nm = node_mask ? node_mask : t->ones;
+    egcl_gemm(g, EPI_BIAS_SILU, true, gemm_args(t->hin, H, H, 2 * H, t->agg, g->wn1_img, g->bn1, t->Tn, H, M, H, nullptr), s);
+    if (!c.recurrent) HIP_TRY(hipMemsetAsync(t->hres, 0, (size_t)t->Mp * H * sizeof(float), s));
+    egcl_gemm(g, EPI_RESID_MASK, false, gemm_args(t->Tn, H, H, H, nullptr, g->wn2_img, g->bn2, t->hres, H, M, H, nm), s);
+    if (c.edge_update && E > 0) {
+        // edge_mlp: E1 = SiLU([edge_feat | edge_attr] We1^T + radial w_er + be1);  edge_attr' = (E1 We2^T + be2) * edge_mask
+        egcl_gemm(g, EPI_BIAS, true, gemm_args(t->M1, H, H, 2 * H, t->ea, g->we1_img, g->be1, t->C1, H, E, H, nullptr), s);
+        EgclEwArgs a;
+        a.X = t->C1; a.w = W + g->w_er; a.geo = t->geo; a.emask = nullptr; a.E = E; a.H = H;
+        hipLaunchKernelGGL((k_egcl_ew<0>), blocks((long long)E * (H / 4)), dim3(256), 0, s, a);
+        egcl_gemm(g, EPI_BIAS, false, gemm_args(t->C1, H, H, H, nullptr, g->we2_img, g->be2, t->P, H, E, H, nullptr), s);
+        if (edge_mask) {
+            a.X = t->P; a.emask = edge_mask;
+            hipLaunchKernelGGL((k_egcl_ew<1>), blocks((long long)E * (H / 4)), dim3(256), 0, s, a);
+        }
+        HIP_TRY(hipMemcpyAsync(edge_attr_out, t->P, (size_t)E * H * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    {
+        EgclNodeOutArgs a;
+        a.hnew = t->hres; a.hin = t->hin; a.x4 = t->x4; a.xagg = c.coord_update ? t->xagg : nullptr; a.nmask = node_mask;
+        a.h_out = h_out; a.x_out = x_out; a.M = M; a.H = H; a.ctx = ctx;
+        hipLaunchKernelGGL(k_egcl_node_out, blocks((long long)M * (H + ctx)), dim3(256), 0, s, a);
+    }
     HIP_TRY(hipGetLastError());
     return HD_OK;
 }

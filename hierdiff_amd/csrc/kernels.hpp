@@ -12,10 +12,11 @@
 //   * in bf16x3 mode the whole row-local node chain (neighbour-sum reduction, node MLP, residual, the next
 //     layers' first edge Linear) is one launch (k_node).
 // Files: common.hpp (types, helpers, RNG), k_node.hpp, k_edge.hpp, k_edge_bwd.hpp (training: backward of an edge layer),
-// k_sampling.hpp (output stage, posterior step, decode, noise).  (The slower one-wave-per-SIMD edge-kernel experiment of round 1 lives in scratch/experiments/.)
+// k_sampling.hpp (output stage, posterior step, decode, noise), k_egcl.hpp (stage-2 layer E_GCL, forward).  (The slower one-wave-per-SIMD edge-kernel experiment of round 1 lives in scratch/experiments/.)
 #pragma once
 #include "common.hpp"
 #include "k_node.hpp"
 #include "k_edge.hpp"
 #include "k_edge_bwd.hpp"
 #include "k_sampling.hpp"
+#include "k_egcl.hpp"

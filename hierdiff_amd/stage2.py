@@ -1,0 +1,200 @@
+"""Stage-2 layer `E_GCL` on MI355X (forward) - drop-in for /root/reference/models/egnn/gcl.py:9-205.
+
+The layer of HierDiff's second stage (`models/edge_denoise.py:35-43`: gcl_full_i, gcl_focal_i, gcl_edge, gcl_denoise):
+same constructor, same `state_dict` keys (mes_mlp.0.weight, edge_mlp.0.weight, node_mlp.0.weight, coord_mlp.0.weight,
+att_mlp.0.weight, ...), same `forward(h, edge_index, coord, edge_attr, node_attr, node_mask, edge_mask)` and return value.
+The arithmetic runs in libhierdiff_hip.so (`hd_egcl_forward`, exact fp32 MFMA GEMMs over edge / node rows + row kernels);
+the torch modules below only hold parameters.  Inference only (value); no CPU fallback.
+Not supported (config-off in the reference's stage-2 models): geo=True, agg='mean', node_attr, angle_net, act_fn != SiLU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import hashlib
+import math
+import weakref
+from collections import OrderedDict
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import HdEgclConfig, HierDiffHipError
+
+
+def egcl_param_shapes(hidden_nf: int, edges_in_d: int, context_nf: int = 0, attention: bool = False,
+                      edge_update: bool = True, coord_update: bool = True) -> "OrderedDict[str, Tuple[int, ...]]":
+    """E_GCL parameters in the reference's registration order (gcl.py:31-63)."""
+    H = hidden_nf
+    s: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+    s["mes_mlp.0.weight"] = (H, 2 * H + 1 + edges_in_d + context_nf); s["mes_mlp.0.bias"] = (H,)
+    s["mes_mlp.2.weight"] = (H, H); s["mes_mlp.2.bias"] = (H,)
+    if edge_update:
+        s["edge_mlp.0.weight"] = (H, H + 1 + edges_in_d); s["edge_mlp.0.bias"] = (H,)
+        s["edge_mlp.2.weight"] = (H, H); s["edge_mlp.2.bias"] = (H,)
+    s["node_mlp.0.weight"] = (H, 2 * H); s["node_mlp.0.bias"] = (H,)
+    s["node_mlp.2.weight"] = (H, H); s["node_mlp.2.bias"] = (H,)
+    if coord_update:
+        s["coord_mlp.0.weight"] = (H, H); s["coord_mlp.0.bias"] = (H,)
+        s["coord_mlp.2.weight"] = (1, H)
+    if attention:
+        s["att_mlp.0.weight"] = (1, H); s["att_mlp.0.bias"] = (1,)
+    return s
+
+
+def synthetic_egcl_state_dict(hidden_nf: int, edges_in_d: int, context_nf: int = 0, attention: bool = False,
+                              edge_update: bool = True, seed: int = 0, coord_gain: float = 0.001) -> "OrderedDict[str, np.ndarray]":
+    """Deterministic nn.Linear-style weights keyed by tensor name (the reference ships no stage-2 checkpoint)."""
+    out: "OrderedDict[str, np.ndarray]" = OrderedDict()
+    shapes = egcl_param_shapes(hidden_nf, edges_in_d, context_nf, attention, edge_update)
+    for name, shape in shapes.items():
+        digest = hashlib.sha256(f"egcl:{seed}:{name}".encode()).digest()
+        rng = np.random.Generator(np.random.PCG64(int.from_bytes(digest[:8], "little")))
+        wshape = shapes[name[:-4] + "weight"] if name.endswith("bias") else shape
+        bound = 1.0 / math.sqrt(wshape[1])
+        if name == "coord_mlp.2.weight":
+            bound = coord_gain * math.sqrt(6.0 / (shape[0] + shape[1]))
+        out[name] = rng.uniform(-bound, bound, size=shape).astype(np.float32)
+    return out
+
+
+class _Graph:
+    def __init__(self, owner: "E_GCL", row: torch.Tensor, col: torch.Tensor, M: int):
+        lib = _lib.load()
+        r = row.detach().to("cpu", torch.int32).contiguous().numpy()
+        c = col.detach().to("cpu", torch.int32).contiguous().numpy()
+        self.E, self.M = int(r.shape[0]), int(M)
+        self._h = C.c_void_p()
+        _lib.check(lib.hd_egcl_graph_create(owner._handle(), r.ctypes.data, c.ctypes.data, self.M, self.E, C.byref(self._h)),
+                   "hd_egcl_graph_create")
+        self._finalizer = weakref.finalize(self, lib.hd_egcl_graph_destroy, self._h)
+
+
+class E_GCL(nn.Module):
+    """HIP implementation of models/egnn/gcl.py:9-205."""
+
+    def __init__(self, input_nf, output_nf, hidden_nf, context_nf=0, edges_in_d=0, nodes_att_dim=0, act_fn=nn.SiLU(),
+                 recurrent=True, attention=False, clamp=False, tanh=False, coords_range=1, agg='sum', coord_update=True,
+                 edge_update=True, angle_net=False, geo=False):
+        super().__init__()
+        if not (input_nf == output_nf == hidden_nf):
+            raise NotImplementedError("E_GCL on MI355X: input_nf == output_nf == hidden_nf (as in edge_denoise.py:35-43)")
+        if hidden_nf not in (32, 64, 128, 256):
+            raise NotImplementedError("hidden_nf must be one of 32, 64, 128, 256")
+        if geo or angle_net or nodes_att_dim or agg != 'sum' or not isinstance(act_fn, nn.SiLU):
+            raise NotImplementedError("geo / angle_net / node_attr / agg='mean' / act_fn != SiLU are config-off in the reference")
+        if not (edges_in_d == hidden_nf or 0 <= edges_in_d < 32):
+            raise NotImplementedError("edges_in_d must be hidden_nf or < 32")
+        if edge_update and edges_in_d != hidden_nf:
+            raise NotImplementedError("edge_update needs edges_in_d == hidden_nf")
+        H = hidden_nf
+        self.recurrent, self.attention, self.tanh, self.context_nf = recurrent, attention, tanh, context_nf
+        self.coord_update, self.edge_update, self.agg_type, self.geo, self.clamp = coord_update, edge_update, agg, geo, clamp
+        self.mes_mlp = nn.Sequential(nn.Linear(2 * H + 1 + edges_in_d + context_nf, H), nn.SiLU(), nn.Linear(H, H), nn.SiLU())
+        if edge_update:
+            self.edge_mlp = nn.Sequential(nn.Linear(H + 1 + edges_in_d, H), nn.SiLU(), nn.Linear(H, H))
+        self.node_mlp = nn.Sequential(nn.Linear(2 * H, H), nn.SiLU(), nn.Linear(H, H))
+        if coord_update:
+            layer = nn.Linear(H, 1, bias=False)
+            torch.nn.init.xavier_uniform_(layer.weight, gain=0.001)
+            mods = [nn.Linear(H, H), nn.SiLU(), layer]
+            if tanh:
+                mods.append(nn.Tanh())
+                self.coords_range = coords_range
+            self.coord_mlp = nn.Sequential(*mods)
+        if attention:
+            self.att_mlp = nn.Sequential(nn.Linear(H, 1), nn.Sigmoid())
+        self._cfg = HdEgclConfig(hidden_nf=H, edges_in_d=edges_in_d, context_nf=context_nf, attention=int(bool(attention)),
+                                 tanh=int(bool(tanh)), coord_update=int(bool(coord_update)), edge_update=int(bool(edge_update)),
+                                 recurrent=int(bool(recurrent)), coords_range=float(coords_range))
+        self._hd = None
+        self._weights_key = None
+        self._graphs: Dict[Tuple, Tuple] = {}
+
+    # ------------------------------------------------------------------ handle / weights / graphs
+    def _handle(self) -> C.c_void_p:
+        dev = self.mes_mlp[0].weight.device
+        if dev.type != "cuda":
+            raise HierDiffHipError("E_GCL runs only on an MI355X: move the module to a cuda device (there is no CPU fallback)")
+        _lib.require_gpu()
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        if self._hd is None or self._hd[1] != idx:
+            self._graphs.clear()
+            if self._hd is not None:
+                self._finalizer()
+            lib = _lib.load()
+            h = C.c_void_p()
+            _lib.check(lib.hd_egcl_create(C.byref(self._cfg), idx, C.byref(h)), "hd_egcl_create")
+            self._hd = (h, idx)
+            self._weights_key = None
+            self._finalizer = weakref.finalize(self, lib.hd_egcl_destroy, h)
+        return self._hd[0]
+
+    def _sync_weights(self):
+        h = self._handle()
+        key = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if key == self._weights_key:
+            return
+        blob = torch.cat([p.detach().reshape(-1).to(torch.float32) for p in self.parameters()]).contiguous()
+        lib = _lib.load()
+        if blob.numel() != lib.hd_egcl_weight_count(h):
+            raise HierDiffHipError(f"parameter count {blob.numel()} != library layout {lib.hd_egcl_weight_count(h)}")
+        _lib.check(lib.hd_egcl_set_weights(h, blob.data_ptr(), blob.numel(), 1, torch.cuda.current_stream(blob.device).cuda_stream),
+                   "hd_egcl_set_weights")
+        self._weights_key = key
+
+    def _apply(self, fn, *a, **k):
+        self._weights_key = None
+        return super()._apply(fn, *a, **k)
+
+    def _graph(self, row, col, M) -> _Graph:
+        """Cached per edge-index tensors (identity + version), like the reference caches its edge lists."""
+        self._handle()
+        key = (id(row), row._version, id(col), col._version, M)
+        hit = self._graphs.get(key)
+        if hit is not None and hit[1] is row and hit[2] is col:
+            return hit[0]
+        if len(self._graphs) >= 8:
+            self._graphs.pop(next(iter(self._graphs)))
+        g = _Graph(self, row, col, M)
+        self._graphs[key] = (g, row, col)
+        return g
+
+    # ------------------------------------------------------------------ reference API
+    @torch.no_grad()
+    def forward(self, h, edge_index, coord, edge_attr=None, node_attr=None, node_mask=None, edge_mask=None):
+        if node_attr is not None:
+            raise NotImplementedError("node_attr is not used by the reference's stage-2 models")
+        if h.device.type != "cuda":
+            raise HierDiffHipError("E_GCL.forward needs cuda tensors (no CPU fallback)")
+        row, col = edge_index
+        M = h.shape[0]
+        H, ctx, De = self._cfg.hidden_nf, self._cfg.context_nf, self._cfg.edges_in_d
+        if h.shape[1] != H + ctx:
+            raise ValueError(f"h has {h.shape[1]} columns, layer expects {H + ctx}")
+        if De > 0 and (edge_attr is None or edge_attr.shape != (row.shape[0], De)):
+            raise ValueError(f"edge_attr must be [E, {De}]")
+        self._sync_weights()
+        g = self._graph(row, col, M)
+        dev = h.device
+        f32 = lambda t: None if t is None else t.detach().to(dev, torch.float32).contiguous()
+        hc, xc, ea = f32(h), f32(coord), f32(edge_attr)
+        nm = None if node_mask is None else f32(node_mask).reshape(-1)
+        em = None if edge_mask is None else f32(edge_mask).reshape(-1)
+        h_out = torch.empty_like(hc)
+        x_out = torch.empty_like(xc)
+        ea_out = torch.empty((g.E, H), device=dev, dtype=torch.float32) if self.edge_update else None
+        p = lambda t: None if t is None else t.data_ptr()
+        _lib.check(_lib.load().hd_egcl_forward(self._handle(), g._h, p(hc), p(xc), p(ea), p(nm), p(em), p(h_out), p(x_out), p(ea_out),
+                                               torch.cuda.current_stream(dev).cuda_stream), "hd_egcl_forward")
+        if self.edge_update:
+            return h_out, x_out, ea_out
+        return h_out, x_out
+
+    def coord2radial(self, row, col, coord):
+        """gcl.py:198-205 (host-side helper; the HIP path computes it per edge)."""
+        diff = coord[row] - coord[col]
+        radial = torch.sum(diff ** 2, 1).unsqueeze(1)
+        return radial, diff / (torch.sqrt(radial + 1e-8) + 1)

@@ -190,6 +190,34 @@ int hd_edge_layer_backward(hd_handle* h, hd_topology* topo, int coord, const flo
                            const float* ba, const float* gout, float* G2, float* P, float* G1, float* escal, float* colpart,
                            float* bapart, float* dAB, float* dx, float* dx0, void* stream);
 
+/* ---- Stage-2 layer: E_GCL forward (/root/reference/models/egnn/gcl.py:9-205), exact fp32.
+ * The layer of the edge-denoise / refine models: messages from [h_row; h_col; radial; edge_attr; context], optional
+ * attention gate, coordinate update and node update aggregated over the RECEIVING index `col`, optional update of the
+ * H-wide edge features.  geo = False, agg = 'sum', node_attr = None, act_fn = SiLU. */
+typedef struct hd_egcl hd_egcl;
+typedef struct hd_egcl_graph hd_egcl_graph;
+typedef struct hd_egcl_config {        /* E_GCL.__init__ arguments (gcl.py:19) */
+    int32_t hidden_nf;                 /* input_nf == output_nf == hidden_nf: 32, 64, 128 or 256 */
+    int32_t edges_in_d;                /* hidden_nf (edge features) or < 32 (scalar edge attributes, e.g. 1) */
+    int32_t context_nf;
+    int32_t attention, tanh, coord_update, edge_update, recurrent;
+    float coords_range;
+} hd_egcl_config;
+int hd_egcl_create(const hd_egcl_config* cfg, int device, hd_egcl** out);
+int hd_egcl_destroy(hd_egcl* g);
+long long hd_egcl_weight_count(const hd_egcl* g);
+/* Parameters flattened in state_dict registration order: mes_mlp.{0,2}, [edge_mlp.{0,2}], node_mlp.{0,2},
+ * [coord_mlp.{0,2}], [att_mlp.0] (weight then bias each; coord_mlp.2 has no bias). */
+int hd_egcl_set_weights(hd_egcl* g, const float* blob, long long n, int on_device, void* stream);
+/* Edge list (HOST int32 arrays row, col [E], node ids < M) + workspaces; reusable across layers of the same width. */
+int hd_egcl_graph_create(hd_egcl* g, const int* row, const int* col, int M, int E, hd_egcl_graph** out);
+int hd_egcl_graph_destroy(hd_egcl_graph* t);
+/* (h_out [M][H+ctx], x_out [M][3], edge_attr_out [E][H]) = E_GCL.forward(h [M][H+ctx], edges, x [M][3], edge_attr [E][De],
+ * node_mask [M] or NULL, edge_mask [E] or NULL); all device fp32; edge_attr_out only with edge_update. */
+int hd_egcl_forward(hd_egcl* g, hd_egcl_graph* t, const float* h, const float* x, const float* edge_attr,
+                    const float* node_mask, const float* edge_mask, float* h_out, float* x_out, float* edge_attr_out,
+                    void* stream);
+
 /* Host implementation of the library's normal generator (same bits as the device one up to libm
  * round-off); used by tests and by callers that want to reproduce a draw on the CPU. */
 float hd_philox_normal_host(uint64_t seed, uint64_t sample_id, uint32_t draw, uint32_t index);
