@@ -239,10 +239,13 @@ class EGNN_dynamics_QM9(nn.Module):
         """Cached per mask tensors (identity + in-place version), as the reference caches its edge
         lists per (n_nodes, batch_size) in `_edges_dict` (en_dynamics.py:124-143)."""
         self._handle()
-        key = (id(node_mask), node_mask._version, None if edge_mask is None else id(edge_mask),
-               None if edge_mask is None else edge_mask._version, B, N)
+        # keyed on storage address + in-place version + shape (views of one mask tensor - e.g. the `.view(bs, n*n)` the
+        # reference's forward(batch) makes every step - hit the same entry); the cached tensors are kept alive, so an
+        # address cannot be recycled while its entry exists
+        sig = lambda m: None if m is None else (m.data_ptr(), m._version, m.numel(), m.dtype, str(m.device))
+        key = (sig(node_mask), sig(edge_mask), B, N)
         hit = self._topo_cache.get(key)
-        if hit is not None and hit[1] is node_mask and hit[2] is edge_mask:
+        if hit is not None:
             return hit[0]
         if len(self._topo_cache) >= 8:
             self._topo_cache.pop(next(iter(self._topo_cache)))
