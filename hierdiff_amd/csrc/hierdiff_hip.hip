@@ -836,11 +836,6 @@ static bool launch_edge_ablated(hd_handle* h, const EdgeArgs& a, hipStream_t s) 
         case 20: run(std::integral_constant<int, 20>{}); return true;
         case 24: run(std::integral_constant<int, 24>{}); return true;
         case 30: run(std::integral_constant<int, 30>{}); return true;
-        case 32: run(std::integral_constant<int, 32>{}); return true;       // epilogue at default priority
-        case 64: run(std::integral_constant<int, 64>{}); return true;       // + prologue at raised priority
-        case 96: run(std::integral_constant<int, 96>{}); return true;       // prologue raised, epilogue default
-        case 128: run(std::integral_constant<int, 128>{}); return true;     // loop at priority 1 (epilogue 3)
-        case 192: run(std::integral_constant<int, 192>{}); return true;
         default: return false;
     }
 }

@@ -177,7 +177,6 @@ __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
     }
     long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0;
     if constexpr (ABL & 16) ts0 = __builtin_readcyclecounter();
-    if constexpr (ABL & 64) __builtin_amdgcn_s_setprio(3);      // experiment: prologue (VALU / memory only) at raised priority
 
     for (int k = tid; k < 2 * H; k += 256) wrd_s[k] = a.wrd[k];
     for (int k = tid; k < H; k += 256) { wrd_s[2 * H + k] = a.b2[k]; wrd_s[3 * H + k] = a.wa[k]; }
@@ -312,8 +311,6 @@ __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
         for (int r = 0; r < 16; ++r) acc[ct][r] = b2v;
     }
     if constexpr (ABL & 16) ts1 = __builtin_readcyclecounter();
-    if constexpr (ABL & 64) __builtin_amdgcn_s_setprio(0);
-    if constexpr (ABL & 128) __builtin_amdgcn_s_setprio(1);     // experiment: MFMA loop above default priority
     // (Unrolling this loop by two with swapped operand sets, to drop the 16 register copies per chunk, was
     // measured twice: 9-17 spilled registers, 125 vs 109 us and later 110-116 vs 103-106 us; fp32 285 vs 278.)
 #pragma unroll 1
@@ -463,10 +460,8 @@ __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
     }
     if constexpr (ABL & 16) ts2 = __builtin_readcyclecounter();
     if (!tile_ok) return;                  // padding tile of the last workgroup: nothing to store
-    // The epilogue is VALU-only.  On this chip a VALU-only wavefront and an MFMA-streaming wavefront on one SIMD serialise
-    // unless the VALU one has the higher priority (scratch/mb/phased.hip), so the epilogue runs at raised priority: its
-    // instructions slip in beside the co-resident wavefront's MFMAs instead of waiting behind them.
-    if constexpr (ABL & 32) {} else __builtin_amdgcn_s_setprio(3);
+    // (Priority experiments - s_setprio raised for the VALU-only prologue / epilogue, for the MFMA loop, or both - were
+    // all null within +-0.5 % on both precisions: profiles/r02_ablate_fp32.log.)
     if constexpr (ABL & 1) {
         float sacc = 0.f;
 #pragma unroll
