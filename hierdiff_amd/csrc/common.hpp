@@ -81,6 +81,19 @@ HD_DEVINL void bf16_split2(float y0, float y1, uint32_t& hi, uint32_t& lo) {
     lo = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){l0, l1}, bf16x2_t));
 }
 
+// three-way split (head, middle, tail: 24 significant bits, |y - h - m - l| <= 2^-27 |y|) for the bf16x6 contraction
+HD_DEVINL void bf16_split3(float y0, float y1, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+    const uint32_t hp = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){y0, y1}, bf16x2_t));
+    const float r0 = y0 - __builtin_bit_cast(float, hp << 16);
+    const float r1 = y1 - __builtin_bit_cast(float, hp & 0xffff0000u);
+    const uint32_t mp = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){r0, r1}, bf16x2_t));
+    const float s0 = r0 - __builtin_bit_cast(float, mp << 16);
+    const float s1 = r1 - __builtin_bit_cast(float, mp & 0xffff0000u);
+    hi = hp;
+    mid = mp;
+    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){s0, s1}, bf16x2_t));
+}
+
 // compile-time loop: f(std::integral_constant<int, I>) for I = 0..N-1
 template <int I, int N, typename F>
 HD_DEVINL void static_for(F&& f) {

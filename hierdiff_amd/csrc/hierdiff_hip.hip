@@ -47,6 +47,8 @@ struct hd_handle {
     int device;
     int H, fin, F, D, NS;       // NS: 32-column sub-tiles per node-GEMM workgroup tile
     bool fused;                 // bf16x3: one k_node launch per node update instead of k_gemm x3 + k_agg
+    bool x6;                    // bf16x6: the edge kernels contract on six bf16 MFMAs per product (H >= 128; below that
+                                // the mode runs the exact-fp32 kernels), everything else is the fp32 path
     long long n_weights;
     bool weights_set;
     float* dw;                  // packed weights
@@ -172,7 +174,7 @@ extern "C" int hd_create(const hd_config* cfg, int device, hd_handle** out) {
     const int F = cfg->in_node_nf - (cfg->condition_time ? 1 : 0);
     if (F < 1) return fail(HD_E_INVALID, "hd_create: in_node_nf must leave at least one feature column");
     if (cfg->context_node_nf < 0) return fail(HD_E_INVALID, "hd_create: context_node_nf < 0");
-    if (cfg->precision != 0 && cfg->precision != 1) return fail(HD_E_INVALID, "hd_create: precision must be 0 (fp32) or 1 (bf16x3)");
+    if (cfg->precision < 0 || cfg->precision > 2) return fail(HD_E_INVALID, "hd_create: precision must be 0 (fp32), 1 (bf16x3) or 2 (bf16x6)");
     if (!(cfg->normalization_factor != 0.0f)) return fail(HD_E_INVALID, "hd_create: normalization_factor == 0");
     if (hd_device_count() <= device || device < 0)
         return fail(HD_E_HIP, "hd_create: no such HIP device (is a GPU visible?)");
@@ -186,6 +188,7 @@ extern "C" int hd_create(const hd_config* cfg, int device, hd_handle** out) {
     h->D = 3 + F;
     h->NS = (H == 32) ? 1 : 2;
     h->fused = cfg->precision == 1;
+    h->x6 = cfg->precision == 2 && cfg->hidden_nf >= 128;
     h->n_weights = weight_count(*cfg);
     h->weights_set = false;
     h->dw = nullptr;
@@ -313,6 +316,25 @@ static void pack_node_b(std::vector<float>& dstf, size_t off, int K, int Nc, Fn 
                 }
 }
 
+// bf16x6 edge kernel: per 16-wide K chunk [head|middle|tail][H/32 ct][64 lanes][8], k = 16c + 8*(lane>>5) + i
+// (1.5x the bytes of the fp32 image: three bf16 pieces per weight).
+static void pack_edge_w2_x6(std::vector<float>& dstf, size_t off, int H, const float* W2) {
+    uint16_t* dst = reinterpret_cast<uint16_t*>(dstf.data() + off);
+    const int NCT = H / 32;
+    for (int c = 0; c < H / 16; ++c)
+        for (int ct = 0; ct < NCT; ++ct)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int i = 0; i < 8; ++i) {
+                    const float v = W2[(size_t)(32 * ct + (lane & 31)) * H + 16 * c + 8 * (lane >> 5) + i];
+                    const uint16_t hi = bf16_rne(v);
+                    const float r = v - bf16_to_f32(hi);
+                    const uint16_t mi = bf16_rne(r);
+                    const uint16_t lo = bf16_rne(r - bf16_to_f32(mi));
+                    const size_t base = (size_t)c * 3 * NCT * 512 + (size_t)ct * 512 + (size_t)lane * 8 + i;
+                    dst[base] = hi; dst[base + (size_t)NCT * 512] = mi; dst[base + (size_t)2 * NCT * 512] = lo;
+                }
+}
+
 // edge kernel: per K chunk [hi|lo][2 k-steps][H/32 ct][64 lanes][8], k = 32c + 16*(lane>>5) + 8s + i.
 static void pack_edge_w2_bf(std::vector<float>& dstf, size_t off, int H, const float* W2) {
     uint16_t* dst = reinterpret_cast<uint16_t*>(dstf.data() + off);
@@ -348,7 +370,8 @@ extern "C" int hd_set_weights(hd_handle* h, const float* blob, long long n, int 
     const hd_config& c = h->cfg;
     const int H = h->H, fin = h->fin, WN = h->NS;
     const int L = c.n_layers, S = c.inv_sublayers;
-    const bool bf = c.precision != 0;
+    const bool bf = c.precision == 1;
+    const size_t w2_floats = h->x6 ? (size_t)H * H * 3 / 2 : (size_t)H * H;
     // layout of the packed buffer
     size_t off = 0;
     auto take = [&](size_t cnt) { size_t o = off; off += (cnt + 3) & ~size_t(3); return o; };
@@ -359,12 +382,12 @@ extern "C" int hd_set_weights(hd_handle* h, const float* blob, long long n, int 
         for (int j = 0; j < S; ++j) {
             LayerW& w = h->gcl[(size_t)i * S + j];
             w.ab_img = take((size_t)H * 2 * H); w.ab_bias = take(2 * H); w.wrd = take(2 * H);
-            w.w2_img = take((size_t)H * H); w.b2 = take(H); w.wa = take(H);
+            w.w2_img = take(w2_floats); w.b2 = take(H); w.wa = take(H);
             w.w3_img = take((size_t)2 * H * H); w.b3 = take(H); w.w4_img = take((size_t)H * H); w.b4 = take(H);
         }
         LayerW& w = h->coord[i];
         w.ab_img = take((size_t)H * 2 * H); w.ab_bias = take(2 * H); w.wrd = take(2 * H);
-        w.w2_img = take((size_t)H * H); w.b2 = take(H); w.wa = take(H);
+        w.w2_img = take(w2_floats); w.b2 = take(H); w.wa = take(H);
         w.w3_img = w.b3 = w.w4_img = w.b4 = 0;
     }
     std::vector<float> pk(off, 0.0f);
@@ -414,6 +437,7 @@ extern "C" int hd_set_weights(hd_handle* h, const float* blob, long long n, int 
             auto w3 = [&](int col, int k) { const float v = W3[(size_t)col * 2 * H + k]; return k >= H ? sc_inv(v) : v; };
             auto w4 = [&](int col, int k) { return W4[(size_t)col * H + k]; };
             if (bf) pack_edge_w2_bf(pk, w.w2_img, H, W2);
+            else if (h->x6) pack_edge_w2_x6(pk, w.w2_img, H, W2);
             else pack_edge_w2(pk, w.w2_img, H, W2);
             if (h->fused) {
                 pack_node_b(pk, w.w3_img, 2 * H, H, w3);
@@ -439,6 +463,7 @@ extern "C" int hd_set_weights(hd_handle* h, const float* blob, long long n, int 
         const float* w7 = next(H);
         pack_first(w, W5, b5);
         if (bf) pack_edge_w2_bf(pk, w.w2_img, H, W6);
+        else if (h->x6) pack_edge_w2_x6(pk, w.w2_img, H, W6);
         else pack_edge_w2(pk, w.w2_img, H, W6);
         for (int k = 0; k < H; ++k) { pk[w.b2 + k] = sc(b6[k]); pk[w.wa + k] = sc_inv(w7[k]); }
         w.ba = 0.0f;
@@ -793,7 +818,9 @@ static void node_update(hd_handle* h, bool upd, int nab, const NodeArgs& a, hipS
 }
 
 template <int H>
-static int edge_lds_bytes() { return (2 * 32 * H + 2 * H + 4 * 136) * 4; }   // dynamic part (w_r/w_d/b2/wa are static)
+static int edge_lds_bytes(bool x6 = false) {       // dynamic part: W2 double buffer + wave scratch (w_r/w_d/b2/wa are static)
+    return (2 * (x6 ? 24 : 32) * H + 2 * H + 4 * 136) * 4;
+}
 
 #ifdef HD_DEBUG_KERNELS
 // Measurement build only (python -m hierdiff_amd.build --debug-kernels): HD_ABLATE=<bits> selects an ablated
@@ -853,7 +880,15 @@ static int launch_edge_h(hd_handle* h, bool coord, const EdgeArgs& a, hipStream_
         if (h->ablate && !coord && (prec == 1 ? launch_edge_ablated<1>(h, a, s) : launch_edge_ablated<0>(h, a, s))) return HD_OK;
     }
 #endif
-    if (prec == 0) {
+    if constexpr (H >= 128) {
+        if (h->x6) {
+            const int lds6 = edge_lds_bytes<H>(true);
+            if (coord) hipLaunchKernelGGL((k_edge<H, true, 2>), grid, block, lds6, s, a);
+            else hipLaunchKernelGGL((k_edge<H, false, 2>), grid, block, lds6, s, a);
+            return HD_OK;
+        }
+    }
+    if (prec != 1) {
         if (coord) hipLaunchKernelGGL((k_edge<H, true, 0>), grid, block, lds, s, a);
         else hipLaunchKernelGGL((k_edge<H, false, 0>), grid, block, lds, s, a);
     } else {
@@ -872,6 +907,10 @@ static int prepare_edge_h() {
     HIP_TRY(hipFuncSetAttribute((const void*)k_edge<H, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIP_TRY(hipFuncSetAttribute((const void*)k_edge<H, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIP_TRY(hipFuncSetAttribute((const void*)k_edge<H, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    if constexpr (H >= 128) {
+        HIP_TRY(hipFuncSetAttribute((const void*)k_edge<H, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, edge_lds_bytes<H>(true)));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_edge<H, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, edge_lds_bytes<H>(true)));
+    }
     return HD_OK;
 }
 

@@ -43,6 +43,12 @@ struct EdgeArgs {
 // head and a bf16 tail (a = ah + al, |a - ah - al| <= 2^-18 |a|) and the product is formed as
 // ah*bh + al*bh + ah*bl with fp32 accumulation on v_mfma_f32_32x32x16_bf16: 3 matrix instructions at
 // 16x the fp32 rate, per-product error ~1e-5 (the dropped al*bl term), i.e. ~1e-6 on a 256-term dot.
+// PREC 2: "bf16x6" - three-way split a = ah + am + al (24 significant bits), product = ah*bh + ah*bm + am*bh + am*bm +
+// ah*bl + al*bh: six bf16 MFMAs, the dropped terms are <= 2^-26 of the product, i.e. below the rounding of the fp32
+// accumulation that every mode shares (scratch/split_numerics.py: 5e-9 rel-L2 against 2.9e-7 for an fp32 GEMM).  The
+// matrix cores proper only take 16-bit inputs - the fp32 MFMA runs on the SIMD's packed-fp32 datapath and nothing
+// overlaps with it - so this is the fp32-accurate form that leaves the VALU free for the SiLUs.
+// Everything else of the mode is the fp32 one (unscaled domain, compensated SiLU, fp32 node GEMMs); H >= 128.
 
 // Four LDS fragment reads / a counted wait that releases them (see k_edge).  The reads are inline asm so
 // they stay where they are written (hipcc otherwise sinks every LDS read next to its MFMA to save registers,
@@ -61,6 +67,13 @@ template <int N, typename V>
 HD_DEVINL void lds_wait4(V (&f)[4]) {
     asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]) : "i"(N));
 }
+
+template <typename V, unsigned O0, unsigned O1>
+HD_DEVINL void lds_read2f(V (&f)[2], unsigned addr) {
+    asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4" : "=&v"(f[0]), "=&v"(f[1]) : "v"(addr), "i"(O0), "i"(O1));
+}
+template <int N, typename V>
+HD_DEVINL void lds_wait2f(V (&f)[2]) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f[0]), "+v"(f[1]) : "i"(N)); }
 
 // x[lane] + x[lane ^ 32] in every lane, on the VALU (gfx950 v_permlane32_swap: upper half of the first operand
 // <-> lower half of the second) instead of a ds_bpermute round trip.  The s_nops cover the VALU-write ->
@@ -135,6 +148,9 @@ HD_DEVINL void vm_wait2(f32x4& va, f32x4& vb) {
 template <int NCT>
 constexpr unsigned frag_off_bf(int u, int hl) { return (unsigned)((((hl * 2 + u / NCT) * NCT + u % NCT) * 64) * 16); }
 constexpr unsigned frag_off_f32(int u) { return (unsigned)(u * 64 * 16); }
+//   bf16x6: one k-step per chunk, part p = head / middle / tail, column tile ct
+template <int NCT>
+constexpr unsigned frag_off_x6(int p, int ct) { return (unsigned)((p * NCT + ct) * 64 * 16); }
 
 // ABL: ablation switches for bottleneck hunting (never set in production launches; env HD_ABLATE, H=256 bf16x3 GCL):
 //   1 = skip the epilogue, 2 = skip operand generation (SiLU etc.), 4 = no per-chunk barrier / W2 streaming,
@@ -146,8 +162,10 @@ constexpr unsigned frag_off_f32(int u) { return (unsigned)(u * 64 * 16); }
 template <int H, bool COORD, int PREC, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
     constexpr int NCT = H / 32;          // 32-column tiles
-    constexpr int NCH = H / 32;          // 32-wide K chunks
-    constexpr int CHF = 32 * H;          // floats per W2 chunk image
+    constexpr int KC = PREC == 2 ? 16 : 32;          // K chunk width (bf16x6: one MFMA k-step, its image is 1.5x as dense)
+    constexpr int NCH = H / KC;          // K chunks
+    constexpr int CHF = PREC == 2 ? 24 * H : 32 * H;   // floats per W2 chunk image
+    static_assert(CHF % 1024 == 0, "a chunk image is streamed in 1 KiB pieces, four waves");
     constexpr int GL_PER_WAVE = CHF / (4 * 256);   // 1 KiB pieces per wave per chunk
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* wbuf = smem;                   // [2][CHF]
@@ -225,12 +243,12 @@ __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
     const int nseg = tile_ok ? a.tile_nseg[tile] : 0;
     if (hh == 0) reinterpret_cast<uint8_t*>(seg_s)[n] = (uint8_t)segb_t;
 
-    const float* Arow = a.AB + (size_t)ni * (2 * H) + 16 * hh;
-    const float* Brow = a.AB + (size_t)nj * (2 * H) + H + 16 * hh;
+    const float* Arow = a.AB + (size_t)ni * (2 * H) + (KC / 2) * hh;
+    const float* Brow = a.AB + (size_t)nj * (2 * H) + H + (KC / 2) * hh;
     f32x4 pa[4], pb[4];
     auto rows_issue = [&](int u, int c) {                  // quad u of chunk c (see vm_load2)
         if constexpr (ABL & 8) { pa[u] = f32x4{radial, d0, radial, d0}; pb[u] = pa[u]; }
-        else vm_load2(pa[u], pb[u], Arow + 32 * c + 4 * u, Brow + 32 * c + 4 * u);
+        else vm_load2(pa[u], pb[u], Arow + KC * c + 4 * u, Brow + KC * c + 4 * u);
     };
     // first-layer activations of this lane's edge row for K chunk c (k = 32c + 16*hh + 0..15)
     auto make_P = [&](int c, float (&P)[16]) {             // fp32 mode
@@ -286,21 +304,47 @@ __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
         }
     };
 
+    // bf16x6: four first-layer activations (unscaled domain, compensated SiLU as in fp32 mode) -> head / middle / tail dwords
+    auto make_quad_x6 = [&](f32x4 av, f32x4 bv, f32x4 wr4, f32x4 wd4, uint32_t (&hi)[2], uint32_t (&mi)[2], uint32_t (&lo)[2]) {
+        float y[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float pre = av[j] + bv[j];
+            pre = __builtin_fmaf(radial, wr4[j], pre);
+            pre = __builtin_fmaf(d0, wd4[j], pre);
+            y[j] = silu_f(pre);
+        }
+        bf16_split3(y[0], y[1], hi[0], mi[0], lo[0]);
+        bf16_split3(y[2], y[3], hi[1], mi[1], lo[1]);
+    };
     // Software pipeline: the operands of chunk c+1 are produced (VALU) while the matrix pipe works on
     // chunk c; the AB rows are fetched two chunks ahead.
     float Pc[16];
     u32x4 phc[2], plc[2];                  // bf16x3: head / tail of the 16 operand values, 8 bf16 per k-step
     // Both precision modes fetch the AB rows with the hand-counted inline-asm loads (see vm_load2): a compiler-visible
     // load next to the W2 stream makes hipcc wait vmcnt(0) - i.e. for the stream it has just started - every chunk.
+    constexpr int NQ = KC / 8;             // row quads per lane per chunk
+    u32x4 xh, xm, xl;                      // bf16x6: head / middle / tail of the 8 operand values of the chunk
 #pragma unroll
-    for (int u = 0; u < 4; ++u) rows_issue(u, 0);
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(pa[0]), "+v"(pa[1]), "+v"(pa[2]), "+v"(pa[3]),
-                                        "+v"(pb[0]), "+v"(pb[1]), "+v"(pb[2]), "+v"(pb[3]));
+    for (int u = 0; u < NQ; ++u) rows_issue(u, 0);
+    if constexpr (NQ == 4) asm volatile("s_waitcnt vmcnt(0)" : "+v"(pa[0]), "+v"(pa[1]), "+v"(pa[2]), "+v"(pa[3]),
+                                                              "+v"(pb[0]), "+v"(pb[1]), "+v"(pb[2]), "+v"(pb[3]));
+    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(pa[0]), "+v"(pa[1]), "+v"(pb[0]), "+v"(pb[1]));
     __syncthreads();               // chunk 0 landed in every wave's share (w_r / w_d staged on the first pass)
     if constexpr (PREC == 0) make_P(0, Pc);
-    else make_P_bf(0, phc, plc);
+    else if constexpr (PREC == 1) make_P_bf(0, phc, plc);
+    else {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) rows_issue(u, NCH > 1 ? 1 : 0);
+        for (int u = 0; u < 2; ++u) {
+            const f32x4 wr4 = *reinterpret_cast<const f32x4*>(wrd_s + 8 * hh + 4 * u);
+            const f32x4 wd4 = *reinterpret_cast<const f32x4*>(wrd_s + H + 8 * hh + 4 * u);
+            uint32_t hi[2], mi[2], lo[2];
+            make_quad_x6(pa[u], pb[u], wr4, wd4, hi, mi, lo);
+            xh[2 * u] = hi[0]; xh[2 * u + 1] = hi[1]; xm[2 * u] = mi[0]; xm[2 * u + 1] = mi[1]; xl[2 * u] = lo[0]; xl[2 * u + 1] = lo[1];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) rows_issue(u, NCH > 1 ? 1 : 0);
 
     // accumulators start at the second layer's bias (saves the H/32 * 16 bias adds of the epilogue)
     f32x16 acc[NCT];
@@ -319,7 +363,8 @@ __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
         if constexpr (!(ABL & 4)) {
             // chunk c landed in LDS and every wave is done with the other buffer.  The only VMEM operations younger
             // than chunk c's stream are the 8 row gathers of the previous iteration.
-            if (c > 0) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+            if constexpr (PREC == 2) { if (c > 0) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory"); }
+            else if (c > 0) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
             // The stream of the next chunk is issued unconditionally further down (the last chunk re-requests chunk 0,
             // unused unless a further tile follows): with the stream inside a branch hipcc has to assume "no stream in
             // flight" at the join and waits vmcnt(0) - i.e. for the stream itself - before the first use of the
@@ -329,8 +374,8 @@ __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
         // recomputes the final chunk's operands and refetches its rows, results unused.
         u32x4 phn[2], pln[2];
         const int cn1 = c + 1 < NCH ? c + 1 : NCH - 1, cn2 = c + 2 < NCH ? c + 2 : NCH - 1;
-        const float* Arow_n2 = Arow + 32 * cn2;        // rows of chunk c+2: one address pair per chunk,
-        const float* Brow_n2 = Brow + 32 * cn2;        // the quad offset rides in the load's immediate
+        const float* Arow_n2 = Arow + KC * cn2;        // rows of chunk c+2: one address pair per chunk,
+        const float* Brow_n2 = Brow + KC * cn2;        // the quad offset rides in the load's immediate
         const float* wb = wbuf + buf * CHF;
         const unsigned wb_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)wb + lane * 16;
         if constexpr (PREC == 0) {
@@ -379,7 +424,7 @@ __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
                     else vm_load2o<16 * q>(pa[q], pb[q], Arow_n2, Brow_n2);
                 }
             });
-        } else {
+        } else if constexpr (PREC == 1) {
             // chunk image: [hi|lo][2 k-steps][NCT][64 lanes][8 bf16]; lane (h, n), element i of step s is
             // W2[32ct + n][32c + 16h + 8s + i] - the same k order as P[8s + i].  Units u = (k-step, ct) of
             // three MFMAs (head*head, tail*head, head*tail) on one accumulator, two units per group.
@@ -451,12 +496,68 @@ __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
             });
 #pragma unroll
             for (int st = 0; st < 2; ++st) { phc[st] = phn[st]; plc[st] = pln[st]; }
+        } else {
+            // bf16x6.  Chunk image: [head|middle|tail][NCT][64 lanes][8 bf16]; lane (h, n), element i is W2[32ct + n][16c + 8h + i],
+            // the k order of the operand dwords.  Per pair of column tiles two stages of six MFMAs, the two accumulators
+            // alternating: stage A on the tail and middle fragments (h*L, h*M, m*M - the small terms first), stage B on the
+            // head fragments (h*H, m*H, l*H).  A stage's fragments are requested while the previous stage's MFMAs run.
+            const float* wr_n = wrd_s + 16 * cn1 + 8 * hh;
+            const float* wd_n = wrd_s + H + 16 * cn1 + 8 * hh;
+            u32x4 nh, nm, nl;
+            bf16x8 fA[4], fB[2];
+            lds_read4<bf16x8, frag_off_x6<NCT>(2, 0), frag_off_x6<NCT>(2, 1), frag_off_x6<NCT>(1, 0), frag_off_x6<NCT>(1, 1)>(fA, wb_lds);
+            issue_chunk(c + 1 < NCH ? c + 1 : 0, buf ^ 1);
+            const bf16x8 A_h = __builtin_bit_cast(bf16x8, xh), A_m = __builtin_bit_cast(bf16x8, xm), A_l = __builtin_bit_cast(bf16x8, xl);
+            static_for<0, NCT / 2>([&](auto Gc) {
+                constexpr int g = decltype(Gc)::value, c0 = 2 * g, c1 = 2 * g + 1;
+                lds_wait4<0>(fA);
+                lds_read2f<bf16x8, frag_off_x6<NCT>(0, c0), frag_off_x6<NCT>(0, c1)>(fB, wb_lds);
+                // operands of the next chunk: quad g in the first two pairs, then its registers take the rows of chunk c+2
+                // (outstanding, oldest first: quads g..1 of chunk c+1, the stream pieces, quads 0..g-1 of chunk c+2)
+                if constexpr (g < 2) {
+                    vm_wait2<2 + GL_PER_WAVE>(pa[g], pb[g]);
+                    const f32x4 wr4 = *reinterpret_cast<const f32x4*>(wr_n + 4 * g);
+                    const f32x4 wd4 = *reinterpret_cast<const f32x4*>(wd_n + 4 * g);
+                    uint32_t hi[2], mi[2], lo[2];
+                    make_quad_x6(pa[g], pb[g], wr4, wd4, hi, mi, lo);
+                    nh[2 * g] = hi[0]; nh[2 * g + 1] = hi[1]; nm[2 * g] = mi[0]; nm[2 * g + 1] = mi[1]; nl[2 * g] = lo[0]; nl[2 * g + 1] = lo[1];
+                    vm_load2o<16 * g>(pa[g], pb[g], Arow_n2, Brow_n2);
+                }
+                acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_h, fA[0], acc[c0], 0, 0, 0);
+                acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_h, fA[1], acc[c1], 0, 0, 0);
+                acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_h, fA[2], acc[c0], 0, 0, 0);
+                acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_h, fA[3], acc[c1], 0, 0, 0);
+                acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_m, fA[2], acc[c0], 0, 0, 0);
+                acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_m, fA[3], acc[c1], 0, 0, 0);
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                }
+                lds_wait2f<0>(fB);
+                if constexpr (g + 1 < NCT / 2)
+                    lds_read4<bf16x8, frag_off_x6<NCT>(2, c0 + 2), frag_off_x6<NCT>(2, c1 + 2), frag_off_x6<NCT>(1, c0 + 2),
+                              frag_off_x6<NCT>(1, c1 + 2)>(fA, wb_lds);
+                acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_h, fB[0], acc[c0], 0, 0, 0);
+                acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_h, fB[1], acc[c1], 0, 0, 0);
+                acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_m, fB[0], acc[c0], 0, 0, 0);
+                acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_m, fB[1], acc[c1], 0, 0, 0);
+                acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_l, fB[0], acc[c0], 0, 0, 0);
+                acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_l, fB[1], acc[c1], 0, 0, 0);
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                }
+            });
+            xh = nh; xm = nm; xl = nl;
         }
     }
 
     {                                      // drain the (unused) last gathers before their registers are reused
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(pa[0]), "+v"(pa[1]), "+v"(pa[2]), "+v"(pa[3]),
-                                            "+v"(pb[0]), "+v"(pb[1]), "+v"(pb[2]), "+v"(pb[3]));
+        if constexpr (NQ == 4) asm volatile("s_waitcnt vmcnt(0)" : "+v"(pa[0]), "+v"(pa[1]), "+v"(pa[2]), "+v"(pa[3]),
+                                                                  "+v"(pb[0]), "+v"(pb[1]), "+v"(pb[2]), "+v"(pb[3]));
+        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(pa[0]), "+v"(pa[1]), "+v"(pb[0]), "+v"(pb[1]));
     }
     if constexpr (ABL & 16) ts2 = __builtin_readcyclecounter();
     if (!tile_ok) return;                  // padding tile of the last workgroup: nothing to store
@@ -479,7 +580,7 @@ __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {
         const float wav = wrd_s[3 * H + 32 * ct + n];
-        if constexpr (PREC == 0) {
+        if constexpr (PREC != 1) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float mv = silu_f(acc[ct][r]);
@@ -553,7 +654,7 @@ __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
         float att_mine = 1.0f;
         if (a.attention) {
             const float ba = a.ba_ptr ? *a.ba_ptr : a.ba;
-            if constexpr (PREC == 0) att_mine = sigmoid_f(rowdot + ba);
+            if constexpr (PREC != 1) att_mine = sigmoid_f(rowdot + ba);
             else att_mine = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(rowdot + ba));   // scaled domain
         }
         float w[16];

@@ -22,7 +22,7 @@ from . import _lib
 from ._lib import HdConfig, HierDiffHipError
 
 
-PRECISIONS = {"fp32": 0, "bf16x3": 1}
+PRECISIONS = {"fp32": 0, "bf16x3": 1, "bf16x6": 2}
 # Arithmetic of the H x H contractions.  The drop-in default is "fp32": exact fp32 matrix instructions
 # (v_mfma_f32_32x32x2_f32), the arithmetic the reference computes in (en_dynamics.py has no notion of reduced
 # precision; per-forward error vs the reference ~5e-7 rel-L2).  "bf16x3" is opt-in (`model.precision = "bf16x3"`
@@ -169,7 +169,9 @@ class EGNN_dynamics_QM9(nn.Module):
     @precision.setter
     def precision(self, name: str) -> None:
         """"fp32": exact fp32 matrix instructions.  "bf16x3": fp32 operands split into bf16 head+tail, three
-        bf16 matrix instructions with fp32 accumulation (error ~1e-6 per contraction, ~5x the throughput)."""
+        bf16 matrix instructions with fp32 accumulation (error ~1e-6 per contraction, ~5x the throughput).  "bf16x6": the
+        per-edge contraction on a three-way bf16 split, six bf16 matrix instructions per product - truncation below the
+        rounding of the fp32 accumulation, everything else as in "fp32"."""
         if name not in PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(PRECISIONS)}")
         if PRECISIONS[name] != self._cfg.precision:

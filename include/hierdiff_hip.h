@@ -71,7 +71,11 @@ typedef struct hd_config {
                                     0 = exact fp32 (v_mfma_f32_32x32x2_f32) - what the reference computes in,
                                         and the default of the Python mirror,
                                     1 = "bf16x3" (opt-in): fp32 operands split into bf16 head + tail, 3 bf16 MFMAs
-                                        with fp32 accumulation (~1e-6 relative on a 256-term dot product) */
+                                        with fp32 accumulation (~1e-6 relative on a 256-term dot product),
+                                    2 = "bf16x6" (opt-in): the per-edge H x H contraction on a three-way bf16 split,
+                                        6 bf16 MFMAs per product, fp32 accumulation - truncation <= 2^-26 per product,
+                                        below the rounding of the fp32 accumulation itself; everything else as in
+                                        mode 0 (hidden_nf < 128 runs mode 0's kernels) */
 } hd_config;
 
 int hd_version(void);
