@@ -836,7 +836,7 @@ extern "C" int hd_debug_edge_trace(hd_handle* h, long long* out, int max_wg) {
 
 template <int PREC>
 static bool launch_edge_ablated(hd_handle* h, const EdgeArgs& a, hipStream_t s) {
-    const int lds = edge_lds_bytes<256>();
+    const int lds = edge_lds_bytes<256>(PREC == 2);
     const dim3 grid(a.n_wg), block(256);
     auto run = [&](auto Abl) {
         constexpr int ABL = decltype(Abl)::value;
@@ -877,7 +877,7 @@ static int launch_edge_h(hd_handle* h, bool coord, const EdgeArgs& a, hipStream_
     const dim3 grid(a.n_wg), block(256);
 #ifdef HD_DEBUG_KERNELS
     if constexpr (H == 256) {
-        if (h->ablate && !coord && (prec == 1 ? launch_edge_ablated<1>(h, a, s) : launch_edge_ablated<0>(h, a, s))) return HD_OK;
+        if (h->ablate && !coord && (h->x6 ? launch_edge_ablated<2>(h, a, s) : prec == 1 ? launch_edge_ablated<1>(h, a, s) : launch_edge_ablated<0>(h, a, s))) return HD_OK;
     }
 #endif
     if constexpr (H >= 128) {

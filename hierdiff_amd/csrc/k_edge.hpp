@@ -15,6 +15,10 @@
 // sums below are invariant under 4-row shifts of a piece inside a tile, so a sample's bits do not depend on its
 // batch neighbours (hd_topology_create).
 
+#ifndef HD_X6_SILU
+#define HD_X6_SILU silu_f
+#endif
+
 struct EdgeArgs {
     const float* AB;        // [M_pad][2H]: cols <H: W1a.h+b1 ; cols >=H: W1b.h
     const float* wrd;       // [2][H]: w_r (current radial column), w_d (initial distance column)
@@ -312,7 +316,11 @@ __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
             float pre = av[j] + bv[j];
             pre = __builtin_fmaf(radial, wr4[j], pre);
             pre = __builtin_fmaf(d0, wd4[j], pre);
-            y[j] = silu_f(pre);
+            y[j] = (ABL & 2) ? pre : HD_X6_SILU(pre);
+        }
+        if constexpr (ABL & 2) {
+            hi[0] = mi[0] = lo[0] = __builtin_bit_cast(uint32_t, y[0] + y[1]); hi[1] = mi[1] = lo[1] = __builtin_bit_cast(uint32_t, y[2] + y[3]);
+            return;
         }
         bf16_split3(y[0], y[1], hi[0], mi[0], lo[0]);
         bf16_split3(y[2], y[3], hi[1], mi[1], lo[1]);
@@ -506,7 +514,7 @@ __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
             u32x4 nh, nm, nl;
             bf16x8 fA[4], fB[2];
             lds_read4<bf16x8, frag_off_x6<NCT>(2, 0), frag_off_x6<NCT>(2, 1), frag_off_x6<NCT>(1, 0), frag_off_x6<NCT>(1, 1)>(fA, wb_lds);
-            issue_chunk(c + 1 < NCH ? c + 1 : 0, buf ^ 1);
+            if constexpr (!(ABL & 4)) issue_chunk(c + 1 < NCH ? c + 1 : 0, buf ^ 1);
             const bf16x8 A_h = __builtin_bit_cast(bf16x8, xh), A_m = __builtin_bit_cast(bf16x8, xm), A_l = __builtin_bit_cast(bf16x8, xl);
             static_for<0, NCT / 2>([&](auto Gc) {
                 constexpr int g = decltype(Gc)::value, c0 = 2 * g, c1 = 2 * g + 1;
@@ -521,7 +529,8 @@ __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
                     uint32_t hi[2], mi[2], lo[2];
                     make_quad_x6(pa[g], pb[g], wr4, wd4, hi, mi, lo);
                     nh[2 * g] = hi[0]; nh[2 * g + 1] = hi[1]; nm[2 * g] = mi[0]; nm[2 * g + 1] = mi[1]; nl[2 * g] = lo[0]; nl[2 * g + 1] = lo[1];
-                    vm_load2o<16 * g>(pa[g], pb[g], Arow_n2, Brow_n2);
+                    if constexpr (ABL & 8) { pa[g] = f32x4{radial, d0, radial, d0}; pb[g] = pa[g]; }
+                    else vm_load2o<16 * g>(pa[g], pb[g], Arow_n2, Brow_n2);
                 }
                 acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_h, fA[0], acc[c0], 0, 0, 0);
                 acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_h, fA[1], acc[c1], 0, 0, 0);
@@ -583,7 +592,7 @@ __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
         if constexpr (PREC != 1) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float mv = silu_f(acc[ct][r]);
+                const float mv = PREC == 2 ? HD_X6_SILU(acc[ct][r]) : silu_f(acc[ct][r]);
                 acc[ct][r] = mv;
                 dot[r] = __builtin_fmaf(mv, wav, dot[r]);
             }

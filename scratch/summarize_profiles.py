@@ -6,6 +6,7 @@ Per precision and per edge-kernel variant (GCL / coordinate): launches, average 
 bytes per launch from the FETCH_SIZE / WRITE_SIZE passes with the gfx950 correction of
 /opt/skills/guides/MI355X_MICROARCH.md (FETCH_SIZE counts 64 B per 128-B request on wide coalesced reads: doubled;
 both are in KiB), and the SQ activity fractions:
+    (bf16x6: six bf16 MFMAs per product, precision number 2 in the kernel names)
     mfma_busy       = SQ_VALU_MFMA_BUSY_CYCLES / (32 * SQ_BUSY_CYCLES)     matrix-pipe busy cycles per SIMD-cycle of the
                       kernel: the numerator is summed over the chip's 1024 SIMDs (it equals 64 x #MFMA for
                       v_mfma_f32_32x32x2_f32 and 32 x #MFMA for v_mfma_f32_32x32x16_bf16 - checked against the launch
@@ -49,7 +50,7 @@ def main():
            "correction": "hbm bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE counts 64 B per 128-B request); "
                          "counters include Infinity-Cache hits",
            "edge_kernel": {}, "kernels": {}}
-    for prec, pnum in (("fp32", 0), ("bf16x3", 1)):
+    for prec, pnum in (("fp32", 0), ("bf16x3", 1), ("bf16x6", 2)):
         stats = {}
         sp = os.path.join(d, f"{tag}_{prec}_T50_kernel_stats.csv")
         if os.path.exists(sp):
