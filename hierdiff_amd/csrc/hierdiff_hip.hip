@@ -316,6 +316,29 @@ static void pack_node_b(std::vector<float>& dstf, size_t off, int K, int Nc, Fn 
                 }
 }
 
+// bf16x6 node GEMM (k_gemm6): per (column tile, 32-wide K chunk) [head|middle|tail][NS sub-tiles][2 k-steps][64 lanes][8 bf16],
+// k = 32c + 16s + 8*(lane>>5) + i, col = ct*32*NS + 32*sub + (lane&31); 1.5x the bytes of the fp32 image.
+template <typename Fn>
+static void pack_gemm_b6(std::vector<float>& dstf, size_t off, int K, int Nc, int NS, Fn W) {
+    uint16_t* dst = reinterpret_cast<uint16_t*>(dstf.data() + off);
+    const int BN = 32 * NS, ntile = Nc / BN, nchunk = K / 32;
+    const size_t part = (size_t)NS * 2 * 512;                 // bf16 elements per piece of one chunk
+    for (int ct = 0; ct < ntile; ++ct)
+        for (int c = 0; c < nchunk; ++c)
+            for (int sub = 0; sub < NS; ++sub)
+                for (int st = 0; st < 2; ++st)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int i = 0; i < 8; ++i) {
+                            const float v = W(ct * BN + 32 * sub + (lane & 31), 32 * c + 16 * st + 8 * (lane >> 5) + i);
+                            const uint16_t hi = bf16_rne(v);
+                            const float r = v - bf16_to_f32(hi);
+                            const uint16_t mi = bf16_rne(r);
+                            const uint16_t lo = bf16_rne(r - bf16_to_f32(mi));
+                            const size_t base = (size_t)(ct * nchunk + c) * 3 * part + (size_t)(sub * 2 + st) * 512 + (size_t)lane * 8 + i;
+                            dst[base] = hi; dst[base + part] = mi; dst[base + 2 * part] = lo;
+                        }
+}
+
 // bf16x6 edge kernel: per 16-wide K chunk [head|middle|tail][H/32 ct][64 lanes][8], k = 16c + 8*(lane>>5) + i
 // (1.5x the bytes of the fp32 image: three bf16 pieces per weight).
 static void pack_edge_w2_x6(std::vector<float>& dstf, size_t off, int H, const float* W2) {
@@ -372,6 +395,7 @@ extern "C" int hd_set_weights(hd_handle* h, const float* blob, long long n, int 
     const int L = c.n_layers, S = c.inv_sublayers;
     const bool bf = c.precision == 1;
     const size_t w2_floats = h->x6 ? (size_t)H * H * 3 / 2 : (size_t)H * H;
+    const size_t gx = h->x6 ? 3 : 2;                          // node-GEMM images: x gx / 2 (bf16x6: three bf16 pieces per weight)
     // layout of the packed buffer
     size_t off = 0;
     auto take = [&](size_t cnt) { size_t o = off; off += (cnt + 3) & ~size_t(3); return o; };
@@ -381,12 +405,12 @@ extern "C" int hd_set_weights(hd_handle* h, const float* blob, long long n, int 
     for (int i = 0; i < L; ++i) {
         for (int j = 0; j < S; ++j) {
             LayerW& w = h->gcl[(size_t)i * S + j];
-            w.ab_img = take((size_t)H * 2 * H); w.ab_bias = take(2 * H); w.wrd = take(2 * H);
+            w.ab_img = take((size_t)H * 2 * H * gx / 2); w.ab_bias = take(2 * H); w.wrd = take(2 * H);
             w.w2_img = take(w2_floats); w.b2 = take(H); w.wa = take(H);
-            w.w3_img = take((size_t)2 * H * H); w.b3 = take(H); w.w4_img = take((size_t)H * H); w.b4 = take(H);
+            w.w3_img = take((size_t)2 * H * H * gx / 2); w.b3 = take(H); w.w4_img = take((size_t)H * H * gx / 2); w.b4 = take(H);
         }
         LayerW& w = h->coord[i];
-        w.ab_img = take((size_t)H * 2 * H); w.ab_bias = take(2 * H); w.wrd = take(2 * H);
+        w.ab_img = take((size_t)H * 2 * H * gx / 2); w.ab_bias = take(2 * H); w.wrd = take(2 * H);
         w.w2_img = take(w2_floats); w.b2 = take(H); w.wa = take(H);
         w.w3_img = w.b3 = w.w4_img = w.b4 = 0;
     }
@@ -417,6 +441,7 @@ extern "C" int hd_set_weights(hd_handle* h, const float* blob, long long n, int 
             return sc((col < H) ? W1[(size_t)col * ld + k] : W1[(size_t)(col - H) * ld + H + k]);
         };
         if (h->fused) pack_node_b(pk, w.ab_img, H, 2 * H, wab);
+        else if (h->x6) pack_gemm_b6(pk, w.ab_img, H, 2 * H, WN, wab);
         else pack_gemm_b(pk, w.ab_img, H, 2 * H, WN, wab);
         for (int k = 0; k < H; ++k) {
             pk[w.ab_bias + k] = sc(b1[k]);
@@ -442,6 +467,9 @@ extern "C" int hd_set_weights(hd_handle* h, const float* blob, long long n, int 
             if (h->fused) {
                 pack_node_b(pk, w.w3_img, 2 * H, H, w3);
                 pack_node_b(pk, w.w4_img, H, H, w4);
+            } else if (h->x6) {
+                pack_gemm_b6(pk, w.w3_img, 2 * H, H, WN, w3);
+                pack_gemm_b6(pk, w.w4_img, H, H, WN, w4);
             } else {
                 pack_gemm_b(pk, w.w3_img, 2 * H, H, WN, w3);
                 pack_gemm_b(pk, w.w4_img, H, H, WN, w4);
@@ -767,12 +795,24 @@ static void launch_gemm(int epi, bool cat, const GemmArgs& g, hipStream_t s) {
     else hipLaunchKernelGGL((k_gemm<WM, WN, CN, EPI_RESID_MASK, false>), grid, block, 0, s, g);
 }
 
+static void launch_gemm6(int epi, bool cat, const GemmArgs& g, hipStream_t s) {      // bf16x6 mode: 64 x 64 tiles (H >= 128)
+    const int nrt = (g.M + 63) / 64, nct = g.Nc / 64;
+    dim3 grid(8 * ((nrt + 7) / 8) * nct);
+    dim3 block(256);
+    if (cat && epi == EPI_BIAS) hipLaunchKernelGGL((k_gemm6<2, 2, 1, EPI_BIAS, true>), grid, block, 0, s, g);
+    else if (cat) hipLaunchKernelGGL((k_gemm6<2, 2, 1, EPI_BIAS_SILU, true>), grid, block, 0, s, g);
+    else if (epi == EPI_BIAS_SILU) hipLaunchKernelGGL((k_gemm6<2, 2, 1, EPI_BIAS_SILU, false>), grid, block, 0, s, g);
+    else if (epi == EPI_BIAS) hipLaunchKernelGGL((k_gemm6<2, 2, 1, EPI_BIAS, false>), grid, block, 0, s, g);
+    else hipLaunchKernelGGL((k_gemm6<2, 2, 1, EPI_RESID_MASK, false>), grid, block, 0, s, g);
+}
+
 // Node-GEMM tile shape per hidden size: (waves M, waves N, accumulators per wave); the weight images are
 // packed for the matching number of 32-column sub-tiles NS = WN*CN.
 static void gemm(hd_handle* h, int epi, bool cat, const GemmArgs& g, hipStream_t s) {
     ProfScope ps(h, s, 1);
 
-    if (h->NS == 1) launch_gemm<4, 1, 1>(epi, cat, g, s);        // H = 32: 128 x 32 tiles
+    if (h->x6) launch_gemm6(epi, cat, g, s);
+    else if (h->NS == 1) launch_gemm<4, 1, 1>(epi, cat, g, s);   // H = 32: 128 x 32 tiles
     else launch_gemm<2, 2, 1>(epi, cat, g, s);                   // 64 x 64 tiles (fastest measured)
 }
 

@@ -512,14 +512,28 @@ __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
             const float* wr_n = wrd_s + 16 * cn1 + 8 * hh;
             const float* wd_n = wrd_s + H + 16 * cn1 + 8 * hh;
             u32x4 nh, nm, nl;
-            bf16x8 fA[4], fB[2];
-            lds_read4<bf16x8, frag_off_x6<NCT>(2, 0), frag_off_x6<NCT>(2, 1), frag_off_x6<NCT>(1, 0), frag_off_x6<NCT>(1, 1)>(fA, wb_lds);
+            // fragments are requested TWO stages ahead (pair g+1's while pair g runs): with one stage (192 matrix-pipe
+            // cycles) of lead the LDS latency under eight streaming waves per CU was regularly exposed
+            bf16x8 fA[2][4], fB[2][2];
+            auto req_A = [&](auto G, bf16x8 (&f)[4]) {
+                constexpr int g = decltype(G)::value;
+                lds_read4<bf16x8, frag_off_x6<NCT>(2, 2 * g), frag_off_x6<NCT>(2, 2 * g + 1), frag_off_x6<NCT>(1, 2 * g),
+                          frag_off_x6<NCT>(1, 2 * g + 1)>(f, wb_lds);
+            };
+            auto req_B = [&](auto G, bf16x8 (&f)[2]) {
+                constexpr int g = decltype(G)::value;
+                lds_read2f<bf16x8, frag_off_x6<NCT>(0, 2 * g), frag_off_x6<NCT>(0, 2 * g + 1)>(f, wb_lds);
+            };
+            req_A(std::integral_constant<int, 0>{}, fA[0]);
+            req_B(std::integral_constant<int, 0>{}, fB[0]);
             if constexpr (!(ABL & 4)) issue_chunk(c + 1 < NCH ? c + 1 : 0, buf ^ 1);
             const bf16x8 A_h = __builtin_bit_cast(bf16x8, xh), A_m = __builtin_bit_cast(bf16x8, xm), A_l = __builtin_bit_cast(bf16x8, xl);
             static_for<0, NCT / 2>([&](auto Gc) {
-                constexpr int g = decltype(Gc)::value, c0 = 2 * g, c1 = 2 * g + 1;
-                lds_wait4<0>(fA);
-                lds_read2f<bf16x8, frag_off_x6<NCT>(0, c0), frag_off_x6<NCT>(0, c1)>(fB, wb_lds);
+                constexpr int g = decltype(Gc)::value, c0 = 2 * g, c1 = 2 * g + 1, NP = NCT / 2;
+                bf16x8(&a4)[4] = fA[g & 1];
+                bf16x8(&b2f)[2] = fB[g & 1];
+                lds_wait4<2>(a4);                       // outstanding behind this pair's A request: its B request (2 reads)
+                if constexpr (g + 1 < NP) req_A(std::integral_constant<int, g + 1>{}, fA[(g + 1) & 1]);
                 // operands of the next chunk: quad g in the first two pairs, then its registers take the rows of chunk c+2
                 // (outstanding, oldest first: quads g..1 of chunk c+1, the stream pieces, quads 0..g-1 of chunk c+2)
                 if constexpr (g < 2) {
@@ -532,27 +546,26 @@ __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
                     if constexpr (ABL & 8) { pa[g] = f32x4{radial, d0, radial, d0}; pb[g] = pa[g]; }
                     else vm_load2o<16 * g>(pa[g], pb[g], Arow_n2, Brow_n2);
                 }
-                acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_h, fA[0], acc[c0], 0, 0, 0);
-                acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_h, fA[1], acc[c1], 0, 0, 0);
-                acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_h, fA[2], acc[c0], 0, 0, 0);
-                acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_h, fA[3], acc[c1], 0, 0, 0);
-                acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_m, fA[2], acc[c0], 0, 0, 0);
-                acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_m, fA[3], acc[c1], 0, 0, 0);
+                acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_h, a4[0], acc[c0], 0, 0, 0);
+                acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_h, a4[1], acc[c1], 0, 0, 0);
+                acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_h, a4[2], acc[c0], 0, 0, 0);
+                acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_h, a4[3], acc[c1], 0, 0, 0);
+                acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_m, a4[2], acc[c0], 0, 0, 0);
+                acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_m, a4[3], acc[c1], 0, 0, 0);
 #pragma unroll
                 for (int k = 0; k < 6; ++k) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
                 }
-                lds_wait2f<0>(fB);
-                if constexpr (g + 1 < NCT / 2)
-                    lds_read4<bf16x8, frag_off_x6<NCT>(2, c0 + 2), frag_off_x6<NCT>(2, c1 + 2), frag_off_x6<NCT>(1, c0 + 2),
-                              frag_off_x6<NCT>(1, c1 + 2)>(fA, wb_lds);
-                acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_h, fB[0], acc[c0], 0, 0, 0);
-                acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_h, fB[1], acc[c1], 0, 0, 0);
-                acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_m, fB[0], acc[c0], 0, 0, 0);
-                acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_m, fB[1], acc[c1], 0, 0, 0);
-                acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_l, fB[0], acc[c0], 0, 0, 0);
-                acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_l, fB[1], acc[c1], 0, 0, 0);
+                // outstanding behind this pair's B request: the next pair's A request (4 reads), if there is one
+                if constexpr (g + 1 < NP) { lds_wait2f<4>(b2f); req_B(std::integral_constant<int, g + 1>{}, fB[(g + 1) & 1]); }
+                else lds_wait2f<0>(b2f);
+                acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_h, b2f[0], acc[c0], 0, 0, 0);
+                acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_h, b2f[1], acc[c1], 0, 0, 0);
+                acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_m, b2f[0], acc[c0], 0, 0, 0);
+                acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_m, b2f[1], acc[c1], 0, 0, 0);
+                acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_l, b2f[0], acc[c0], 0, 0, 0);
+                acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_l, b2f[1], acc[c1], 0, 0, 0);
 #pragma unroll
                 for (int k = 0; k < 6; ++k) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);

@@ -213,6 +213,154 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm(GemmArgs g) {
     }
 }
 
+// ----------------------------------------------------------------------------- node GEMM (bf16x6)
+// Same contract, tiling and epilogues as k_gemm, with the contraction of the "bf16x6" mode: both operands in three bf16
+// pieces (head / middle / tail, 24 significant bits), six v_mfma_f32_32x32x16_bf16 per product with fp32 accumulation
+// (small terms first) - fp32-accurate (k_edge.hpp) at 6/16 of the fp32 MFMA's matrix time, and on the matrix cores proper.
+// The A tile is split while it is staged into LDS ([piece][row][32 k] bf16, rows padded to 80 B); the weight image is
+// pre-split on the host: per (column tile, 32-wide K chunk) [piece][NS sub-tiles][2 k-steps][64 lanes][8 bf16],
+// k = 32c + 16s + 8*(lane>>5) + i, column = tile*32*NS + 32*sub + (lane&31)  (1.5x the bytes of the fp32 image).
+template <int WM, int WN, int CN, int EPI, bool CAT>
+__global__ __launch_bounds__(WM * WN * 64) void k_gemm6(GemmArgs g) {
+    constexpr int NS = WN * CN;
+    constexpr int BM = 32 * WM, BN = 32 * NS, NT = 64 * WM * WN;
+    constexpr int A_F4 = BM * 8 / NT;                    // float4 of the A tile per thread
+    constexpr int B_BYTES = 3 * BN * 32 * 2;             // weight image of one chunk
+    constexpr int B_U4 = B_BYTES / 16 / NT;
+    constexpr int A_ROW = 80;                            // bytes per A row and piece: 32 bf16 + 16 B pad
+    constexpr int A_PART = BM * A_ROW;
+    constexpr int A_BYTES = 3 * A_PART;
+    static_assert(B_BYTES % (16 * NT) == 0, "weight image must divide evenly over the threads");
+    constexpr int STAGE = A_BYTES + B_BYTES;
+    constexpr int LDC_S = BN + 4;
+    constexpr int SMEM = 2 * STAGE > BM * LDC_S * 4 ? 2 * STAGE : BM * LDC_S * 4;
+    __shared__ __attribute__((aligned(16))) char smem_g[SMEM];
+    auto As = [&](int buf) { return smem_g + buf * STAGE; };
+    auto Bs = [&](int buf) { return smem_g + buf * STAGE + A_BYTES; };
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave / WN, wc = wave % WN;
+    const int hh = lane >> 5, m = lane & 31;
+    int rt, ctile;                                        // XCD-aware tile order, as in k_gemm
+    {
+        const int nrt = (g.M + BM - 1) / BM, nct = g.Nc / BN;
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int q = nrt >> 3, r = nrt & 7;
+        const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        const int len = q + (xcd < r ? 1 : 0);
+        if (idx >= len * nct) return;
+        rt = start + idx / nct;
+        ctile = idx % nct;
+    }
+    const int row0 = rt * BM;
+    const int nchunk = g.K >> 5;
+    const u32x4* Bsrc = reinterpret_cast<const u32x4*>(g.Bimg) + (size_t)ctile * nchunk * (B_BYTES / 16);
+
+    f32x4 ra3[3][A_F4];
+    u32x4 rb3[3][B_U4];
+    auto load_tiles = [&](int c, f32x4 (&ra)[A_F4], u32x4 (&rb)[B_U4]) {
+        const int k0 = c << 5;
+#pragma unroll
+        for (int u = 0; u < A_F4; ++u) {
+            const int idx = tid + u * NT;
+            const int r = idx >> 3, sg = idx & 7;
+            const int row = row0 + r;
+            if (!CAT || k0 < g.K1) ra[u] = *reinterpret_cast<const f32x4*>(g.A + (size_t)row * g.lda + k0 + 4 * sg);
+            else ra[u] = *reinterpret_cast<const f32x4*>(g.A2 + (size_t)row * (g.K - g.K1) + (k0 - g.K1) + 4 * sg);
+        }
+#pragma unroll
+        for (int u = 0; u < B_U4; ++u) rb[u] = Bsrc[(size_t)c * (B_BYTES / 16) + tid + u * NT];
+    };
+    auto store_tiles = [&](int buf, const f32x4 (&ra)[A_F4], const u32x4 (&rb)[B_U4]) {
+#pragma unroll
+        for (int u = 0; u < A_F4; ++u) {
+            const int idx = tid + u * NT;
+            const int r = idx >> 3, sg = idx & 7;
+            uint32_t hi[2], mi[2], lo[2];
+            bf16_split3(ra[u][0], ra[u][1], hi[0], mi[0], lo[0]);
+            bf16_split3(ra[u][2], ra[u][3], hi[1], mi[1], lo[1]);
+            char* dst = As(buf) + r * A_ROW + sg * 8;
+            *reinterpret_cast<uint2*>(dst) = make_uint2(hi[0], hi[1]);
+            *reinterpret_cast<uint2*>(dst + A_PART) = make_uint2(mi[0], mi[1]);
+            *reinterpret_cast<uint2*>(dst + 2 * A_PART) = make_uint2(lo[0], lo[1]);
+        }
+#pragma unroll
+        for (int u = 0; u < B_U4; ++u) reinterpret_cast<u32x4*>(Bs(buf))[tid + u * NT] = rb[u];
+    };
+
+    f32x16 acc[CN];
+#pragma unroll
+    for (int cn = 0; cn < CN; ++cn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[cn][r] = 0.f;
+
+    auto compute = [&](int buf) {
+        const char* Ab = As(buf) + (32 * wr + m) * A_ROW + 16 * hh;
+        const char* Bb = Bs(buf) + lane * 16;
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            bf16x8 a[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) a[p] = *reinterpret_cast<const bf16x8*>(Ab + p * A_PART + 32 * st);
+#pragma unroll
+            for (int cn = 0; cn < CN; ++cn) {
+                bf16x8 b[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) b[p] = *reinterpret_cast<const bf16x8*>(Bb + ((p * NS + wc * CN + cn) * 2 + st) * 1024);
+                acc[cn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc[cn], 0, 0, 0);
+                acc[cn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc[cn], 0, 0, 0);
+                acc[cn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc[cn], 0, 0, 0);
+                acc[cn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc[cn], 0, 0, 0);
+                acc[cn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc[cn], 0, 0, 0);
+                acc[cn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc[cn], 0, 0, 0);
+            }
+        }
+    };
+
+    load_tiles(0, ra3[0], rb3[0]);
+    if (nchunk > 1) load_tiles(1, ra3[1], rb3[1]);
+    if (nchunk > 2) load_tiles(2, ra3[2], rb3[2]);
+    store_tiles(0, ra3[0], rb3[0]);
+    __syncthreads();
+    for (int c0 = 0; c0 < nchunk; c0 += 3) {
+        static_for<0, 3>([&](auto Rc) {
+            constexpr int rslot = decltype(Rc)::value;
+            const int c = c0 + rslot;
+            if (c < nchunk) {
+                compute(c & 1);
+                if (c + 1 < nchunk) store_tiles((c + 1) & 1, ra3[(rslot + 1) % 3], rb3[(rslot + 1) % 3]);
+                if (c + 3 < nchunk) load_tiles(c + 3, ra3[rslot], rb3[rslot]);
+                __syncthreads();
+            }
+        });
+    }
+
+    float* Cs = reinterpret_cast<float*>(smem_g);
+#pragma unroll
+    for (int cn = 0; cn < CN; ++cn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            Cs[(32 * wr + (r & 3) + 8 * (r >> 2) + 4 * hh) * LDC_S + 32 * (wc * CN + cn) + m] = acc[cn][r];
+    __syncthreads();
+    constexpr int C_F4 = BM * BN / 4 / NT;
+#pragma unroll
+    for (int u = 0; u < C_F4; ++u) {
+        const int idx = tid + u * NT;
+        const int r = idx / (BN / 4), c4 = idx % (BN / 4);
+        const int row = row0 + r, col = ctile * BN + 4 * c4;
+        if (row < g.M) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(Cs + r * LDC_S + 4 * c4) + *reinterpret_cast<const f32x4*>(g.bias + col);
+            f32x4* dst = reinterpret_cast<f32x4*>(g.C + (size_t)row * g.ldc + col);
+            if (EPI == EPI_BIAS_SILU) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = silu_f(v[j]);
+            }
+            if (EPI == EPI_RESID_MASK) v = (*dst + v) * g.nmask[row];
+            *dst = v;
+        }
+    }
+}
+
 // ----------------------------------------------------------------------------- fused node update (bf16x3)
 // One workgroup owns 32 node rows and runs the whole row-local chain of a GCL's node model plus the first
 // edge Linear of the layer(s) that follow, so the intermediate activations never leave the CU:
