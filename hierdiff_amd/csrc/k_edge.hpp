@@ -18,6 +18,9 @@
 #ifndef HD_X6_SILU
 #define HD_X6_SILU silu_f
 #endif
+#ifndef HD_F32_SILU
+#define HD_F32_SILU silu_f
+#endif
 
 struct EdgeArgs {
     const float* AB;        // [M_pad][2H]: cols <H: W1a.h+b1 ; cols >=H: W1b.h
@@ -265,7 +268,7 @@ __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
                 float pre = pa[u][j] + pb[u][j];
                 pre = __builtin_fmaf(radial, wr4[j], pre);
                 pre = __builtin_fmaf(d0, wd4[j], pre);
-                P[4 * u + j] = silu_f(pre);
+                P[4 * u + j] = HD_F32_SILU(pre);
             }
         }
     };
@@ -426,7 +429,7 @@ __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
                         float pre = pa[q][j] + pb[q][j];
                         pre = __builtin_fmaf(radial, wr4[j], pre);
                         pre = __builtin_fmaf(d0, wd4[j], pre);
-                        Pc[4 * q + j] = silu_f(pre);
+                        Pc[4 * q + j] = HD_F32_SILU(pre);
                     }
                     if constexpr (ABL & 8) { pa[q] = f32x4{radial, d0, radial, d0}; pb[q] = pa[q]; }
                     else vm_load2o<16 * q>(pa[q], pb[q], Arow_n2, Brow_n2);
@@ -605,7 +608,7 @@ __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
         if constexpr (PREC != 1) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float mv = PREC == 2 ? HD_X6_SILU(acc[ct][r]) : silu_f(acc[ct][r]);
+                const float mv = PREC == 2 ? HD_X6_SILU(acc[ct][r]) : HD_F32_SILU(acc[ct][r]);
                 acc[ct][r] = mv;
                 dot[r] = __builtin_fmaf(mv, wav, dot[r]);
             }
