@@ -46,7 +46,7 @@ struct hd_handle {
     hd_config cfg;
     int device;
     int H, fin, F, D, NS;       // NS: 32-column sub-tiles per node-GEMM workgroup tile
-    bool fused;                 // bf16x3: one k_node launch per node update instead of k_gemm x3 + k_agg
+    bool fused;                 // bf16x3 / bf16x6: one k_node launch per node update instead of k_gemm x3 + k_agg
     bool x6;                    // bf16x6: the edge kernels contract on six bf16 MFMAs per product (H >= 128; below that
                                 // the mode runs the exact-fp32 kernels), everything else is the fp32 path
     long long n_weights;
@@ -187,8 +187,8 @@ extern "C" int hd_create(const hd_config* cfg, int device, hd_handle** out) {
     h->F = F;
     h->D = 3 + F;
     h->NS = (H == 32) ? 1 : 2;
-    h->fused = cfg->precision == 1;
     h->x6 = cfg->precision == 2 && cfg->hidden_nf >= 128;
+    h->fused = cfg->precision == 1 || h->x6;
     h->n_weights = weight_count(*cfg);
     h->weights_set = false;
     h->dw = nullptr;
@@ -301,42 +301,21 @@ static inline void bf16_split(float v, uint16_t& hi, uint16_t& lo) {
 // bf16x3 images (same byte size as the fp32 ones: 2 B head + 2 B tail per weight).
 // fused node kernel (k_node): [k-step s][column tile ct][hi|lo][64 lanes][8], k = 16s + 8*(lane>>5) + i, col = 32ct + (lane&31).
 template <typename Fn>
-static void pack_node_b(std::vector<float>& dstf, size_t off, int K, int Nc, Fn W) {
+static void pack_node_b(std::vector<float>& dstf, size_t off, int K, int Nc, Fn W, int NP = 2) {
     uint16_t* dst = reinterpret_cast<uint16_t*>(dstf.data() + off);
     const int nct = Nc / 32;
     for (int st = 0; st < K / 16; ++st)
         for (int ct = 0; ct < nct; ++ct)
             for (int lane = 0; lane < 64; ++lane)
                 for (int i = 0; i < 8; ++i) {
-                    uint16_t hi, lo;
-                    bf16_split(W(32 * ct + (lane & 31), 16 * st + 8 * (lane >> 5) + i), hi, lo);
-                    const size_t base = ((size_t)(st * nct + ct) * 2) * 512;
-                    dst[base + (size_t)lane * 8 + i] = hi;
-                    dst[base + 512 + (size_t)lane * 8 + i] = lo;
+                    float v = W(32 * ct + (lane & 31), 16 * st + 8 * (lane >> 5) + i);
+                    const size_t base = ((size_t)(st * nct + ct) * NP) * 512;
+                    for (int p = 0; p < NP; ++p) {                    // NP = 2: head, tail; 3 (bf16x6): head, middle, tail
+                        const uint16_t piece = bf16_rne(v);
+                        dst[base + (size_t)p * 512 + (size_t)lane * 8 + i] = piece;
+                        v -= bf16_to_f32(piece);
+                    }
                 }
-}
-
-// bf16x6 node GEMM (k_gemm6): per (column tile, 32-wide K chunk) [head|middle|tail][NS sub-tiles][2 k-steps][64 lanes][8 bf16],
-// k = 32c + 16s + 8*(lane>>5) + i, col = ct*32*NS + 32*sub + (lane&31); 1.5x the bytes of the fp32 image.
-template <typename Fn>
-static void pack_gemm_b6(std::vector<float>& dstf, size_t off, int K, int Nc, int NS, Fn W) {
-    uint16_t* dst = reinterpret_cast<uint16_t*>(dstf.data() + off);
-    const int BN = 32 * NS, ntile = Nc / BN, nchunk = K / 32;
-    const size_t part = (size_t)NS * 2 * 512;                 // bf16 elements per piece of one chunk
-    for (int ct = 0; ct < ntile; ++ct)
-        for (int c = 0; c < nchunk; ++c)
-            for (int sub = 0; sub < NS; ++sub)
-                for (int st = 0; st < 2; ++st)
-                    for (int lane = 0; lane < 64; ++lane)
-                        for (int i = 0; i < 8; ++i) {
-                            const float v = W(ct * BN + 32 * sub + (lane & 31), 32 * c + 16 * st + 8 * (lane >> 5) + i);
-                            const uint16_t hi = bf16_rne(v);
-                            const float r = v - bf16_to_f32(hi);
-                            const uint16_t mi = bf16_rne(r);
-                            const uint16_t lo = bf16_rne(r - bf16_to_f32(mi));
-                            const size_t base = (size_t)(ct * nchunk + c) * 3 * part + (size_t)(sub * 2 + st) * 512 + (size_t)lane * 8 + i;
-                            dst[base] = hi; dst[base + part] = mi; dst[base + 2 * part] = lo;
-                        }
 }
 
 // bf16x6 edge kernel: per 16-wide K chunk [head|middle|tail][H/32 ct][64 lanes][8], k = 16c + 8*(lane>>5) + i
@@ -395,7 +374,8 @@ extern "C" int hd_set_weights(hd_handle* h, const float* blob, long long n, int 
     const int L = c.n_layers, S = c.inv_sublayers;
     const bool bf = c.precision == 1;
     const size_t w2_floats = h->x6 ? (size_t)H * H * 3 / 2 : (size_t)H * H;
-    const size_t gx = h->x6 ? 3 : 2;                          // node-GEMM images: x gx / 2 (bf16x6: three bf16 pieces per weight)
+    const size_t gx = h->x6 ? 3 : 2;                          // node weight images: x gx / 2 (bf16x6: three bf16 pieces per weight)
+    const int NPc = h->x6 ? 3 : 2;
     // layout of the packed buffer
     size_t off = 0;
     auto take = [&](size_t cnt) { size_t o = off; off += (cnt + 3) & ~size_t(3); return o; };
@@ -440,8 +420,7 @@ extern "C" int hd_set_weights(hd_handle* h, const float* blob, long long n, int 
         auto wab = [&](int col, int k) {
             return sc((col < H) ? W1[(size_t)col * ld + k] : W1[(size_t)(col - H) * ld + H + k]);
         };
-        if (h->fused) pack_node_b(pk, w.ab_img, H, 2 * H, wab);
-        else if (h->x6) pack_gemm_b6(pk, w.ab_img, H, 2 * H, WN, wab);
+        if (h->fused) pack_node_b(pk, w.ab_img, H, 2 * H, wab, NPc);
         else pack_gemm_b(pk, w.ab_img, H, 2 * H, WN, wab);
         for (int k = 0; k < H; ++k) {
             pk[w.ab_bias + k] = sc(b1[k]);
@@ -465,11 +444,8 @@ extern "C" int hd_set_weights(hd_handle* h, const float* blob, long long n, int 
             else if (h->x6) pack_edge_w2_x6(pk, w.w2_img, H, W2);
             else pack_edge_w2(pk, w.w2_img, H, W2);
             if (h->fused) {
-                pack_node_b(pk, w.w3_img, 2 * H, H, w3);
-                pack_node_b(pk, w.w4_img, H, H, w4);
-            } else if (h->x6) {
-                pack_gemm_b6(pk, w.w3_img, 2 * H, H, WN, w3);
-                pack_gemm_b6(pk, w.w4_img, H, H, WN, w4);
+                pack_node_b(pk, w.w3_img, 2 * H, H, w3, NPc);
+                pack_node_b(pk, w.w4_img, H, H, w4, NPc);
             } else {
                 pack_gemm_b(pk, w.w3_img, 2 * H, H, WN, w3);
                 pack_gemm_b(pk, w.w4_img, H, H, WN, w4);
@@ -795,35 +771,35 @@ static void launch_gemm(int epi, bool cat, const GemmArgs& g, hipStream_t s) {
     else hipLaunchKernelGGL((k_gemm<WM, WN, CN, EPI_RESID_MASK, false>), grid, block, 0, s, g);
 }
 
-static void launch_gemm6(int epi, bool cat, const GemmArgs& g, hipStream_t s) {      // bf16x6 mode: 64 x 64 tiles (H >= 128)
-    const int nrt = (g.M + 63) / 64, nct = g.Nc / 64;
-    dim3 grid(8 * ((nrt + 7) / 8) * nct);
-    dim3 block(256);
-    if (cat && epi == EPI_BIAS) hipLaunchKernelGGL((k_gemm6<2, 2, 1, EPI_BIAS, true>), grid, block, 0, s, g);
-    else if (cat) hipLaunchKernelGGL((k_gemm6<2, 2, 1, EPI_BIAS_SILU, true>), grid, block, 0, s, g);
-    else if (epi == EPI_BIAS_SILU) hipLaunchKernelGGL((k_gemm6<2, 2, 1, EPI_BIAS_SILU, false>), grid, block, 0, s, g);
-    else if (epi == EPI_BIAS) hipLaunchKernelGGL((k_gemm6<2, 2, 1, EPI_BIAS, false>), grid, block, 0, s, g);
-    else hipLaunchKernelGGL((k_gemm6<2, 2, 1, EPI_RESID_MASK, false>), grid, block, 0, s, g);
-}
-
 // Node-GEMM tile shape per hidden size: (waves M, waves N, accumulators per wave); the weight images are
 // packed for the matching number of 32-column sub-tiles NS = WN*CN.
 static void gemm(hd_handle* h, int epi, bool cat, const GemmArgs& g, hipStream_t s) {
     ProfScope ps(h, s, 1);
 
-    if (h->x6) launch_gemm6(epi, cat, g, s);
-    else if (h->NS == 1) launch_gemm<4, 1, 1>(epi, cat, g, s);   // H = 32: 128 x 32 tiles
+    if (h->NS == 1) launch_gemm<4, 1, 1>(epi, cat, g, s);        // H = 32: 128 x 32 tiles
     else launch_gemm<2, 2, 1>(epi, cat, g, s);                   // 64 x 64 tiles (fastest measured)
 }
 
 // Fused node update (bf16x3 only): min(4, H/32) wavefronts per 32-row workgroup.
 template <int H>
-static int node_lds_bytes(bool upd) { return 32 * ((upd ? 2 * H : H) + 8) * 4 + 32 * (H + 8) * 4; }
+static int node_lds_bytes(bool upd, int np = 2) {        // region 0: the np bf16 pieces of X; region 1: those of T / the fp32 staging tile
+    const int r1 = std::max(32 * (H + 8) * 2 * np, 32 * (H + 4) * 4);
+    return 32 * ((upd ? 2 * H : H) + 8) * 2 * np + r1;
+}
 
 template <int H, int NW>
-static void launch_node_hw(bool upd, int nab, const NodeArgs& a, hipStream_t s) {
+static void launch_node_hw(bool upd, int nab, bool x6, const NodeArgs& a, hipStream_t s) {
     const int nrt = (a.M + 31) / 32;
     const dim3 grid(8 * ((nrt + 7) / 8)), block(64 * NW);
+    if constexpr (H >= 128) {
+        if (x6) {
+            const int lds6 = node_lds_bytes<H>(upd, 3);
+            if (!upd) hipLaunchKernelGGL((k_node<H, NW, false, 1, 3>), grid, block, lds6, s, a);
+            else if (nab == 1) hipLaunchKernelGGL((k_node<H, NW, true, 1, 3>), grid, block, lds6, s, a);
+            else hipLaunchKernelGGL((k_node<H, NW, true, 2, 3>), grid, block, lds6, s, a);
+            return;
+        }
+    }
     const int lds = node_lds_bytes<H>(upd);
     if (!upd) hipLaunchKernelGGL((k_node<H, NW, false, 1>), grid, block, lds, s, a);
     else if (nab == 1) hipLaunchKernelGGL((k_node<H, NW, true, 1>), grid, block, lds, s, a);
@@ -835,13 +811,18 @@ static int prepare_node_hw() {
     HIP_TRY(hipFuncSetAttribute((const void*)k_node<H, NW, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, node_lds_bytes<H>(false)));
     HIP_TRY(hipFuncSetAttribute((const void*)k_node<H, NW, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, node_lds_bytes<H>(true)));
     HIP_TRY(hipFuncSetAttribute((const void*)k_node<H, NW, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, node_lds_bytes<H>(true)));
+    if constexpr (H >= 128) {
+        HIP_TRY(hipFuncSetAttribute((const void*)k_node<H, NW, false, 1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, node_lds_bytes<H>(false, 3)));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_node<H, NW, true, 1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, node_lds_bytes<H>(true, 3)));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_node<H, NW, true, 2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, node_lds_bytes<H>(true, 3)));
+    }
     return HD_OK;
 }
 
 // wavefronts per 32-row workgroup: one 32-column tile of an H-wide output each, at most 8 (two per SIMD)
 template <int H>
-static void launch_node_h(bool upd, int nab, const NodeArgs& a, hipStream_t s) {
-    launch_node_hw<H, (H / 32 < 8 ? H / 32 : 8)>(upd, nab, a, s);
+static void launch_node_h(bool upd, int nab, bool x6, const NodeArgs& a, hipStream_t s) {
+    launch_node_hw<H, (H / 32 < 8 ? H / 32 : 8)>(upd, nab, x6, a, s);
 }
 
 template <int H>
@@ -850,10 +831,10 @@ static int prepare_node_h() { return prepare_node_hw<H, (H / 32 < 8 ? H / 32 : 8
 static void node_update(hd_handle* h, bool upd, int nab, const NodeArgs& a, hipStream_t s) {
     ProfScope ps(h, s, 1);
     switch (h->H) {
-        case 32: launch_node_h<32>(upd, nab, a, s); break;
-        case 64: launch_node_h<64>(upd, nab, a, s); break;
-        case 128: launch_node_h<128>(upd, nab, a, s); break;
-        default: launch_node_h<256>(upd, nab, a, s); break;
+        case 32: launch_node_h<32>(upd, nab, h->x6, a, s); break;
+        case 64: launch_node_h<64>(upd, nab, h->x6, a, s); break;
+        case 128: launch_node_h<128>(upd, nab, h->x6, a, s); break;
+        default: launch_node_h<256>(upd, nab, h->x6, a, s); break;
     }
 }
 
