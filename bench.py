@@ -256,6 +256,9 @@ def other_configs(args, dev) -> dict:
             64, timeit(lambda: m5.sample(64, 30, nm5, em5, ctx5, fix_noise=True)), Ts)
         nm = torch.ones(64, 30, 1, dtype=torch.bool, device=dev)
         blk["B64_N30_L6"] = entry(64, timeit(lambda: m6.sample_from_masks(nm, None, None)), Ts)
+        # graph size of a pocket-conditioned job (30 fragments + 170 pocket residues in one graph, diffusion_qm9.py:362-371)
+        nm = torch.ones(32, 200, 1, dtype=torch.bool, device=dev)
+        blk["pocket_sized_B32_N200_L6"] = entry(32, timeit(lambda: m6.sample_from_masks(nm, None, None), reps=1), Ts)
         # the reference's shipped job: batch_size 2 (conf/sample/default.yaml:1-2), full T = 1000, graph replay
         nm = torch.ones(2, 30, 1, dtype=torch.bool, device=dev)
         m1k.use_graph = True

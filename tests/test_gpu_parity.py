@@ -213,6 +213,28 @@ def test_general_edge_mask_and_options_vs_oracle():
     assert_parity(out.numpy(), ref.numpy(), "general edge mask")
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x6"])
+def test_pocket_sized_graph_vs_oracle(precision):
+    """Pocket-conditioned jobs put the ligand fragments AND the pocket residues into one graph (diffusion_qm9.py:362-371):
+    N in the hundreds, a node's edges span 7 tiles, ligand rows fixed through mol_shape.  N = 200 / 137, dense edges plus
+    a block the mask removes, against the oracle."""
+    sd_np, sd, cfg, xh, nm, em = _oracle_case([200, 137], 64, 2, seed=808, n_max=200)
+    em = em.clone()
+    em[1, :30, 100:137] = False                     # ligand fragments do not see the far half of this pocket
+    em[1, 100:137, :30] = False
+    t = torch.tensor([[0.2], [0.7]])
+    with torch.no_grad():
+        ref = orc.dynamics_forward(sd, cfg, t, xh, nm, em, None, 30, prefix="dynamics.egnn.")
+    dyn = build_dynamics(sd_np, 64, 2)
+    dyn.precision = precision
+    out = dyn._forward(t.to(DEV), xh.to(DEV), nm.to(DEV), em.to(DEV), None, 30).cpu()
+    assert_parity(out.numpy(), ref.numpy(), f"pocket-sized graph {precision}")
+    assert np.all(out.numpy()[~nm.numpy()[..., 0]] == 0.0)
+    # nodes >= mol_shape are fixed: their velocity is that of a rigid translation only (the centre-of-gravity removal)
+    v = out[0, 30:200, :3]
+    assert float((v - v[0:1]).abs().max()) < 1e-6
+
+
 def test_equivariance_permutation_padding_full_size():
     """Size-independent properties at the headline shape B=256, N=30, H=256, L=6."""
     from hierdiff_amd.weights import synthetic_state_dict
