@@ -15,6 +15,8 @@
 // sums below are invariant under 4-row shifts of a piece inside a tile, so a sample's bits do not depend on its
 // batch neighbours (hd_topology_create).
 
+// SiLU of the fp32 and bf16x6 modes.  A measurement build may substitute the 5-instruction silu_fast (-DHD_F32_SILU=silu_fast
+// -DHD_X6_SILU=silu_fast): measured -2 % / -2.4 % on the edge kernels at unchanged distance to the float64 oracle, not adopted.
 #ifndef HD_X6_SILU
 #define HD_X6_SILU silu_f
 #endif
@@ -163,9 +165,11 @@ constexpr unsigned frag_off_x6(int p, int ct) { return (unsigned)((p * NCT + ct)
 //   1 = skip the epilogue, 2 = skip operand generation (SiLU etc.), 4 = no per-chunk barrier / W2 streaming,
 //   8 = no AB row gathers, 16 = record per-wave cycle stamps + HW placement (hd_debug_edge_trace, scratch/edge_trace.py)
 //
-// One workgroup = one 128-edge workgroup-tile (4 wavefronts x 32 edges).  (A persistent form that walks several
-// tiles per workgroup was measured no faster and spilled; so was the pipelined one-wave-per-SIMD form of round 1,
-// scratch/experiments/k_edge_pipelined.hpp.)
+// One workgroup = one 128-edge workgroup-tile (4 wavefronts x 32 edges), two workgroups per CU.  Forms that were built and
+// measured slower: a persistent one that walks several tiles per workgroup (spilled); the pipelined one-wave-per-SIMD form of
+// round 1 for bf16x3 (scratch/experiments/k_edge_pipelined.hpp); its round-2 successor for fp32 with the epilogue of tile t
+// riding under the MFMAs of tile t+1 (scratch/experiments/k_edge_f32p.hpp: bit-identical, 15 % slower - nothing overlaps with
+// the fp32 MFMA inside a wavefront).
 template <int H, bool COORD, int PREC, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
     constexpr int NCT = H / 32;          // 32-column tiles
