@@ -355,11 +355,11 @@ def test_pocket_loss_golden(precision):
 def test_switching_precision_keeps_the_schedule():
     """a new handle (other precision / device) must get the schedule again even if it re-uses the freed
     handle's address."""
-    sd_np = _syn(32, 1, seed=27)
-    model = build_diffusion(sd_np, 32, 1, T=6, precision="fp32")
+    sd_np = _syn(128, 1, seed=27)                      # width 128: the bf16x6 mode runs its own kernels (>= 128)
+    model = build_diffusion(sd_np, 128, 1, T=6, precision="fp32")
     nm, _ = orc.canonical_masks([4, 3])
     x0, _ = model.sample_from_masks(nm.to(DEV), None, None)
-    for p in ("bf16x3", "fp32", "bf16x3"):
+    for p in ("bf16x3", "bf16x6", "fp32", "bf16x6", "bf16x3"):
         model.dynamics.precision = p
         x1, _ = model.sample_from_masks(nm.to(DEV), None, None)
         assert torch.isfinite(x1).all()
