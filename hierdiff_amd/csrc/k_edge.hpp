@@ -169,7 +169,8 @@ constexpr unsigned frag_off_x6(int p, int ct) { return (unsigned)((p * NCT + ct)
 // measured slower: a persistent one that walks several tiles per workgroup (spilled); the pipelined one-wave-per-SIMD form of
 // round 1 for bf16x3 (scratch/experiments/k_edge_pipelined.hpp); its round-2 successor for fp32 with the epilogue of tile t
 // riding under the MFMAs of tile t+1 (scratch/experiments/k_edge_f32p.hpp: bit-identical, 15 % slower - nothing overlaps with
-// the fp32 MFMA inside a wavefront).
+// the fp32 MFMA inside a wavefront); the same for bf16x6 (k_edge_x6p.hpp: no faster - the W2 stream and
+// the barrier have no second wavefront to hide behind).
 template <int H, bool COORD, int PREC, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void k_edge(EdgeArgs a) {
     constexpr int NCT = H / 32;          // 32-column tiles
