@@ -528,3 +528,241 @@ __global__ __launch_bounds__(64 * NW, 1) void k_node(NodeArgs a) {
         }
     }
 }
+
+// ----------------------------------------------------------------------------- fused node update, exact fp32
+// The same launch structure as k_node (one launch per node update: neighbour-sum reduction, node MLP, residual, the next
+// layers' first edge Linear) on v_mfma_f32_32x32x2_f32 - the fp32 mode's node side (round 1 and most of round 2 ran it as
+// k_agg + 3 x k_gemm: 62-83 us per update at M = 7,680 rows, bound by launch / tile-prologue costs rather than math).
+//   * the 32-row activation tile lives in LDS as fp32, row stride K+4 floats (conflict-free ds_read_b128);
+//   * weights go L2 -> registers in fragment order, per 32-wide K chunk and column tile [4 q][64 lanes][4 j] floats with
+//     k = 32 s + 16 (lane>>5) + 4 q + j, col = 32 ct + (lane&31)   (pack_node_b_f32), a ring of PF chunks per wavefront.
+template <int KS, int CTn, int CTW, int PF, int NCT>
+struct NodeMmaF {
+    typedef u32x4 Ring[PF][CTn][4];
+    template <int s, int slot>
+    static HD_DEVINL void load(Ring& br, const u32x4* Bl, int ct0, int CTG) {
+#pragma unroll
+        for (int c = 0; c < CTn; ++c) {
+            const int ct = (c / CTW) * CTG + ct0 + c % CTW;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) br[slot][c][q] = Bl[((size_t)(s * NCT + ct) * 4 + q) * 64];
+        }
+    }
+    static HD_DEVINL void prefetch(Ring& br, const u32x4* Bl, int ct0, int CTG) {
+        static_for<0, (PF < KS ? PF : KS)>([&](auto S) { load<decltype(S)::value, decltype(S)::value>(br, Bl, ct0, CTG); });
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    static HD_DEVINL void run(f32x16 (&acc)[CTn], Ring& br, const float* Arow, const u32x4* Bl, int ct0, int CTG) {
+        f32x4 a[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[q] = *reinterpret_cast<const f32x4*>(Arow + 4 * q);
+        static_for<0, KS>([&](auto S) {
+            constexpr int s = decltype(S)::value, slot = s % PF;
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 an[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) an[q] = a[q];
+            if constexpr (s + 1 < KS) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) an[q] = *reinterpret_cast<const f32x4*>(Arow + 32 * (s + 1) + 4 * q);
+            }
+            __builtin_amdgcn_sched_barrier(0);         // next A fragments are in flight under this chunk's MFMAs
+            f32x4 b[CTn][4];
+#pragma unroll
+            for (int c = 0; c < CTn; ++c)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) b[c][q] = __builtin_bit_cast(f32x4, br[slot][c][q]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int c = 0; c < CTn; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][j], b[c][q][j], acc[c], 0, 0, 0);
+            if constexpr (s + PF < KS) load<s + PF, slot>(br, Bl, ct0, CTG);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[q] = an[q];
+        });
+        __builtin_amdgcn_sched_barrier(0);
+    }
+};
+
+template <int H, int NW, bool UPD, int NAB>
+__global__ __launch_bounds__(64 * NW, 1) void k_node_f32(NodeArgs a) {
+    constexpr int NT = 64 * NW;
+    constexpr int NCT = H / 32;            // column tiles of an H-wide output
+    constexpr int CT = NCT / NW;           // ... per wavefront
+    static_assert(CT >= 1 && CT * NW == NCT, "NW must divide H/32");
+    constexpr int KX = UPD ? 2 * H : H;
+    constexpr int LDX = KX + 4, LDH = H + 4;
+    constexpr int PF12 = 2, PF3 = 2;       // 32-wide K chunks of weights in flight per wavefront (= 4 bf16 k-steps of bytes)
+    constexpr int R0_BYTES = 32 * LDX * 4;
+    extern __shared__ __attribute__((aligned(16))) char smem_n[];
+    float* X = reinterpret_cast<float*>(smem_n);                    // region 0: X = [h | agg], later h'
+    float* T = reinterpret_cast<float*>(smem_n + R0_BYTES);         // region 1: T, later the AB staging tile (same stride)
+    float* Nn = X;                                                  // h' [32][LDH] (UPD) - or X itself (stride LDX == LDH)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hh = lane >> 5, n = lane & 31;
+    int rt;                                                         // XCD-aware row-tile order, as in k_node
+    {
+        const int nrt = (a.M + 31) >> 5;
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int q = nrt >> 3, r = nrt & 7;
+        const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        const int len = q + (xcd < r ? 1 : 0);
+        if (idx >= len) return;
+        rt = start + idx;
+    }
+    const int row0 = rt * 32;
+
+    typedef NodeMmaF<KX / 32, CT, CT, PF12, NCT> M1;            // X W3^T      (UPD only)
+    typedef NodeMmaF<H / 32, CT, CT, PF12, NCT> M2;             // T W4^T      (UPD only)
+    typedef NodeMmaF<H / 32, 2 * CT, CT, PF3, 2 * NCT> M3;      // h' [W1a|W1b]^T
+    typename M1::Ring br1;
+    typename M2::Ring br2;
+    typename M3::Ring br3;
+    const int ct0 = wave * CT;
+    const u32x4* W3l = reinterpret_cast<const u32x4*>(a.W3img) + lane;
+    const u32x4* W4l = reinterpret_cast<const u32x4*>(a.W4img) + lane;
+    const u32x4* AB0l = reinterpret_cast<const u32x4*>(a.ABimg[0]) + lane;
+    if constexpr (UPD) M1::prefetch(br1, W3l, ct0, 0);
+
+    // ---- phase 0: X -> LDS.  NT/32 threads per row, each moving every (NT/32)-th float4 of the row.
+    {
+        constexpr int Q = H / 4;                     // float4 per H-wide row
+        constexpr int TPR = NT / 32;                 // threads per row
+        constexpr int NPT = Q / TPR;                 // pieces per thread and source
+        static_assert(Q % TPR == 0, "row pieces must divide evenly");
+        const int r = tid / TPR, cq = tid % TPR;
+        const int row = row0 + r;
+        int p0 = 0, p1 = 0;
+        if constexpr (UPD) {
+            if (row < a.M) { p0 = a.pstart[row]; p1 = a.pstart[row + 1]; }
+        }
+        f32x4 hv[NPT];
+#pragma unroll
+        for (int u = 0; u < NPT; ++u)
+            hv[u] = *reinterpret_cast<const f32x4*>(a.h_in + (size_t)row * H + 4 * (cq + u * TPR));   // pad rows are zero
+        if constexpr (UPD) {
+            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+            const bool has0 = p0 < p1, has1 = p0 + 1 < p1;
+            const float* s0 = a.part + (size_t)(has0 ? p0 : 0) * H;
+            const float* s1 = a.part + (size_t)(has1 ? p0 + 1 : 0) * H;
+            f32x4 g0[NPT], g1[NPT];
+#pragma unroll
+            for (int u = 0; u < NPT; ++u) {
+                g0[u] = *reinterpret_cast<const f32x4*>(s0 + 4 * (cq + u * TPR));
+                g1[u] = *reinterpret_cast<const f32x4*>(s1 + 4 * (cq + u * TPR));
+            }
+#pragma unroll
+            for (int u = 0; u < NPT; ++u) *reinterpret_cast<f32x4*>(X + r * LDX + 4 * (cq + u * TPR)) = hv[u];
+#pragma unroll
+            for (int u = 0; u < NPT; ++u) {
+                f32x4 v = z4;                        // same order of additions as k_agg: parts ascending, then / norm
+                if (has0) v += g0[u];
+                if (has1) v += g1[u];
+                for (int p = p0 + 2; p < p1; ++p) v += *reinterpret_cast<const f32x4*>(a.part + (size_t)p * H + 4 * (cq + u * TPR));
+                *reinterpret_cast<f32x4*>(X + r * LDX + H + 4 * (cq + u * TPR)) = v / a.norm;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < NPT; ++u) *reinterpret_cast<f32x4*>(X + r * LDX + 4 * (cq + u * TPR)) = hv[u];
+        }
+    }
+
+    if constexpr (UPD) {
+        // ---- phase 1: T = silu(X W3^T + b3)
+        {
+            f32x16 acc[CT];
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                const float b = a.b3[32 * (ct0 + c) + n];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[c][r] = b;
+            }
+            __syncthreads();                                         // X complete
+            M2::prefetch(br2, W4l, ct0, 0);
+            M1::run(acc, br1, X + n * LDX + 16 * hh, W3l, ct0, 0);
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    T[((r & 3) + 8 * (r >> 2) + 4 * hh) * LDH + 32 * (ct0 + c) + n] = silu_f(acc[c][r]);
+        }
+        __syncthreads();
+        // ---- phase 2: h' = (h + T W4^T + b4) * mask
+        {
+            f32x16 acc[CT];
+            float hres[CT][16], mk[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mk[r] = a.nmask[row0 + (r & 3) + 8 * (r >> 2) + 4 * hh];
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                const float b = a.b4[32 * (ct0 + c) + n];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    acc[c][r] = b;
+                    hres[c][r] = a.h_in[(size_t)(row0 + (r & 3) + 8 * (r >> 2) + 4 * hh) * H + 32 * (ct0 + c) + n];
+                }
+            }
+            M3::prefetch(br3, AB0l, ct0, NCT);
+            M2::run(acc, br2, T + n * LDH + 16 * hh, W4l, ct0, 0);
+            // every wave is done reading X once it is past its own M1::run AND the barrier above: h' may overwrite region 0
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int R = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    Nn[R * LDH + 32 * (ct0 + c) + n] = (hres[c][r] + acc[c][r]) * mk[r];
+                }
+        }
+        __syncthreads();
+        {
+            constexpr int Q = H / 4, NPT = 32 * Q / NT;
+#pragma unroll
+            for (int u = 0; u < NPT; ++u) {
+                const int idx = tid + u * NT, r = idx / Q, c4 = idx % Q;
+                if (row0 + r < a.M)
+                    *reinterpret_cast<f32x4*>(a.h_out + (size_t)(row0 + r) * H + 4 * c4) = *reinterpret_cast<const f32x4*>(Nn + r * LDH + 4 * c4);
+            }
+        }
+    }
+
+    // ---- phase 3: AB_q = h' [W1a | W1b]^T + bias, two H-wide halves per wavefront, staged through region 1
+#pragma unroll
+    for (int q = 0; q < NAB; ++q) {
+        f32x16 acc[2 * CT];
+#pragma unroll
+        for (int c = 0; c < 2 * CT; ++c) {
+            const float b = a.ABbias[q][(c / CT) * H + 32 * (ct0 + c % CT) + n];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][r] = b;
+        }
+        const u32x4* ABl = reinterpret_cast<const u32x4*>(a.ABimg[q]) + lane;
+        if (q > 0 || !UPD) {
+            M3::prefetch(br3, ABl, ct0, NCT);
+            if (!UPD) __syncthreads();                               // h tile complete
+        }
+        M3::run(acc, br3, Nn + n * LDH + 16 * hh, ABl, ct0, NCT);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            if (half || q) __syncthreads();                 // previous staging tile fully stored
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    T[((r & 3) + 8 * (r >> 2) + 4 * hh) * LDH + 32 * (ct0 + c) + n] = acc[half * CT + c][r];
+            __syncthreads();
+            constexpr int Q = H / 4, NPT = 32 * Q / NT;
+#pragma unroll
+            for (int u = 0; u < NPT; ++u) {
+                const int idx = tid + u * NT, r = idx / Q, c4 = idx % Q;
+                if (row0 + r < a.M)
+                    *reinterpret_cast<f32x4*>(a.ABout[q] + (size_t)(row0 + r) * 2 * H + half * H + 4 * c4) =
+                        *reinterpret_cast<const f32x4*>(T + r * LDH + 4 * c4);
+            }
+        }
+    }
+}
