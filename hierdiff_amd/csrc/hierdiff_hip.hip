@@ -45,8 +45,7 @@ struct ProfRec { int fam; hipEvent_t a, b; };
 struct hd_handle {
     hd_config cfg;
     int device;
-    int H, fin, F, D, NS;       // NS: 32-column sub-tiles per node-GEMM workgroup tile
-    bool fused;                 // bf16x3 / bf16x6: one k_node launch per node update instead of k_gemm x3 + k_agg
+    int H, fin, F, D;
     bool x6;                    // bf16x6: the edge kernels contract on six bf16 MFMAs per product (H >= 128; below that
                                 // the mode runs the exact-fp32 kernels), everything else is the fp32 path
     long long n_weights;
@@ -112,7 +111,7 @@ struct hd_topology {
     uint8_t *eseg, *nm_bytes;
     float* nmask;
     // workspace
-    float *hbuf, *AB, *AB2, *Tb, *agg, *x0, *xcur, *part, *xpart, *eps;
+    float *hbuf, *AB, *AB2, *x0, *xcur, *part, *xpart, *eps;
     // hd_sample_loop with use_graph: the captured step works on library-owned copies of z / context so that the
     // instantiated graph survives across calls (the caller's tensors move); one graph per topology
     float *zbuf, *ctxbuf;
@@ -186,9 +185,7 @@ extern "C" int hd_create(const hd_config* cfg, int device, hd_handle** out) {
     h->fin = cfg->in_node_nf + cfg->context_node_nf;
     h->F = F;
     h->D = 3 + F;
-    h->NS = (H == 32) ? 1 : 2;
     h->x6 = cfg->precision == 2 && cfg->hidden_nf >= 128;
-    h->fused = cfg->precision == 1 || h->x6;
     h->n_weights = weight_count(*cfg);
     h->weights_set = false;
     h->dw = nullptr;
@@ -337,6 +334,20 @@ static void pack_edge_w2_x6(std::vector<float>& dstf, size_t off, int H, const f
                 }
 }
 
+// fused fp32 node kernel (k_node_f32): [32-wide K chunk s][column tile ct][4 q][64 lanes][4 j] floats,
+// k = 32s + 16*(lane>>5) + 4q + j, col = 32ct + (lane&31).
+template <typename Fn>
+static void pack_node_b_f32(std::vector<float>& dst, size_t off, int K, int Nc, Fn W) {
+    const int nct = Nc / 32;
+    for (int st = 0; st < K / 32; ++st)
+        for (int ct = 0; ct < nct; ++ct)
+            for (int q = 0; q < 4; ++q)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 4; ++j)
+                        dst[off + (((size_t)(st * nct + ct) * 4 + q) * 64 + lane) * 4 + j] =
+                            W(32 * ct + (lane & 31), 32 * st + 16 * (lane >> 5) + 4 * q + j);
+}
+
 // edge kernel: per K chunk [hi|lo][2 k-steps][H/32 ct][64 lanes][8], k = 32c + 16*(lane>>5) + 8s + i.
 static void pack_edge_w2_bf(std::vector<float>& dstf, size_t off, int H, const float* W2) {
     uint16_t* dst = reinterpret_cast<uint16_t*>(dstf.data() + off);
@@ -370,12 +381,13 @@ extern "C" int hd_set_weights(hd_handle* h, const float* blob, long long n, int 
         src = host.data();
     }
     const hd_config& c = h->cfg;
-    const int H = h->H, fin = h->fin, WN = h->NS;
+    const int H = h->H, fin = h->fin;
     const int L = c.n_layers, S = c.inv_sublayers;
     const bool bf = c.precision == 1;
     const size_t w2_floats = h->x6 ? (size_t)H * H * 3 / 2 : (size_t)H * H;
     const size_t gx = h->x6 ? 3 : 2;                          // node weight images: x gx / 2 (bf16x6: three bf16 pieces per weight)
     const int NPc = h->x6 ? 3 : 2;
+    const bool nodef32 = !bf && !h->x6;                       // fp32 mode (and bf16x6 below width 128): k_node_f32
     // layout of the packed buffer
     size_t off = 0;
     auto take = [&](size_t cnt) { size_t o = off; off += (cnt + 3) & ~size_t(3); return o; };
@@ -420,8 +432,8 @@ extern "C" int hd_set_weights(hd_handle* h, const float* blob, long long n, int 
         auto wab = [&](int col, int k) {
             return sc((col < H) ? W1[(size_t)col * ld + k] : W1[(size_t)(col - H) * ld + H + k]);
         };
-        if (h->fused) pack_node_b(pk, w.ab_img, H, 2 * H, wab, NPc);
-        else pack_gemm_b(pk, w.ab_img, H, 2 * H, WN, wab);
+        if (nodef32) pack_node_b_f32(pk, w.ab_img, H, 2 * H, wab);
+        else pack_node_b(pk, w.ab_img, H, 2 * H, wab, NPc);
         for (int k = 0; k < H; ++k) {
             pk[w.ab_bias + k] = sc(b1[k]);
             pk[w.ab_bias + H + k] = 0.0f;
@@ -443,12 +455,12 @@ extern "C" int hd_set_weights(hd_handle* h, const float* blob, long long n, int 
             if (bf) pack_edge_w2_bf(pk, w.w2_img, H, W2);
             else if (h->x6) pack_edge_w2_x6(pk, w.w2_img, H, W2);
             else pack_edge_w2(pk, w.w2_img, H, W2);
-            if (h->fused) {
+            if (nodef32) {
+                pack_node_b_f32(pk, w.w3_img, 2 * H, H, w3);
+                pack_node_b_f32(pk, w.w4_img, H, H, w4);
+            } else {
                 pack_node_b(pk, w.w3_img, 2 * H, H, w3, NPc);
                 pack_node_b(pk, w.w4_img, H, H, w4, NPc);
-            } else {
-                pack_gemm_b(pk, w.w3_img, 2 * H, H, WN, w3);
-                pack_gemm_b(pk, w.w4_img, H, H, WN, w4);
             }
             for (int k = 0; k < H; ++k) pk[w.b2 + k] = sc(b2[k]);
             std::copy(b3, b3 + H, pk.begin() + w.b3);
@@ -495,7 +507,7 @@ extern "C" int hd_topology_destroy(hd_topology* t) {
     if (t->gexec) hipGraphExecDestroy(t->gexec);
     hipFree(t->node_of); hipFree(t->slot_of); hipFree(t->ei); hipFree(t->ej); hipFree(t->seg_part);
     hipFree(t->tile_nseg); hipFree(t->pstart); hipFree(t->nvalid); hipFree(t->eseg); hipFree(t->nm_bytes);
-    hipFree(t->nmask); hipFree(t->hbuf); hipFree(t->AB); hipFree(t->AB2); hipFree(t->Tb); hipFree(t->agg); hipFree(t->x0); hipFree(t->xcur);
+    hipFree(t->nmask); hipFree(t->hbuf); hipFree(t->AB); hipFree(t->AB2); hipFree(t->x0); hipFree(t->xcur);
     hipFree(t->part); hipFree(t->xpart); hipFree(t->eps); hipFree(t->zbuf); hipFree(t->ctxbuf);
     hipFree(t->rptr); hipFree(t->rrows); hipFree(t->sptr); hipFree(t->srows); hipFree(t->w2img); hipFree(t->w2timg);
     delete t->node_of_host;
@@ -688,8 +700,7 @@ extern "C" int hd_topology_create(hd_handle* h, const uint8_t* node_mask, const 
             return HD_OK;
         };
         HD_TRY(zalloc(&t->hbuf, (size_t)M_pad * H)); HD_TRY(zalloc(&t->AB, (size_t)M_pad * 2 * H));
-        HD_TRY(zalloc(&t->AB2, h->fused ? (size_t)M_pad * 2 * H : 1));
-        HD_TRY(zalloc(&t->Tb, (size_t)M_pad * H)); HD_TRY(zalloc(&t->agg, (size_t)M_pad * H));
+        HD_TRY(zalloc(&t->AB2, (size_t)M_pad * 2 * H));
         HD_TRY(zalloc(&t->x0, (size_t)M_pad * 4)); HD_TRY(zalloc(&t->xcur, (size_t)M_pad * 4));
         HD_TRY(zalloc(&t->part, (size_t)std::max(1, n_parts) * H)); HD_TRY(zalloc(&t->xpart, (size_t)std::max(1, n_parts) * 4));
         HD_TRY(zalloc(&t->eps, BN * h->D)); HD_TRY(zalloc(&t->zbuf, BN * h->D));
@@ -771,15 +782,6 @@ static void launch_gemm(int epi, bool cat, const GemmArgs& g, hipStream_t s) {
     else hipLaunchKernelGGL((k_gemm<WM, WN, CN, EPI_RESID_MASK, false>), grid, block, 0, s, g);
 }
 
-// Node-GEMM tile shape per hidden size: (waves M, waves N, accumulators per wave); the weight images are
-// packed for the matching number of 32-column sub-tiles NS = WN*CN.
-static void gemm(hd_handle* h, int epi, bool cat, const GemmArgs& g, hipStream_t s) {
-    ProfScope ps(h, s, 1);
-
-    if (h->NS == 1) launch_gemm<4, 1, 1>(epi, cat, g, s);        // H = 32: 128 x 32 tiles
-    else launch_gemm<2, 2, 1>(epi, cat, g, s);                   // 64 x 64 tiles (fastest measured)
-}
-
 // Fused node update (bf16x3 only): min(4, H/32) wavefronts per 32-row workgroup.
 template <int H>
 static int node_lds_bytes(bool upd, int np = 2) {        // region 0: the np bf16 pieces of X; region 1: those of T / the fp32 staging tile
@@ -787,10 +789,21 @@ static int node_lds_bytes(bool upd, int np = 2) {        // region 0: the np bf1
     return 32 * ((upd ? 2 * H : H) + 8) * 2 * np + r1;
 }
 
+template <int H>
+static int node_f32_lds_bytes(bool upd) { return 32 * ((upd ? 2 * H : H) + 4) * 4 + 32 * (H + 4) * 4; }
+
 template <int H, int NW>
-static void launch_node_hw(bool upd, int nab, bool x6, const NodeArgs& a, hipStream_t s) {
+static void launch_node_hw(bool upd, int nab, int mode, const NodeArgs& a, hipStream_t s) {      // mode: 0 fp32, 1 bf16x3, 2 bf16x6
     const int nrt = (a.M + 31) / 32;
     const dim3 grid(8 * ((nrt + 7) / 8)), block(64 * NW);
+    const bool x6 = mode == 2;
+    if (mode == 0) {
+        const int ldsf = node_f32_lds_bytes<H>(upd);
+        if (!upd) hipLaunchKernelGGL((k_node_f32<H, NW, false, 1>), grid, block, ldsf, s, a);
+        else if (nab == 1) hipLaunchKernelGGL((k_node_f32<H, NW, true, 1>), grid, block, ldsf, s, a);
+        else hipLaunchKernelGGL((k_node_f32<H, NW, true, 2>), grid, block, ldsf, s, a);
+        return;
+    }
     if constexpr (H >= 128) {
         if (x6) {
             const int lds6 = node_lds_bytes<H>(upd, 3);
@@ -811,6 +824,9 @@ static int prepare_node_hw() {
     HIP_TRY(hipFuncSetAttribute((const void*)k_node<H, NW, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, node_lds_bytes<H>(false)));
     HIP_TRY(hipFuncSetAttribute((const void*)k_node<H, NW, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, node_lds_bytes<H>(true)));
     HIP_TRY(hipFuncSetAttribute((const void*)k_node<H, NW, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, node_lds_bytes<H>(true)));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_node_f32<H, NW, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, node_f32_lds_bytes<H>(false)));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_node_f32<H, NW, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, node_f32_lds_bytes<H>(true)));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_node_f32<H, NW, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, node_f32_lds_bytes<H>(true)));
     if constexpr (H >= 128) {
         HIP_TRY(hipFuncSetAttribute((const void*)k_node<H, NW, false, 1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, node_lds_bytes<H>(false, 3)));
         HIP_TRY(hipFuncSetAttribute((const void*)k_node<H, NW, true, 1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, node_lds_bytes<H>(true, 3)));
@@ -821,8 +837,8 @@ static int prepare_node_hw() {
 
 // wavefronts per 32-row workgroup: one 32-column tile of an H-wide output each, at most 8 (two per SIMD)
 template <int H>
-static void launch_node_h(bool upd, int nab, bool x6, const NodeArgs& a, hipStream_t s) {
-    launch_node_hw<H, (H / 32 < 8 ? H / 32 : 8)>(upd, nab, x6, a, s);
+static void launch_node_h(bool upd, int nab, int mode, const NodeArgs& a, hipStream_t s) {
+    launch_node_hw<H, (H / 32 < 8 ? H / 32 : 8)>(upd, nab, mode, a, s);
 }
 
 template <int H>
@@ -830,11 +846,12 @@ static int prepare_node_h() { return prepare_node_hw<H, (H / 32 < 8 ? H / 32 : 8
 
 static void node_update(hd_handle* h, bool upd, int nab, const NodeArgs& a, hipStream_t s) {
     ProfScope ps(h, s, 1);
+    const int mode = h->x6 ? 2 : (h->cfg.precision == 1 ? 1 : 0);
     switch (h->H) {
-        case 32: launch_node_h<32>(upd, nab, h->x6, a, s); break;
-        case 64: launch_node_h<64>(upd, nab, h->x6, a, s); break;
-        case 128: launch_node_h<128>(upd, nab, h->x6, a, s); break;
-        default: launch_node_h<256>(upd, nab, h->x6, a, s); break;
+        case 32: launch_node_h<32>(upd, nab, mode, a, s); break;
+        case 64: launch_node_h<64>(upd, nab, mode, a, s); break;
+        case 128: launch_node_h<128>(upd, nab, mode, a, s); break;
+        default: launch_node_h<256>(upd, nab, mode, a, s); break;
     }
 }
 
@@ -976,8 +993,8 @@ static int forward_impl(hd_handle* h, hd_topology* t, const float* xh, const flo
         }
         const float range = c.coords_range / (float)c.n_layers;
         const int S = c.inv_sublayers;
-        // fused path: AB of the layer about to run is produced by the previous node update (or, for the very
-        // first layer, by an AB-only launch); `ab_cur` is the buffer the next edge kernel reads
+        // AB of the layer about to run is produced by the previous node update (or, for the very first layer, by an
+        // AB-only launch); `ab_cur` is the buffer the next edge kernel reads
         const float* ab_cur = t->AB;
         auto node_args = [&]() {
             NodeArgs a;
@@ -989,7 +1006,7 @@ static int forward_impl(hd_handle* h, hd_topology* t, const float* xh, const flo
         auto set_ab = [&](NodeArgs& a, int q, const LayerW& nw, float* dst) {
             a.ABimg[q] = W + nw.ab_img; a.ABbias[q] = W + nw.ab_bias; a.ABout[q] = dst;
         };
-        if (h->fused) {
+        {
             NodeArgs a = node_args();
             set_ab(a, 0, h->gcl[0], t->AB);
             node_update(h, false, 1, a, s);
@@ -998,13 +1015,6 @@ static int forward_impl(hd_handle* h, hd_topology* t, const float* xh, const flo
             for (int j = 0; j <= c.inv_sublayers; ++j) {
                 const bool coord = (j == c.inv_sublayers);
                 const LayerW& w = coord ? h->coord[i] : h->gcl[(size_t)i * c.inv_sublayers + j];
-                if (!h->fused) {
-                    GemmArgs g;
-                    std::memset(&g, 0, sizeof(g));
-                    g.A = t->hbuf; g.lda = H; g.K1 = H; g.K = H; g.Bimg = W + w.ab_img; g.bias = W + w.ab_bias;
-                    g.C = t->AB; g.ldc = 2 * H; g.M = M; g.Nc = 2 * H; g.nmask = t->nmask;
-                    gemm(h, EPI_BIAS, false, g, s);
-                }
                 EdgeArgs e;
                 std::memset(&e, 0, sizeof(e));
                 e.AB = ab_cur; e.wrd = W + w.wrd; e.W2img = W + w.w2_img; e.b2 = W + w.b2; e.wa = W + w.wa;
@@ -1013,7 +1023,7 @@ static int forward_impl(hd_handle* h, hd_topology* t, const float* xh, const flo
                 e.norm_constant = c.norm_constant; e.coords_range = range; e.attention = c.attention;
                 e.use_tanh = c.tanh; e.n_tiles = t->n_tiles; e.n_wg = t->n_wg;
                 HD_TRY(edge(h, coord, e, s));
-                if (!coord && h->fused) {
+                if (!coord) {
                     NodeArgs a = node_args();
                     a.W3img = W + w.w3_img; a.b3 = W + w.b3; a.W4img = W + w.w4_img; a.b4 = W + w.b4;
                     int nab = 1;
@@ -1025,33 +1035,13 @@ static int forward_impl(hd_handle* h, hd_topology* t, const float* xh, const flo
                     }
                     node_update(h, true, nab, a, s);
                     ab_cur = t->AB;
-                } else if (!coord) {
-                    GemmArgs g1;
-                    std::memset(&g1, 0, sizeof(g1));
-                    {
-                        ProfScope ps(h, s, 2);
-                        AggArgs ag;
-                        ag.part = t->part; ag.pstart = t->pstart; ag.agg = t->agg; ag.norm = c.normalization_factor;
-                        ag.M = M; ag.H = H;
-                        const long long total = (long long)M * (H / 4);
-                        hipLaunchKernelGGL(k_agg, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ag);
-                    }
-                    g1.A = t->hbuf; g1.lda = H; g1.K1 = H; g1.K = 2 * H; g1.A2 = t->agg;
-                    g1.Bimg = W + w.w3_img; g1.bias = W + w.b3; g1.C = t->Tb;
-                    g1.ldc = H; g1.M = M; g1.Nc = H; g1.nmask = t->nmask;
-                    gemm(h, EPI_BIAS_SILU, true, g1, s);
-                    GemmArgs g2;
-                    std::memset(&g2, 0, sizeof(g2));
-                    g2.A = t->Tb; g2.lda = H; g2.K1 = H; g2.K = H; g2.Bimg = W + w.w4_img; g2.bias = W + w.b4;
-                    g2.C = t->hbuf; g2.ldc = H; g2.M = M; g2.Nc = H; g2.nmask = t->nmask;
-                    gemm(h, EPI_RESID_MASK, false, g2, s);
                 } else {
                     ProfScope ps(h, s, 2);
                     XupdArgs x;
                     x.part = t->xpart; x.pstart = t->pstart; x.nmask = t->nmask; x.xcur = t->xcur;
                     x.norm = c.normalization_factor; x.M = M;
                     hipLaunchKernelGGL(k_xupd, dim3((M + 255) / 256), dim3(256), 0, s, x);
-                    if (h->fused) ab_cur = t->AB2;          // next block's first GCL (written by the last node update)
+                    ab_cur = t->AB2;                        // next block's first GCL (written by the last node update)
                 }
             }
         }

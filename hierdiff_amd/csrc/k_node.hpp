@@ -1,5 +1,5 @@
-// Node-side kernels: input embedding (k_node_init), fp32-mode node GEMMs (k_gemm) and the fused bf16x3 node update
-// (k_node).  Included through kernels.hpp.
+// Node-side kernels: input embedding (k_node_init), the fp32 tile GEMM k_gemm (stage-2 layer E_GCL), and the fused node update
+// of the sampler in its three arithmetics (k_node: bf16x3 / bf16x6; k_node_f32: exact fp32).  Included through kernels.hpp.
 #pragma once
 #include "common.hpp"
 
@@ -70,7 +70,7 @@ struct GemmArgs {
 
 
 // WM x WN wavefronts, each owning 32 rows x (32*CN) columns (CN accumulators); workgroup tile
-// (32*WM) x (32*WN*CN).  Exact-fp32 precision mode only (the bf16x3 mode runs the fused k_node below).
+// (32*WM) x (32*WN*CN).  Used by the stage-2 layer (hd_egcl_forward); the sampler's node side is the fused k_node / k_node_f32.
 // Weight image per (column tile, 32-wide K chunk): [NS][4 q][64 lanes][4 j], k = 32c + 16*(lane>>5) + 4q + j,
 // with NS = WN*CN 32-column sub-tiles, column = tile*32*NS + 32*sub + (lane&31).
 template <int WM, int WN, int CN, int EPI, bool CAT>
@@ -595,7 +595,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_node_f32(NodeArgs a) {
     static_assert(CT >= 1 && CT * NW == NCT, "NW must divide H/32");
     constexpr int KX = UPD ? 2 * H : H;
     constexpr int LDX = KX + 4, LDH = H + 4;
-    constexpr int PF12 = 2, PF3 = 2;       // 32-wide K chunks of weights in flight per wavefront (= 4 bf16 k-steps of bytes)
+    constexpr int PF12 = 2, PF3 = 2;       // 32-wide K chunks of weights in flight per wavefront (3: no faster, 4: spills)
     constexpr int R0_BYTES = 32 * LDX * 4;
     extern __shared__ __attribute__((aligned(16))) char smem_n[];
     float* X = reinterpret_cast<float*>(smem_n);                    // region 0: X = [h | agg], later h'

@@ -5,14 +5,15 @@
 //     materialised: only unmasked edges exist, packed in tiles of 32 edge rows;
 //   * the first edge Linear is factorised, W1.[h_i;h_j;r;d0]+b = (W1a.h_i+b) + W1b.h_j + r.w_r + d0.w_d,
 //     so per edge only an H x H contraction remains; it runs on the matrix cores, one 32-edge x H tile per
-//     64-wide wavefront, either exactly in fp32 (v_mfma_f32_32x32x2_f32) or as three bf16 MFMAs per product
-//     on head/tail-split fp32 operands ("bf16x3", v_mfma_f32_32x32x16_bf16; opt-in, the default is exact fp32);
+//     64-wide wavefront, either exactly in fp32 (v_mfma_f32_32x32x2_f32, the default) or, opt-in, on bf16 splits of the
+//     fp32 operands with fp32 accumulation (v_mfma_f32_32x32x16_bf16): three pieces / six MFMAs per product ("bf16x6",
+//     fp32-accurate) or two pieces / three MFMAs ("bf16x3");
 //   * per-node sums over neighbours are wavefront-local, written as per-tile partial sums that the consuming
 //     node kernel adds in a fixed order (bit-reproducible);
-//   * in bf16x3 mode the whole row-local node chain (neighbour-sum reduction, node MLP, residual, the next
-//     layers' first edge Linear) is one launch (k_node).
+//   * the whole row-local node chain (neighbour-sum reduction, node MLP, residual, the next layers' first edge Linear) is
+//     one launch in every mode (k_node for the bf16 splits, k_node_f32).
 // Files: common.hpp (types, helpers, RNG), k_node.hpp, k_edge.hpp, k_edge_bwd.hpp (training: backward of an edge layer),
-// k_sampling.hpp (output stage, posterior step, decode, noise), k_egcl.hpp (stage-2 layer E_GCL, forward).  (The slower one-wave-per-SIMD edge-kernel experiment of round 1 lives in scratch/experiments/.)
+// k_sampling.hpp (output stage, posterior step, decode, noise), k_egcl.hpp (stage-2 layer E_GCL, forward).  (The one-wave-per-SIMD edge-kernel experiments live in scratch/experiments/.)
 #pragma once
 #include "common.hpp"
 #include "k_node.hpp"
