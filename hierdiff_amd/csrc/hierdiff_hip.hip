@@ -35,8 +35,12 @@ static int fail(int code, const std::string& msg) {
 
 // ----------------------------------------------------------------------------- objects
 
+// fp32 mode: batches with fewer active rows than this run the node side as k_agg + 3 x k_gemm instead of the fused k_node_f32
+#define HD_FUSE_MIN_ROWS 6144
+
 struct LayerW {                 // float offsets into hd_handle::dw
     size_t ab_img, ab_bias, wrd, w2_img, b2, wa, w3_img, b3, w4_img, b4;
+    size_t ab_gimg, w3_gimg, w4_gimg;      // fp32 mode: the same weights as k_gemm images (node chain of small batches)
     float ba;
 };
 
@@ -45,7 +49,7 @@ struct ProfRec { int fam; hipEvent_t a, b; };
 struct hd_handle {
     hd_config cfg;
     int device;
-    int H, fin, F, D;
+    int H, fin, F, D, NS;       // NS: 32-column sub-tiles per k_gemm workgroup tile
     bool x6;                    // bf16x6: the edge kernels contract on six bf16 MFMAs per product (H >= 128; below that
                                 // the mode runs the exact-fp32 kernels), everything else is the fp32 path
     long long n_weights;
@@ -111,7 +115,7 @@ struct hd_topology {
     uint8_t *eseg, *nm_bytes;
     float* nmask;
     // workspace
-    float *hbuf, *AB, *AB2, *x0, *xcur, *part, *xpart, *eps;
+    float *hbuf, *AB, *AB2, *Tb, *agg, *x0, *xcur, *part, *xpart, *eps;
     // hd_sample_loop with use_graph: the captured step works on library-owned copies of z / context so that the
     // instantiated graph survives across calls (the caller's tensors move); one graph per topology
     float *zbuf, *ctxbuf;
@@ -186,6 +190,7 @@ extern "C" int hd_create(const hd_config* cfg, int device, hd_handle** out) {
     h->F = F;
     h->D = 3 + F;
     h->x6 = cfg->precision == 2 && cfg->hidden_nf >= 128;
+    h->NS = (cfg->hidden_nf == 32) ? 1 : 2;
     h->n_weights = weight_count(*cfg);
     h->weights_set = false;
     h->dw = nullptr;
@@ -400,11 +405,15 @@ extern "C" int hd_set_weights(hd_handle* h, const float* blob, long long n, int 
             w.ab_img = take((size_t)H * 2 * H * gx / 2); w.ab_bias = take(2 * H); w.wrd = take(2 * H);
             w.w2_img = take(w2_floats); w.b2 = take(H); w.wa = take(H);
             w.w3_img = take((size_t)2 * H * H * gx / 2); w.b3 = take(H); w.w4_img = take((size_t)H * H * gx / 2); w.b4 = take(H);
+            w.ab_gimg = w.w3_gimg = w.w4_gimg = 0;
+            if (nodef32) { w.ab_gimg = take((size_t)H * 2 * H); w.w3_gimg = take((size_t)2 * H * H); w.w4_gimg = take((size_t)H * H); }
         }
         LayerW& w = h->coord[i];
         w.ab_img = take((size_t)H * 2 * H * gx / 2); w.ab_bias = take(2 * H); w.wrd = take(2 * H);
         w.w2_img = take(w2_floats); w.b2 = take(H); w.wa = take(H);
         w.w3_img = w.b3 = w.w4_img = w.b4 = 0;
+        w.ab_gimg = w.w3_gimg = w.w4_gimg = 0;
+        if (nodef32) w.ab_gimg = take((size_t)H * 2 * H);
     }
     std::vector<float> pk(off, 0.0f);
     // walk the canonical blob
@@ -432,7 +441,7 @@ extern "C" int hd_set_weights(hd_handle* h, const float* blob, long long n, int 
         auto wab = [&](int col, int k) {
             return sc((col < H) ? W1[(size_t)col * ld + k] : W1[(size_t)(col - H) * ld + H + k]);
         };
-        if (nodef32) pack_node_b_f32(pk, w.ab_img, H, 2 * H, wab);
+        if (nodef32) { pack_node_b_f32(pk, w.ab_img, H, 2 * H, wab); pack_gemm_b(pk, w.ab_gimg, H, 2 * H, h->NS, wab); }
         else pack_node_b(pk, w.ab_img, H, 2 * H, wab, NPc);
         for (int k = 0; k < H; ++k) {
             pk[w.ab_bias + k] = sc(b1[k]);
@@ -458,6 +467,8 @@ extern "C" int hd_set_weights(hd_handle* h, const float* blob, long long n, int 
             if (nodef32) {
                 pack_node_b_f32(pk, w.w3_img, 2 * H, H, w3);
                 pack_node_b_f32(pk, w.w4_img, H, H, w4);
+                pack_gemm_b(pk, w.w3_gimg, 2 * H, H, h->NS, w3);
+                pack_gemm_b(pk, w.w4_gimg, H, H, h->NS, w4);
             } else {
                 pack_node_b(pk, w.w3_img, 2 * H, H, w3, NPc);
                 pack_node_b(pk, w.w4_img, H, H, w4, NPc);
@@ -507,7 +518,7 @@ extern "C" int hd_topology_destroy(hd_topology* t) {
     if (t->gexec) hipGraphExecDestroy(t->gexec);
     hipFree(t->node_of); hipFree(t->slot_of); hipFree(t->ei); hipFree(t->ej); hipFree(t->seg_part);
     hipFree(t->tile_nseg); hipFree(t->pstart); hipFree(t->nvalid); hipFree(t->eseg); hipFree(t->nm_bytes);
-    hipFree(t->nmask); hipFree(t->hbuf); hipFree(t->AB); hipFree(t->AB2); hipFree(t->x0); hipFree(t->xcur);
+    hipFree(t->nmask); hipFree(t->hbuf); hipFree(t->AB); hipFree(t->AB2); hipFree(t->Tb); hipFree(t->agg); hipFree(t->x0); hipFree(t->xcur);
     hipFree(t->part); hipFree(t->xpart); hipFree(t->eps); hipFree(t->zbuf); hipFree(t->ctxbuf);
     hipFree(t->rptr); hipFree(t->rrows); hipFree(t->sptr); hipFree(t->srows); hipFree(t->w2img); hipFree(t->w2timg);
     delete t->node_of_host;
@@ -701,6 +712,7 @@ extern "C" int hd_topology_create(hd_handle* h, const uint8_t* node_mask, const 
         };
         HD_TRY(zalloc(&t->hbuf, (size_t)M_pad * H)); HD_TRY(zalloc(&t->AB, (size_t)M_pad * 2 * H));
         HD_TRY(zalloc(&t->AB2, (size_t)M_pad * 2 * H));
+        HD_TRY(zalloc(&t->Tb, (size_t)M_pad * H)); HD_TRY(zalloc(&t->agg, (size_t)M_pad * H));      // small-batch fp32 node chain
         HD_TRY(zalloc(&t->x0, (size_t)M_pad * 4)); HD_TRY(zalloc(&t->xcur, (size_t)M_pad * 4));
         HD_TRY(zalloc(&t->part, (size_t)std::max(1, n_parts) * H)); HD_TRY(zalloc(&t->xpart, (size_t)std::max(1, n_parts) * 4));
         HD_TRY(zalloc(&t->eps, BN * h->D)); HD_TRY(zalloc(&t->zbuf, BN * h->D));
@@ -780,6 +792,15 @@ static void launch_gemm(int epi, bool cat, const GemmArgs& g, hipStream_t s) {
     else if (epi == EPI_BIAS_SILU) hipLaunchKernelGGL((k_gemm<WM, WN, CN, EPI_BIAS_SILU, false>), grid, block, 0, s, g);
     else if (epi == EPI_BIAS) hipLaunchKernelGGL((k_gemm<WM, WN, CN, EPI_BIAS, false>), grid, block, 0, s, g);
     else hipLaunchKernelGGL((k_gemm<WM, WN, CN, EPI_RESID_MASK, false>), grid, block, 0, s, g);
+}
+
+// Node-GEMM tile shape per hidden size: (waves M, waves N, accumulators per wave); the weight images are
+// packed for the matching number of 32-column sub-tiles NS = WN*CN.
+static void gemm(hd_handle* h, int epi, bool cat, const GemmArgs& g, hipStream_t s) {
+    ProfScope ps(h, s, 1);
+
+    if (h->NS == 1) launch_gemm<4, 1, 1>(epi, cat, g, s);        // H = 32: 128 x 32 tiles
+    else launch_gemm<2, 2, 1>(epi, cat, g, s);                   // 64 x 64 tiles (fastest measured)
 }
 
 // Fused node update (bf16x3 only): min(4, H/32) wavefronts per 32-row workgroup.
@@ -1006,7 +1027,12 @@ static int forward_impl(hd_handle* h, hd_topology* t, const float* xh, const flo
         auto set_ab = [&](NodeArgs& a, int q, const LayerW& nw, float* dst) {
             a.ABimg[q] = W + nw.ab_img; a.ABbias[q] = W + nw.ab_bias; a.ABout[q] = dst;
         };
-        {
+        // fp32 mode, few rows: the fused kernel's serial chain per 32-row workgroup (~50 us) is not hidden by other workgroups
+        // (60 of them at B = 64), the k_agg + 3 x k_gemm chain spreads the same work over 64 x 64 tiles.  Both paths are
+        // bit-identical (same MFMA order per output element, bias added after the contraction), so a sample's bits do
+        // not depend on which one its batch size selects (test_fp32_node_paths_agree_bitwise).
+        const bool fused = c.precision == 1 || h->x6 || M >= HD_FUSE_MIN_ROWS;
+        if (fused) {
             NodeArgs a = node_args();
             set_ab(a, 0, h->gcl[0], t->AB);
             node_update(h, false, 1, a, s);
@@ -1015,6 +1041,13 @@ static int forward_impl(hd_handle* h, hd_topology* t, const float* xh, const flo
             for (int j = 0; j <= c.inv_sublayers; ++j) {
                 const bool coord = (j == c.inv_sublayers);
                 const LayerW& w = coord ? h->coord[i] : h->gcl[(size_t)i * c.inv_sublayers + j];
+                if (!fused) {
+                    GemmArgs g;
+                    std::memset(&g, 0, sizeof(g));
+                    g.A = t->hbuf; g.lda = H; g.K1 = H; g.K = H; g.Bimg = W + w.ab_gimg; g.bias = W + w.ab_bias;
+                    g.C = t->AB; g.ldc = 2 * H; g.M = M; g.Nc = 2 * H; g.nmask = t->nmask;
+                    gemm(h, EPI_BIAS, false, g, s);
+                }
                 EdgeArgs e;
                 std::memset(&e, 0, sizeof(e));
                 e.AB = ab_cur; e.wrd = W + w.wrd; e.W2img = W + w.w2_img; e.b2 = W + w.b2; e.wa = W + w.wa;
@@ -1023,7 +1056,7 @@ static int forward_impl(hd_handle* h, hd_topology* t, const float* xh, const flo
                 e.norm_constant = c.norm_constant; e.coords_range = range; e.attention = c.attention;
                 e.use_tanh = c.tanh; e.n_tiles = t->n_tiles; e.n_wg = t->n_wg;
                 HD_TRY(edge(h, coord, e, s));
-                if (!coord) {
+                if (!coord && fused) {
                     NodeArgs a = node_args();
                     a.W3img = W + w.w3_img; a.b3 = W + w.b3; a.W4img = W + w.w4_img; a.b4 = W + w.b4;
                     int nab = 1;
@@ -1035,13 +1068,33 @@ static int forward_impl(hd_handle* h, hd_topology* t, const float* xh, const flo
                     }
                     node_update(h, true, nab, a, s);
                     ab_cur = t->AB;
+                } else if (!coord) {
+                    GemmArgs g1;
+                    std::memset(&g1, 0, sizeof(g1));
+                    {
+                        ProfScope ps(h, s, 2);
+                        AggArgs ag;
+                        ag.part = t->part; ag.pstart = t->pstart; ag.agg = t->agg; ag.norm = c.normalization_factor;
+                        ag.M = M; ag.H = H;
+                        const long long total = (long long)M * (H / 4);
+                        hipLaunchKernelGGL(k_agg, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ag);
+                    }
+                    g1.A = t->hbuf; g1.lda = H; g1.K1 = H; g1.K = 2 * H; g1.A2 = t->agg;
+                    g1.Bimg = W + w.w3_gimg; g1.bias = W + w.b3; g1.C = t->Tb;
+                    g1.ldc = H; g1.M = M; g1.Nc = H; g1.nmask = t->nmask;
+                    gemm(h, EPI_BIAS_SILU, true, g1, s);
+                    GemmArgs g2;
+                    std::memset(&g2, 0, sizeof(g2));
+                    g2.A = t->Tb; g2.lda = H; g2.K1 = H; g2.K = H; g2.Bimg = W + w.w4_gimg; g2.bias = W + w.b4;
+                    g2.C = t->hbuf; g2.ldc = H; g2.M = M; g2.Nc = H; g2.nmask = t->nmask;
+                    gemm(h, EPI_RESID_MASK, false, g2, s);
                 } else {
                     ProfScope ps(h, s, 2);
                     XupdArgs x;
                     x.part = t->xpart; x.pstart = t->pstart; x.nmask = t->nmask; x.xcur = t->xcur;
                     x.norm = c.normalization_factor; x.M = M;
                     hipLaunchKernelGGL(k_xupd, dim3((M + 255) / 256), dim3(256), 0, s, x);
-                    ab_cur = t->AB2;                        // next block's first GCL (written by the last node update)
+                    if (fused) ab_cur = t->AB2;             // next block's first GCL (written by the last node update)
                 }
             }
         }

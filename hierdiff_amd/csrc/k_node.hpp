@@ -675,21 +675,23 @@ __global__ __launch_bounds__(64 * NW, 1) void k_node_f32(NodeArgs a) {
     if constexpr (UPD) {
         // ---- phase 1: T = silu(X W3^T + b3)
         {
+            // accumulators start at zero and the bias is added after the contraction, like k_gemm's epilogue: together with the
+            // same MFMA order per output element this makes the fused kernel bit-identical to the k_agg + k_gemm chain
             f32x16 acc[CT];
 #pragma unroll
-            for (int c = 0; c < CT; ++c) {
-                const float b = a.b3[32 * (ct0 + c) + n];
+            for (int c = 0; c < CT; ++c)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[c][r] = b;
-            }
+                for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
             __syncthreads();                                         // X complete
             M2::prefetch(br2, W4l, ct0, 0);
             M1::run(acc, br1, X + n * LDX + 16 * hh, W3l, ct0, 0);
 #pragma unroll
-            for (int c = 0; c < CT; ++c)
+            for (int c = 0; c < CT; ++c) {
+                const float b = a.b3[32 * (ct0 + c) + n];
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    T[((r & 3) + 8 * (r >> 2) + 4 * hh) * LDH + 32 * (ct0 + c) + n] = silu_f(acc[c][r]);
+                    T[((r & 3) + 8 * (r >> 2) + 4 * hh) * LDH + 32 * (ct0 + c) + n] = silu_f(acc[c][r] + b);
+            }
         }
         __syncthreads();
         // ---- phase 2: h' = (h + T W4^T + b4) * mask
@@ -699,24 +701,24 @@ __global__ __launch_bounds__(64 * NW, 1) void k_node_f32(NodeArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) mk[r] = a.nmask[row0 + (r & 3) + 8 * (r >> 2) + 4 * hh];
 #pragma unroll
-            for (int c = 0; c < CT; ++c) {
-                const float b = a.b4[32 * (ct0 + c) + n];
+            for (int c = 0; c < CT; ++c)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    acc[c][r] = b;
+                    acc[c][r] = 0.f;
                     hres[c][r] = a.h_in[(size_t)(row0 + (r & 3) + 8 * (r >> 2) + 4 * hh) * H + 32 * (ct0 + c) + n];
                 }
-            }
             M3::prefetch(br3, AB0l, ct0, NCT);
             M2::run(acc, br2, T + n * LDH + 16 * hh, W4l, ct0, 0);
             // every wave is done reading X once it is past its own M1::run AND the barrier above: h' may overwrite region 0
 #pragma unroll
-            for (int c = 0; c < CT; ++c)
+            for (int c = 0; c < CT; ++c) {
+                const float b = a.b4[32 * (ct0 + c) + n];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int R = (r & 3) + 8 * (r >> 2) + 4 * hh;
-                    Nn[R * LDH + 32 * (ct0 + c) + n] = (hres[c][r] + acc[c][r]) * mk[r];
+                    Nn[R * LDH + 32 * (ct0 + c) + n] = (hres[c][r] + (acc[c][r] + b)) * mk[r];
                 }
+            }
         }
         __syncthreads();
         {
@@ -735,11 +737,9 @@ __global__ __launch_bounds__(64 * NW, 1) void k_node_f32(NodeArgs a) {
     for (int q = 0; q < NAB; ++q) {
         f32x16 acc[2 * CT];
 #pragma unroll
-        for (int c = 0; c < 2 * CT; ++c) {
-            const float b = a.ABbias[q][(c / CT) * H + 32 * (ct0 + c % CT) + n];
+        for (int c = 0; c < 2 * CT; ++c)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[c][r] = b;
-        }
+            for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
         const u32x4* ABl = reinterpret_cast<const u32x4*>(a.ABimg[q]) + lane;
         if (q > 0 || !UPD) {
             M3::prefetch(br3, ABl, ct0, NCT);
@@ -750,10 +750,12 @@ __global__ __launch_bounds__(64 * NW, 1) void k_node_f32(NodeArgs a) {
         for (int half = 0; half < 2; ++half) {
             if (half || q) __syncthreads();                 // previous staging tile fully stored
 #pragma unroll
-            for (int c = 0; c < CT; ++c)
+            for (int c = 0; c < CT; ++c) {
+                const float b = a.ABbias[q][half * H + 32 * (ct0 + c) + n];
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    T[((r & 3) + 8 * (r >> 2) + 4 * hh) * LDH + 32 * (ct0 + c) + n] = acc[half * CT + c][r];
+                    T[((r & 3) + 8 * (r >> 2) + 4 * hh) * LDH + 32 * (ct0 + c) + n] = acc[half * CT + c][r] + b;
+            }
             __syncthreads();
             constexpr int Q = H / 4, NPT = 32 * Q / NT;
 #pragma unroll

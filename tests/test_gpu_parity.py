@@ -235,6 +235,25 @@ def test_pocket_sized_graph_vs_oracle(precision):
     assert float((v - v[0:1]).abs().max()) < 1e-6
 
 
+def test_fp32_node_paths_agree_bitwise():
+    """fp32 mode runs the node side fused (k_node_f32) from 6,144 active rows on and as k_agg + 3 x k_gemm below (small
+    batches: 60 row tiles do not fill 256 CUs with a serial per-tile chain).  The two are bit-identical by construction
+    (same MFMA order per output element, bias added after the contraction), so a molecule's bits do not depend on the
+    size of the batch it is sampled in: 210 molecules (6,300 rows, fused) against their first 8 alone (240 rows, unfused)."""
+    from hierdiff_amd.weights import synthetic_state_dict
+    H, L, N = 64, 2, 30
+    sd_np = synthetic_state_dict(9, 0, H, L, 2, True, 515, 1.0)
+    dyn = build_dynamics(sd_np, H, L)
+    dyn.precision = "fp32"
+    xh, nm, em = orc.random_inputs([N] * 210, 8, 33)
+    xh, nm = xh.to(DEV), nm.to(DEV)
+    t = torch.linspace(0.05, 0.95, 210, device=DEV).view(-1, 1)
+    big = dyn._forward(t, xh, nm, None, None, None)
+    small = dyn._forward(t[:8], xh[:8], nm[:8], None, None, None)
+    assert torch.isfinite(big).all()
+    assert torch.equal(big[:8], small)
+
+
 def test_equivariance_permutation_padding_full_size():
     """Size-independent properties at the headline shape B=256, N=30, H=256, L=6."""
     from hierdiff_amd.weights import synthetic_state_dict
