@@ -10,6 +10,8 @@ m = DiffusionQM9(default_config(hidden_nf=256, n_layers=6, timesteps=T))
 sd = synthetic_state_dict(9, 0, 256, 6, 2, True, 0, 1.0)
 m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
 m = m.to(DEV)
+m.dynamics.precision = sys.argv[2] if len(sys.argv) > 2 else "fp32"
+print("precision", m.dynamics.precision)
 nm = torch.ones(256, 30, 1, dtype=torch.bool, device=DEV)
 outs = []
 for rep in range(4):
