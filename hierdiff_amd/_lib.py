@@ -55,7 +55,7 @@ SIGNATURES = {
                                  C.c_uint64, C.c_uint64, C.c_int, _VP]),
     "hd_topology_nodes": (C.c_int, [_VP, _VP]),
     "hd_edge_layer_forward": (C.c_int, [_VP, _VP, C.c_int] + [_FP] * 9 + [_VP]),
-    "hd_edge_layer_backward": (C.c_int, [_VP, _VP, C.c_int] + [_FP] * 18 + [_VP]),
+    "hd_edge_layer_backward": (C.c_int, [_VP, _VP, C.c_int] + [_FP] * 20 + [_VP]),
     "hd_egcl_create": (C.c_int, [C.POINTER(HdEgclConfig), C.c_int, C.POINTER(_VP)]),
     "hd_egcl_destroy": (C.c_int, [_VP]),
     "hd_egcl_weight_count": (C.c_longlong, [_VP]),
@@ -69,7 +69,7 @@ SIGNATURES = {
     "hd_debug_edge_trace": (C.c_int, [_VP, C.c_void_p, C.c_int]),
 }
 
-ABI_VERSION = 2          # HD_ABI_VERSION of include/hierdiff_hip.h
+ABI_VERSION = 3          # HD_ABI_VERSION of include/hierdiff_hip.h
 _lib: Optional[C.CDLL] = None
 
 

@@ -1153,7 +1153,7 @@ extern "C" int hd_topology_nodes(const hd_topology* t, int* node_of) {
 }
 
 template <int H>
-static int edge_bwd_lds_bytes() { return (32 * H + 4 * 288) * 4; }
+static int edge_bwd_lds_bytes() { return (2 * 32 * H + 4 * 288) * 4; }      // two weight chunks + per-wave scratch
 
 template <int H>
 static int prepare_edge_bwd_h() {
@@ -1224,29 +1224,33 @@ extern "C" int hd_edge_layer_forward(hd_handle* h, hd_topology* t, int coord, co
 extern "C" int hd_edge_layer_backward(hd_handle* h, hd_topology* t, int coord, const float* AB, const float* x,
                                       const float* x0, const float* wrd, const float* W2, const float* b2,
                                       const float* wa, const float* ba, const float* gout, float* G2, float* P, float* G1,
-                                      float* escal, float* colpart, float* bapart, float* dAB, float* dx, float* dx0,
-                                      void* stream) {
+                                      float* escal, float* colpart, float* bapart, float* b2part, float* wrdpart,
+                                      float* dAB, float* dx, float* dx0, void* stream) {
     HD_TRY(check_train(h, t, "hd_edge_layer_backward"));
     if (!AB || !x || !x0 || !wrd || !W2 || !b2 || !wa || !gout || !G2 || !P || !G1 || !escal || !colpart || !bapart ||
-        !dAB || !dx || !dx0)
+        !b2part || !wrdpart || !dAB || !dx || !dx0)
         return fail(HD_E_INVALID, "hd_edge_layer_backward: null tensor");
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
     const hd_config& c = h->cfg;
     const int H = h->H, M = t->M;
-    HIP_TRY(hipMemsetAsync(dAB, 0, (size_t)std::max(1, M) * 2 * H * sizeof(float), s));
-    HIP_TRY(hipMemsetAsync(dx, 0, (size_t)std::max(1, M) * 4 * sizeof(float), s));
-    HIP_TRY(hipMemsetAsync(dx0, 0, (size_t)std::max(1, M) * 4 * sizeof(float), s));
     const int tiles = std::max(1, t->n_wg * 4);
-    HIP_TRY(hipMemsetAsync(escal, 0, (size_t)tiles * 32 * 8 * sizeof(float), s));
     if (t->n_wg == 0 || M == 0) {
+        HIP_TRY(hipMemsetAsync(dAB, 0, (size_t)std::max(1, M) * 2 * H * sizeof(float), s));
+        HIP_TRY(hipMemsetAsync(dx, 0, (size_t)std::max(1, M) * 4 * sizeof(float), s));
+        HIP_TRY(hipMemsetAsync(dx0, 0, (size_t)std::max(1, M) * 4 * sizeof(float), s));
+        HIP_TRY(hipMemsetAsync(escal, 0, (size_t)tiles * 32 * 8 * sizeof(float), s));
         HIP_TRY(hipMemsetAsync(colpart, 0, (size_t)tiles * H * sizeof(float), s));
         HIP_TRY(hipMemsetAsync(bapart, 0, (size_t)tiles * sizeof(float), s));
+        HIP_TRY(hipMemsetAsync(b2part, 0, (size_t)tiles * H * sizeof(float), s));
+        HIP_TRY(hipMemsetAsync(wrdpart, 0, (size_t)tiles * 2 * H * sizeof(float), s));
         HIP_TRY(hipMemsetAsync(G2, 0, (size_t)tiles * 32 * H * sizeof(float), s));
         HIP_TRY(hipMemsetAsync(P, 0, (size_t)tiles * 32 * H * sizeof(float), s));
         HIP_TRY(hipMemsetAsync(G1, 0, (size_t)tiles * 32 * H * sizeof(float), s));
         return HD_OK;
     }
+    // every output row is written by the kernels below (all tiles of the padded table exist; the CSR sums and k_edge_dx
+    // cover every active node), so nothing is cleared first; escal[:, 0:4] is only defined (and only read) in coordinate layers
     if (coord) HIP_TRY(hipMemsetAsync(bapart, 0, (size_t)tiles * sizeof(float), s));     // no attention bias in a coordinate layer
     hipLaunchKernelGGL((k_pack_w2<false>), dim3((H * H + 255) / 256), dim3(256), 0, s, W2, t->w2img, H);
     hipLaunchKernelGGL((k_pack_w2<true>), dim3((H * H + 255) / 256), dim3(256), 0, s, W2, t->w2timg, H);
@@ -1256,6 +1260,7 @@ extern "C" int hd_edge_layer_backward(hd_handle* h, hd_topology* t, int coord, c
     a.ba_ptr = ba; a.norm_constant = c.norm_constant; a.coords_range = c.coords_range / (float)c.n_layers;
     a.inv_norm = 1.0f / c.normalization_factor; a.attention = c.attention; a.use_tanh = c.tanh; a.n_tiles = t->n_tiles;
     a.gin = gout; a.G2 = G2; a.escal = escal; a.colpart = colpart; a.bapart = bapart; a.Pout = P; a.G1 = G1;
+    a.b2part = b2part; a.wrdpart = wrdpart;
     a.Wimg = t->w2img;
     launch_edge_bwd(h, coord != 0, 0, a, t->n_wg, s);
     a.Wimg = t->w2timg;

@@ -12,7 +12,11 @@
 // followed by two deterministic CSR reductions (rows by receiving node -> dA, rows by sending node -> dB) and a per-node
 // coordinate-gradient kernel.  The dense reductions over all edges (dW2 = G2^T P, db2, d(w_r), d(w_d)) are plain GEMMs on the
 // materialised [E_pad][H] operands and are left to the BLAS library by the host (hierdiff_amd/training.py).
-// These kernels favour clarity over speed (one LDS buffer, two barriers per K chunk): training is not the headline path.
+// The weight chunks are double-buffered in LDS (one barrier per K chunk; the next chunk's stream and the next operand's
+// row gathers are in flight under the current chunk's MFMAs) and the kernels are held to 256 registers, so two workgroups
+// share a CU and one wavefront's epilogue runs under the other's matrix work (the fp32 MFMA hides nothing inside a wavefront,
+// DESIGN.md section 4).  The column reductions that need no second pass over the materialised operands - db2 = colsum(G2),
+// d(w_r), d(w_d) = {radial, d0}^T G1 - leave the kernels as per-tile partial sums (b2part, wrdpart).
 #pragma once
 #include "common.hpp"
 
@@ -34,12 +38,14 @@ struct EdgeBwdArgs {
     // stage A
     const float* gin;       // GCL: d(agg) [M_pad][H];  COORD: d(xagg) [M_pad][4]
     float* G2;              // [E_pad][H]
-    float* escal;           // [E_pad][8]: {du_x, du_y, du_z, dphi, d(radial), d(d0), radial, d0}
+    float* escal;           // [E_pad][8]: {du_x, du_y, du_z, dphi, d(radial), d(d0), -, -}
     float* colpart;         // [tiles][H] per-tile partial of d(wa) / d(w7)
     float* bapart;          // [tiles]    per-tile partial of d(ba)
+    float* b2part;          // [tiles][H] per-tile column sums of G2 (d(b2))
     // stage B
     float* Pout;            // [E_pad][H]
     float* G1;              // [E_pad][H]
+    float* wrdpart;         // [tiles][2][H] per-tile sum_r radial_r G1[r][:], sum_r d0_r G1[r][:]   (d(w_r), d(w_d))
 };
 
 // sigmoid and the SiLU derivative from it: silu'(x) = s (1 + x (1 - s))
@@ -47,11 +53,11 @@ HD_DEVINL float dsilu_from_sigmoid(float x, float s) { return s * __builtin_fmaf
 
 // STAGE 0 = A, 1 = B.  One workgroup = four 32-row tiles (one per wavefront), grid = tiles / 4.
 template <int H, bool COORD, int STAGE>
-__global__ __launch_bounds__(256) void k_edge_bwd(EdgeBwdArgs a) {
+__global__ __launch_bounds__(256, 2) void k_edge_bwd(EdgeBwdArgs a) {
     constexpr int NCT = H / 32, NCH = H / 32, CHF = 32 * H;
     extern __shared__ __attribute__((aligned(16))) float smem_b[];
-    float* wbuf = smem_b;                        // [CHF] one K chunk of the weight image
-    float* scr = smem_b + CHF;                   // per wave: 32 phi + 96 unit dir + 32 ni + 32 nj + 32 radial + 32 d0 + 32 valid
+    float* wbuf0 = smem_b;                       // [2][CHF] two K chunks of the weight image (double buffer)
+    float* scr = smem_b + 2 * CHF;               // per wave: 32 phi + 96 unit dir + 32 ni + 32 nj + 32 radial + 32 d0 + 32 valid
     __shared__ __attribute__((aligned(16))) float wrd_s[4 * H];    // [w_r | w_d | b2 | wa]
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -89,34 +95,55 @@ __global__ __launch_bounds__(256) void k_edge_bwd(EdgeBwdArgs a) {
         }
     }
 
-    // A operand of K chunk c for this lane's edge row (k = 32c + 16hh + 0..15)
+    // A operand of K chunk c for this lane's edge row (k = 32c + 16hh + 0..15).  The raw rows are requested one chunk ahead
+    // (load_raw, in flight under the MFMAs of the current chunk) and finished behind them (finish_P: first-layer
+    // pre-activation + SiLU; stage B: the G2 row as it is).
     const float* Arow = a.AB + (size_t)ni * (2 * H) + 16 * hh;
     const float* Brow = a.AB + (size_t)nj * (2 * H) + H + 16 * hh;
     const float* Grow = a.G2 + (size_t)e * H + 16 * hh;
-    auto make_P = [&](int c, float (&P)[16]) {
+    struct Raw { f32x4 a[4]; f32x4 b[4]; };
+    auto load_raw = [&](int c, Raw& w) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             if constexpr (STAGE == 0) {
-                const f32x4 av = *reinterpret_cast<const f32x4*>(Arow + 32 * c + 4 * u);
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(Brow + 32 * c + 4 * u);
+                w.a[u] = *reinterpret_cast<const f32x4*>(Arow + 32 * c + 4 * u);
+                w.b[u] = *reinterpret_cast<const f32x4*>(Brow + 32 * c + 4 * u);
+            } else {
+                w.a[u] = *reinterpret_cast<const f32x4*>(Grow + 32 * c + 4 * u);
+            }
+        }
+    };
+    auto finish_P = [&](int c, const Raw& w, float (&P)[16]) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if constexpr (STAGE == 0) {
                 const f32x4 wr4 = *reinterpret_cast<const f32x4*>(wrd_s + 32 * c + 16 * hh + 4 * u);
                 const f32x4 wd4 = *reinterpret_cast<const f32x4*>(wrd_s + H + 32 * c + 16 * hh + 4 * u);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    float pre = av[j] + bv[j];                       // same operation order as the forward kernel
+                    float pre = w.a[u][j] + w.b[u][j];               // same operation order as the forward kernel
                     pre = __builtin_fmaf(radial, wr4[j], pre);
                     pre = __builtin_fmaf(d0, wd4[j], pre);
                     P[4 * u + j] = silu_f(pre);
                 }
             } else {
-                const f32x4 gv = *reinterpret_cast<const f32x4*>(Grow + 32 * c + 4 * u);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) P[4 * u + j] = gv[j];
+                for (int j = 0; j < 4; ++j) P[4 * u + j] = w.a[u][j];
             }
         }
     };
+    auto issue_chunk = [&](int c) {                              // 1 KiB per wave-instruction, lane-linear image
+        const float* src = a.Wimg + (size_t)c * CHF;
+        float* dst = wbuf0 + (c & 1) * CHF;
+        for (int k = tid * 4; k < CHF; k += 256 * 4) glds16(src + k, dst + (k - lane * 4));
+    };
 
+    issue_chunk(0);
     __syncthreads();                                             // wrd_s staged
+    float P[16];
+    Raw raw;
+    load_raw(0, raw);
+    finish_P(0, raw, P);
     f32x16 acc[NCT];
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {
@@ -126,26 +153,35 @@ __global__ __launch_bounds__(256) void k_edge_bwd(EdgeBwdArgs a) {
     }
 #pragma unroll 1
     for (int c = 0; c < NCH; ++c) {
-        __syncthreads();                                         // every wave is done with the previous chunk
-        {
-            const float* src = a.Wimg + (size_t)c * CHF;
-            for (int k = tid * 4; k < CHF; k += 256 * 4) glds16(src + k, wbuf + (k - lane * 4));   // 1 KiB per wave-instruction
-        }
-        float P[16];
-        make_P(c, P);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of the chunk have landed
-        __syncthreads();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of chunk c have landed
+        __syncthreads();                                         // chunk c is complete; nobody reads the other buffer any more
+        if (c + 1 < NCH) { issue_chunk(c + 1); load_raw(c + 1, raw); }
+        const float* wbuf = wbuf0 + (c & 1) * CHF;
+        // eight groups of (k-quad q, half of the column tiles); the B fragments of group g+1 are requested before the
+        // MFMAs of group g.  sched_barrier keeps hipcc from hoisting more fragment reads than that (it spills otherwise).
+        constexpr int GC = (NCT >= 2) ? NCT / 2 : 1, NG = 4 * (NCT / GC);
+        f32x4 bcur[GC], bnxt[GC];
+        auto load_b = [&](int g, f32x4 (&b)[GC]) {
+            const int q = g / (NCT / GC), c0 = (g % (NCT / GC)) * GC;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            f32x4 bv[NCT];
+            for (int k = 0; k < GC; ++k) b[k] = *reinterpret_cast<const f32x4*>(wbuf + ((q * NCT + c0 + k) * 64 + lane) * 4);
+        };
+        load_b(0, bcur);
 #pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) bv[ct] = *reinterpret_cast<const f32x4*>(wbuf + ((q * NCT + ct) * 64 + lane) * 4);
+        for (int g = 0; g < NG; ++g) {
+            const int q = g / (NCT / GC), c0 = (g % (NCT / GC)) * GC;
+            if (g + 1 < NG) load_b(g + 1, bnxt);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int ct = 0; ct < NCT; ++ct)
-                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(P[4 * q + j], bv[ct][j], acc[ct], 0, 0, 0);
+                for (int k = 0; k < GC; ++k)
+                    acc[c0 + k] = __builtin_amdgcn_mfma_f32_32x32x2f32(P[4 * q + j], bcur[k][j], acc[c0 + k], 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < GC; ++k) bcur[k] = bnxt[k];
+            __builtin_amdgcn_sched_barrier(0);
         }
+        if (c + 1 < NCH) finish_P(c + 1, raw, P);
+        __builtin_amdgcn_sched_barrier(0);
     }
 
     // acc[ct][r] = row rho(r) = (r&3) + 8*(r>>2) + 4*hh, column 32*ct + n.
@@ -166,30 +202,51 @@ __global__ __launch_bounds__(256) void k_edge_bwd(EdgeBwdArgs a) {
     const int my_rho = (my_slot & 3) + 8 * (my_slot >> 2) + 4 * hh;
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    int rho[16];
-    float vr[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { rho[r] = (r & 3) + 8 * (r >> 2) + 4 * hh; vr[r] = rval_s[rho[r]]; }
+    auto rho = [&](int r) { return (r & 3) + 8 * (r >> 2) + 4 * hh; };
+    // The epilogues walk the accumulators one column tile (or one row) at a time; what they gather from global memory for
+    // step k+1 is requested before the arithmetic of step k and sched_barrier(0) closes every step, so at most two steps'
+    // worth of gathered values are live (left alone hipcc hoists all 128-256 gathers to the top and spills).
 
     if constexpr (STAGE == 0) {
-        float colsum[NCT];
+        // per-tile partials of d(wa) / d(w7) and of d(b2): the two halves of the wavefront added, one row of H per tile
+        auto store_partials = [&](int ct, float cs, float bs) {
+            const float cst = cs + __shfl_xor(cs, 32), bst = bs + __shfl_xor(bs, 32);
+            if (hh == 0) {
+                a.colpart[(size_t)tile * H + 32 * ct + n] = cst;
+                a.b2part[(size_t)tile * H + 32 * ct + n] = bst;
+            }
+        };
         if constexpr (!COORD) {
-            int nir[16];
+            // incoming gradient of the neighbour sum at (row's receiving node, column): zero for padding rows
+            const float* gbase[16];
+            unsigned vmask = 0;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) nir[r] = rowi_s[rho[r]];
-            float dot[16], sd[16];
+            for (int r = 0; r < 16; ++r) {
+                gbase[r] = a.gin + (size_t)rowi_s[rho(r)] * H + n;
+                vmask |= (rval_s[rho(r)] != 0.0f) ? (1u << r) : 0u;
+            }
+            auto load_g = [&](int ct, float (&g)[16]) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) g[r] = gbase[r][32 * ct];
+            };
+            auto gval = [&](const float (&g)[16], int r) { return ((vmask >> r) & 1u) ? g[r] * a.inv_norm : 0.0f; };
+            float dot[16], sd[16], gc[16], gn[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) { dot[r] = 0.f; sd[r] = 0.f; }
+            load_g(0, gc);
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
+                if (ct + 1 < NCT) load_g(ct + 1, gn);
                 const float wav = wrd_s[3 * H + 32 * ct + n];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float m = silu_f(acc[ct][r]);
                     dot[r] = __builtin_fmaf(m, wav, dot[r]);
-                    const float g = vr[r] * a.gin[(size_t)nir[r] * H + 32 * ct + n] * a.inv_norm;
-                    sd[r] = __builtin_fmaf(m, g, sd[r]);
+                    sd[r] = __builtin_fmaf(m, gval(gc, r), sd[r]);
                 }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) gc[r] = gn[r];
+                __builtin_amdgcn_sched_barrier(0);
             }
             const float rowdot = row_reduce(dot), rowsd = row_reduce(sd);
             float att = 1.0f, q = 0.0f;
@@ -204,23 +261,33 @@ __global__ __launch_bounds__(256) void k_edge_bwd(EdgeBwdArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 attr[r] = __shfl(att, (lane & 32) | (2 * r));
-                qr[r] = __shfl(q, (lane & 32) | (2 * r)) * vr[r];
+                const float qv = __shfl(q, (lane & 32) | (2 * r));
+                qr[r] = ((vmask >> r) & 1u) ? qv : 0.0f;
             }
+            __builtin_amdgcn_sched_barrier(0);
+            load_g(0, gc);
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
+                if (ct + 1 < NCT) load_g(ct + 1, gn);
                 const float wav = wrd_s[3 * H + 32 * ct + n];
-                float cs = 0.f;
+                float* g2p = a.G2 + ((size_t)tile * 32 + 4 * hh) * H + 32 * ct + n;
+                float cs = 0.f, bs = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float x = acc[ct][r];
+                    float x = acc[ct][r];
+                    asm volatile("" : "+v"(x));        // opaque: hipcc otherwise keeps all 128 sigmoids of the first pass alive for this one (spills)
                     const float s = sigmoid_f(x);
                     const float m = x * s;
-                    const float g = vr[r] * a.gin[(size_t)nir[r] * H + 32 * ct + n] * a.inv_norm;
-                    const float dM = __builtin_fmaf(qr[r], wav, g * attr[r]);       // d(msg)*att + (d(msg).M) att(1-att) wa
-                    a.G2[((size_t)tile * 32 + rho[r]) * H + 32 * ct + n] = vr[r] * dM * dsilu_from_sigmoid(x, s);
+                    const float dM = __builtin_fmaf(qr[r], wav, gval(gc, r) * attr[r]);     // d(msg)*att + (d(msg).M) att(1-att) wa
+                    const float g2 = dM * dsilu_from_sigmoid(x, s);                          // zero for padding rows (g, qr)
+                    g2p[(size_t)((r & 3) + 8 * (r >> 2)) * H] = g2;
                     cs = __builtin_fmaf(qr[r], m, cs);
+                    bs += g2;
                 }
-                colsum[ct] = cs;
+                store_partials(ct, cs, bs);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) gc[r] = gn[r];
+                __builtin_amdgcn_sched_barrier(0);
             }
         } else {
             float dot[16];
@@ -231,6 +298,7 @@ __global__ __launch_bounds__(256) void k_edge_bwd(EdgeBwdArgs a) {
                 const float wav = wrd_s[3 * H + 32 * ct + n];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) dot[r] = __builtin_fmaf(silu_f(acc[ct][r]), wav, dot[r]);
+                __builtin_amdgcn_sched_barrier(0);
             }
             const float rowdot = row_reduce(dot);                     // phi of row rho(my_slot)
             if ((n & 1) == 0) phi_s[my_rho] = rowdot;
@@ -254,55 +322,82 @@ __global__ __launch_bounds__(256) void k_edge_bwd(EdgeBwdArgs a) {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             float dphir[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dphir[r] = phi_s[rho[r]];
+            for (int r = 0; r < 16; ++r) dphir[r] = phi_s[rho(r)];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
                 const float wav = wrd_s[3 * H + 32 * ct + n];
-                float cs = 0.f;
+                float* g2p = a.G2 + ((size_t)tile * 32 + 4 * hh) * H + 32 * ct + n;
+                float cs = 0.f, bs = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float x = acc[ct][r];
+                    float x = acc[ct][r];
+                    asm volatile("" : "+v"(x));        // opaque, as in the GCL variant
                     const float s = sigmoid_f(x);
-                    a.G2[((size_t)tile * 32 + rho[r]) * H + 32 * ct + n] = dphir[r] * wav * dsilu_from_sigmoid(x, s);
+                    const float g2 = dphir[r] * wav * dsilu_from_sigmoid(x, s);     // dphi is zero for padding rows
+                    g2p[(size_t)((r & 3) + 8 * (r >> 2)) * H] = g2;
                     cs = __builtin_fmaf(dphir[r], x * s, cs);
+                    bs += g2;
                 }
-                colsum[ct] = cs;
+                store_partials(ct, cs, bs);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
-        // per-tile partial of d(wa) / d(w7): add the two halves of the wavefront
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) {
-            const float tot = colsum[ct] + __shfl_xor(colsum[ct], 32);
-            if (hh == 0) a.colpart[(size_t)tile * H + 32 * ct + n] = tot;
-        }
     } else {
-        float drr[16], ddd[16];
+        // stage B: row by row (the two AB rows of an edge are gathered once per row, one row ahead); a row's two dots with
+        // w_r / w_d are reduced over its half-wave on the spot (keeping 2 x 16 running dots for a transposed reduction at
+        // the end costs the registers that make the difference between one and two wavefronts per SIMD)
+        float wrp[NCT], wdp[NCT];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { drr[r] = 0.f; ddd[r] = 0.f; }
+        for (int ct = 0; ct < NCT; ++ct) { wrp[ct] = 0.f; wdp[ct] = 0.f; }
+        auto load_ab = [&](int r, float (&ai)[NCT], float (&bj)[NCT]) {
+            const float* pa = a.AB + (size_t)rowi_s[rho(r)] * (2 * H) + n;
+            const float* pb = a.AB + (size_t)rowj_s[rho(r)] * (2 * H) + H + n;
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) { ai[ct] = pa[32 * ct]; bj[ct] = pb[32 * ct]; }
+        };
+        float aic[NCT], bjc[NCT], ain[NCT], bjn[NCT];
+        load_ab(0, aic, bjc);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int rni = rowi_s[rho[r]], rnj = rowj_s[rho[r]];
-            const float rad = rrad_s[rho[r]], dd0 = rd0_s[rho[r]];
-            const size_t orow = ((size_t)tile * 32 + rho[r]) * H;
+            if (r + 1 < 16) load_ab(r + 1, ain, bjn);
+            const float rad = rrad_s[rho(r)], dd0 = rd0_s[rho(r)], vrr = rval_s[rho(r)];
+            float* po = a.Pout + ((size_t)tile * 32 + rho(r)) * H + n;
+            float* go = a.G1 + ((size_t)tile * 32 + rho(r)) * H + n;
+            float dr = 0.f, dd = 0.f;
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
                 const int col = 32 * ct + n;
                 const float wr = wrd_s[col], wd = wrd_s[H + col];
-                float pre = a.AB[(size_t)rni * (2 * H) + col] + a.AB[(size_t)rnj * (2 * H) + H + col];
+                float pre = aic[ct] + bjc[ct];
                 pre = __builtin_fmaf(rad, wr, pre);
                 pre = __builtin_fmaf(dd0, wd, pre);
                 const float s = sigmoid_f(pre);
-                const float g1 = vr[r] * acc[ct][r] * dsilu_from_sigmoid(pre, s);
-                a.Pout[orow + col] = vr[r] * pre * s;
-                a.G1[orow + col] = g1;
-                drr[r] = __builtin_fmaf(g1, wr, drr[r]);
-                ddd[r] = __builtin_fmaf(g1, wd, ddd[r]);
+                const float g1 = vrr * acc[ct][r] * dsilu_from_sigmoid(pre, s);
+                po[32 * ct] = vrr * pre * s;
+                go[32 * ct] = g1;
+                dr = __builtin_fmaf(g1, wr, dr);
+                dd = __builtin_fmaf(g1, wd, dd);
+                wrp[ct] = __builtin_fmaf(g1, rad, wrp[ct]);
+                wdp[ct] = __builtin_fmaf(g1, dd0, wdp[ct]);
             }
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) { dr += __shfl_xor(dr, o); dd += __shfl_xor(dd, o); }
+            if (n == 0) {                                            // d(radial), d(d0) of row rho(r)
+                float* es = a.escal + ((size_t)tile * 32 + rho(r)) * 8;
+                es[4] = dr; es[5] = dd;
+            }
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) { aic[ct] = ain[ct]; bjc[ct] = bjn[ct]; }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        const float rowdr = row_reduce(drr), rowdd = row_reduce(ddd);
-        if ((n & 1) == 0) {
-            float* es = a.escal + ((size_t)tile * 32 + my_rho) * 8;
-            es[4] = rowdr; es[5] = rowdd; es[6] = rrad_s[my_rho]; es[7] = rd0_s[my_rho];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {                           // per-tile partials of d(w_r), d(w_d)
+            const float wrt = wrp[ct] + __shfl_xor(wrp[ct], 32), wdt = wdp[ct] + __shfl_xor(wdp[ct], 32);
+            if (hh == 0) {
+                a.wrdpart[((size_t)tile * 2) * H + 32 * ct + n] = wrt;
+                a.wrdpart[((size_t)tile * 2 + 1) * H + 32 * ct + n] = wdt;
+            }
         }
     }
 }

@@ -48,11 +48,21 @@ class _TrainTables:
         self.device = device
         self._ws = None
 
+    # dW2 = G2^T P is a GEMM whose contraction runs over every edge row (K = 223,232 at B=256, N=30 against a 256 x 256
+    # result): it is cut into SPLIT_K slabs (one batched GEMM + a sum over slabs) so that the BLAS library has SPLIT_K x
+    # the workgroups to fill the chip with.  The workspaces are rounded up to whole slabs; the rows behind the last tile
+    # are zeroed once here and never written by the kernels.
+    SPLIT_K = 32
+
     def workspace(self):
         if self._ws is None:
             z = lambda *s: torch.empty(s, device=self.device, dtype=torch.float32)
-            self._ws = dict(G2=z(self.rows, self.H), P=z(self.rows, self.H), G1=z(self.rows, self.H),
-                            escal=z(self.rows, 8), colpart=z(self.tiles, self.H), bapart=z(self.tiles))
+            slab = 128 * self.SPLIT_K
+            rows_pad = (self.rows + slab - 1) // slab * slab
+            big = lambda: torch.zeros((rows_pad, self.H), device=self.device, dtype=torch.float32)
+            self._ws = dict(G2=big(), P=big(), G1=z(self.rows, self.H),
+                            escal=z(self.rows, 8), colpart=z(self.tiles, self.H), bapart=z(self.tiles),
+                            b2part=z(self.tiles, self.H), wrdpart=z(self.tiles, 2, self.H))
         return self._ws
 
 
@@ -92,8 +102,10 @@ class _EdgeLayer(torch.autograd.Function):
         ws = tr.workspace()
         dev = AB.device
         M = max(1, tr.M)
-        g = torch.zeros((M, gout.shape[1]), device=dev, dtype=torch.float32)
-        g[:tr.M] = gout
+        if tr.M == M:
+            g = gout.contiguous()
+        else:
+            g = torch.zeros((M, gout.shape[1]), device=dev, dtype=torch.float32)
         dAB = torch.empty((M, 2 * tr.H), device=dev, dtype=torch.float32)
         dx = torch.empty((M, 4), device=dev, dtype=torch.float32)
         dx0 = torch.empty((M, 4), device=dev, dtype=torch.float32)
@@ -101,11 +113,14 @@ class _EdgeLayer(torch.autograd.Function):
             dyn._handle(), topo.ptr, int(coord), AB.data_ptr(), x4.data_ptr(), x04.data_ptr(), wrd.data_ptr(), W2.data_ptr(),
             b2.data_ptr(), wa.data_ptr(), None if ba is None else ba.data_ptr(), g.data_ptr(), ws["G2"].data_ptr(),
             ws["P"].data_ptr(), ws["G1"].data_ptr(), ws["escal"].data_ptr(), ws["colpart"].data_ptr(), ws["bapart"].data_ptr(),
-            dAB.data_ptr(), dx.data_ptr(), dx0.data_ptr(), _stream(dev)), "hd_edge_layer_backward")
-        # dense reductions over all edge rows: plain library GEMMs on the materialised operands
-        dW2 = ws["G2"].t() @ ws["P"]                           # [H, H]: dL/dW2[c][k] = sum_e G2[e][c] P[e][k]
-        db2 = ws["G2"].sum(0)
-        dwrd = ws["escal"][:, 6:8].t() @ ws["G1"]              # [2, H]: sum_e {radial, d0}_e G1[e][:]
+            ws["b2part"].data_ptr(), ws["wrdpart"].data_ptr(), dAB.data_ptr(), dx.data_ptr(), dx0.data_ptr(), _stream(dev)),
+            "hd_edge_layer_backward")
+        # the one dense reduction over all edge rows: dL/dW2[c][k] = sum_e G2[e][c] P[e][k], split-K through the BLAS library
+        S = tr.SPLIT_K
+        dW2 = torch.bmm(ws["G2"].view(S, -1, tr.H).transpose(1, 2), ws["P"].view(S, -1, tr.H)).sum(0)      # [H, H]
+        # everything else left the kernels as per-tile partial sums
+        db2 = ws["b2part"].sum(0)
+        dwrd = ws["wrdpart"].sum(0)                            # [2, H]: sum_e {radial, d0}_e G1[e][:]
         dwa = ws["colpart"].sum(0)
         dba = ws["bapart"].sum().view(1) if has_ba else None
         return (None, None, None, None, dAB[:tr.M], dx[:tr.M], dx0[:tr.M], dwrd, dW2, db2, dwa, dba)

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define HD_ABI_VERSION 2
+#define HD_ABI_VERSION 3
 
 #define HD_OK 0
 #define HD_E_INVALID (-1)      /* bad argument / unsupported configuration */
@@ -184,15 +184,18 @@ int hd_edge_layer_forward(hd_handle* h, hd_topology* topo, int coord, const floa
                           const float* x0, const float* wrd, const float* W2, const float* b2, const float* wa,
                           const float* ba, float* out, void* stream);
 /* Backward of hd_edge_layer_forward given gout = dL/d(out).  Per-edge activations are recomputed; the caller provides
- * workspaces G2, P, G1 [rows][H], escal [rows][8], colpart [tiles][H], bapart [tiles] (rows / tiles from
- * hd_topology_layout's counts).  Written: dAB [M][2H], dx, dx0 [M][4] and, for the caller's dense reductions,
- *     G2 = dL/d(W2 P + b2),  P,  G1 = dL/d(pre1)        =>  dW2 = G2^T P,  db2 = colsum(G2),
- *     escal[:, 6:8] = {radial, d0}                      =>  d(wrd) = escal[:, 6:8]^T G1,
- *     colpart, bapart                                   =>  d(wa) = colsum(colpart),  d(ba) = sum(bapart). */
+ * workspaces G2, P, G1 [rows][H], escal [rows][8], colpart, b2part [tiles][H], wrdpart [tiles][2][H], bapart [tiles]
+ * (rows / tiles from hd_topology_layout's counts, tiles rounded up to a multiple of 4).  Written: dAB [M][2H],
+ * dx, dx0 [M][4] and, for the caller's reductions over all edge rows,
+ *     G2 = dL/d(W2 P + b2),  P                          =>  dW2 = G2^T P              (one dense GEMM, K = rows),
+ *     per-tile partial sums                             =>  db2 = colsum(b2part),  d(wa) = colsum(colpart),
+ *                                                           d(ba) = sum(bapart),
+ *                                                           d(w_r), d(w_d) = colsum(wrdpart[:, 0]), colsum(wrdpart[:, 1]);
+ * G1 = dL/d(pre1) is the operand of the two CSR sums behind dAB and is left in the workspace. */
 int hd_edge_layer_backward(hd_handle* h, hd_topology* topo, int coord, const float* AB, const float* x,
                            const float* x0, const float* wrd, const float* W2, const float* b2, const float* wa,
                            const float* ba, const float* gout, float* G2, float* P, float* G1, float* escal, float* colpart,
-                           float* bapart, float* dAB, float* dx, float* dx0, void* stream);
+                           float* bapart, float* b2part, float* wrdpart, float* dAB, float* dx, float* dx0, void* stream);
 
 /* ---- Stage-2 layer: E_GCL forward (/root/reference/models/egnn/gcl.py:9-205), exact fp32.
  * The layer of the edge-denoise / refine models: messages from [h_row; h_col; radial; edge_attr; context], optional
