@@ -269,6 +269,82 @@ def other_configs(args, dev) -> dict:
     return out
 
 
+def next_rows(dev) -> dict:
+    """Timings of the rows behind the hot path: one training step of the same EGNN (row 2: loss
+    forward + backward through the HIP edge-layer kernels + AdamW, exact fp32, synthetic batch) and one stage-2 E_GCL
+    layer forward on a beam-sized dense batch (row 4).  Parity of both is the GPU test tier's job (tests/test_gpu_training.py,
+    tests/test_stage2.py); these are single-GPU figures, reported for completeness, not part of `value`."""
+    from hierdiff_amd import DiffusionQM9, default_config
+    from hierdiff_amd.stage2 import E_GCL, synthetic_egcl_state_dict
+    from hierdiff_amd.weights import synthetic_state_dict
+    out = {}
+    H, L, N = 256, 6, 30
+    m = DiffusionQM9(default_config(hidden_nf=H, n_layers=L))
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in synthetic_state_dict(9, 0, H, L, 2, True, 0, 0.5).items()})
+    m = m.to(dev).train()
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-4)
+    for B in (256, 64):
+        g = torch.Generator().manual_seed(0)
+        x = torch.randn(B, N, 3, generator=g)
+        x = x - x.mean(1, keepdim=True)
+        h = torch.cat([torch.randint(0, 5, (B, N, 5), generator=g).float(), torch.randn(B, N, 3, generator=g)], 2)
+        batch = {"positions": x.to(dev), "atom_mask": torch.ones(B, N, 1, dtype=torch.bool, device=dev),
+                 "edge_mask": (~torch.eye(N, dtype=torch.bool))[None].expand(B, N, N).contiguous().to(dev),
+                 "node_feature": h.to(dev)}
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            loss = m.training_step(batch, 0)
+            loss.backward()
+            opt.step()
+
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t0) / 5
+        with torch.no_grad():
+            m.forward(batch)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(5):
+                m.forward(batch)
+            torch.cuda.synchronize(dev)
+            dv = (time.perf_counter() - t0) / 5
+        out[f"training_step_B{B}_N30_L6_f32"] = {"ms_per_step": round(dt * 1e3, 2), "molecules_per_s": round(B / dt, 1),
+                                                 "loss_value_no_grad_ms": round(dv * 1e3, 2),
+                                                 "what": "DiffusionQM9.training_step + backward + AdamW.step, masks cached"}
+    del m, opt
+    # stage 2: gcl_full layer of edge_denoise.py:35-43 (H-wide edge features, attention, edge update), bs graphs of n nodes
+    bs, n = 24, 12
+    ar = torch.arange(n)
+    row = (ar.repeat_interleave(n).repeat(bs) + (torch.arange(bs) * n).repeat_interleave(n * n)).to(dev)
+    col = (ar.repeat(n).repeat(bs) + (torch.arange(bs) * n).repeat_interleave(n * n)).to(dev)
+    g = torch.Generator().manual_seed(1)
+    hh = torch.randn(bs * n, H, generator=g).to(dev)
+    xx = torch.randn(bs * n, 3, generator=g).to(dev)
+    ea = torch.randn(row.numel(), H, generator=g).to(dev)
+    nmask = torch.ones(bs * n, 1, device=dev)
+    emask = (row != col).float().unsqueeze(1)
+    lay = E_GCL(H, H, H, edges_in_d=H, attention=True, tanh=True, coords_range=30, edge_update=True)
+    lay.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in synthetic_egcl_state_dict(H, H, 0, True, True, 40, coord_gain=0.3).items()})
+    lay = lay.to(dev)
+    for _ in range(3):
+        lay(hh, [row, col], xx, edge_attr=ea, node_mask=nmask, edge_mask=emask)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(20):
+        lay(hh, [row, col], xx, edge_attr=ea, node_mask=nmask, edge_mask=emask)
+    torch.cuda.synchronize(dev)
+    out["stage2_E_GCL_layer_bs24_n12_H256"] = {"ms_per_layer_forward": round((time.perf_counter() - t0) / 20 * 1e3, 3),
+                                               "nodes": bs * n, "edges": int(row.numel()),
+                                               "what": "gcl_full layer (edge features + attention + edge update), exact fp32"}
+    return out
+
+
 NOTES = {"fp32": "exact fp32 MFMA (v_mfma_f32_32x32x2_f32), the reference's arithmetic",
          "bf16x6": "fp32-accurate: per-edge H x H contraction on a three-way bf16 split (24 significant bits), 6 bf16 MFMAs per "
                    "product, fp32 accumulate; node-level GEMMs exact fp32",
@@ -352,6 +428,7 @@ def main() -> None:
             out[mode] = sib
     if world == 1 and not args.no_configs:
         out["configs"] = other_configs(args, dev)
+        out["next_rows"] = next_rows(dev)
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(H, L, B, N, T)
     print(json.dumps(out), flush=True)

@@ -212,12 +212,21 @@ class DiffusionQM9(_Base):
 
     def _gamma_rows(self, t, key, gammas):
         """gamma at the [B,1] times `t`: fp64 evaluation rounded once (noise_model.evaluate_gamma) unless the caller
-        replays recorded values (`gammas[key]`)."""
+        replays recorded values (`gammas[key]`).  Every time the loss asks for lies on the grid k / T, k = -1 .. T
+        (s = (t_int - 1) / T, t = t_int / T, 0, 1: diffusion_qm9.py:541-552), so without autograd the values come from a
+        device-resident table of the T + 2 grid values - the same fp64 evaluation at the same fp32 arguments, tabulated
+        once per version of the schedule parameters - and a loss evaluation needs no host round trip."""
         if gammas is not None and key in gammas:
             return torch.as_tensor(gammas[key], dtype=torch.float32, device=t.device).view(-1, 1)
         if torch.is_grad_enabled():        # training: the schedule network is part of the graph (fp32, like the reference)
             return self.gamma(t).view(-1, 1)
-        return evaluate_gamma(self.gamma, t).to(t.device)
+        ver = (self.T, str(t.device)) + tuple((p.data_ptr(), p._version) for p in self.gamma.state_dict(keep_vars=True).values())
+        if getattr(self, "_gamma_grid_key", None) != ver:
+            k = torch.arange(-1, self.T + 1, dtype=torch.float32).view(-1, 1)
+            self._gamma_grid = evaluate_gamma(self.gamma, k / self.T).view(-1).to(t.device)
+            self._gamma_grid_key = ver
+        idx = torch.round(t.to(torch.float32) * self.T).long().view(-1) + 1
+        return self._gamma_grid[idx].view(-1, 1)
 
     def compute_error(self, net_out, gamma_t, eps):
         err = (eps - net_out) ** 2
