@@ -220,3 +220,36 @@ def test_predefined_noise_schedules_equal_reference():
     elem["node_coarse_type"] = "elem"
     m = DiffusionQM9(elem)
     assert m.in_node_nf == 3 and m.state_dict()["dynamics.egnn.embedding.weight"].shape == (32, 4)
+
+
+def test_loss_gamma_grid_equals_rowwise_evaluation():
+    """The loss value (no autograd) reads gamma at s = (t_int - 1) / T, t = t_int / T, 0 and 1 (diffusion_qm9.py:541-552)
+    from a tabulated grid k / T, k = -1 .. T: same bits as evaluating the fp64 schedule row by row, for the learned network
+    and for a predefined table (whose lookup at -1/T wraps to the last entry, like the reference's negative index); the
+    table follows in-place updates of the schedule parameters."""
+    from hierdiff_amd import DiffusionQM9, default_config
+    from hierdiff_amd.noise_model import evaluate_gamma
+    g = torch.Generator().manual_seed(3)
+    cfgs = [default_config(hidden_nf=32, n_layers=1, timesteps=1000)]
+    c2 = default_config(hidden_nf=32, n_layers=1, timesteps=50)
+    c2["noise_schedule"] = "cosine"
+    c2["loss_type"] = "l2"
+    c2["pre_noise"] = dict(noise_schedule="cosine", timesteps=50, precision=1e-4)
+    cfgs.append(c2)
+    for cfg in cfgs:
+        model = DiffusionQM9(cfg)
+        T = model.T
+        t_int = torch.cat([torch.tensor([0., 1., float(T)]), torch.randint(0, T + 1, (61,), generator=g).float()]).view(-1, 1)
+        with torch.no_grad():
+            for t in ((t_int - 1) / T, t_int / T, torch.zeros_like(t_int), torch.ones_like(t_int)):
+                assert torch.equal(model._gamma_rows(t, "gamma_t", None), evaluate_gamma(model.gamma, t).view(-1, 1))
+            assert torch.equal(model._gamma_rows(t_int / T, "gamma_t", {"gamma_t": np.full(64, 0.25, np.float32)}),
+                               torch.full((64, 1), 0.25))
+            if hasattr(model.gamma, "l2"):                      # learned schedule: an optimiser step must invalidate the table
+                before = model._gamma_rows(t_int / T, "gamma_t", None).clone()
+                model.gamma.l2.weight.add_(0.05)
+                after = model._gamma_rows(t_int / T, "gamma_t", None)
+                assert torch.equal(after, evaluate_gamma(model.gamma, t_int / T).view(-1, 1)) and not torch.equal(after, before)
+        if hasattr(model.gamma, "l2"):                          # with autograd the network itself is in the graph
+            with torch.enable_grad():
+                assert model._gamma_rows(t_int / T, "gamma_t", None).requires_grad
