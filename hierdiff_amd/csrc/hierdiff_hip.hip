@@ -37,6 +37,9 @@ static int fail(int code, const std::string& msg) {
 
 // fp32 mode: batches with fewer active rows than this run the node side as k_agg + 3 x k_gemm instead of the fused k_node_f32
 #define HD_FUSE_MIN_ROWS 6144
+// fp32 mode: topologies with at most this many edge tiles run k_edge_split (one tile per workgroup, columns over its four
+// wavefronts) instead of k_edge (one tile per wavefront); bit-identical, see k_edge_split.hpp
+#define HD_SPLIT_MAX_TILES 512
 
 struct LayerW {                 // float offsets into hd_handle::dw
     size_t ab_img, ab_bias, wrd, w2_img, b2, wa, w3_img, b3, w4_img, b4;
@@ -75,6 +78,7 @@ struct hd_handle {
     hipStream_t own_stream;     // capture / replay stream used when the caller passes the legacy NULL stream
     hipEvent_t ev_in, ev_out;   // order own_stream against the caller's stream without host syncs
     unsigned long long weights_gen, sched_gen;   // bumped when the packed weights / schedule tables are re-allocated
+    int split_max_tiles;        // HD_SPLIT_MAX_TILES (a measurement build may override it from the environment)
 #ifdef HD_DEBUG_KERNELS
     long long* d_trace;         // HD_ABLATE bit 16: cycle stamps of the last traced edge launch
     int trace_wg;
@@ -207,9 +211,11 @@ extern "C" int hd_create(const hd_config* cfg, int device, hd_handle** out) {
     h->weights_gen = h->sched_gen = 0;
     h->d_nanflag = nullptr; h->d_nan_events = nullptr; h->d_step = nullptr; h->d_draw = nullptr; h->d_tcur = nullptr;
     h->d_base = nullptr;
+    h->split_max_tiles = HD_SPLIT_MAX_TILES;
 #ifdef HD_DEBUG_KERNELS
     h->d_trace = nullptr; h->trace_wg = 0;
     { const char* e = getenv("HD_ABLATE"); h->ablate = e ? atoi(e) : 0; }
+    { const char* e = getenv("HD_SPLIT_MAX_TILES"); if (e) h->split_max_tiles = atoi(e); }
 #endif
     auto create_rest = [&]() -> int {        // every failure below leaves through hd_destroy (frees what exists)
         HD_TRY(dev_alloc(&h->d_nanflag, 1));
@@ -944,6 +950,15 @@ static int launch_edge_h(hd_handle* h, bool coord, const EdgeArgs& a, hipStream_
             const int lds6 = edge_lds_bytes<H>(true);
             if (coord) hipLaunchKernelGGL((k_edge<H, true, 2>), grid, block, lds6, s, a);
             else hipLaunchKernelGGL((k_edge<H, false, 2>), grid, block, lds6, s, a);
+            return HD_OK;
+        }
+    }
+    if constexpr (H >= 128) {
+        // exact fp32, at most one tile per SIMD-quad: one tile per workgroup, columns split over its four wavefronts
+        // (k_edge_split.hpp; bit-identical to k_edge, a quarter of the serial MFMA chain)
+        if (prec == 0 && a.n_tiles > 0 && a.n_tiles <= h->split_max_tiles) {
+            if (coord) hipLaunchKernelGGL((k_edge_split<H, true>), dim3(a.n_tiles), block, 0, s, a);
+            else hipLaunchKernelGGL((k_edge_split<H, false>), dim3(a.n_tiles), block, 0, s, a);
             return HD_OK;
         }
     }

@@ -1,0 +1,270 @@
+// Edge kernel for very small batches (exact fp32): ONE 32-edge tile per workgroup, its H output columns split over the four
+// wavefronts.  Included through kernels.hpp after k_edge.hpp (same EdgeArgs, same tile tables, same weight image).
+//
+// Why: in k_edge a wavefront owns a whole 32-edge x H tile, i.e. a serial chain of H*H/64 fp32 MFMAs (1,024 at H = 256:
+// 65.5 k matrix-pipe cycles = 29 us) plus prologue and epilogue - 43 us per launch however few tiles there are.  The
+// reference's shipped sampling job is batch_size 2 (conf/sample/default.yaml:1-2): 56 tiles, 14 workgroups on a 256-CU
+// chip.  Here every tile is spread over the four SIMDs of a CU: wavefront w computes columns [w*H/4, (w+1)*H/4) - a quarter
+// of the MFMAs - with its W2 fragments going L2 -> registers directly (no LDS staging, no barrier in the loop: nothing is
+// shared between the wavefronts there); the first-layer operand P = SiLU(A_i + B_j + r w_r + d0 w_d) is built redundantly
+// by all four.
+//
+// Bit-identical to k_edge<H, COORD, 0> by construction, so a molecule's bits still do not depend on the size of its batch:
+//   * every output element sees the same MFMA chain (accumulator from b2, K chunks ascending, k-quad q, j);
+//   * the row dot with w_a / w_7 is one FMA chain per lane over the column tiles in ascending order - here it is handed
+//     from wavefront to wavefront through LDS (three hand-offs) and finished by the same transposed reduction;
+//   * gate / tanh head, masked per-node sums and the cross-half add are the same expressions on the same operands.
+// tests/test_gpu_parity.py::test_small_batch_edge_kernel_is_bit_identical compares a 2-molecule batch (this kernel) with
+// the same molecules inside a 64-molecule batch (k_edge).
+#pragma once
+#include "k_edge.hpp"
+
+template <int H, bool COORD>
+__global__ __launch_bounds__(256) void k_edge_split(EdgeArgs a) {
+    constexpr int NCT = H / 32, NCW = NCT / 4, NCH = H / 32, CHF = 32 * H;
+    static_assert(NCT % 4 == 0, "column tiles are dealt to four wavefronts");
+    __shared__ __attribute__((aligned(16))) float wrd_s[4 * H];     // [w_r | w_d | b2 | wa]
+    __shared__ float dot_x[16 * 64];                                 // running row dots, handed from wavefront to wavefront
+    __shared__ float att_s[64];                                      // gate per (half, row slot) as wavefront 3 holds it
+    __shared__ uint32_t seg_s[8];                                    // segment byte of the 32 rows
+    __shared__ float cs_phi[32], cs_tr[96];                          // coordinate head scratch (wavefront 3)
+    __shared__ int nan_s;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hh = lane >> 5, n = lane & 31;
+    const int tile = blockIdx.x;                                     // grid = n_tiles
+
+    for (int k = tid; k < 2 * H; k += 256) wrd_s[k] = a.wrd[k];
+    for (int k = tid; k < H; k += 256) { wrd_s[2 * H + k] = a.b2[k]; wrd_s[3 * H + k] = a.wa[k]; }
+
+    // per-row metadata (lanes n and n + 32 both describe row n), as in k_edge
+    const int e = tile * 32 + n;
+    const int ni = a.ei[e], nj = a.ej[e];
+    const uint32_t segb = a.eseg[e];
+    const f32x4 xi = *reinterpret_cast<const f32x4*>(a.xcur + (size_t)ni * 4);
+    const f32x4 xj = *reinterpret_cast<const f32x4*>(a.xcur + (size_t)nj * 4);
+    const f32x4 yi = *reinterpret_cast<const f32x4*>(a.x0 + (size_t)ni * 4);
+    const f32x4 yj = *reinterpret_cast<const f32x4*>(a.x0 + (size_t)nj * 4);
+    const float dx = xi[0] - xj[0], dy = xi[1] - xj[1], dz = xi[2] - xj[2];
+    const float radial = dx * dx + dy * dy + dz * dz;
+    const float ex = yi[0] - yj[0], ey = yi[1] - yj[1], ez = yi[2] - yj[2];
+    const float d0 = ex * ex + ey * ey + ez * ez;
+    const int pid_l = a.seg_part[tile * 32 + n];
+    const int nseg = a.tile_nseg[tile];
+    if (wave == 3 && hh == 0) {
+        reinterpret_cast<uint8_t*>(seg_s)[n] = (uint8_t)segb;
+        if constexpr (COORD) {
+            const float inv = ((segb != 255) ? 1.0f : 0.0f) / (sqrtf(radial + 1e-8f) + a.norm_constant);
+            cs_tr[n * 3 + 0] = dx * inv; cs_tr[n * 3 + 1] = dy * inv; cs_tr[n * 3 + 2] = dz * inv;
+        }
+    }
+
+    // first-layer operand of K chunk c for this lane's edge row (k = 32c + 16hh + 0..15): rows requested a chunk ahead
+    const float* Arow = a.AB + (size_t)ni * (2 * H) + 16 * hh;
+    const float* Brow = a.AB + (size_t)nj * (2 * H) + H + 16 * hh;
+    struct Raw { f32x4 a[4], b[4]; };
+    auto load_raw = [&](int c, Raw& w) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            w.a[u] = *reinterpret_cast<const f32x4*>(Arow + 32 * c + 4 * u);
+            w.b[u] = *reinterpret_cast<const f32x4*>(Brow + 32 * c + 4 * u);
+        }
+    };
+    auto finish_P = [&](int c, const Raw& w, float (&P)[16]) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const f32x4 wr4 = *reinterpret_cast<const f32x4*>(wrd_s + 32 * c + 16 * hh + 4 * u);
+            const f32x4 wd4 = *reinterpret_cast<const f32x4*>(wrd_s + H + 32 * c + 16 * hh + 4 * u);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float pre = w.a[u][j] + w.b[u][j];                   // same operation order as k_edge's make_P
+                pre = __builtin_fmaf(radial, wr4[j], pre);
+                pre = __builtin_fmaf(d0, wd4[j], pre);
+                P[4 * u + j] = HD_F32_SILU(pre);
+            }
+        }
+    };
+    // W2 fragments of this wavefront's column tiles: chunk image [4 q][NCT][64 lanes][4 floats] (k_edge), L2 -> registers
+    const int ct0 = wave * NCW;
+    const float* wimg = a.W2img + ((size_t)ct0 * 64 + lane) * 4;
+    auto load_frags = [&](int c, f32x4 (&f)[4][NCW]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int k = 0; k < NCW; ++k) f[q][k] = *reinterpret_cast<const f32x4*>(wimg + (size_t)c * CHF + ((q * NCT + k) * 64) * 4);
+    };
+
+    f32x4 fr[3][4][NCW];                                             // fragments two chunks ahead of the MFMAs
+    Raw raw[2];
+    float P[16];
+    load_frags(0, fr[0]);
+    if (NCH > 1) load_frags(1, fr[1]);
+    load_raw(0, raw[0]);
+    if (NCH > 1) load_raw(1, raw[1]);
+    __syncthreads();                                                 // wrd_s, seg_s, cs_tr staged
+    finish_P(0, raw[0], P);
+    f32x16 acc[NCW];
+#pragma unroll
+    for (int k = 0; k < NCW; ++k) {
+        const float b2v = wrd_s[2 * H + 32 * (ct0 + k) + n];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][r] = b2v;
+    }
+    static_for<0, NCH>([&](auto Cc) {
+        constexpr int c = decltype(Cc)::value;
+        if constexpr (c + 2 < NCH) load_frags(c + 2, fr[(c + 2) % 3]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int k = 0; k < NCW; ++k)
+                    acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(P[4 * q + j], fr[c % 3][q][k][j], acc[k], 0, 0, 0);
+        if constexpr (c + 1 < NCH) {
+            finish_P(c + 1, raw[(c + 1) & 1], P);
+            if constexpr (c + 2 < NCH) load_raw(c + 2, raw[c & 1]);
+        }
+    });
+
+    // ---- epilogue.  acc[k][r] = row rho(r) = (r&3) + 8*(r>>2) + 4*hh, column 32*(ct0+k) + n.
+#pragma unroll
+    for (int k = 0; k < NCW; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][r] = HD_F32_SILU(acc[k][r]);
+    // the row dot is one FMA chain per lane over ct = 0 .. NCT-1: wavefront w continues where w-1 stopped
+    float dot[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dot[r] = 0.f;
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+            if (w > 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dot[r] = dot_x[r * 64 + lane];
+            }
+#pragma unroll
+            for (int k = 0; k < NCW; ++k) {
+                const float wav = wrd_s[3 * H + 32 * (ct0 + k) + n];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dot[r] = __builtin_fmaf(acc[k][r], wav, dot[r]);
+            }
+            if (w < 3) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dot_x[r * 64 + lane] = dot[r];
+            }
+        }
+        __syncthreads();
+    }
+    if (wave == 3) {
+        // transpose-reduce over the 32 lanes of a half, exactly as in k_edge: lanes 2s, 2s+1 end with the dot of row slot s
+        float rowdot;
+        {
+            float v8[8], v4[4], v2[2];
+            const bool b4 = n & 16, b3 = n & 8, b2_ = n & 4, b1 = n & 2;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float send = b4 ? dot[k] : dot[k + 8];
+                const float keep = b4 ? dot[k + 8] : dot[k];
+                v8[k] = keep + __shfl_xor(send, 16);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float send = b3 ? v8[k] : v8[k + 4];
+                const float keep = b3 ? v8[k + 4] : v8[k];
+                v4[k] = keep + __shfl_xor(send, 8);
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const float send = b2_ ? v4[k] : v4[k + 2];
+                const float keep = b2_ ? v4[k + 2] : v4[k];
+                v2[k] = keep + __shfl_xor(send, 4);
+            }
+            {
+                const float send = b1 ? v2[0] : v2[1];
+                const float keep = b1 ? v2[1] : v2[0];
+                rowdot = keep + __shfl_xor(send, 2);
+            }
+            rowdot += __shfl_xor(rowdot, 1);
+        }
+        const int my_slot = (n >> 1) & 15;
+        if constexpr (!COORD) {
+            float att_mine = 1.0f;
+            if (a.attention) {
+                const float ba = a.ba_ptr ? *a.ba_ptr : a.ba;
+                att_mine = sigmoid_f(rowdot + ba);
+            }
+            att_s[lane] = att_mine;
+            const bool tile_has_nan = __builtin_amdgcn_ballot_w64(rowdot != rowdot) != 0;
+            if (lane == 0) nan_s = tile_has_nan ? 1 : 0;
+        } else {
+            // phi of row rho(slot) is in lanes 2 slot, 2 slot + 1 of half hh; then lane n handles row n (k_edge's coordinate head)
+            if ((n & 1) == 0) cs_phi[(my_slot & 3) + 8 * (my_slot >> 2) + 4 * hh] = rowdot;
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (hh == 0) {
+                const float phi = cs_phi[n];
+                const float sc = a.use_tanh ? tanhf(phi) * a.coords_range : phi;
+                cs_tr[n * 3 + 0] *= sc;
+                cs_tr[n * 3 + 1] *= sc;
+                cs_tr[n * 3 + 2] *= sc;
+            }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (lane < nseg) {
+                const uint8_t* sb = reinterpret_cast<const uint8_t*>(seg_s);
+                float sx = 0.f, sy = 0.f, sz = 0.f;
+                for (int rr = 0; rr < 32; ++rr) {
+                    if (sb[rr] == lane) { sx += cs_tr[rr * 3]; sy += cs_tr[rr * 3 + 1]; sz += cs_tr[rr * 3 + 2]; }
+                }
+                const f32x4 o = {sx, sy, sz, 0.f};
+                *reinterpret_cast<f32x4*>(a.part + (size_t)pid_l * 4) = o;   // lane < nseg <= 32: pid_l is segment `lane`'s id
+            }
+        }
+    }
+    if constexpr (COORD) return;
+    __syncthreads();                                                 // att_s, nan_s published
+    {
+        uint32_t sw[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sw[q] = seg_s[2 * q + hh];
+        float w[16];
+        int sg[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            sg[r] = (sw[r >> 2] >> (8 * (r & 3))) & 255;
+            const float att = att_s[(lane & 32) | (2 * r)];
+            w[r] = (sg[r] != 255) ? att : 0.0f;
+        }
+        const bool tile_has_nan = nan_s != 0;
+        for (int s = 0; s < nseg; ++s) {
+            float ws[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ws[r] = (sg[r] == s) ? w[r] : 0.0f;
+            float* dst = a.part + (size_t)__builtin_amdgcn_readlane(pid_l, s) * H + 32 * ct0 + n;
+            float sums[NCW];
+            if (__builtin_expect(tile_has_nan, 0)) {
+#pragma unroll
+                for (int k = 0; k < NCW; ++k) {
+                    float sum = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sum = (sg[r] == s) ? __builtin_fmaf(ws[r], acc[k][r], sum) : sum;
+                    sums[k] = sum;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < NCW; ++k) {
+                    float sum = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sum = __builtin_fmaf(ws[r], acc[k][r], sum);
+                    sums[k] = sum;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NCW; ++k) sums[k] = xhalf_sum(sums[k]);
+            if (hh == 0) {
+#pragma unroll
+                for (int k = 0; k < NCW; ++k) dst[32 * k] = sums[k];
+            }
+        }
+    }
+}
