@@ -1,5 +1,5 @@
-// Edge kernel for very small batches (exact fp32): ONE 32-edge tile per workgroup, its H output columns split over the four
-// wavefronts.  Included through kernels.hpp after k_edge.hpp (same EdgeArgs, same tile tables, same weight image).
+// Edge kernel for very small batches (every precision mode): ONE 32-edge tile per workgroup, its H output columns split over
+// the four wavefronts.  Included through kernels.hpp after k_edge.hpp (same EdgeArgs, same tile tables, same weight image).
 //
 // Why: in k_edge a wavefront owns a whole 32-edge x H tile, i.e. a serial chain of H*H/64 fp32 MFMAs (1,024 at H = 256:
 // 65.5 k matrix-pipe cycles = 29 us) plus prologue and epilogue - 43 us per launch however few tiles there are.  The
@@ -9,8 +9,10 @@
 // shared between the wavefronts there); the first-layer operand P = SiLU(A_i + B_j + r w_r + d0 w_d) is built redundantly
 // by all four.
 //
-// Bit-identical to k_edge<H, COORD, 0> by construction, so a molecule's bits still do not depend on the size of its batch:
-//   * every output element sees the same MFMA chain (accumulator from b2, K chunks ascending, k-quad q, j);
+// Bit-identical to k_edge<H, COORD, PREC> by construction, so a molecule's bits still do not depend on the size of its batch:
+//   * every output element sees the same MFMA chain (accumulator from b2, K chunks ascending; fp32: k-quad q, j;
+//     bf16x3: k-step s, then head*head, tail*head, head*tail; bf16x6: h*L, h*M, m*M, h*H, m*H, l*H per 16-wide chunk)
+//     on operands produced by the same expressions (k_edge's make_P / make_quad / make_quad_x6);
 //   * the row dot with w_a / w_7 is one FMA chain per lane over the column tiles in ascending order - here it is handed
 //     from wavefront to wavefront through LDS (three hand-offs) and finished by the same transposed reduction;
 //   * gate / tanh head, masked per-node sums and the cross-half add are the same expressions on the same operands.
@@ -19,9 +21,10 @@
 #pragma once
 #include "k_edge.hpp"
 
-template <int H, bool COORD>
+template <int H, bool COORD, int PREC>
 __global__ __launch_bounds__(256) void k_edge_split(EdgeArgs a) {
-    constexpr int NCT = H / 32, NCW = NCT / 4, NCH = H / 32, CHF = 32 * H;
+    constexpr int KC = PREC == 2 ? 16 : 32;                          // K chunk width, as in k_edge
+    constexpr int NCT = H / 32, NCW = NCT / 4, NCH = H / KC, CHF = PREC == 2 ? 24 * H : 32 * H, NQ = KC / 8;
     static_assert(NCT % 4 == 0, "column tiles are dealt to four wavefronts");
     __shared__ __attribute__((aligned(16))) float wrd_s[4 * H];     // [w_r | w_d | b2 | wa]
     __shared__ float dot_x[16 * 64];                                 // running row dots, handed from wavefront to wavefront
@@ -60,50 +63,99 @@ __global__ __launch_bounds__(256) void k_edge_split(EdgeArgs a) {
         }
     }
 
-    // first-layer operand of K chunk c for this lane's edge row (k = 32c + 16hh + 0..15): rows requested a chunk ahead
-    const float* Arow = a.AB + (size_t)ni * (2 * H) + 16 * hh;
-    const float* Brow = a.AB + (size_t)nj * (2 * H) + H + 16 * hh;
-    struct Raw { f32x4 a[4], b[4]; };
+    // first-layer operand of K chunk c for this lane's edge row (k = KC c + (KC/2) hh + 0 .. KC/2-1): rows requested two
+    // chunks ahead, finished behind the MFMAs of the chunk before
+    const float* Arow = a.AB + (size_t)ni * (2 * H) + (KC / 2) * hh;
+    const float* Brow = a.AB + (size_t)nj * (2 * H) + H + (KC / 2) * hh;
+    struct Raw { f32x4 a[NQ], b[NQ]; };
     auto load_raw = [&](int c, Raw& w) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            w.a[u] = *reinterpret_cast<const f32x4*>(Arow + 32 * c + 4 * u);
-            w.b[u] = *reinterpret_cast<const f32x4*>(Brow + 32 * c + 4 * u);
+        for (int u = 0; u < NQ; ++u) {
+            w.a[u] = *reinterpret_cast<const f32x4*>(Arow + KC * c + 4 * u);
+            w.b[u] = *reinterpret_cast<const f32x4*>(Brow + KC * c + 4 * u);
         }
     };
-    auto finish_P = [&](int c, const Raw& w, float (&P)[16]) {
+    // operand registers: fp32 16 floats; bf16x3 head / tail of the two k-steps; bf16x6 head / middle / tail of the one k-step
+    struct Opnd { float P[PREC == 0 ? 16 : 1]; u32x4 ph[2], pl[2], xh, xm, xl; };
+    auto finish_P = [&](int c, const Raw& w, Opnd& o) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const f32x4 wr4 = *reinterpret_cast<const f32x4*>(wrd_s + 32 * c + 16 * hh + 4 * u);
-            const f32x4 wd4 = *reinterpret_cast<const f32x4*>(wrd_s + H + 32 * c + 16 * hh + 4 * u);
+        for (int u = 0; u < NQ; ++u) {
+            const f32x4 wr4 = *reinterpret_cast<const f32x4*>(wrd_s + KC * c + (KC / 2) * hh + 4 * u);
+            const f32x4 wd4 = *reinterpret_cast<const f32x4*>(wrd_s + H + KC * c + (KC / 2) * hh + 4 * u);
+            if constexpr (PREC == 0) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float pre = w.a[u][j] + w.b[u][j];                   // same operation order as k_edge's make_P
-                pre = __builtin_fmaf(radial, wr4[j], pre);
-                pre = __builtin_fmaf(d0, wd4[j], pre);
-                P[4 * u + j] = HD_F32_SILU(pre);
+                for (int j = 0; j < 4; ++j) {
+                    float pre = w.a[u][j] + w.b[u][j];               // same operation order as k_edge's make_P
+                    pre = __builtin_fmaf(radial, wr4[j], pre);
+                    pre = __builtin_fmaf(d0, wd4[j], pre);
+                    o.P[4 * u + j] = HD_F32_SILU(pre);
+                }
+            } else if constexpr (PREC == 1) {                        // k_edge's make_quad (scaled domain) + make_P_bf
+                float pre[4], ev[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pre[j] = w.a[u][j] + w.b[u][j];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pre[j] = __builtin_fmaf(radial, wr4[j], pre[j]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pre[j] = __builtin_fmaf(d0, wd4[j], pre[j]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ev[j] = __builtin_amdgcn_exp2f(pre[j]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ev[j] = 1.0f + ev[j];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ev[j] = __builtin_amdgcn_rcpf(ev[j]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pre[j] *= ev[j];
+                uint32_t hi[2], lo[2];
+                bf16_split2(pre[0], pre[1], hi[0], lo[0]);
+                bf16_split2(pre[2], pre[3], hi[1], lo[1]);
+                o.ph[u >> 1][2 * (u & 1)] = hi[0]; o.ph[u >> 1][2 * (u & 1) + 1] = hi[1];
+                o.pl[u >> 1][2 * (u & 1)] = lo[0]; o.pl[u >> 1][2 * (u & 1) + 1] = lo[1];
+            } else {                                                 // k_edge's make_quad_x6
+                float y[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float pre = w.a[u][j] + w.b[u][j];
+                    pre = __builtin_fmaf(radial, wr4[j], pre);
+                    pre = __builtin_fmaf(d0, wd4[j], pre);
+                    y[j] = HD_X6_SILU(pre);
+                }
+                uint32_t hi[2], mi[2], lo[2];
+                bf16_split3(y[0], y[1], hi[0], mi[0], lo[0]);
+                bf16_split3(y[2], y[3], hi[1], mi[1], lo[1]);
+                o.xh[2 * u] = hi[0]; o.xh[2 * u + 1] = hi[1]; o.xm[2 * u] = mi[0]; o.xm[2 * u + 1] = mi[1];
+                o.xl[2 * u] = lo[0]; o.xl[2 * u + 1] = lo[1];
             }
         }
     };
-    // W2 fragments of this wavefront's column tiles: chunk image [4 q][NCT][64 lanes][4 floats] (k_edge), L2 -> registers
+    // W2 fragments of this wavefront's column tiles, L2 -> registers, in k_edge's chunk-image layouts:
+    //   fp32   [4 q][NCT][64 lanes][4 floats]                       NF = 4 NCW fragments per chunk: (q, k)
+    //   bf16x3 [head|tail][2 k-steps][NCT][64 lanes][8 bf16]        NF = 4 NCW: (head / tail, s, k)
+    //   bf16x6 [head|middle|tail][NCT][64 lanes][8 bf16]            NF = 3 NCW: (part, k)
     const int ct0 = wave * NCW;
-    const float* wimg = a.W2img + ((size_t)ct0 * 64 + lane) * 4;
-    auto load_frags = [&](int c, f32x4 (&f)[4][NCW]) {
+    constexpr int NF = (PREC == 2 ? 3 : 4) * NCW;
+    const char* wimg = reinterpret_cast<const char*>(a.W2img) + lane * 16;
+    auto load_frags = [&](int c, u32x4 (&f)[NF]) {
+        const char* base = wimg + (size_t)c * CHF * 4;
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int k = 0; k < NCW; ++k) f[q][k] = *reinterpret_cast<const f32x4*>(wimg + (size_t)c * CHF + ((q * NCT + k) * 64) * 4);
+        for (int i = 0; i < NF; ++i) {
+            const int x = i / NCW, k = i % NCW;
+            unsigned off;
+            if constexpr (PREC == 0) off = frag_off_f32(x * NCT + ct0 + k);                       // x = q
+            else if constexpr (PREC == 1) off = (unsigned)(((((x >> 1) * 2 + (x & 1)) * NCT + ct0 + k) * 64) * 16);   // x = 2 hl + s
+            else off = (unsigned)((x * NCT + ct0 + k) * 64 * 16);                                 // x = part
+            f[i] = *reinterpret_cast<const u32x4*>(base + off);
+        }
     };
-
-    f32x4 fr[3][4][NCW];                                             // fragments two chunks ahead of the MFMAs
+    constexpr int RING = PREC == 0 ? 3 : (PREC == 1 ? 4 : 6);        // chunks of fragments in flight ahead of the MFMAs
+    u32x4 fr[RING][NF];
     Raw raw[2];
-    float P[16];
-    load_frags(0, fr[0]);
-    if (NCH > 1) load_frags(1, fr[1]);
+    Opnd op;
+    static_for<0, (RING - 1 < NCH ? RING - 1 : NCH)>([&](auto Cc) { load_frags(decltype(Cc)::value, fr[decltype(Cc)::value]); });
     load_raw(0, raw[0]);
     if (NCH > 1) load_raw(1, raw[1]);
     __syncthreads();                                                 // wrd_s, seg_s, cs_tr staged
-    finish_P(0, raw[0], P);
+    finish_P(0, raw[0], op);
     f32x16 acc[NCW];
 #pragma unroll
     for (int k = 0; k < NCW; ++k) {
@@ -113,16 +165,44 @@ __global__ __launch_bounds__(256) void k_edge_split(EdgeArgs a) {
     }
     static_for<0, NCH>([&](auto Cc) {
         constexpr int c = decltype(Cc)::value;
-        if constexpr (c + 2 < NCH) load_frags(c + 2, fr[(c + 2) % 3]);
+        if constexpr (c + RING - 1 < NCH) load_frags(c + RING - 1, fr[(c + RING - 1) % RING]);
+        u32x4(&f)[NF] = fr[c % RING];
+        if constexpr (PREC == 0) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+            for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int k = 0; k < NCW; ++k)
-                    acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(P[4 * q + j], fr[c % 3][q][k][j], acc[k], 0, 0, 0);
+                    for (int k = 0; k < NCW; ++k)
+                        acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(op.P[4 * q + j], __builtin_bit_cast(f32x4, f[q * NCW + k])[j], acc[k], 0, 0, 0);
+        } else if constexpr (PREC == 1) {
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const bf16x8 A_h = __builtin_bit_cast(bf16x8, op.ph[st]), A_l = __builtin_bit_cast(bf16x8, op.pl[st]);
+#pragma unroll
+                for (int k = 0; k < NCW; ++k) {
+                    const bf16x8 Wh = __builtin_bit_cast(bf16x8, f[(0 + st) * NCW + k]), Wl = __builtin_bit_cast(bf16x8, f[(2 + st) * NCW + k]);
+                    acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_h, Wh, acc[k], 0, 0, 0);
+                    acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_l, Wh, acc[k], 0, 0, 0);
+                    acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_h, Wl, acc[k], 0, 0, 0);
+                }
+            }
+        } else {
+            const bf16x8 A_h = __builtin_bit_cast(bf16x8, op.xh), A_m = __builtin_bit_cast(bf16x8, op.xm), A_l = __builtin_bit_cast(bf16x8, op.xl);
+#pragma unroll
+            for (int k = 0; k < NCW; ++k) {
+                const bf16x8 Wh = __builtin_bit_cast(bf16x8, f[0 * NCW + k]), Wm = __builtin_bit_cast(bf16x8, f[1 * NCW + k]),
+                             Wt = __builtin_bit_cast(bf16x8, f[2 * NCW + k]);
+                acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_h, Wt, acc[k], 0, 0, 0);
+                acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_h, Wm, acc[k], 0, 0, 0);
+                acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_m, Wm, acc[k], 0, 0, 0);
+                acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_h, Wh, acc[k], 0, 0, 0);
+                acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_m, Wh, acc[k], 0, 0, 0);
+                acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_l, Wh, acc[k], 0, 0, 0);
+            }
+        }
         if constexpr (c + 1 < NCH) {
-            finish_P(c + 1, raw[(c + 1) & 1], P);
+            finish_P(c + 1, raw[(c + 1) & 1], op);
             if constexpr (c + 2 < NCH) load_raw(c + 2, raw[c & 1]);
         }
     });
@@ -131,7 +211,11 @@ __global__ __launch_bounds__(256) void k_edge_split(EdgeArgs a) {
 #pragma unroll
     for (int k = 0; k < NCW; ++k)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[k][r] = HD_F32_SILU(acc[k][r]);
+        for (int r = 0; r < 16; ++r) {
+            if constexpr (PREC == 0) acc[k][r] = HD_F32_SILU(acc[k][r]);
+            else if constexpr (PREC == 2) acc[k][r] = HD_X6_SILU(acc[k][r]);
+            else acc[k][r] = acc[k][r] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[k][r]));   // scaled domain
+        }
     // the row dot is one FMA chain per lane over ct = 0 .. NCT-1: wavefront w continues where w-1 stopped
     float dot[16];
 #pragma unroll
@@ -191,7 +275,8 @@ __global__ __launch_bounds__(256) void k_edge_split(EdgeArgs a) {
             float att_mine = 1.0f;
             if (a.attention) {
                 const float ba = a.ba_ptr ? *a.ba_ptr : a.ba;
-                att_mine = sigmoid_f(rowdot + ba);
+                if constexpr (PREC != 1) att_mine = sigmoid_f(rowdot + ba);
+                else att_mine = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(rowdot + ba));   // scaled domain
             }
             att_s[lane] = att_mine;
             const bool tile_has_nan = __builtin_amdgcn_ballot_w64(rowdot != rowdot) != 0;

@@ -254,18 +254,20 @@ def test_fp32_node_paths_agree_bitwise():
     assert torch.equal(big[:8], small)
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("H,C_,general", [(256, 0, False), (128, 1, True)])
-def test_small_batch_edge_kernel_is_bit_identical(H, C_, general):
-    """fp32 mode runs topologies of at most 512 edge tiles (B <= 18 at N = 30: the reference's shipped job is batch_size 2)
-    through k_edge_split - one tile per workgroup, its columns over the four wavefronts - and larger ones through k_edge
-    (one tile per wavefront).  Same MFMA chain per output element, the row dot handed from wavefront to wavefront in
-    column order, same gate / head / masked sums: the first molecules of a 40-molecule batch (k_edge) against the same
-    molecules alone (k_edge_split), GCL and coordinate layers, ragged sizes, context, holes in the edge mask, torch.equal."""
+def test_small_batch_edge_kernel_is_bit_identical(H, C_, general, precision):
+    """Topologies of at most 512 edge tiles (B <= 18 at N = 30: the reference's shipped job is batch_size 2) run through
+    k_edge_split - one tile per workgroup, its columns over the four wavefronts - and larger ones through k_edge (one tile
+    per wavefront), in every precision mode.  Same MFMA chain per output element, the row dot handed from wavefront to
+    wavefront in column order, same gate / head / masked sums: the first molecules of a 40-molecule batch (k_edge) against
+    the same molecules alone (k_edge_split), GCL and coordinate layers, ragged sizes, context, holes in the edge mask,
+    torch.equal."""
     from hierdiff_amd.weights import synthetic_state_dict
     L, N = 2, 30
     sd_np = synthetic_state_dict(9, C_, H, L, 2, True, 615, 1.0)
     dyn = build_dynamics(sd_np, H, L, C_)
-    dyn.precision = "fp32"
+    dyn.precision = precision
     n_list = [30, 17, 1, 24, 30, 9] + [30] * 34
     xh, nm, em = orc.random_inputs(n_list, 8, 35, N)
     if general:
