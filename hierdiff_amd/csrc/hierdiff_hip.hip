@@ -37,7 +37,7 @@ static int fail(int code, const std::string& msg) {
 
 // fp32 mode: batches with fewer active rows than this run the node side as k_agg + 3 x k_gemm instead of the fused k_node_f32
 #define HD_FUSE_MIN_ROWS 6144
-// topologies with at most this many edge tiles (half as many in bf16x3) run k_edge_split (one tile per workgroup, columns
+// topologies with at most this many edge tiles (a third more in fp32) run k_edge_split (one tile per workgroup, columns
 // over its four wavefronts) instead of k_edge (one tile per wavefront); bit-identical, see k_edge_split.hpp
 #define HD_SPLIT_MAX_TILES 512
 
@@ -949,9 +949,9 @@ static int launch_edge_h(hd_handle* h, bool coord, const EdgeArgs& a, hipStream_
         // at most 512 tiles: one tile per workgroup, columns split over its four wavefronts (k_edge_split.hpp; bit-identical
         // to k_edge in every precision mode, a quarter of the serial MFMA chain per wavefront)
         const int mode = h->x6 ? 2 : (prec == 1 ? 1 : 0);
-        // measured break-even (profiles/r02_split_sweep.log): 512 tiles in fp32 and bf16x6, half that in bf16x3, whose short
-        // MFMA chain leaves less to split against the operand generation that every wavefront repeats
-        if (a.n_tiles > 0 && a.n_tiles <= (mode == 1 ? h->split_max_tiles / 2 : h->split_max_tiles)) {
+        // measured break-even (profiles/r02_split_sweep.log): between 490 and 654 tiles in the bf16 modes, between 654 and 870
+        // in fp32 (the longer MFMA chain has more to gain from the split)
+        if (a.n_tiles > 0 && a.n_tiles <= (mode == 0 ? h->split_max_tiles + h->split_max_tiles / 3 : h->split_max_tiles)) {
             const dim3 sgrid(a.n_tiles);
             if (mode == 0) {
                 if (coord) hipLaunchKernelGGL((k_edge_split<H, true, 0>), sgrid, block, 0, s, a);

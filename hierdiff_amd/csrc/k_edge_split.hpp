@@ -6,8 +6,8 @@
 // reference's shipped sampling job is batch_size 2 (conf/sample/default.yaml:1-2): 56 tiles, 14 workgroups on a 256-CU
 // chip.  Here every tile is spread over the four SIMDs of a CU: wavefront w computes columns [w*H/4, (w+1)*H/4) - a quarter
 // of the MFMAs - with its W2 fragments going L2 -> registers directly (no LDS staging, no barrier in the loop: nothing is
-// shared between the wavefronts there); the first-layer operand P = SiLU(A_i + B_j + r w_r + d0 w_d) is built redundantly
-// by all four.
+// shared between the wavefronts there); the first-layer operand P = SiLU(A_i + B_j + r w_r + d0 w_d), which all four need
+// in full, is built cooperatively - each wavefront a quarter of the K chunks - and shared through LDS (one barrier).
 //
 // Bit-identical to k_edge<H, COORD, PREC> by construction, so a molecule's bits still do not depend on the size of its batch:
 //   * every output element sees the same MFMA chain (accumulator from b2, K chunks ascending; fp32: k-quad q, j;
@@ -149,13 +149,41 @@ __global__ __launch_bounds__(256) void k_edge_split(EdgeArgs a) {
     };
     constexpr int RING = PREC == 0 ? 3 : (PREC == 1 ? 4 : 6);        // chunks of fragments in flight ahead of the MFMAs
     u32x4 fr[RING][NF];
-    Raw raw[2];
-    Opnd op;
     static_for<0, (RING - 1 < NCH ? RING - 1 : NCH)>([&](auto Cc) { load_frags(decltype(Cc)::value, fr[decltype(Cc)::value]); });
-    load_raw(0, raw[0]);
-    if (NCH > 1) load_raw(1, raw[1]);
-    __syncthreads();                                                 // wrd_s, seg_s, cs_tr staged
-    finish_P(0, raw[0], op);
+    // The operand tile (32 edge rows x H) is the same for the four wavefronts: each builds a quarter of the K chunks
+    // (c = wave, wave + 4, ...) and leaves the finished operand registers in LDS, [chunk][slot][lane] x 16 B (lane-linear:
+    // conflict-free ds_write_b128 / ds_read_b128); lane l of every wavefront describes the same (row, half).
+    constexpr int SL = PREC == 2 ? 3 : 4;                            // 16-byte slots per lane and chunk
+    constexpr int CPW = NCH / 4;                                     // chunks per wavefront
+    __shared__ u32x4 opnd_s[NCH * SL * 64];
+    {
+        Raw raw[CPW];
+#pragma unroll
+        for (int i = 0; i < CPW; ++i) load_raw(4 * i + wave, raw[i]);
+        __syncthreads();                                             // wrd_s, seg_s, cs_tr staged
+#pragma unroll
+        for (int i = 0; i < CPW; ++i) {
+            const int c = 4 * i + wave;
+            Opnd o;
+            finish_P(c, raw[i], o);
+            u32x4* dst = opnd_s + (size_t)c * SL * 64 + lane;
+            if constexpr (PREC == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dst[q * 64] = __builtin_bit_cast(u32x4, f32x4{o.P[4 * q], o.P[4 * q + 1], o.P[4 * q + 2], o.P[4 * q + 3]});
+            } else if constexpr (PREC == 1) {
+                dst[0] = o.ph[0]; dst[64] = o.ph[1]; dst[128] = o.pl[0]; dst[192] = o.pl[1];
+            } else {
+                dst[0] = o.xh; dst[64] = o.xm; dst[128] = o.xl;
+            }
+        }
+    }
+    __syncthreads();                                                 // operands of every chunk are in LDS
+    auto read_op = [&](int c, u32x4 (&v)[SL]) {
+#pragma unroll
+        for (int q = 0; q < SL; ++q) v[q] = opnd_s[((size_t)c * SL + q) * 64 + lane];
+    };
+    u32x4 opv[2][SL];
+    read_op(0, opv[0]);
     f32x16 acc[NCW];
 #pragma unroll
     for (int k = 0; k < NCW; ++k) {
@@ -166,7 +194,9 @@ __global__ __launch_bounds__(256) void k_edge_split(EdgeArgs a) {
     static_for<0, NCH>([&](auto Cc) {
         constexpr int c = decltype(Cc)::value;
         if constexpr (c + RING - 1 < NCH) load_frags(c + RING - 1, fr[(c + RING - 1) % RING]);
+        if constexpr (c + 1 < NCH) read_op(c + 1, opv[(c + 1) & 1]);
         u32x4(&f)[NF] = fr[c % RING];
+        u32x4(&ov)[SL] = opv[c & 1];
         if constexpr (PREC == 0) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
@@ -174,11 +204,11 @@ __global__ __launch_bounds__(256) void k_edge_split(EdgeArgs a) {
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int k = 0; k < NCW; ++k)
-                        acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(op.P[4 * q + j], __builtin_bit_cast(f32x4, f[q * NCW + k])[j], acc[k], 0, 0, 0);
+                        acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(f32x4, ov[q])[j], __builtin_bit_cast(f32x4, f[q * NCW + k])[j], acc[k], 0, 0, 0);
         } else if constexpr (PREC == 1) {
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
-                const bf16x8 A_h = __builtin_bit_cast(bf16x8, op.ph[st]), A_l = __builtin_bit_cast(bf16x8, op.pl[st]);
+                const bf16x8 A_h = __builtin_bit_cast(bf16x8, ov[st]), A_l = __builtin_bit_cast(bf16x8, ov[2 + st]);
 #pragma unroll
                 for (int k = 0; k < NCW; ++k) {
                     const bf16x8 Wh = __builtin_bit_cast(bf16x8, f[(0 + st) * NCW + k]), Wl = __builtin_bit_cast(bf16x8, f[(2 + st) * NCW + k]);
@@ -188,7 +218,7 @@ __global__ __launch_bounds__(256) void k_edge_split(EdgeArgs a) {
                 }
             }
         } else {
-            const bf16x8 A_h = __builtin_bit_cast(bf16x8, op.xh), A_m = __builtin_bit_cast(bf16x8, op.xm), A_l = __builtin_bit_cast(bf16x8, op.xl);
+            const bf16x8 A_h = __builtin_bit_cast(bf16x8, ov[0]), A_m = __builtin_bit_cast(bf16x8, ov[1]), A_l = __builtin_bit_cast(bf16x8, ov[2]);
 #pragma unroll
             for (int k = 0; k < NCW; ++k) {
                 const bf16x8 Wh = __builtin_bit_cast(bf16x8, f[0 * NCW + k]), Wm = __builtin_bit_cast(bf16x8, f[1 * NCW + k]),
@@ -200,10 +230,6 @@ __global__ __launch_bounds__(256) void k_edge_split(EdgeArgs a) {
                 acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_m, Wh, acc[k], 0, 0, 0);
                 acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_l, Wh, acc[k], 0, 0, 0);
             }
-        }
-        if constexpr (c + 1 < NCH) {
-            finish_P(c + 1, raw[(c + 1) & 1], op);
-            if constexpr (c + 2 < NCH) load_raw(c + 2, raw[c & 1]);
         }
     });
 
