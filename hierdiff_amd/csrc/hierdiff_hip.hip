@@ -40,6 +40,10 @@ static int fail(int code, const std::string& msg) {
 // topologies with at most this many edge tiles (a third more in fp32) run k_edge_split (one tile per workgroup, columns
 // over its four wavefronts) instead of k_edge (one tile per wavefront); bit-identical, see k_edge_split.hpp
 #define HD_SPLIT_MAX_TILES 512
+// fp32 node chain (batches below HD_FUSE_MIN_ROWS): GEMMs of at most this many rows (B <= 17 at N = 30) run k_gemm_direct
+// (one wavefront per 16 x 16 tile, operands L2 -> registers) instead of k_gemm (64 x 64 tiles staged through LDS);
+// bit-identical; measured break-even between 480 and 960 rows (profiles/r02_direct_sweep.log)
+#define HD_DIRECT_MAX_ROWS 512
 
 struct LayerW {                 // float offsets into hd_handle::dw
     size_t ab_img, ab_bias, wrd, w2_img, b2, wa, w3_img, b3, w4_img, b4;
@@ -79,6 +83,7 @@ struct hd_handle {
     hipEvent_t ev_in, ev_out;   // order own_stream against the caller's stream without host syncs
     unsigned long long weights_gen, sched_gen;   // bumped when the packed weights / schedule tables are re-allocated
     int split_max_tiles;        // HD_SPLIT_MAX_TILES (a measurement build may override it from the environment)
+    int direct_max_rows;        // HD_DIRECT_MAX_ROWS: node GEMMs of at most this many rows run k_gemm_direct
 #ifdef HD_DEBUG_KERNELS
     long long* d_trace;         // HD_ABLATE bit 16: cycle stamps of the last traced edge launch
     int trace_wg;
@@ -212,10 +217,12 @@ extern "C" int hd_create(const hd_config* cfg, int device, hd_handle** out) {
     h->d_nanflag = nullptr; h->d_nan_events = nullptr; h->d_step = nullptr; h->d_draw = nullptr; h->d_tcur = nullptr;
     h->d_base = nullptr;
     h->split_max_tiles = HD_SPLIT_MAX_TILES;
+    h->direct_max_rows = HD_DIRECT_MAX_ROWS;
 #ifdef HD_DEBUG_KERNELS
     h->d_trace = nullptr; h->trace_wg = 0;
     { const char* e = getenv("HD_ABLATE"); h->ablate = e ? atoi(e) : 0; }
     { const char* e = getenv("HD_SPLIT_MAX_TILES"); if (e) h->split_max_tiles = atoi(e); }
+    { const char* e = getenv("HD_DIRECT_MAX_ROWS"); if (e) h->direct_max_rows = atoi(e); }
 #endif
     auto create_rest = [&]() -> int {        // every failure below leaves through hd_destroy (frees what exists)
         HD_TRY(dev_alloc(&h->d_nanflag, 1));
@@ -806,7 +813,14 @@ static void gemm(hd_handle* h, int epi, bool cat, const GemmArgs& g, hipStream_t
     ProfScope ps(h, s, 1);
 
     if (h->NS == 1) launch_gemm<4, 1, 1>(epi, cat, g, s);        // H = 32: 128 x 32 tiles
-    else launch_gemm<2, 2, 1>(epi, cat, g, s);                   // 64 x 64 tiles (fastest measured)
+    else if (g.M <= h->direct_max_rows) {                        // small M: one wavefront per 16 x 16 tile, no LDS staging (bit-identical)
+        const dim3 grid(((g.M + 15) / 16) * (g.Nc / 64)), block(256);
+        if (cat && epi == EPI_BIAS) hipLaunchKernelGGL((k_gemm_direct<EPI_BIAS, true>), grid, block, 0, s, g);
+        else if (cat) hipLaunchKernelGGL((k_gemm_direct<EPI_BIAS_SILU, true>), grid, block, 0, s, g);
+        else if (epi == EPI_BIAS_SILU) hipLaunchKernelGGL((k_gemm_direct<EPI_BIAS_SILU, false>), grid, block, 0, s, g);
+        else if (epi == EPI_BIAS) hipLaunchKernelGGL((k_gemm_direct<EPI_BIAS, false>), grid, block, 0, s, g);
+        else hipLaunchKernelGGL((k_gemm_direct<EPI_RESID_MASK, false>), grid, block, 0, s, g);
+    } else launch_gemm<2, 2, 1>(epi, cat, g, s);                 // 64 x 64 tiles (fastest measured)
 }
 
 // Fused node update (bf16x3 only): min(4, H/32) wavefronts per 32-row workgroup.
