@@ -2,7 +2,8 @@
 // the four wavefronts.  Included through kernels.hpp after k_edge.hpp (same EdgeArgs, same tile tables, same weight image).
 //
 // Why: in k_edge a wavefront owns a whole 32-edge x H tile, i.e. a serial chain of H*H/64 fp32 MFMAs (1,024 at H = 256:
-// 65.5 k matrix-pipe cycles = 29 us) plus prologue and epilogue - 43 us per launch however few tiles there are.  The
+// 65.5 k matrix-pipe cycles = 29 us) plus prologue and epilogue - 43 us per launch however few tiles there are (18 - 25 us
+// in the bf16 modes).  The
 // reference's shipped sampling job is batch_size 2 (conf/sample/default.yaml:1-2): 56 tiles, 14 workgroups on a 256-CU
 // chip.  Here every tile is spread over the four SIMDs of a CU: wavefront w computes columns [w*H/4, (w+1)*H/4) - a quarter
 // of the MFMAs - with its W2 fragments going L2 -> registers directly (no LDS staging, no barrier in the loop: nothing is
@@ -16,8 +17,8 @@
 //   * the row dot with w_a / w_7 is one FMA chain per lane over the column tiles in ascending order - here it is handed
 //     from wavefront to wavefront through LDS (three hand-offs) and finished by the same transposed reduction;
 //   * gate / tanh head, masked per-node sums and the cross-half add are the same expressions on the same operands.
-// tests/test_gpu_parity.py::test_small_batch_edge_kernel_is_bit_identical compares a 2-molecule batch (this kernel) with
-// the same molecules inside a 64-molecule batch (k_edge).
+// tests/test_gpu_parity.py::test_small_batch_edge_kernel_is_bit_identical compares 1-, 2- and 6-molecule batches (this kernel)
+// with the same molecules inside a 40-molecule batch (k_edge), in every precision mode.
 #pragma once
 #include "k_edge.hpp"
 
