@@ -209,7 +209,7 @@ def other_configs(args, dev) -> dict:
     """BASELINE.json configs 2, 3, 5, the L=9 variant of the headline and the reference's shipped job (batch_size 2),
     each timed on a short chain (T_short posterior steps + decode, after one untimed pass), per precision.
     mol/s figures are per-forward cost scaled to 1001 forwards; b2_latency is a real T=1000 run."""
-    from hierdiff_amd import EnVariationalDiffusion
+    from hierdiff_amd import EnVariationalDiffusion, TwoStreamSampler
     from hierdiff_amd.geom_stats import GEOM_FRAGMENT_HISTOGRAM as HIST
     Ts = args.config_timesteps
     out = {"timesteps_timed": Ts, "note": "molecules_per_s = B / (ms_per_forward * 1001)"}
@@ -256,6 +256,10 @@ def other_configs(args, dev) -> dict:
             64, timeit(lambda: m5.sample(64, 30, nm5, em5, ctx5, fix_noise=True)), Ts)
         nm = torch.ones(64, 30, 1, dtype=torch.bool, device=dev)
         blk["B64_N30_L6"] = entry(64, timeit(lambda: m6.sample_from_masks(nm, None, None)), Ts)
+        # opt-in: the same batch as two halves on two HIP streams (hierdiff_amd.TwoStreamSampler, bit-identical results)
+        two = TwoStreamSampler(m6)
+        blk["B64_N30_L6_two_streams"] = entry(64, timeit(lambda: two.sample_from_masks(nm, None, None)), Ts)
+        del two
         # graph size of a pocket-conditioned job (30 fragments + 170 pocket residues in one graph, diffusion_qm9.py:362-371)
         nm = torch.ones(32, 200, 1, dtype=torch.bool, device=dev)
         blk["pocket_sized_B32_N200_L6"] = entry(32, timeit(lambda: m6.sample_from_masks(nm, None, None), reps=1), Ts)

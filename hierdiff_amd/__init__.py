@@ -8,10 +8,11 @@ Public surface mirrors the reference (qiangbo1222/HierDiff, endiffusion/):
 The compute lives in lib/libhierdiff_hip.so (include/hierdiff_hip.h); build it with
 `python -m hierdiff_amd.build`.
 """
+from .concurrent import TwoStreamSampler  # noqa: F401
 from .diffusion import AttrDict, DiffusionQM9, EnVariationalDiffusion, default_config  # noqa: F401
 from .distributions import DistributionNodes  # noqa: F401
 from .dynamics import EGNN_dynamics_QM9, Topology  # noqa: F401
 from .noise_model import GammaNetwork, PredefinedNoiseSchedule  # noqa: F401
 
 __all__ = ["EGNN_dynamics_QM9", "DiffusionQM9", "EnVariationalDiffusion", "GammaNetwork",
-           "PredefinedNoiseSchedule", "DistributionNodes", "Topology", "AttrDict", "default_config"]
+           "PredefinedNoiseSchedule", "DistributionNodes", "Topology", "AttrDict", "default_config", "TwoStreamSampler"]

@@ -1,0 +1,91 @@
+"""Opt-in: sample a small batch as two independent half batches on two HIP streams.
+
+Why.  At B = 32 .. 128 the node kernels of the bf16 modes occupy a fraction of the chip (60 workgroups at B = 64) while
+the edge kernels fill it; the molecules of a batch are independent and the edge tiles are cut per molecule, so a batch
+can be cut in two and the halves run side by side - the node kernels of one beside the edge kernels of the other - with
+BIT-IDENTICAL results (a sample's bits depend on its global id, mask and weights only).  Measured on one MI355X at B = 64,
+N = 30, H = 256, L = 6 (scratch/concurrent_shards.py, profiles/r02_concurrent_shards.log): bf16x3 72.4 -> 82.1
+molecules/s, bf16x6 49.5 -> 57.2; exact fp32 does NOT gain (32.2 -> 31.0: its node GEMMs compete with the edge kernel for
+the same fp32 MFMA pipe), more than two streams serialise, and at B = 256 the chip is full either way (+-2 %).  Hence
+opt-in, and meant for the bf16 modes at medium batch sizes.
+
+The second half runs on a twin model (own C-ABI handle, own packed copy of the weights - the library serialises calls per
+handle) that is kept in step with the original's parameters and sampling knobs.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+
+class TwoStreamSampler:
+    """`sampler = TwoStreamSampler(model); x, h = sampler.sample_from_masks(node_mask, edge_mask, context)` - the same
+    (x, h) as `model.sample_from_masks(...)` with the library's counter-based noise (`noise_mode == "philox"`)."""
+
+    def __init__(self, model):
+        if model.noise_mode != "philox":
+            raise ValueError("TwoStreamSampler needs the library's counter-based noise (noise_mode = 'philox'): it is what "
+                             "makes a sample independent of how the batch is cut")
+        self.model = model
+        self._twin = None
+        self._twin_key = None
+        self._side: Optional[torch.cuda.Stream] = None
+        self._cuts = {}
+
+    def _sync_twin(self):
+        m = self.model
+        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in m.state_dict(keep_vars=True).values())
+        if self._twin is None:
+            self._twin = type(m)(m.cfg)
+        t = self._twin
+        if key != self._twin_key:
+            t.load_state_dict(m.state_dict())
+            t.to(next(m.parameters()).device)
+            self._twin_key = key
+        t.dynamics.precision = m.dynamics.precision
+        for knob in ("noise_mode", "seed", "use_graph", "debug_checks", "schedule_gammas"):
+            setattr(t, knob, getattr(m, knob))
+        t.eval()
+        return t
+
+    @torch.no_grad()
+    def sample_from_masks(self, node_mask: torch.Tensor, edge_mask: Optional[torch.Tensor] = None, context=None,
+                          sample_id_base: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
+        m = self.model
+        dev = node_mask.device
+        if dev.type != "cuda":
+            raise _lib.HierDiffHipError("sampling runs only on an MI355X (no CPU fallback)")
+        B = node_mask.shape[0]
+        if B < 2:
+            return m.sample_from_masks(node_mask, edge_mask, context, sample_id_base=sample_id_base)
+        twin = self._sync_twin()
+        if self._side is None or self._side.device != dev:
+            self._side = torch.cuda.Stream(dev)
+        b0 = (B + 1) // 2
+        cut = lambda t, lo, hi: None if t is None else t[lo:hi].contiguous()
+        main = torch.cuda.current_stream(dev)
+        # the halves of the masks are kept per mask tensor (identity + in-place version), so that repeated calls hit the
+        # topology / hipGraph caches of the two models like an uncut batch does
+        sig = lambda t: None if t is None else (t.data_ptr(), t._version, tuple(t.shape))
+        mkey = (sig(node_mask), sig(edge_mask))
+        hit = self._cuts.get(mkey)
+        if hit is None:
+            if len(self._cuts) >= 4:
+                self._cuts.pop(next(iter(self._cuts)))
+            hit = (cut(node_mask, 0, b0), cut(edge_mask, 0, b0), cut(node_mask, b0, B), cut(edge_mask, b0, B), node_mask, edge_mask)
+            self._cuts[mkey] = hit                    # holding the originals pins their addresses
+        nm0, em0, nm1, em1 = hit[:4]
+        cx1 = cut(context, b0, B)                      # produced on the caller's stream
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            x1, h1 = twin.sample_from_masks(nm1, em1, cx1, sample_id_base=sample_id_base + b0)
+        x0, h0 = m.sample_from_masks(nm0, em0, cut(context, 0, b0), sample_id_base=sample_id_base)
+        main.wait_stream(self._side)
+        x1.record_stream(main)                         # allocated on the side stream, consumed on the caller's
+        h1.record_stream(main)
+        if cx1 is not None:
+            cx1.record_stream(self._side)              # and the other way round
+        return torch.cat([x0, x1], dim=0), torch.cat([h0, h1], dim=0)

@@ -413,3 +413,31 @@ def test_world2_processes_reproduce_single_process_bits(tmp_path):
         assert np.array_equal(d["x"], x[lo:lo + cnt, :n2]) and np.array_equal(d["h"], h[lo:lo + cnt, :n2]), r
         seen += cnt
     assert seen == len(n_list)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_two_stream_sampler_reproduces_single_stream_bits(precision):
+    """hierdiff_amd.TwoStreamSampler (opt-in: two half batches on two HIP streams, twin handle) returns the bits of the
+    plain sampler: ragged sizes, an odd batch, a context model, repeated calls (cached cuts / topologies / graphs) and a
+    weight update in between."""
+    from hierdiff_amd import EnVariationalDiffusion, TwoStreamSampler, default_config
+    from hierdiff_amd.weights import synthetic_state_dict
+    H, L, T, N = 128, 2, 12, 12
+    sd = synthetic_state_dict(9, 1, H, L, 2, True, 71, 1.0)
+    m = EnVariationalDiffusion(default_config(hidden_nf=H, n_layers=L, context_node_nf=1, timesteps=T))
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v).copy()) for k, v in sd.items()})
+    m = m.to(DEV).eval()
+    m.dynamics.precision = precision
+    sizes = torch.tensor([12, 5, 9, 1, 12, 7, 3])
+    nm = (torch.arange(N)[None, :] < sizes[:, None]).unsqueeze(-1).to(DEV)
+    ctx = torch.linspace(-0.4, 4.9, 7).view(7, 1, 1).expand(7, N, 1).contiguous().to(DEV)
+    two = TwoStreamSampler(m)
+    with torch.no_grad():
+        for rep in range(3):
+            if rep == 2:
+                m.dynamics.egnn.embedding.weight.mul_(1.01)          # the twin must follow the original's parameters
+            x_ref, h_ref = m.sample_from_masks(nm, None, ctx, sample_id_base=40)
+            x, h = two.sample_from_masks(nm, None, ctx, sample_id_base=40)
+            torch.cuda.synchronize()
+            assert torch.isfinite(x_ref).all() and torch.equal(x, x_ref) and torch.equal(h, h_ref), f"rep {rep}"
