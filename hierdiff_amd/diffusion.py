@@ -154,6 +154,10 @@ class DiffusionQM9(_Base):
         self.use_graph = True
         self.debug_checks = False       # True re-enables the reference's host-synchronising asserts
         self.schedule_gammas = None     # optional [T+1] gamma grid overriding the network (replay a run)
+        # "fp64" (default): the schedule network is evaluated once in float64 on the host and rounded - the same table on
+        # every machine.  "fp32": evaluated like the reference (float32, a [B,1] column per grid value, CPU BLAS): agrees
+        # run for run with a CPU reference on the same host, host-dependent otherwise.
+        self.schedule_eval = "fp64"
         self._sched_key = None
         self._sched = None
 
@@ -394,14 +398,15 @@ class DiffusionQM9(_Base):
         self.dynamics.sync_weights()
         return self.dynamics._handle()
 
-    def _schedule(self):
+    def _schedule(self, rows: int = 1):
         """Tabulated schedule, uploaded to the handle (hd_set_schedule); recomputed when gamma changes."""
         handle = self._lib_handle()          # creates the handle if needed: its generation is part of the key (a new
         # handle - other precision, other device - has no schedule yet, even if it re-uses a freed handle's address)
         key = (self.T, self.dynamics._handle_gen) + tuple(
-            (p.data_ptr(), p._version) for p in self.gamma.parameters()) + (id(self.schedule_gammas),)
+            (p.data_ptr(), p._version) for p in self.gamma.parameters()) + (
+                id(self.schedule_gammas), self.schedule_eval, rows if self.schedule_eval == "fp32" else 0)
         if key != self._sched_key:
-            tabs = schedule_tables(self.gamma, self.T, self.schedule_gammas)
+            tabs = schedule_tables(self.gamma, self.T, self.schedule_gammas, self.schedule_eval, rows)
             tau = tabs["tau"].numpy().astype(np.float32)
             coef = tabs["coef"].numpy().astype(np.float32).reshape(-1)
             _lib.check(_lib.load().hd_set_schedule(
@@ -527,7 +532,7 @@ class DiffusionQM9(_Base):
         D = self.n_dims + self.in_node_nf
         lib = _lib.load()
         h = self._lib_handle()
-        tabs = self._schedule()
+        tabs = self._schedule(rows=B)
         topo = self.dynamics.topology(node_mask, edge_mask, B, N)
         ctx = None
         if self.dynamics.context_node_nf > 0:

@@ -153,6 +153,20 @@ def _fp64_twin(gamma_module: torch.nn.Module) -> torch.nn.Module:
     return twin
 
 
+def evaluate_gamma_fp32(gamma_module: torch.nn.Module, t: torch.Tensor, rows: int = 1) -> torch.Tensor:
+    """gamma(t) the way the reference computes it (models/noise_model.py:186-200 called with a [B,1] column of one repeated
+    time, diffusion_qm9.py:376-379): fp32 on the CPU, one evaluation per grid value on a [rows,1] batch.  Opt-in
+    (`DiffusionQM9.schedule_eval = "fp32"`): the result depends on the host's BLAS summation order (CPU model, torch
+    thread count, `rows`), i.e. it agrees run for run with a CPU reference ON THE SAME HOST evaluated with the same batch
+    size (tests/test_oracle_golden.py reproduces fixture F16's recorded grid bit for bit in the build container) and is
+    otherwise one more member of the reference's own 1e-3 spread."""
+    import copy
+    twin = copy.deepcopy(gamma_module).to("cpu").float()
+    tt = t.detach().to("cpu", torch.float32).reshape(-1, 1)
+    with torch.no_grad():
+        return torch.stack([twin(tt[k:k + 1].expand(max(1, int(rows)), 1))[0, 0] for k in range(tt.shape[0])]).view(-1, 1)
+
+
 def decode_coefficients(gamma_0: torch.Tensor) -> torch.Tensor:
     """{sigma_0, alpha_0, sigma_x = exp(0.5*gamma_0)} (diffusion_qm9.py:148-158, 296-299)."""
     g0 = gamma_0.reshape(-1)[0:1].to(torch.float32)
@@ -162,7 +176,7 @@ def decode_coefficients(gamma_0: torch.Tensor) -> torch.Tensor:
 
 
 @torch.no_grad()
-def schedule_tables(gamma_module: torch.nn.Module, T: int, gammas=None) -> Dict[str, torch.Tensor]:
+def schedule_tables(gamma_module: torch.nn.Module, T: int, gammas=None, eval_mode: str = "fp64", rows: int = 1) -> Dict[str, torch.Tensor]:
     """Schedule on the sampling grid tau_k = int64(k) / T (fp32; diffusion_qm9.py:376-379).  Returns CPU
     tensors: tau [T+1], gamma [T+1], coef [T,4] (row s: transition t=s+1 -> s; diffusion_qm9.py:314-334),
     decode {sigma_0, alpha_0, sigma_x}.  `gammas` ([T+1] fp32) overrides the network, e.g. to replay the
@@ -170,7 +184,9 @@ def schedule_tables(gamma_module: torch.nn.Module, T: int, gammas=None) -> Dict[
     k = torch.arange(0, T + 1, dtype=torch.int64).view(-1, 1)
     tau = k / T
     if gammas is None:
-        g = evaluate_gamma(gamma_module, tau)
+        if eval_mode not in ("fp64", "fp32"):
+            raise ValueError("schedule_eval must be 'fp64' or 'fp32'")
+        g = evaluate_gamma(gamma_module, tau) if eval_mode == "fp64" else evaluate_gamma_fp32(gamma_module, tau, rows)
     else:
         g = torch.as_tensor(gammas, dtype=torch.float32).reshape(-1, 1)
         assert g.shape[0] == T + 1, "need T+1 gamma values"

@@ -46,3 +46,11 @@ def fixture_model(fx, context_node_nf=0):
     cfg = orc.DynCfg(in_node_nf=9, context_node_nf=context_node_nf, hidden_nf=H, n_layers=L,
                      normalization_factor=10.0)
     return sd_np, orc.as_torch_sd(sd_np), cfg
+
+
+def chain_noise(seed, T, B, N, F=8):
+    """The (T+2) x (randn_x [B,N,3], randn_h [B,N,F]) draws of a chain fixture that stores `noise_seed` instead of the
+    draws (oracle/make_golden.py:fixture_chain): numpy PCG64, x then h per draw."""
+    rng = np.random.Generator(np.random.PCG64(int(seed)))
+    return [(torch.from_numpy(rng.standard_normal((B, N, 3)).astype(np.float32)),
+             torch.from_numpy(rng.standard_normal((B, N, F)).astype(np.float32))) for _ in range(T + 2)]

@@ -7,6 +7,7 @@ padding invariance, centre of gravity, finiteness).  Tolerance: the per-forward 
 over the whole output, max-abs < 1e-4 * max(1, max|ref|)) unless a test states otherwise.
 """
 import copy
+import os
 import ctypes as C
 
 import numpy as np
@@ -441,3 +442,77 @@ def test_two_stream_sampler_reproduces_single_stream_bits(precision):
             x, h = two.sample_from_masks(nm, None, ctx, sample_id_base=40)
             torch.cuda.synchronize()
             assert torch.isfinite(x_ref).all() and torch.equal(x, x_ref) and torch.equal(h, h_ref), f"rep {rep}"
+
+
+# ----------------------------------------------------------------------------- (k) config 4: B = 2048 as 8 shards, RCCL path
+
+def test_config4_b2048_equals_eight_shards_of_256():
+    """BASELINE.json config 4 at its stated size: ONE B = 2048 topology on one GPU against 8 shards of 256 molecules with
+    sample_id_base = 256 r (what rank r of an 8-GPU job computes, hierdiff_amd/sharding.py), production network H = 256,
+    L = 6, T = 20 posterior steps + decode, exact fp32: every molecule is bit-identical (`torch.equal`) - a sample's bits
+    do not depend on the batch / rank / world size it is computed in.  N = 30 with ragged
+    sizes so that tail tiles are shared between neighbouring molecules differently in the two layouts."""
+    H, L, T, N, B, W = 256, 6, 20, 30, 2048, 8
+    model = build_diffusion(_syn(H, L, seed=44, gain=0.02), H, L, T=T)
+    g = torch.Generator().manual_seed(5)
+    sizes = torch.randint(1, N + 1, (B,), generator=g)
+    sizes[::3] = N                                        # a third of the batch at the full size
+    nm = (torch.arange(N)[None, :] < sizes[:, None]).unsqueeze(-1).to(DEV)
+    x_all, h_all = model.sample_from_masks(nm, None, None, sample_id_base=7000)
+    assert torch.isfinite(x_all).all() and torch.isfinite(h_all).all()
+    from hierdiff_amd.sharding import shard_sample_ids
+    for r in range(W):
+        lo, cnt = shard_sample_ids(7000, B, r, W)
+        assert cnt == 256
+        sl = slice(lo - 7000, lo - 7000 + cnt)
+        x, h = model.sample_from_masks(nm[sl].contiguous(), None, None, sample_id_base=lo)
+        assert torch.equal(x, x_all[sl]) and torch.equal(h, h_all[sl]), f"shard {r}"
+    # centre of gravity of every molecule stays at the origin (size-independent property of the path)
+    cog = (x_all * nm).sum(1) / sizes.view(-1, 1).to(DEV)
+    assert float(cog.abs().max()) < 1e-3
+
+
+def _run_bench(args, launcher, tmp_path, tag):
+    """bench.py in a fresh process, plain or under torch.distributed.run with ONE rank; returns the parsed JSON line."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    bench = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")
+    cmd = [sys.executable]
+    if launcher:
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                "--master-port", str(port)]
+    cmd += [bench] + args
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, f"{tag}: rc {p.returncode}\n{p.stdout[-2000:]}\n{p.stderr[-4000:]}"
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, f"{tag}: expected ONE JSON line, got {len(lines)}"
+    return json.loads(lines[0])
+
+
+def test_bench_rccl_path_at_world_one(tmp_path):
+    """The N > 1 code path of bench.py, for real, on this box's single GPU: launched like the driver launches N = 8
+    (python -m torch.distributed.run --nproc-per-node 1 ... bench.py --gpus 1) the process initialises the "nccl" backend
+    (= RCCL), broadcasts the packed weights with ncclBroadcast, brackets the timed region with RCCL barriers and
+    all-gathers the per-rank times.  The line must report rccl_ranks and agree with a plain N = 1 run of the same
+    workload within 5 % (same box, back to back; the 2 % the collectives could cost is inside the run-to-run spread)."""
+    args = ["--gpus", "1", "--steps", "3", "--warmup", "1", "--timesteps", "250", "--precision", "fp32", "--no-configs",
+            "--no-cpu-baseline"]
+    plain = _run_bench(args, False, tmp_path, "plain")
+    rccl = _run_bench(args, True, tmp_path, "launcher")
+    assert "rccl_ranks" not in plain
+    assert rccl["rccl_ranks"] == 1 and rccl["rccl"]["backend"] == "nccl"
+    assert rccl["rccl"]["broadcast_elements"] > 5_900_000            # 5,932,309 dynamics + 3,077 schedule parameters
+    assert len(rccl["rank_elapsed_s"]) == 1 and rccl["rank_elapsed_s"][0] <= rccl["elapsed_max_s"] + 1e-6
+    assert rccl["n_gpus"] == 1 and rccl["scaling"] == "weak"
+    ratio = rccl["value"] / plain["value"]
+    print(f"bench value plain {plain['value']} vs under the launcher with RCCL {rccl['value']} molecules/s (ratio {ratio:.3f})")
+    assert 0.95 < ratio < 1.05
+    for line in (plain, rccl):                                        # the contract's keys
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                  "vs_baseline", "dtype", "data", "config", "roofline"):
+            assert k in line, k
+        assert line["roofline"]["bound"] == "mfma" and 0.0 < line["roofline"]["frac"] < 1.0
