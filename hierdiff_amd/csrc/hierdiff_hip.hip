@@ -44,6 +44,9 @@ static int fail(int code, const std::string& msg) {
 // (one wavefront per 16 x 16 tile, operands L2 -> registers) instead of k_gemm (64 x 64 tiles staged through LDS);
 // bit-identical; measured break-even between 480 and 960 rows (profiles/r02_direct_sweep.log)
 #define HD_DIRECT_MAX_ROWS 512
+// topologies above one whole-tile workgroup per CU and below this many tiles may run k_edge_mixed: a multiple of the CU count
+// of whole-tile workgroups plus column-split single-tile workgroups that back-fill (k_edge_split.hpp; rule in launch_edge_h)
+#define HD_MIX_MAX_TILES 16384
 
 struct LayerW {                 // float offsets into hd_handle::dw
     size_t ab_img, ab_bias, wrd, w2_img, b2, wa, w3_img, b3, w4_img, b4;
@@ -84,6 +87,9 @@ struct hd_handle {
     unsigned long long weights_gen, sched_gen;   // bumped when the packed weights / schedule tables are re-allocated
     int split_max_tiles;        // HD_SPLIT_MAX_TILES (a measurement build may override it from the environment)
     int direct_max_rows;        // HD_DIRECT_MAX_ROWS: node GEMMs of at most this many rows run k_gemm_direct
+    int mix_max_tiles;          // HD_MIX_MAX_TILES
+    int mix_rounds;             // measurement build: force the number of whole-tile rounds of k_edge_mixed (-1 = rule)
+    int n_cu;                   // compute units of the device
 #ifdef HD_DEBUG_KERNELS
     long long* d_trace;         // HD_ABLATE bit 16: cycle stamps of the last traced edge launch
     int trace_wg;
@@ -218,11 +224,19 @@ extern "C" int hd_create(const hd_config* cfg, int device, hd_handle** out) {
     h->d_base = nullptr;
     h->split_max_tiles = HD_SPLIT_MAX_TILES;
     h->direct_max_rows = HD_DIRECT_MAX_ROWS;
+    h->mix_max_tiles = HD_MIX_MAX_TILES;
+    h->mix_rounds = -1;
+    {
+        hipDeviceProp_t prop;
+        h->n_cu = (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
 #ifdef HD_DEBUG_KERNELS
     h->d_trace = nullptr; h->trace_wg = 0;
     { const char* e = getenv("HD_ABLATE"); h->ablate = e ? atoi(e) : 0; }
     { const char* e = getenv("HD_SPLIT_MAX_TILES"); if (e) h->split_max_tiles = atoi(e); }
     { const char* e = getenv("HD_DIRECT_MAX_ROWS"); if (e) h->direct_max_rows = atoi(e); }
+    { const char* e = getenv("HD_MIX_MAX_TILES"); if (e) h->mix_max_tiles = atoi(e); }
+    { const char* e = getenv("HD_MIX_ROUNDS"); if (e) h->mix_rounds = atoi(e); }
 #endif
     auto create_rest = [&]() -> int {        // every failure below leaves through hd_destroy (frees what exists)
         HD_TRY(dev_alloc(&h->d_nanflag, 1));
@@ -981,6 +995,38 @@ static int launch_edge_h(hd_handle* h, bool coord, const EdgeArgs& a, hipStream_
         }
     }
     if constexpr (H >= 128) {
+        // between one whole-tile workgroup per CU and HD_MIX_MAX_TILES: R * n_cu whole-tile workgroups (every CU the same
+        // number) + the remaining tiles as column-split workgroups that back-fill (k_edge_mixed; bit-identical per tile)
+        const int mode = h->x6 ? 2 : (prec == 1 ? 1 : 0);
+        const int per_round = 4 * h->n_cu;
+        // Measured (profiles/r03_mix_sweep*.log, ms per forward, plain -> mixed): fp32 B = 40 1.89 -> 1.45, 64 1.93 -> 1.88,
+        // 96 2.66 -> 2.60, 128 3.29 -> 3.17, 160 4.15 -> 3.89, 192 4.79 -> 4.40, 256 5.41 -> 5.51; the bf16 modes gain only
+        // while few tiles are left over (B = 40: -14 %; B = 64 ... 256: +2 ... +8 %).  A column-split tile costs about 1.5 x a
+        // whole one in SIMD time, so the mix pays when it replaces a badly filled last round: at most 2.9 left-over tiles per
+        // CU in fp32, 1.0 in the bf16 modes.
+        int R = a.n_tiles / per_round;
+        const int left = a.n_tiles - R * per_round;
+        const bool pays = left > 0 && left * 10 <= (mode == 0 ? 29 : 10) * h->n_cu;
+        if (a.n_tiles > per_round && a.n_tiles < h->mix_max_tiles && (pays || h->mix_rounds >= 0)) {
+            if (h->mix_rounds >= 0) R = std::min(R, h->mix_rounds);
+            EdgeArgs m = a;
+            m.n_wg = R * h->n_cu;
+            const dim3 mgrid(m.n_wg + (a.n_tiles - 4 * m.n_wg));
+            const int ldsm = std::max(edge_lds_bytes<H>(mode == 2), mode == 2 ? edge_split_lds_bytes<H, 2>() : edge_split_lds_bytes<H, 0>());
+            if (mode == 0) {
+                if (coord) hipLaunchKernelGGL((k_edge_mixed<H, true, 0>), mgrid, block, ldsm, s, m);
+                else hipLaunchKernelGGL((k_edge_mixed<H, false, 0>), mgrid, block, ldsm, s, m);
+            } else if (mode == 1) {
+                if (coord) hipLaunchKernelGGL((k_edge_mixed<H, true, 1>), mgrid, block, ldsm, s, m);
+                else hipLaunchKernelGGL((k_edge_mixed<H, false, 1>), mgrid, block, ldsm, s, m);
+            } else {
+                if (coord) hipLaunchKernelGGL((k_edge_mixed<H, true, 2>), mgrid, block, ldsm, s, m);
+                else hipLaunchKernelGGL((k_edge_mixed<H, false, 2>), mgrid, block, ldsm, s, m);
+            }
+            return HD_OK;
+        }
+    }
+    if constexpr (H >= 128) {
         if (h->x6) {
             const int lds6 = edge_lds_bytes<H>(true);
             if (coord) hipLaunchKernelGGL((k_edge<H, true, 2>), grid, block, lds6, s, a);
@@ -1010,6 +1056,13 @@ static int prepare_edge_h() {
     if constexpr (H >= 128) {
         HIP_TRY(hipFuncSetAttribute((const void*)k_edge<H, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, edge_lds_bytes<H>(true)));
         HIP_TRY(hipFuncSetAttribute((const void*)k_edge<H, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, edge_lds_bytes<H>(true)));
+        const int m0 = std::max(edge_lds_bytes<H>(false), edge_split_lds_bytes<H, 0>()), m2 = std::max(edge_lds_bytes<H>(true), edge_split_lds_bytes<H, 2>());
+        HIP_TRY(hipFuncSetAttribute((const void*)k_edge_mixed<H, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, m0));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_edge_mixed<H, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, m0));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_edge_mixed<H, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, m0));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_edge_mixed<H, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, m0));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_edge_mixed<H, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, m2));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_edge_mixed<H, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, m2));
     }
     return HD_OK;
 }

@@ -22,22 +22,30 @@
 #pragma once
 #include "k_edge.hpp"
 
+// LDS of the split form besides wrd_s: operand tile + hand-off scratch, carved from one byte buffer so that k_edge_mixed can
+// place it in the dynamic LDS the whole-tile form uses for its W2 double buffer
+template <int H, int PREC>
+constexpr int edge_split_lds_bytes() {
+    return (H / (PREC == 2 ? 16 : 32)) * (PREC == 2 ? 3 : 4) * 64 * 16 + (16 * 64 + 64 + 8 + 32 + 96 + 4) * 4;
+}
+
 template <int H, bool COORD, int PREC>
-__global__ __launch_bounds__(256) void k_edge_split(EdgeArgs a) {
+HD_DEVINL void edge_split_body(const EdgeArgs& a, char* lds, float* wrd_s, const int tile) {
     constexpr int KC = PREC == 2 ? 16 : 32;                          // K chunk width, as in k_edge
     constexpr int NCT = H / 32, NCW = NCT / 4, NCH = H / KC, CHF = PREC == 2 ? 24 * H : 32 * H, NQ = KC / 8;
     static_assert(NCT % 4 == 0, "column tiles are dealt to four wavefronts");
-    __shared__ __attribute__((aligned(16))) float wrd_s[4 * H];     // [w_r | w_d | b2 | wa]
-    __shared__ float dot_x[16 * 64];                                 // running row dots, handed from wavefront to wavefront
-    __shared__ float att_s[64];                                      // gate per (half, row slot) as wavefront 3 holds it
-    __shared__ uint32_t seg_s[8];                                    // segment byte of the 32 rows
-    __shared__ float cs_phi[32], cs_tr[96];                          // coordinate head scratch (wavefront 3)
-    __shared__ int nan_s;
+    constexpr int SL = PREC == 2 ? 3 : 4;                            // 16-byte slots per lane and chunk
+    u32x4* opnd_s = reinterpret_cast<u32x4*>(lds);                   // [NCH * SL * 64] operand tile
+    float* dot_x = reinterpret_cast<float*>(lds + NCH * SL * 64 * 16);   // [16 * 64] running row dots, handed from wavefront to wavefront
+    float* att_s = dot_x + 16 * 64;                                  // [64] gate per (half, row slot) as wavefront 3 holds it
+    uint32_t* seg_s = reinterpret_cast<uint32_t*>(att_s + 64);       // [8] segment byte of the 32 rows
+    float* cs_phi = reinterpret_cast<float*>(seg_s + 8);             // [32] coordinate head scratch (wavefront 3)
+    float* cs_tr = cs_phi + 32;                                      // [96]
+    int* nan_p = reinterpret_cast<int*>(cs_tr + 96);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hh = lane >> 5, n = lane & 31;
-    const int tile = blockIdx.x;                                     // grid = n_tiles
 
     for (int k = tid; k < 2 * H; k += 256) wrd_s[k] = a.wrd[k];
     for (int k = tid; k < H; k += 256) { wrd_s[2 * H + k] = a.b2[k]; wrd_s[3 * H + k] = a.wa[k]; }
@@ -154,9 +162,7 @@ __global__ __launch_bounds__(256) void k_edge_split(EdgeArgs a) {
     // The operand tile (32 edge rows x H) is the same for the four wavefronts: each builds a quarter of the K chunks
     // (c = wave, wave + 4, ...) and leaves the finished operand registers in LDS, [chunk][slot][lane] x 16 B (lane-linear:
     // conflict-free ds_write_b128 / ds_read_b128); lane l of every wavefront describes the same (row, half).
-    constexpr int SL = PREC == 2 ? 3 : 4;                            // 16-byte slots per lane and chunk
     constexpr int CPW = NCH / 4;                                     // chunks per wavefront
-    __shared__ u32x4 opnd_s[NCH * SL * 64];
     {
         Raw raw[CPW];
 #pragma unroll
@@ -307,7 +313,7 @@ __global__ __launch_bounds__(256) void k_edge_split(EdgeArgs a) {
             }
             att_s[lane] = att_mine;
             const bool tile_has_nan = __builtin_amdgcn_ballot_w64(rowdot != rowdot) != 0;
-            if (lane == 0) nan_s = tile_has_nan ? 1 : 0;
+            if (lane == 0) *nan_p = tile_has_nan ? 1 : 0;
         } else {
             // phi of row rho(slot) is in lanes 2 slot, 2 slot + 1 of half hh; then lane n handles row n (k_edge's coordinate head)
             if ((n & 1) == 0) cs_phi[(my_slot & 3) + 8 * (my_slot >> 2) + 4 * hh] = rowdot;
@@ -347,7 +353,7 @@ __global__ __launch_bounds__(256) void k_edge_split(EdgeArgs a) {
             const float att = att_s[(lane & 32) | (2 * r)];
             w[r] = (sg[r] != 255) ? att : 0.0f;
         }
-        const bool tile_has_nan = nan_s != 0;
+        const bool tile_has_nan = *nan_p != 0;
         for (int s = 0; s < nseg; ++s) {
             float ws[16];
 #pragma unroll
@@ -379,4 +385,27 @@ __global__ __launch_bounds__(256) void k_edge_split(EdgeArgs a) {
             }
         }
     }
+}
+
+template <int H, bool COORD, int PREC>
+__global__ __launch_bounds__(256) void k_edge_split(EdgeArgs a) {
+    __shared__ __attribute__((aligned(16))) float wrd_s[4 * H];     // [w_r | w_d | b2 | wa]
+    __shared__ __attribute__((aligned(16))) char lds[edge_split_lds_bytes<H, PREC>()];
+    edge_split_body<H, COORD, PREC>(a, lds, wrd_s, blockIdx.x);      // grid = n_tiles
+}
+
+// Whole-tile and column-split workgroups in ONE launch, for topologies between one and three tiles per SIMD.  There a
+// k_edge launch leaves the chip unevenly loaded: all its workgroups are resident at once (two per CU at most), a CU that got
+// two takes twice as long as a CU that got one, and nothing is left to back-fill (B = 64 at N = 30: 436 workgroups on 512
+// slots, 81 us against 43 us for one workgroup per CU).  Here the first a.n_wg blocks are whole-tile workgroups (four tiles
+// each, k_edge's body) - a multiple of the CU count, so every CU gets the same number - and the remaining tiles follow as
+// column-split single-tile workgroups (k_edge_split's body), which the dispatcher deals out as slots free up.  Both bodies are
+// bit-identical per tile, so which one computes a tile does not show in the result.  Dynamic LDS = the larger of the two needs.
+template <int H, bool COORD, int PREC>
+__global__ __launch_bounds__(256, 2) void k_edge_mixed(EdgeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ __attribute__((aligned(16))) float wrd_s[4 * H];
+    const int bid = blockIdx.x;
+    if (bid < a.n_wg) edge_tile_body<H, COORD, PREC, 0>(a, smem, wrd_s, bid, a.n_wg);
+    else edge_split_body<H, COORD, PREC>(a, reinterpret_cast<char*>(smem), wrd_s, 4 * a.n_wg + (bid - a.n_wg));
 }

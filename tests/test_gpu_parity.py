@@ -315,6 +315,38 @@ def test_small_batch_edge_kernel_is_bit_identical(H, C_, general, precision):
         assert torch.equal(big[:k], small), f"k={k}: max diff {(big[:k] - small).abs().max().item():.3e}"
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_mixed_edge_launch_is_bit_identical(precision):
+    """Above one whole-tile workgroup per CU (1,024 tiles), when few tiles are left over after the last full round, the edge
+    layers run k_edge_mixed: a multiple of the CU count of whole-tile workgroups (k_edge's body) plus the left-over tiles as
+    column-split workgroups (k_edge_split's body) that back-fill (BASELINE config 2's B = 64 in fp32).  The molecules of such
+    batches against the same molecules at the head of a 150-molecule batch (3,928 tiles: plain k_edge) and the first six alone
+    (k_edge_split): torch.equal, ragged sizes, every precision mode."""
+    from hierdiff_amd.weights import synthetic_state_dict
+    H, L, N = 256, 2, 30
+    sd_np = synthetic_state_dict(9, 0, H, L, 2, True, 616, 1.0)
+    dyn = build_dynamics(sd_np, H, L, 0)
+    dyn.precision = precision
+    n_list = ([30, 17, 1, 24, 30, 9] + [30] * 26) * 2 + [30] * 86
+    xh, nm, em = orc.random_inputs(n_list, 8, 36, N)
+    xh, nm, em = xh.to(DEV), nm.to(DEV), em.to(DEV)
+    t = torch.linspace(0.05, 0.95, len(n_list), device=DEV).view(-1, 1)
+    big = dyn._forward(t, xh, nm, em, None, None)
+    assert dyn.topology(nm, em, len(n_list), N).info()["tiles"] > 3072
+    # 46 molecules: 1,092 tiles = 256 whole-tile workgroups + 68 column-split tiles (mixed in every mode); 64 molecules:
+    # 1,584 tiles, 560 left over (mixed in fp32 only: the rule of launch_edge_h)
+    for k in (46, 64):
+        nmk, emk = nm[:k].contiguous(), em[:k].contiguous()
+        tiles = dyn.topology(nmk, emk, k, N).info()["tiles"]
+        assert 1024 < tiles < 3072, tiles
+        mid = dyn._forward(t[:k], xh[:k], nmk, emk, None, None)
+        assert torch.isfinite(mid).all()
+        assert torch.equal(big[:k], mid), f"k={k}: max diff {(big[:k] - mid).abs().max().item():.3e}"
+    nm6, em6 = nm[:6].contiguous(), em[:6].contiguous()
+    small = dyn._forward(t[:6], xh[:6], nm6, em6, None, None)
+    assert torch.equal(mid[:6], small)
+
+
 def test_equivariance_permutation_padding_full_size():
     """Size-independent properties at the headline shape B=256, N=30, H=256, L=6."""
     from hierdiff_amd.weights import synthetic_state_dict
