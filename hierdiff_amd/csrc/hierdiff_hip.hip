@@ -35,22 +35,19 @@ static int fail(int code, const std::string& msg) {
 
 // ----------------------------------------------------------------------------- objects
 
-// fp32 mode: batches with fewer active rows than this run the node side as k_agg + 3 x k_gemm instead of the fused k_node_f32
-#define HD_FUSE_MIN_ROWS 6144
+// fp32 mode: batches with fewer active rows than this run the node side as three k_gemm_r16 launches instead of the fused
+// k_node_f32 (profiles/r03_r16_sweep.log: B = 128 3.22 vs 3.31 ms per forward, B = 160 equal, B = 192 4.46 vs 4.29)
+#define HD_FUSE_MIN_ROWS 4800
 // topologies with at most this many edge tiles (a third more in fp32) run k_edge_split (one tile per workgroup, columns
 // over its four wavefronts) instead of k_edge (one tile per wavefront); bit-identical, see k_edge_split.hpp
 #define HD_SPLIT_MAX_TILES 512
-// fp32 node chain (batches below HD_FUSE_MIN_ROWS): GEMMs of at most this many rows (B <= 17 at N = 30) run k_gemm_direct
-// (one wavefront per 16 x 16 tile, operands L2 -> registers) instead of k_gemm (64 x 64 tiles staged through LDS);
-// bit-identical; measured break-even between 480 and 960 rows (profiles/r02_direct_sweep.log)
-#define HD_DIRECT_MAX_ROWS 512
 // topologies above one whole-tile workgroup per CU and below this many tiles may run k_edge_mixed: a multiple of the CU count
 // of whole-tile workgroups plus column-split single-tile workgroups that back-fill (k_edge_split.hpp; rule in launch_edge_h)
 #define HD_MIX_MAX_TILES 16384
 
 struct LayerW {                 // float offsets into hd_handle::dw
     size_t ab_img, ab_bias, wrd, w2_img, b2, wa, w3_img, b3, w4_img, b4;
-    size_t ab_gimg, w3_gimg, w4_gimg;      // fp32 mode: the same weights as k_gemm images (node chain of small batches)
+    size_t ab_gimg, w3_gimg, w4_gimg;      // fp32 mode: the same weights as k_gemm_r16 images (node chain below HD_FUSE_MIN_ROWS)
     float ba;
 };
 
@@ -86,7 +83,7 @@ struct hd_handle {
     hipEvent_t ev_in, ev_out;   // order own_stream against the caller's stream without host syncs
     unsigned long long weights_gen, sched_gen;   // bumped when the packed weights / schedule tables are re-allocated
     int split_max_tiles;        // HD_SPLIT_MAX_TILES (a measurement build may override it from the environment)
-    int direct_max_rows;        // HD_DIRECT_MAX_ROWS: node GEMMs of at most this many rows run k_gemm_direct
+    int fuse_min_rows;          // HD_FUSE_MIN_ROWS
     int mix_max_tiles;          // HD_MIX_MAX_TILES
     int mix_rounds;             // measurement build: force the number of whole-tile rounds of k_edge_mixed (-1 = rule)
     int n_cu;                   // compute units of the device
@@ -223,8 +220,8 @@ extern "C" int hd_create(const hd_config* cfg, int device, hd_handle** out) {
     h->d_nanflag = nullptr; h->d_nan_events = nullptr; h->d_step = nullptr; h->d_draw = nullptr; h->d_tcur = nullptr;
     h->d_base = nullptr;
     h->split_max_tiles = HD_SPLIT_MAX_TILES;
-    h->direct_max_rows = HD_DIRECT_MAX_ROWS;
     h->mix_max_tiles = HD_MIX_MAX_TILES;
+    h->fuse_min_rows = HD_FUSE_MIN_ROWS;
     h->mix_rounds = -1;
     {
         hipDeviceProp_t prop;
@@ -234,8 +231,8 @@ extern "C" int hd_create(const hd_config* cfg, int device, hd_handle** out) {
     h->d_trace = nullptr; h->trace_wg = 0;
     { const char* e = getenv("HD_ABLATE"); h->ablate = e ? atoi(e) : 0; }
     { const char* e = getenv("HD_SPLIT_MAX_TILES"); if (e) h->split_max_tiles = atoi(e); }
-    { const char* e = getenv("HD_DIRECT_MAX_ROWS"); if (e) h->direct_max_rows = atoi(e); }
     { const char* e = getenv("HD_MIX_MAX_TILES"); if (e) h->mix_max_tiles = atoi(e); }
+    { const char* e = getenv("HD_FUSE_MIN_ROWS"); if (e) h->fuse_min_rows = atoi(e); }
     { const char* e = getenv("HD_MIX_ROUNDS"); if (e) h->mix_rounds = atoi(e); }
 #endif
     auto create_rest = [&]() -> int {        // every failure below leaves through hd_destroy (frees what exists)
@@ -291,6 +288,20 @@ static void pack_gemm_b(std::vector<float>& dst, size_t off, int K, int Nc, int 
                             const int col = ct * BN + 32 * wc + (lane & 31);
                             dst[off + ((((size_t)(ct * nchunk + c) * WN + wc) * 4 + q) * 64 + lane) * 4 + j] = W(col, k);
                         }
+}
+
+// B-operand image of k_gemm_r16: [16-column tile][32-wide K chunk][64 lanes][8 p]; lane = (m, slot gs = (odd, hf)),
+// value p = W(16 tile + m, 32 chunk + 16 hf + 2 p + odd): the k this lane feeds to instruction p of the chunk.
+template <typename Fn>
+static void pack_gemm_b16(std::vector<float>& dst, size_t off, int K, int Nc, Fn W) {
+    const int nchunk = K / 32;
+    for (int ct = 0; ct < Nc / 16; ++ct)
+        for (int c = 0; c < nchunk; ++c)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int p = 0; p < 8; ++p) {
+                    const int m = lane & 15, gs = lane >> 4, odd = gs >> 1, hf = gs & 1;
+                    dst[off + (((size_t)ct * nchunk + c) * 64 + lane) * 8 + p] = W(16 * ct + m, 32 * c + 16 * hf + 2 * p + odd);
+                }
 }
 
 // B-operand image of the edge kernel: per K chunk [4 q][H/32 ct][64 lanes][4 j],
@@ -468,7 +479,7 @@ extern "C" int hd_set_weights(hd_handle* h, const float* blob, long long n, int 
         auto wab = [&](int col, int k) {
             return sc((col < H) ? W1[(size_t)col * ld + k] : W1[(size_t)(col - H) * ld + H + k]);
         };
-        if (nodef32) { pack_node_b_f32(pk, w.ab_img, H, 2 * H, wab); pack_gemm_b(pk, w.ab_gimg, H, 2 * H, h->NS, wab); }
+        if (nodef32) { pack_node_b_f32(pk, w.ab_img, H, 2 * H, wab); pack_gemm_b16(pk, w.ab_gimg, H, 2 * H, wab); }
         else pack_node_b(pk, w.ab_img, H, 2 * H, wab, NPc);
         for (int k = 0; k < H; ++k) {
             pk[w.ab_bias + k] = sc(b1[k]);
@@ -494,8 +505,8 @@ extern "C" int hd_set_weights(hd_handle* h, const float* blob, long long n, int 
             if (nodef32) {
                 pack_node_b_f32(pk, w.w3_img, 2 * H, H, w3);
                 pack_node_b_f32(pk, w.w4_img, H, H, w4);
-                pack_gemm_b(pk, w.w3_gimg, 2 * H, H, h->NS, w3);
-                pack_gemm_b(pk, w.w4_gimg, H, H, h->NS, w4);
+                pack_gemm_b16(pk, w.w3_gimg, 2 * H, H, w3);
+                pack_gemm_b16(pk, w.w4_gimg, H, H, w4);
             } else {
                 pack_node_b(pk, w.w3_img, 2 * H, H, w3, NPc);
                 pack_node_b(pk, w.w4_img, H, H, w4, NPc);
@@ -821,20 +832,20 @@ static void launch_gemm(int epi, bool cat, const GemmArgs& g, hipStream_t s) {
     else hipLaunchKernelGGL((k_gemm<WM, WN, CN, EPI_RESID_MASK, false>), grid, block, 0, s, g);
 }
 
-// Node-GEMM tile shape per hidden size: (waves M, waves N, accumulators per wave); the weight images are
-// packed for the matching number of 32-column sub-tiles NS = WN*CN.
-static void gemm(hd_handle* h, int epi, bool cat, const GemmArgs& g, hipStream_t s) {
-    ProfScope ps(h, s, 1);
+template <int RT>
+static void launch_r16(int epi, bool agg, const R16Args& g, hipStream_t s) {
+    const int wpt = g.Nc >= 128 ? 8 : (g.Nc >> 4);
+    const dim3 grid(((g.M + 16 * RT - 1) / (16 * RT)) * (g.Nc / (16 * wpt)) * g.n_img), block(512);
+    const int lds = 16 * RT * (g.K + 4) * 4;
+    if (agg) hipLaunchKernelGGL((k_gemm_r16<EPI_BIAS_SILU, true, RT>), grid, block, lds, s, g);
+    else if (epi == EPI_BIAS) hipLaunchKernelGGL((k_gemm_r16<EPI_BIAS, false, RT>), grid, block, lds, s, g);
+    else if (epi == EPI_BIAS_SILU) hipLaunchKernelGGL((k_gemm_r16<EPI_BIAS_SILU, false, RT>), grid, block, lds, s, g);
+    else hipLaunchKernelGGL((k_gemm_r16<EPI_RESID_MASK, false, RT>), grid, block, lds, s, g);
+}
 
-    if (h->NS == 1) launch_gemm<4, 1, 1>(epi, cat, g, s);        // H = 32: 128 x 32 tiles
-    else if (g.M <= h->direct_max_rows) {                        // small M: one wavefront per 16 x 16 tile, no LDS staging (bit-identical)
-        const dim3 grid(((g.M + 15) / 16) * (g.Nc / 64)), block(256);
-        if (cat && epi == EPI_BIAS) hipLaunchKernelGGL((k_gemm_direct<EPI_BIAS, true>), grid, block, 0, s, g);
-        else if (cat) hipLaunchKernelGGL((k_gemm_direct<EPI_BIAS_SILU, true>), grid, block, 0, s, g);
-        else if (epi == EPI_BIAS_SILU) hipLaunchKernelGGL((k_gemm_direct<EPI_BIAS_SILU, false>), grid, block, 0, s, g);
-        else if (epi == EPI_BIAS) hipLaunchKernelGGL((k_gemm_direct<EPI_BIAS, false>), grid, block, 0, s, g);
-        else hipLaunchKernelGGL((k_gemm_direct<EPI_RESID_MASK, false>), grid, block, 0, s, g);
-    } else launch_gemm<2, 2, 1>(epi, cat, g, s);                 // 64 x 64 tiles (fastest measured)
+static void gemm_r16(hd_handle* h, int epi, bool agg, const R16Args& g, hipStream_t s) {
+    ProfScope ps(h, s, 1);
+    launch_r16<1>(epi, agg, g, s);      // 32-row workgroups (RT = 2) were measured: slower up to B = 64, equal above (profiles/r03_r16_sweep2.log)
 }
 
 // Fused node update (bf16x3 only): min(4, H/32) wavefronts per 32-row workgroup.
@@ -1125,23 +1136,34 @@ static int forward_impl(hd_handle* h, hd_topology* t, const float* xh, const flo
         // (60 of them at B = 64), the k_agg + 3 x k_gemm chain spreads the same work over 64 x 64 tiles.  Both paths are
         // bit-identical (same MFMA order per output element, bias added after the contraction), so a sample's bits do
         // not depend on which one its batch size selects (test_fp32_node_paths_agree_bitwise).
-        const bool fused = c.precision == 1 || h->x6 || M >= HD_FUSE_MIN_ROWS;
-        if (fused) {
-            NodeArgs a = node_args();
-            set_ab(a, 0, h->gcl[0], t->AB);
-            node_update(h, false, 1, a, s);
+        const bool fused = c.precision == 1 || h->x6 || M >= h->fuse_min_rows;
+        auto r16_args = [&]() {
+            R16Args g;
+            std::memset(&g, 0, sizeof(g));
+            g.A = t->hbuf; g.lda = H; g.K1 = H; g.K = H; g.M = M; g.n_img = 1; g.nmask = t->nmask; g.norm = c.normalization_factor;
+            return g;
+        };
+        auto ab_r16 = [&](int nab, const LayerW* const* nxt, float* const* dst) {       // AB_q = h [W1a | W1b]_q^T + [b1 | 0]
+            R16Args g = r16_args();
+            g.Nc = 2 * H; g.ldc = 2 * H; g.n_img = nab;
+            for (int q = 0; q < nab; ++q) { g.Bimg[q] = W + nxt[q]->ab_gimg; g.bias[q] = W + nxt[q]->ab_bias; g.C[q] = dst[q]; }
+            gemm_r16(h, EPI_BIAS, false, g, s);
+        };
+        {
+            const LayerW* first[2] = {&h->gcl[0], nullptr};
+            float* dst[2] = {t->AB, nullptr};
+            if (fused) {
+                NodeArgs a = node_args();
+                set_ab(a, 0, h->gcl[0], t->AB);
+                node_update(h, false, 1, a, s);
+            } else {
+                ab_r16(1, first, dst);
+            }
         }
         for (int i = 0; i < c.n_layers; ++i) {
             for (int j = 0; j <= c.inv_sublayers; ++j) {
                 const bool coord = (j == c.inv_sublayers);
                 const LayerW& w = coord ? h->coord[i] : h->gcl[(size_t)i * c.inv_sublayers + j];
-                if (!fused) {
-                    GemmArgs g;
-                    std::memset(&g, 0, sizeof(g));
-                    g.A = t->hbuf; g.lda = H; g.K1 = H; g.K = H; g.Bimg = W + w.ab_gimg; g.bias = W + w.ab_bias;
-                    g.C = t->AB; g.ldc = 2 * H; g.M = M; g.Nc = 2 * H; g.nmask = t->nmask;
-                    gemm(h, EPI_BIAS, false, g, s);
-                }
                 EdgeArgs e;
                 std::memset(&e, 0, sizeof(e));
                 e.AB = ab_cur; e.wrd = W + w.wrd; e.W2img = W + w.w2_img; e.b2 = W + w.b2; e.wa = W + w.wa;
@@ -1150,45 +1172,41 @@ static int forward_impl(hd_handle* h, hd_topology* t, const float* xh, const flo
                 e.norm_constant = c.norm_constant; e.coords_range = range; e.attention = c.attention;
                 e.use_tanh = c.tanh; e.n_tiles = t->n_tiles; e.n_wg = t->n_wg;
                 HD_TRY(edge(h, coord, e, s));
-                if (!coord && fused) {
-                    NodeArgs a = node_args();
-                    a.W3img = W + w.w3_img; a.b3 = W + w.b3; a.W4img = W + w.w4_img; a.b4 = W + w.b4;
+                if (!coord) {
+                    // node update + the first edge Linear of the layer(s) that follow: AB of the next sub-layer, or (after the
+                    // block's last GCL) of the coordinate layer and of the next block's first GCL
+                    const LayerW* nxt[2] = {nullptr, nullptr};
+                    float* dst[2] = {t->AB, t->AB2};
                     int nab = 1;
                     if (j + 1 < S) {
-                        set_ab(a, 0, h->gcl[(size_t)i * S + j + 1], t->AB);
+                        nxt[0] = &h->gcl[(size_t)i * S + j + 1];
                     } else {
-                        set_ab(a, 0, h->coord[i], t->AB);
-                        if (i + 1 < c.n_layers) { set_ab(a, 1, h->gcl[(size_t)(i + 1) * S], t->AB2); nab = 2; }
+                        nxt[0] = &h->coord[i];
+                        if (i + 1 < c.n_layers) { nxt[1] = &h->gcl[(size_t)(i + 1) * S]; nab = 2; }
                     }
-                    node_update(h, true, nab, a, s);
+                    if (fused) {
+                        NodeArgs a = node_args();
+                        a.W3img = W + w.w3_img; a.b3 = W + w.b3; a.W4img = W + w.w4_img; a.b4 = W + w.b4;
+                        for (int q = 0; q < nab; ++q) set_ab(a, q, *nxt[q], dst[q]);
+                        node_update(h, true, nab, a, s);
+                    } else {
+                        R16Args g = r16_args();
+                        g.part = t->part; g.pstart = t->pstart; g.K1 = H; g.K = 2 * H; g.Nc = H;
+                        g.Bimg[0] = W + w.w3_gimg; g.bias[0] = W + w.b3; g.C[0] = t->Tb; g.ldc = H;
+                        gemm_r16(h, EPI_BIAS_SILU, true, g, s);                      // T = silu([h | agg] W3^T + b3)
+                        g = r16_args();
+                        g.A = t->Tb; g.Bimg[0] = W + w.w4_gimg; g.bias[0] = W + w.b4; g.C[0] = t->hbuf; g.ldc = H; g.Nc = H;
+                        gemm_r16(h, EPI_RESID_MASK, false, g, s);                    // h = (h + T W4^T + b4) mask
+                        ab_r16(nab, nxt, dst);
+                    }
                     ab_cur = t->AB;
-                } else if (!coord) {
-                    GemmArgs g1;
-                    std::memset(&g1, 0, sizeof(g1));
-                    {
-                        ProfScope ps(h, s, 2);
-                        AggArgs ag;
-                        ag.part = t->part; ag.pstart = t->pstart; ag.agg = t->agg; ag.norm = c.normalization_factor;
-                        ag.M = M; ag.H = H;
-                        const long long total = (long long)M * (H / 4);
-                        hipLaunchKernelGGL(k_agg, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ag);
-                    }
-                    g1.A = t->hbuf; g1.lda = H; g1.K1 = H; g1.K = 2 * H; g1.A2 = t->agg;
-                    g1.Bimg = W + w.w3_gimg; g1.bias = W + w.b3; g1.C = t->Tb;
-                    g1.ldc = H; g1.M = M; g1.Nc = H; g1.nmask = t->nmask;
-                    gemm(h, EPI_BIAS_SILU, true, g1, s);
-                    GemmArgs g2;
-                    std::memset(&g2, 0, sizeof(g2));
-                    g2.A = t->Tb; g2.lda = H; g2.K1 = H; g2.K = H; g2.Bimg = W + w.w4_gimg; g2.bias = W + w.b4;
-                    g2.C = t->hbuf; g2.ldc = H; g2.M = M; g2.Nc = H; g2.nmask = t->nmask;
-                    gemm(h, EPI_RESID_MASK, false, g2, s);
                 } else {
                     ProfScope ps(h, s, 2);
                     XupdArgs x;
                     x.part = t->xpart; x.pstart = t->pstart; x.nmask = t->nmask; x.xcur = t->xcur;
                     x.norm = c.normalization_factor; x.M = M;
                     hipLaunchKernelGGL(k_xupd, dim3((M + 255) / 256), dim3(256), 0, s, x);
-                    if (fused) ab_cur = t->AB2;             // next block's first GCL (written by the last node update)
+                    ab_cur = t->AB2;                        // next block's first GCL (written with the last node update)
                 }
             }
         }

@@ -1,4 +1,5 @@
-// Node-side kernels: input embedding (k_node_init), the fp32 tile GEMM k_gemm (stage-2 layer E_GCL), and the fused node update
+// Node-side kernels: input embedding (k_node_init), the fp32 tile GEMM k_gemm (stage-2 layer E_GCL; the sampler's fp32 node
+// chain of small batches is k_gemm_r16.hpp), and the fused node update
 // of the sampler in its three arithmetics (k_node: bf16x3 / bf16x6; k_node_f32: exact fp32).  Included through kernels.hpp.
 #pragma once
 #include "common.hpp"
@@ -208,77 +209,6 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm(GemmArgs g) {
                 for (int j = 0; j < 4; ++j) v[j] = silu_f(v[j]);
             }
             if (EPI == EPI_RESID_MASK) v = (*dst + v) * g.nmask[row];
-            *dst = v;
-        }
-    }
-}
-
-// ----------------------------------------------------------------------------- node GEMM without LDS staging (small M)
-// The same C = epi(A Wt + bias) for row counts that leave most of the chip empty (the fp32 node chain of small batches):
-// one wavefront per 16 x 16 output tile on v_mfma_f32_16x16x4_f32, both operands straight from L2 / L1 to registers - no LDS
-// staging, no barrier: k_gemm at M = 60 .. 2,000 rows is bound by its per-chunk barrier and LDS round trip (14 us for
-// K = 512 whatever M), not by math.  Bit-identical to k_gemm and to the fused k_node_f32: the 16 x 16 x 4 instruction fed
-// the k values in the production order (4q+j, 16+4q+j per 32-wide chunk) gives the bits of the 32 x 32 x 2 one and of an
-// fmaf chain (scratch/mb/mfma_order.hip), accumulators start at zero, the epilogue is k_gemm's.
-// Workgroup = 4 wavefronts = 16 rows x 64 columns (one 64-column tile of the NS = 2 weight image); lane = (m, k slot g).
-template <int EPI, bool CAT>
-__global__ __launch_bounds__(256) void k_gemm_direct(GemmArgs g) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int m = lane & 15, gs = lane >> 4, odd = gs >> 1, hf = gs & 1;
-    const int nct = g.Nc >> 6;
-    const int rt = blockIdx.x / nct, ctile = blockIdx.x - rt * nct;
-    const int row = 16 * rt + m;                                          // A row of this lane (< M_pad: buffers are padded to 128 rows)
-    const int nchunk = g.K >> 5;
-    const int sub = wave >> 1, t = wave & 1;
-    // weight image of this column tile: per 32-wide K chunk [2 sub][4 q][64 lanes'][4 j]; lane' = 32 hf + 16 t + m
-    const f32x4* Bsrc = reinterpret_cast<const f32x4*>(g.Bimg) + (size_t)ctile * nchunk * 512 + (sub * 4) * 64 + 32 * hf + 16 * t + m;
-    const float* Arow = g.A + (size_t)row * g.lda + 16 * hf;
-    const float* A2row = CAT ? g.A2 + (size_t)row * (g.K - g.K1) + 16 * hf : nullptr;
-    constexpr int RD = 4;                                                 // chunks in flight ahead of the MFMAs
-    f32x4 ra[RD][4], rb[RD][4];
-    auto load_chunk = [&](int c, f32x4 (&a4)[4], f32x4 (&b4)[4]) {
-        const int k0 = c << 5;
-        const float* ap = (!CAT || k0 < g.K1) ? Arow + k0 : A2row + (k0 - g.K1);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            a4[q] = *reinterpret_cast<const f32x4*>(ap + 4 * q);
-            b4[q] = Bsrc[(size_t)c * 512 + q * 64];
-        }
-    };
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    static_for<0, RD>([&](auto Rc) {
-        constexpr int r = decltype(Rc)::value;
-        if (r < nchunk) load_chunk(r, ra[r], rb[r]);
-    });
-    for (int c0 = 0; c0 < nchunk; c0 += RD) {
-        static_for<0, RD>([&](auto Rc) {
-            constexpr int r = decltype(Rc)::value;
-            const int c = c0 + r;
-            if (c < nchunk) {
-                // instruction p = 2q + pp carries values v = 2p (slots 0, 1: k = v, v + 16) and 2p + 1 (slots 2, 3)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int pp = 0; pp < 2; ++pp) {
-                        const float a = odd ? ra[r][q][2 * pp + 1] : ra[r][q][2 * pp];
-                        const float b = odd ? rb[r][q][2 * pp + 1] : rb[r][q][2 * pp];
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
-                    }
-                if (c + RD < nchunk) load_chunk(c + RD, ra[r], rb[r]);
-            }
-        });
-    }
-    // acc[i] = row 16 rt + 4 gs + i, column 64 ctile + 16 wave + m; k_gemm's epilogue, element by element
-    const int col = 64 * ctile + 16 * wave + m;
-    const float bias = g.bias[col];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int orow = 16 * rt + 4 * gs + i;
-        if (orow < g.M) {
-            float v = acc[i] + bias;
-            float* dst = g.C + (size_t)orow * g.ldc + col;
-            if (EPI == EPI_BIAS_SILU) v = silu_f(v);
-            if (EPI == EPI_RESID_MASK) v = (*dst + v) * g.nmask[orow];
             *dst = v;
         }
     }

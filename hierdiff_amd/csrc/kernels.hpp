@@ -12,11 +12,12 @@
 //     node kernel adds in a fixed order (bit-reproducible);
 //   * the whole row-local node chain (neighbour-sum reduction, node MLP, residual, the next layers' first edge Linear) is
 //     one launch in every mode (k_node for the bf16 splits, k_node_f32).
-// Files: common.hpp (types, helpers, RNG), k_node.hpp, k_edge.hpp, k_edge_split.hpp (fp32 edge kernel of very small batches), k_edge_bwd.hpp (training: backward of an edge layer),
+// Files: k_gemm_r16.hpp (fp32 node GEMMs of small / medium batches), common.hpp (types, helpers, RNG), k_node.hpp, k_edge.hpp, k_edge_split.hpp (fp32 edge kernel of very small batches), k_edge_bwd.hpp (training: backward of an edge layer),
 // k_sampling.hpp (output stage, posterior step, decode, noise), k_egcl.hpp (stage-2 layer E_GCL, forward).  (The one-wave-per-SIMD edge-kernel experiments live in scratch/experiments/.)
 #pragma once
 #include "common.hpp"
 #include "k_node.hpp"
+#include "k_gemm_r16.hpp"
 #include "k_edge.hpp"
 #include "k_edge_split.hpp"
 #include "k_edge_bwd.hpp"

@@ -263,19 +263,22 @@ def test_pocket_sized_graph_vs_oracle(precision):
     assert float((v - v[0:1]).abs().max()) < 1e-6
 
 
-def test_fp32_node_paths_agree_bitwise():
-    """fp32 mode runs the node side fused (k_node_f32) from 6,144 active rows on and as k_agg + 3 x k_gemm below (small
-    batches: 60 row tiles do not fill 256 CUs with a serial per-tile chain).  The two are bit-identical by construction
-    (same MFMA order per output element, bias added after the contraction), so a molecule's bits do not depend on the
-    size of the batch it is sampled in: 210 molecules (6,300 rows, fused) against their first 8 alone (240 rows, unfused)."""
+@pytest.mark.parametrize("H,L,B", [(64, 2, 210), (256, 1, 170), (32, 2, 170)])
+def test_fp32_node_paths_agree_bitwise(H, L, B):
+    """fp32 mode runs the node side fused (k_node_f32: one launch per update, 32-row workgroups on 32 x 32 x 2 MFMAs) from
+    4,800 active rows on and as three k_gemm_r16 launches below (16-row workgroups on 16 x 16 x 4 MFMAs, the neighbour-sum
+    reduction folded into the first: small batches do not fill 256 CUs with a serial 50 us chain per row tile).  The two are
+    bit-identical by construction (the same fmaf chain per output element, bias added after the contraction), so a
+    molecule's bits do not depend on the size of the batch it is sampled in: B molecules (>= 5,100 rows, fused) against
+    their first 8 alone (240 rows, k_gemm_r16), narrow and production widths."""
     from hierdiff_amd.weights import synthetic_state_dict
-    H, L, N = 64, 2, 30
+    N = 30
     sd_np = synthetic_state_dict(9, 0, H, L, 2, True, 515, 1.0)
     dyn = build_dynamics(sd_np, H, L)
     dyn.precision = "fp32"
-    xh, nm, em = orc.random_inputs([N] * 210, 8, 33)
+    xh, nm, em = orc.random_inputs([N] * B, 8, 33)
     xh, nm = xh.to(DEV), nm.to(DEV)
-    t = torch.linspace(0.05, 0.95, 210, device=DEV).view(-1, 1)
+    t = torch.linspace(0.05, 0.95, B, device=DEV).view(-1, 1)
     big = dyn._forward(t, xh, nm, None, None, None)
     small = dyn._forward(t[:8], xh[:8], nm[:8], None, None, None)
     assert torch.isfinite(big).all()
