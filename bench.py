@@ -397,7 +397,36 @@ def next_rows(dev) -> dict:
     for _ in range(20):
         lay(hh, [row, col], xx, edge_attr=ea, node_mask=nmask, edge_mask=emask)
     torch.cuda.synchronize(dev)
-    out["stage2_E_GCL_layer_bs24_n12_H256"] = {"ms_per_layer_forward": round((time.perf_counter() - t0) / 20 * 1e3, 3),
+    t_layer = (time.perf_counter() - t0) / 20
+    del lay
+    # the stage-2 model around the layer: one autoregressive growth step (Edge_denoise.sample_AR) for a beam of 24 half-grown
+    # 12-node trees at the production width (conf/model/edge_denoise.yaml: H = 256, vocabulary 781, 3 + 3 layers)
+    from hierdiff_amd.edge_denoise import Edge_denoise, synthetic_edge_denoise_state_dict
+    kw = dict(vocab_size=781, in_node_nf=8, hidden_nf=H, out_node_nf=780, context_nf=0)
+    ed = Edge_denoise(array_dict=None, full_softmax=True, **kw)
+    ed.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in synthetic_edge_denoise_state_dict(3, **kw).items()})
+    ed = ed.to(dev)
+    rng = np.random.Generator(np.random.PCG64(5))
+    adj = torch.zeros(bs, n, n)
+    for b in range(bs):
+        for v in range(1, 6):                                   # six placed nodes: a random tree over nodes 0..5
+            p = int(rng.integers(0, v))
+            adj[b, v, p] = adj[b, p, v] = 1
+    feat = torch.from_numpy(rng.standard_normal((bs, n, 10)).astype(np.float32))
+    feat[:, :, 9] = torch.from_numpy(rng.integers(0, 780, (bs, n)).astype(np.float32))
+    beam = {'node_feat': [feat.to(dev), torch.ones(bs, n, 10, device=dev)], 'node_pos': (torch.randn(bs, n, 3, generator=g) * 1.5).to(dev),
+            'search_adj_matrix': adj.to(dev), 'edge_mask': (1 - torch.eye(n))[None].expand(bs, n, n).contiguous().to(dev)}
+    for _ in range(2):
+        ed.sample_AR(beam)
+    torch.cuda.synchronize(dev)
+    t1 = time.perf_counter()
+    for _ in range(5):
+        ed.sample_AR(beam)
+    torch.cuda.synchronize(dev)
+    out["stage2_Edge_denoise_sample_AR_bs24_n12_H256"] = {
+        "ms_per_step": round((time.perf_counter() - t1) / 5 * 1e3, 2), "layers": "3 gcl_full + 3 gcl_focal + gcl_edge / gcl_denoise walks",
+        "what": "one growth step of the beam incl. the host-side tree bookkeeping (breadth-first layers, argmax, adjacency)"}
+    out["stage2_E_GCL_layer_bs24_n12_H256"] = {"ms_per_layer_forward": round(t_layer * 1e3, 3),
                                                "nodes": bs * n, "edges": int(row.numel()),
                                                "what": "gcl_full layer (edge features + attention + edge update), exact fp32"}
     return out

@@ -1688,6 +1688,21 @@ extern "C" int hd_egcl_forward(hd_egcl* g, hd_egcl_graph* t, const float* h, con
     return HD_OK;
 }
 
+extern "C" int hd_linear(int device, const float* x, int M, int K, int ldx, const float* W, const float* b, int N, int act,
+                         float* y, int ldy, void* stream) {
+    if (!x || !W || !y) return fail(HD_E_INVALID, "hd_linear: null tensor");
+    if (M < 0 || K < 1 || N < 1 || ldx < K || ldy < N || act < 0 || act > 2) return fail(HD_E_INVALID, "hd_linear: bad shape / act");
+    if (hd_device_count() <= device || device < 0) return fail(HD_E_HIP, "hd_linear: no such HIP device (is a GPU visible?)");
+    if (M == 0) return HD_OK;
+    HIP_TRY(hipSetDevice(device));
+    LinArgs a;
+    a.x = x; a.W = W; a.b = b; a.y = y; a.M = M; a.K = K; a.N = N; a.ldx = ldx; a.ldy = ldy; a.act = act;
+    const long long total = (long long)M * N;
+    hipLaunchKernelGGL(k_linear, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return HD_OK;
+}
+
 // ----------------------------------------------------------------------------- sampling maths
 
 static NoiseSrc make_noise(const float* raw_x, const float* raw_h, int rows, uint64_t seed, uint64_t base,

@@ -29,7 +29,9 @@ constexpr int edge_split_lds_bytes() {
     return (H / (PREC == 2 ? 16 : 32)) * (PREC == 2 ? 3 : 4) * 64 * 16 + (16 * 64 + 64 + 8 + 32 + 96 + 4) * 4;
 }
 
-template <int H, bool COORD, int PREC>
+// DEEP: the standalone launch (at most ~680 workgroups on 256 CUs: registers are free) keeps more K chunks of W2 fragments in
+// flight than the body inside k_edge_mixed, which shares a 256-register budget with the whole-tile form
+template <int H, bool COORD, int PREC, bool DEEP>
 HD_DEVINL void edge_split_body(const EdgeArgs& a, char* lds, float* wrd_s, const int tile) {
     constexpr int KC = PREC == 2 ? 16 : 32;                          // K chunk width, as in k_edge
     constexpr int NCT = H / 32, NCW = NCT / 4, NCH = H / KC, CHF = PREC == 2 ? 24 * H : 32 * H, NQ = KC / 8;
@@ -156,7 +158,8 @@ HD_DEVINL void edge_split_body(const EdgeArgs& a, char* lds, float* wrd_s, const
             f[i] = *reinterpret_cast<const u32x4*>(base + off);
         }
     };
-    constexpr int RING = PREC == 0 ? 3 : (PREC == 1 ? 4 : 6);        // chunks of fragments in flight ahead of the MFMAs
+    constexpr int RING0 = PREC == 0 ? 3 : (PREC == 1 ? 4 : 6);       // chunks of fragments in flight ahead of the MFMAs
+    constexpr int RING = DEEP ? (PREC == 0 ? 6 : (PREC == 1 ? 6 : 8)) : RING0;
     u32x4 fr[RING][NF];
     static_for<0, (RING - 1 < NCH ? RING - 1 : NCH)>([&](auto Cc) { load_frags(decltype(Cc)::value, fr[decltype(Cc)::value]); });
     // The operand tile (32 edge rows x H) is the same for the four wavefronts: each builds a quarter of the K chunks
@@ -391,7 +394,7 @@ template <int H, bool COORD, int PREC>
 __global__ __launch_bounds__(256) void k_edge_split(EdgeArgs a) {
     __shared__ __attribute__((aligned(16))) float wrd_s[4 * H];     // [w_r | w_d | b2 | wa]
     __shared__ __attribute__((aligned(16))) char lds[edge_split_lds_bytes<H, PREC>()];
-    edge_split_body<H, COORD, PREC>(a, lds, wrd_s, blockIdx.x);      // grid = n_tiles
+    edge_split_body<H, COORD, PREC, true>(a, lds, wrd_s, blockIdx.x);      // grid = n_tiles
 }
 
 // Whole-tile and column-split workgroups in ONE launch, for topologies between one and three tiles per SIMD.  There a
@@ -407,5 +410,5 @@ __global__ __launch_bounds__(256, 2) void k_edge_mixed(EdgeArgs a) {
     __shared__ __attribute__((aligned(16))) float wrd_s[4 * H];
     const int bid = blockIdx.x;
     if (bid < a.n_wg) edge_tile_body<H, COORD, PREC, 0>(a, smem, wrd_s, bid, a.n_wg);
-    else edge_split_body<H, COORD, PREC>(a, reinterpret_cast<char*>(smem), wrd_s, 4 * a.n_wg + (bid - a.n_wg));
+    else edge_split_body<H, COORD, PREC, false>(a, reinterpret_cast<char*>(smem), wrd_s, 4 * a.n_wg + (bid - a.n_wg));
 }

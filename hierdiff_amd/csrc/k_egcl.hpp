@@ -183,3 +183,33 @@ __global__ void k_egcl_node_out(EgclNodeOutArgs a) {
     a.h_out[(size_t)i * W + k] = v * m;
     if (k < 3) a.x_out[(size_t)i * 3 + k] = (a.x4[(size_t)i * 4 + k] + (a.xagg ? a.xagg[(size_t)i * 4 + k] : 0.0f)) * m;
 }
+
+// ----------------------------------------------------------------------------- small dense layer (stage-2 embeddings / heads)
+// y[m][n] = act(sum_k x[m][k] W[n][k] + b[n]); one thread per output element, one fmaf chain over k.  The layers it serves
+// are tiny (edge_denoise.py:29-33, 55-57: K = 2 ... 3H + 1, N = 1 ... vocabulary size, M = beam-sized): launch-bound.
+struct LinArgs {
+    const float* x; const float* W; const float* b; float* y;
+    int M, K, N, ldx, ldy, act;
+};
+
+__global__ void k_linear(LinArgs a) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)a.M * a.N) return;
+    const int m = (int)(idx / a.N), n = (int)(idx - (long long)m * a.N);
+    const float* xr = a.x + (size_t)m * a.ldx;
+    const float* wr = a.W + (size_t)n * a.K;
+    float acc = 0.f;
+    int k = 0;
+    if ((a.K & 3) == 0 && (a.ldx & 3) == 0) {
+        for (; k < a.K; k += 4) {
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(xr + k), wv = *reinterpret_cast<const f32x4*>(wr + k);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_fmaf(xv[j], wv[j], acc);
+        }
+    }
+    for (; k < a.K; ++k) acc = __builtin_fmaf(xr[k], wr[k], acc);
+    if (a.b) acc += a.b[n];
+    if (a.act == 1) acc = silu_f(acc);
+    else if (a.act == 2) acc = sigmoid_f(acc);
+    a.y[(size_t)m * a.ldy + n] = acc;
+}

@@ -58,33 +58,71 @@ __global__ __launch_bounds__(512, 4) void k_gemm_r16(R16Args g) {
     const int LDA_S = g.K + 4;
     const int ct16 = wpt * ctile + (wave < wpt ? wave : 0);   // this wavefront's 16-column tile
     const f32x4* Bsrc = reinterpret_cast<const f32x4*>(g.Bimg[img]) + ((size_t)ct16 * nchunk * 64 + lane) * 2;
+    const float bias = g.bias[img][16 * ct16 + m];             // requested here, used in the epilogue
     f32x4 rb[RING][2];
-    static_for<0, RING>([&](auto Rc) {
+    // half of the ring goes out before the A tile's loads, the rest behind them (AGG: the fill below needs the registers)
+    constexpr int PRE = AGG ? RING / 2 : RING;
+    static_for<0, PRE>([&](auto Rc) {
         constexpr int r = decltype(Rc)::value;
         if (r < nchunk) { rb[r][0] = Bsrc[(size_t)r * 128]; rb[r][1] = Bsrc[(size_t)r * 128 + 1]; }
     });
     // ---- A tile -> LDS.  Position of original column o = 16 G + x inside its 16-group: 8 (x & 1) + (x >> 1), so that the
     // eight values a lane feeds to the eight instructions of a chunk (x = 2 p + odd) are contiguous: two ds_read_b128.
+    // All global loads of a thread go out before the first is consumed (four float4 per thread at K = 512; a plain loop
+    // costs one L2 round trip per piece - and two per neighbour-sum piece: pstart, then the parts - 12 instead of 6.5 us).
     {
         const int q4 = g.K >> 2;                              // float4 per row
         const int total = 16 * RT * q4;
-        for (int idx = tid; idx < total; idx += 512) {
-            const int r = idx / q4, c4 = idx - r * q4;
-            const int row = row0 + r, k0 = 4 * c4;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (!AGG || k0 < g.K1) {
-                v = *reinterpret_cast<const f32x4*>(g.A + (size_t)row * g.lda + k0);      // pad rows are zero
-            } else if (row < g.M) {
-                const int HW = g.K - g.K1;
-                for (int p = g.pstart[row]; p < g.pstart[row + 1]; ++p)                  // k_agg: parts ascending, then / norm
-                    v += *reinterpret_cast<const f32x4*>(g.part + (size_t)p * HW + (k0 - g.K1));
-                v = v / g.norm;
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        for (int base = 0; base < total; base += 4 * 512) {
+            f32x4 v[4], g1[4];
+            int pa[4], pb[4], rr[4], kk[4];
+            bool ok[4], ag[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + tid + 512 * u;
+                ok[u] = idx < total;
+                const int r = idx / q4, c4 = idx - r * q4;
+                rr[u] = r; kk[u] = 4 * c4;
+                ag[u] = AGG && kk[u] >= g.K1;
+                pa[u] = pb[u] = 0;
+                v[u] = z4;
+                if (ok[u] && !ag[u]) v[u] = *reinterpret_cast<const f32x4*>(g.A + (size_t)(row0 + r) * g.lda + kk[u]);   // pad rows are zero
+                if (ok[u] && ag[u] && row0 + r < g.M) { pa[u] = g.pstart[row0 + r]; pb[u] = g.pstart[row0 + r + 1]; }
             }
-            float* dst = As + r * LDA_S + (k0 & ~15);
-            const int x0 = k0 & 15;                           // 0, 4, 8, 12: x0 .. x0 + 3 -> positions (x0 >> 1) + {0, 8, 1, 9}
-            dst[(x0 >> 1)] = v[0]; dst[8 + (x0 >> 1)] = v[1]; dst[(x0 >> 1) + 1] = v[2]; dst[8 + (x0 >> 1) + 1] = v[3];
+            if constexpr (AGG) {
+                const int HW = g.K - g.K1;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {                 // the first two parts of every piece in flight together
+                    g1[u] = z4;
+                    if (ag[u] && pa[u] < pb[u]) v[u] = *reinterpret_cast<const f32x4*>(g.part + (size_t)pa[u] * HW + (kk[u] - g.K1));
+                    if (ag[u] && pa[u] + 1 < pb[u]) g1[u] = *reinterpret_cast<const f32x4*>(g.part + (size_t)(pa[u] + 1) * HW + (kk[u] - g.K1));
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (ag[u]) {                              // k_agg: 0 + parts ascending, then / norm
+                        f32x4 sacc = z4;
+                        if (pa[u] < pb[u]) sacc += v[u];
+                        if (pa[u] + 1 < pb[u]) sacc += g1[u];
+                        for (int p = pa[u] + 2; p < pb[u]; ++p) sacc += *reinterpret_cast<const f32x4*>(g.part + (size_t)p * HW + (kk[u] - g.K1));
+                        v[u] = sacc / g.norm;
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (ok[u]) {
+                    float* dst = As + rr[u] * LDA_S + (kk[u] & ~15);
+                    const int x0 = kk[u] & 15;                // 0, 4, 8, 12: x0 .. x0 + 3 -> positions (x0 >> 1) + {0, 8, 1, 9}
+                    dst[(x0 >> 1)] = v[u][0]; dst[8 + (x0 >> 1)] = v[u][1]; dst[(x0 >> 1) + 1] = v[u][2]; dst[8 + (x0 >> 1) + 1] = v[u][3];
+                }
+            }
         }
     }
+    static_for<PRE, RING>([&](auto Rc) {
+        constexpr int r = decltype(Rc)::value;
+        if (r < nchunk) { rb[r][0] = Bsrc[(size_t)r * 128]; rb[r][1] = Bsrc[(size_t)r * 128 + 1]; }
+    });
     __syncthreads();
     if (wave >= wpt) return;
     const float* Arow = As + m * LDA_S + 16 * hf + 8 * odd;
@@ -116,7 +154,6 @@ __global__ __launch_bounds__(512, 4) void k_gemm_r16(R16Args g) {
     }
     // acc[t][i] = row row0 + 16 t + 4 gs + i, column 16 ct16 + m; k_gemm's epilogue, element by element
     const int col = 16 * ct16 + m;
-    const float bias = g.bias[img][col];
     float* Cc = g.C[img];
 #pragma unroll
     for (int ti = 0; ti < 4 * RT; ++ti) {

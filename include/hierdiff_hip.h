@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define HD_ABI_VERSION 3
+#define HD_ABI_VERSION 4
 
 #define HD_OK 0
 #define HD_E_INVALID (-1)      /* bad argument / unsupported configuration */
@@ -224,6 +224,13 @@ int hd_egcl_graph_destroy(hd_egcl_graph* t);
 int hd_egcl_forward(hd_egcl* g, hd_egcl_graph* t, const float* h, const float* x, const float* edge_attr,
                     const float* node_mask, const float* edge_mask, float* h_out, float* x_out, float* edge_attr_out,
                     void* stream);
+
+/* y [M][ldy] (first N columns) = act(x [M][ldx] (first K columns) . W [N][K]^T + b [N] or NULL); device fp32, any M, K, N.
+ * act: 0 none, 1 SiLU, 2 sigmoid.  The small dense layers around the E_GCL chains of the stage-2 model - torch.nn.Linear in
+ * /root/reference/models/edge_denoise.py:29-33 (feature / edge / node embeddings) and :55-57 (focal / edge / node prediction
+ * heads, Linear + SiLU + Linear [+ Sigmoid]).  One fmaf chain over k per output element. */
+int hd_linear(int device, const float* x, int M, int K, int ldx, const float* W, const float* b, int N, int act,
+              float* y, int ldy, void* stream);
 
 /* Host implementation of the library's normal generator (same bits as the device one up to libm
  * round-off); used by tests and by callers that want to reproduce a draw on the CPU. */

@@ -1,0 +1,320 @@
+"""TEST INFRASTRUCTURE - CPU restatement of the reference's stage-2 model `Edge_denoise` (/root/reference/models/edge_denoise.py)
+on top of oracle.egnn_oracle.e_gcl_forward.  Pinned to the reference by golden vectors generated from the imported reference
+module (oracle/make_golden_stage2.py, fixtures F17 / F18).  Only tests/ and the fixture generator import this file; the
+product (hierdiff_amd/edge_denoise.py) never does.
+
+    embed            edge_denoise.py:83-101 (forward) == :275-293 (sample_AR)
+    forward          :61-248   (loss / accuracy values of a training batch)
+    sample_ar        :250-420  (one autoregressive growth step for a batch of partial trees)
+    bfs_layers       data_utils/data_diffuse.py:60-79 (get_bfs_order_new)
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from oracle import egnn_oracle as orc
+
+
+@dataclass
+class EDCfg:
+    """Constructor arguments of Edge_denoise (edge_denoise.py:15-17) that change its arithmetic."""
+    vocab_size: int = 781
+    in_node_nf: int = 8
+    hidden_nf: int = 256
+    out_node_nf: int = 780
+    context_nf: int = 0
+    n_layers_full: int = 3
+    n_layers_focal: int = 3
+    focal_loss: float = 1.0
+    edge_loss: float = 1.0
+    node_loss: float = 1.0
+
+
+def _lin(sd, name, x):
+    return F.linear(x, sd[name + ".weight"], sd.get(name + ".bias"))
+
+
+def _gcl(sd, cfg: EDCfg, name, kind, h, edges, x, edge_attr, node_mask, edge_mask=None):
+    """One E_GCL of the four chains (edge_denoise.py:35-43)."""
+    H = cfg.hidden_nf
+    c = {"full": orc.EGCLCfg(H, H, cfg.context_nf, True, True, 30.0, True, True, True),
+         "focal": orc.EGCLCfg(H, H, cfg.context_nf, False, True, 30.0, True, True, True),
+         "edge": orc.EGCLCfg(H, 1, cfg.context_nf, False, True, 30.0, True, False, True)}[kind]
+    return orc.e_gcl_forward(sd, c, h, edges[0], edges[1], x, edge_attr, node_mask, edge_mask, prefix=name + ".")
+
+
+def dense_edges(n_nodes: int, bs: int):
+    """get_adj_matrix (:507-526): every (i, j) pair incl. i == j, per graph."""
+    ar = torch.arange(n_nodes)
+    r = ar.repeat_interleave(n_nodes).repeat(bs)
+    c = ar.repeat(n_nodes).repeat(bs)
+    off = (torch.arange(bs) * n_nodes).repeat_interleave(n_nodes * n_nodes)
+    return [r + off, c + off]
+
+
+def embed(sd, cfg: EDCfg, h, x, adj_note):
+    """:83-101.  h [bs*n, in_node_nf + context_nf + 1] (last column: vocabulary index), x [bs*n, 3], adj_note [bs*n*n, 1]."""
+    bsn = h.shape[0]
+    h_f = _lin(sd, "feature_embedding", h[:, :cfg.in_node_nf])
+    h_v = sd["vocab_embedding.weight"][h[:, cfg.in_node_nf + cfg.context_nf].long()]
+    hh = _lin(sd, "node_embedding", torch.cat([h_f, h_v], dim=1))
+    if cfg.context_nf > 0:
+        hh = torch.cat([hh, h[:, cfg.in_node_nf:cfg.in_node_nf + cfg.context_nf]], dim=1)
+    return hh
+
+
+def edge_features(sd, x, edges_full, adj_note):
+    radial = torch.sum((x[edges_full[0]] - x[edges_full[1]]) ** 2, dim=1, keepdim=True)
+    return _lin(sd, "edge_embedding", torch.cat([radial, adj_note.to(radial.dtype)], dim=1))
+
+
+def bfs_layers(edges: np.ndarray, n_nodes: int, start: int):
+    """get_bfs_order_new (data_diffuse.py:60-79): layers of [child, parent] pairs found from `start`, farthest layer first."""
+    visited = {start}
+    layers = []
+    while len(visited) < n_nodes:
+        depth_edges, cache = [], []
+        for e in edges:
+            if e[0] in visited and e[1] not in visited:
+                cache.append(e[1])
+                depth_edges.append([e[1], e[0]])
+        for v in cache:
+            visited.add(v)
+        layers.append(depth_edges)
+    layers.reverse()
+    return layers
+
+
+def adj_to_bfs(adj: torch.Tensor, end: int):
+    """adj_matrix_to_edges_bfs (:442-456) on the padding-stripped adjacency."""
+    if adj.sum() == 0:
+        return [[]]
+    edges = adj.nonzero().numpy()
+    nodes = set()
+    for a, b in edges:
+        nodes.add(int(a)); nodes.add(int(b))
+    return bfs_layers(edges, len(nodes), end)
+
+
+def concat_layers(per_sample: List[list], n_nodes: int):
+    """concat_edges + flat_add (:480-494, :528-535): layer l of sample i, offset by i * n_nodes, appended to layer l."""
+    depth = max(len(e) for e in per_sample)
+    out = [[] for _ in range(depth)]
+    for i, layers in enumerate(per_sample):
+        for li, layer in enumerate(layers):
+            if len(layer) > 0 and isinstance(layer[0], (int, np.integer)):
+                out[li].append([int(v) + i * n_nodes for v in layer])          # flat form: one list of ints per sample
+            else:
+                out[li].extend([(int(a) + i * n_nodes, int(b) + i * n_nodes) for a, b in layer])
+    return out
+
+
+def split_nodes(idx, n_nodes, bs):
+    bins = [[] for _ in range(bs)]
+    for i in idx:
+        bins[i // n_nodes].append(i % n_nodes)
+    return bins
+
+
+def _edges_tensor(pairs):
+    return torch.tensor(pairs, dtype=torch.long).reshape(-1, 2).T
+
+
+def _mlp(sd, name, x, last_sigmoid=False):
+    y = _lin(sd, name + ".2", F.silu(_lin(sd, name + ".0", x)))
+    return torch.sigmoid(y) if last_sigmoid else y
+
+
+@torch.no_grad()
+def forward(sd: Dict[str, torch.Tensor], cfg: EDCfg, batch) -> Dict[str, torch.Tensor]:
+    """Edge_denoise.forward (:61-248) with array_dict = None (full softmax, conf/model/edge_denoise.yaml:12)."""
+    h = torch.as_tensor(batch['node_feat'][0], dtype=torch.float32)
+    bs, n = h.shape[:2]
+    x = torch.as_tensor(batch['node_pos'], dtype=torch.float32).reshape(bs * n, -1)
+    predict_idx = list(batch['predict_idx'])
+    edge_search = [list(l) for l in batch['edge_search_pad']]
+    edge_search_orig = [list(l) for l in batch['edge_search_pad_orig']]
+    edge_search_flat = batch['edge_search_flat']
+    node_mask = torch.as_tensor(batch['node_feat'][1], dtype=torch.float32)[:, :, 0].reshape(bs * n, -1)
+    edge_mask = torch.as_tensor(batch['edge_mask'], dtype=torch.float32).reshape(bs * n * n, -1)
+    focal = torch.as_tensor(batch['focal'])
+    focal_cand, real_focal = list(batch['focal_cand']), list(batch['real_focal'])
+    undiscovered, label = batch['undiscovered'], torch.as_tensor(batch['label'])
+    adj = torch.as_tensor(batch['search_adj_matrix'])
+    h = embed(sd, cfg, h.reshape(bs * n, -1), x, None)
+    val = torch.sum(adj.reshape(bs * n, n), dim=-1, keepdim=True).to(torch.float32)
+    edges_full = dense_edges(n, bs)
+    eff = edge_features(sd, x, edges_full, adj.reshape(bs * n * n, 1))
+    for i in range(cfg.n_layers_full):
+        h, x, eff = _gcl(sd, cfg, f"gcl_full_{i}", "full", h, edges_full, x, eff, node_mask, edge_mask)
+    eff = eff.reshape(bs, n, n, -1)
+    max_depth = len(edge_search)
+    focal_loss, focal_acc = torch.tensor(0.0), 0.0
+    if max_depth > 1:                                                         # :116-147
+        e0, e1 = (torch.as_tensor(t).long() for t in edge_search_flat)
+        ef = eff[e0 // n, e0 % n, e1 % n, :].reshape(e0.shape[0], -1)
+        for i in range(cfg.n_layers_focal):
+            h, x, ef = _gcl(sd, cfg, f"gcl_focal_{i}", "focal", h, [e0, e1], x, ef, node_mask)
+        fp = _mlp(sd, "focal_predict", torch.cat([h[focal_cand], val[focal_cand]], dim=1), last_sigmoid=True)
+        # split_edges (:502-506) walks `for e in edge_search_flat`, i.e. over the TWO index tensors, and files e[0] of each:
+        # only the graphs holding the first source and the first target node (graph 0 in practice) count as having edges,
+        # so only their candidates enter the focal loss.  Reproduced as is.
+        ew = [0] * bs
+        for t in (e0, e1):
+            if t.numel() > 0:
+                ew[int(t[0]) // n] += 1
+        bins = split_nodes(focal_cand, n, bs)
+        nw = np.cumsum([0] + [len(b) for b in bins])
+        for i in range(bs):
+            if ew[i] != 0:
+                focal_loss = focal_loss + F.binary_cross_entropy(fp[nw[i]:nw[i + 1]].squeeze(-1), focal[nw[i]:nw[i + 1]].float())
+        hit, cnt = 0, 0
+        for i, fk in enumerate(bins):
+            if len(fk) > 0:
+                pos = [focal_cand.index(j + i * n) for j in fk]
+                if focal[pos[int(torch.argmax(fp[pos]))]] == 1:
+                    hit += 1
+                cnt += 1
+        focal_acc = hit / (cnt + 1e-8)
+    circle = [[i * n, i * n] for i in range(bs)]                              # :153-160
+    eso = [circle] + edge_search_orig
+    for depth in range(max_depth):
+        e = _edges_tensor(eso[depth])
+        ea = torch.sum((x[e[0]] - x[e[1]]) ** 2, dim=1, keepdim=True)
+        h, x, _ = _gcl(sd, cfg, "gcl_edge", "edge", h, e, x, ea, node_mask)
+    edge_loss, edge_acc = torch.tensor(0.0), 0.0
+    if max_depth > 0 and len(real_focal) > 0:                                 # :161-193
+        hf = h[real_focal, :].unsqueeze(1).repeat(1, n, 1)
+        xf = x[real_focal, :].unsqueeze(1).repeat(1, n, 1)
+        efc = torch.stack([eff[f // n, f % n, :, :] for f in real_focal])
+        hv, xv = h.reshape(bs, n, -1), x.reshape(bs, n, -1)
+        ha = torch.stack([hv[f // n] for f in real_focal])
+        xa = torch.stack([xv[f // n] for f in real_focal])
+        dist = torch.sum((xa - xf) ** 2, dim=2, keepdim=True)
+        ep = _mlp(sd, "edge_predict", torch.cat([hf, efc, ha, dist], dim=-1))
+        fi, cnt, hit = 0, 0, 0
+        for i in range(bs):
+            if predict_idx[i] != 0:
+                target = torch.tensor([list(undiscovered[i]).index(predict_idx[i])])
+                logits = ep[fi, list(undiscovered[i]), :].squeeze(-1).unsqueeze(0)
+                edge_loss = edge_loss + F.cross_entropy(logits, target)
+                hit += int(torch.argmax(logits, dim=-1) == target)
+                cnt += 1
+                fi += 1
+        edge_acc = hit / (cnt + 1e-8)
+    h, x = h.reshape(bs * n, -1), x.reshape(bs * n, -1)                       # :197-207
+    es = [circle] + edge_search
+    if max_depth > 0:
+        for depth in range(max_depth + 1):
+            e = _edges_tensor(es[depth])
+            ea = torch.sum((x[e[0]] - x[e[1]]) ** 2, dim=1, keepdim=True)
+            h, x, _ = _gcl(sd, cfg, "gcl_denoise", "edge", h, e, x, ea, node_mask)
+    hv = h.reshape(bs, n, -1)
+    h_node = torch.stack([hv[i, predict_idx[i], :] for i in range(bs)])
+    npred = _mlp(sd, "node_predict", h_node)
+    node_loss, hit = torch.tensor(0.0), 0
+    for i in range(bs):
+        node_loss = node_loss + F.cross_entropy(npred[i].unsqueeze(0), label[i].reshape(1).long())
+        hit += int(torch.argmax(npred[i]) == label[i])
+    total = cfg.focal_loss * focal_loss + cfg.edge_loss * edge_loss + cfg.node_loss * node_loss
+    return {'focal_loss': focal_loss, 'focal_accuracy': torch.tensor(focal_acc), 'edge_loss': edge_loss,
+            'edge_accuracy': torch.tensor(edge_acc), 'node_loss': node_loss, 'node_accuracy': torch.tensor(hit / bs),
+            'total_loss': total, 'node_predict': npred}
+
+
+@torch.no_grad()
+def sample_ar(sd: Dict[str, torch.Tensor], cfg: EDCfg, batch):
+    """Edge_denoise.sample_AR (:250-420) with array_dict = None: (edges_result, node_predict, adj_matrix)."""
+    h = torch.as_tensor(batch['node_feat'][0], dtype=torch.float32)
+    bs, n = h.shape[:2]
+    h = h.reshape(bs * n, -1)
+    x = torch.as_tensor(batch['node_pos'], dtype=torch.float32).reshape(bs * n, -1)
+    nm2 = torch.as_tensor(batch['node_feat'][1], dtype=torch.float32)[:, :, 0]
+    node_nums = torch.sum(nm2, dim=1).int()
+    node_mask = nm2.reshape(bs * n, -1)
+    edge_mask = torch.as_tensor(batch['edge_mask'], dtype=torch.float32).reshape(bs * n * n, -1)
+    adj = torch.as_tensor(batch['search_adj_matrix'], dtype=torch.float32).clone()
+    val = torch.sum(adj.reshape(bs * n, n), dim=-1, keepdim=True)
+    valid = [int(i[0]) for i in node_mask.nonzero()]
+    discovered = [i for i in valid if adj[i // n, i % n, :].sum() > 0]
+    undiscovered = [i for i in valid if adj[i // n, i % n, :].sum() == 0]
+    adj = torch.stack([m - torch.diag_embed(torch.diag(m)) for m in adj])
+    h = embed(sd, cfg, h, x, None)
+    edges_full = dense_edges(n, bs)
+    eff = edge_features(sd, x, edges_full, adj.reshape(bs * n * n, 1))
+    for i in range(cfg.n_layers_full):
+        h, x, eff = _gcl(sd, cfg, f"gcl_full_{i}", "full", h, edges_full, x, eff, node_mask, edge_mask)
+    eff = eff.reshape(bs, n, n, -1)
+    if adj.sum() > 0:                                                         # :300-318
+        flat = [adj[i][:int(node_nums[i]), :int(node_nums[i])].nonzero().T.tolist() for i in range(bs)]
+        cat = concat_layers(flat, n)
+        e0 = torch.tensor([v for sub in cat[0] for v in sub], dtype=torch.long)
+        e1 = torch.tensor([v for sub in cat[1] for v in sub], dtype=torch.long)
+        ef = eff[e0 // n, e0 % n, e1 % n, :].reshape(e0.shape[0], -1)
+        for i in range(cfg.n_layers_focal):
+            h, x, ef = _gcl(sd, cfg, f"gcl_focal_{i}", "focal", h, [e0, e1], x, ef, node_mask)
+        hv, vv = h.reshape(bs, n, -1), val.reshape(bs, n, -1)
+        bins = split_nodes(discovered, n, bs)
+        focal = [bins[i][int(torch.argmax(_mlp(sd, "focal_predict", torch.cat([hv[i, bins[i], :], vv[i, bins[i]]], dim=-1),
+                                              last_sigmoid=True)))] if len(bins[i]) > 0 else -1 for i in range(bs)]
+        focal = [f + i * n if f >= 0 else -1 for i, f in enumerate(focal)]
+    elif len(discovered) == 0:
+        focal = [-1] * bs
+    else:
+        focal = [0] * bs
+    edges_result = []
+    h = h.reshape(bs * n, -1)
+    if len(discovered) > 0:                                                   # :325-371
+        if adj.sum() > 0:
+            per = []
+            for i in range(bs):
+                sm = adj[i][:int(node_nums[i]), :int(node_nums[i])]
+                per.append(adj_to_bfs(sm, focal[i] % n) if focal[i] >= 0 else [])
+            layers = [[[i * n, i * n] for i in range(bs)]] + concat_layers(per, n)
+            for layer in layers:
+                e = _edges_tensor(layer)
+                ea = torch.sum((x[e[0]] - x[e[1]]) ** 2, dim=1, keepdim=True)
+                h, x, _ = _gcl(sd, cfg, "gcl_edge", "edge", h, e, x, ea, node_mask)
+        fr = [f for f in focal if f >= 0]
+        hf = h[fr, :].unsqueeze(1).repeat(1, n, 1)
+        xf = x[fr, :].unsqueeze(1).repeat(1, n, 1)
+        efc = torch.stack([eff[f // n, f % n, :, :] for f in fr])
+        hv, xv = h.reshape(bs, n, -1), x.reshape(bs, n, -1)
+        ha = torch.stack([hv[f // n] for f in fr])
+        xa = torch.stack([xv[f // n] for f in fr])
+        dist = torch.sum((xa - xf) ** 2, dim=2, keepdim=True)
+        ep = _mlp(sd, "edge_predict", torch.cat([hf, efc, ha, dist], dim=-1))
+        ubins = split_nodes(undiscovered, n, bs)
+        fi = 0
+        for i in range(bs):
+            if 0 not in ubins[i]:
+                end = ubins[i][int(torch.argmax(ep[fi, ubins[i], :]))]
+                a = fr[fi] % n
+                adj[i][a, end] = 1
+                adj[i][end, a] = 1
+                edges_result.append([a, end])
+                fi += 1
+            else:
+                edges_result.append([-1, 0])
+    else:
+        edges_result = [[-1, 0] for _ in range(bs)]
+    h, x = h.reshape(bs * n, -1), x.reshape(bs * n, -1)                       # :375-393
+    per = []
+    for i in range(bs):
+        sm = adj[i][:int(node_nums[i]), :int(node_nums[i])]
+        per.append(adj_to_bfs(sm, edges_result[i][1]) if focal[i] > 0 else [])
+    layers = [[[i * n, i * n] for i in range(bs)]] + concat_layers(per, n)
+    for layer in layers:
+        e = _edges_tensor(layer)
+        ea = torch.sum((x[e[0]] - x[e[1]]) ** 2, dim=1, keepdim=True)
+        h, x, _ = _gcl(sd, cfg, "gcl_denoise", "edge", h, e, x, ea, node_mask)
+    hv = h.reshape(bs, n, -1)
+    h_node = torch.stack([hv[i, edges_result[i][1], :] for i in range(bs)])
+    npred = _mlp(sd, "node_predict", h_node)
+    edges_result = [e if e[0] >= 0 else [0] for e in edges_result]
+    return edges_result, npred, adj
