@@ -81,6 +81,8 @@ struct hd_handle {
     unsigned long long* d_base; // global id of the batch's first sample (Philox stream selector)
     hipStream_t own_stream;     // capture / replay stream used when the caller passes the legacy NULL stream
     hipEvent_t ev_in, ev_out;   // order own_stream against the caller's stream without host syncs
+    hipEvent_t ev_last;         // recorded behind the handle's latest graph replay (any stream): the step / draw / time words
+    bool ev_last_set;           // above are shared by every topology of the handle, so replays are serialised on it
     unsigned long long weights_gen, sched_gen;   // bumped when the packed weights / schedule tables are re-allocated
     int split_max_tiles;        // HD_SPLIT_MAX_TILES (a measurement build may override it from the environment)
     int fuse_min_rows;          // HD_FUSE_MIN_ROWS
@@ -118,6 +120,7 @@ struct GraphKey {
 struct hd_topology {
     hd_handle* h;
     int device;
+    char* arena;                               // the one device allocation everything below points into
     int B, N, M, M_pad, E, E_pad, n_tiles, n_wg, n_parts;
     // device tables
     int *node_of, *slot_of, *ei, *ej, *seg_part, *tile_nseg, *pstart, *nvalid;
@@ -216,6 +219,7 @@ extern "C" int hd_create(const hd_config* cfg, int device, hd_handle** out) {
     h->pool_used = 0;
     h->own_stream = nullptr;
     h->ev_in = h->ev_out = nullptr;
+    h->ev_last = nullptr; h->ev_last_set = false;
     h->weights_gen = h->sched_gen = 0;
     h->d_nanflag = nullptr; h->d_nan_events = nullptr; h->d_step = nullptr; h->d_draw = nullptr; h->d_tcur = nullptr;
     h->d_base = nullptr;
@@ -246,6 +250,7 @@ extern "C" int hd_create(const hd_config* cfg, int device, hd_handle** out) {
         HIP_TRY(hipMemset(h->d_nan_events, 0, sizeof(long long)));
         HIP_TRY(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&h->ev_out, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&h->ev_last, hipEventDisableTiming));
         return prepare_kernels(h);
     };
     const int r = create_rest();
@@ -266,6 +271,7 @@ extern "C" int hd_destroy(hd_handle* h) {
     for (auto e : h->pool) hipEventDestroy(e);
     if (h->ev_in) hipEventDestroy(h->ev_in);
     if (h->ev_out) hipEventDestroy(h->ev_out);
+    if (h->ev_last) hipEventDestroy(h->ev_last);
     if (h->own_stream) hipStreamDestroy(h->own_stream);
     delete h;
     return HD_OK;
@@ -554,11 +560,7 @@ extern "C" int hd_topology_destroy(hd_topology* t) {
     (void)hipSetDevice(t->device);
     (void)hipDeviceSynchronize();
     if (t->gexec) hipGraphExecDestroy(t->gexec);
-    hipFree(t->node_of); hipFree(t->slot_of); hipFree(t->ei); hipFree(t->ej); hipFree(t->seg_part);
-    hipFree(t->tile_nseg); hipFree(t->pstart); hipFree(t->nvalid); hipFree(t->eseg); hipFree(t->nm_bytes);
-    hipFree(t->nmask); hipFree(t->hbuf); hipFree(t->AB); hipFree(t->AB2); hipFree(t->Tb); hipFree(t->agg); hipFree(t->x0); hipFree(t->xcur);
-    hipFree(t->part); hipFree(t->xpart); hipFree(t->eps); hipFree(t->zbuf); hipFree(t->ctxbuf);
-    hipFree(t->rptr); hipFree(t->rrows); hipFree(t->sptr); hipFree(t->srows); hipFree(t->w2img); hipFree(t->w2timg);
+    hipFree(t->arena);                                  // tables and workspace live in one allocation
     delete t->node_of_host;
     delete t;
     return HD_OK;
@@ -734,29 +736,49 @@ extern "C" int hd_topology_create(hd_handle* h, const uint8_t* node_mask, const 
     t->h = h; t->device = h->device; t->B = B; t->N = N; t->M = M; t->M_pad = M_pad; t->E = (int)E; t->E_pad = E_pad;
     t->n_tiles = n_tiles; t->n_wg = n_wg; t->n_parts = n_parts;
     const int H = h->H;
+    // ONE device allocation per topology: [index tables | zero-filled activation workspace], filled by ONE host-to-device
+    // copy and ONE memset.  (Round 2 made ~35 hipMalloc / hipMemset / hipMemcpy calls per topology: 1.2 - 3.5 ms for a new
+    // batch of masks, which a training step pays every time - ADVICE round 2.)
+    std::vector<char> blob;
+    auto stage = [&](const void* src, size_t bytes) {               // 256-byte aligned slot in the table region
+        const size_t off = (blob.size() + 255) & ~size_t(255);
+        blob.resize(off + std::max<size_t>(bytes, 4), 0);
+        if (bytes) std::memcpy(blob.data() + off, src, bytes);
+        return off;
+    };
+    auto stage_v = [&](const auto& v) { return stage(v.data(), v.size() * sizeof(v[0])); };
+    const size_t o_node_of = stage_v(node_of), o_slot_of = stage_v(slot_of), o_ei = stage_v(ei), o_ej = stage_v(ej);
+    const size_t o_seg_part = stage_v(seg_part), o_tile_nseg = stage_v(tile_nseg), o_pstart = stage_v(pstart), o_nvalid = stage_v(nvalid);
+    const size_t o_eseg = stage_v(eseg), o_nm = stage_v(nm_bytes), o_nmask = stage_v(nmask);
+    const size_t o_rptr = stage_v(L.rptr), o_rrows = stage_v(L.rrows), o_sptr = stage_v(L.sptr), o_srows = stage_v(L.srows);
+    const size_t table_bytes = (blob.size() + 255) & ~size_t(255);
+    size_t ws_floats = 0;
+    auto carve = [&](size_t count) { const size_t o = ws_floats; ws_floats += (std::max<size_t>(count, 1) + 63) & ~size_t(63); return o; };
+    const size_t f_h = carve((size_t)M_pad * H), f_AB = carve((size_t)M_pad * 2 * H), f_AB2 = carve((size_t)M_pad * 2 * H);
+    const size_t f_Tb = carve((size_t)M_pad * H), f_agg = carve((size_t)M_pad * H);       // fp32 node chain of small batches; training
+    const size_t f_x0 = carve((size_t)M_pad * 4), f_xcur = carve((size_t)M_pad * 4);
+    const size_t f_part = carve((size_t)std::max(1, n_parts) * H), f_xpart = carve((size_t)std::max(1, n_parts) * 4);
+    const size_t f_eps = carve(BN * h->D), f_z = carve(BN * h->D), f_ctx = carve(BN * (size_t)std::max(1, h->cfg.context_node_nf));
+    const size_t f_w2 = carve((size_t)H * H), f_w2t = carve((size_t)H * H);
     auto build = [&]() -> int {
-        HD_TRY(dev_upload(&t->node_of, node_of)); HD_TRY(dev_upload(&t->slot_of, slot_of)); HD_TRY(dev_upload(&t->ei, ei));
-        HD_TRY(dev_upload(&t->ej, ej)); HD_TRY(dev_upload(&t->seg_part, seg_part)); HD_TRY(dev_upload(&t->tile_nseg, tile_nseg));
-        HD_TRY(dev_upload(&t->pstart, pstart)); HD_TRY(dev_upload(&t->nvalid, nvalid)); HD_TRY(dev_upload(&t->eseg, eseg));
-        HD_TRY(dev_upload(&t->nm_bytes, nm_bytes)); HD_TRY(dev_upload(&t->nmask, nmask));
-        HD_TRY(dev_upload(&t->rptr, L.rptr)); HD_TRY(dev_upload(&t->rrows, L.rrows));
-        HD_TRY(dev_upload(&t->sptr, L.sptr)); HD_TRY(dev_upload(&t->srows, L.srows));
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&t->arena), table_bytes + ws_floats * sizeof(float));
+        if (e != hipSuccess) { t->arena = nullptr; return fail(HD_E_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e)); }
+        char* base = t->arena;
+        HIP_TRY(hipMemcpy(base, blob.data(), blob.size(), hipMemcpyHostToDevice));
+        // zero-filled workspace: pad rows stay zero for the lifetime of the topology (kernels never write them)
+        HIP_TRY(hipMemset(base + table_bytes, 0, ws_floats * sizeof(float)));
+        auto I = [&](size_t off) { return reinterpret_cast<int*>(base + off); };
+        t->node_of = I(o_node_of); t->slot_of = I(o_slot_of); t->ei = I(o_ei); t->ej = I(o_ej); t->seg_part = I(o_seg_part);
+        t->tile_nseg = I(o_tile_nseg); t->pstart = I(o_pstart); t->nvalid = I(o_nvalid);
+        t->eseg = reinterpret_cast<uint8_t*>(base + o_eseg); t->nm_bytes = reinterpret_cast<uint8_t*>(base + o_nm);
+        t->nmask = reinterpret_cast<float*>(base + o_nmask);
+        t->rptr = I(o_rptr); t->rrows = I(o_rrows); t->sptr = I(o_sptr); t->srows = I(o_srows);
+        float* ws = reinterpret_cast<float*>(base + table_bytes);
+        t->hbuf = ws + f_h; t->AB = ws + f_AB; t->AB2 = ws + f_AB2; t->Tb = ws + f_Tb; t->agg = ws + f_agg; t->x0 = ws + f_x0;
+        t->xcur = ws + f_xcur; t->part = ws + f_part; t->xpart = ws + f_xpart; t->eps = ws + f_eps; t->zbuf = ws + f_z;
+        t->ctxbuf = ws + f_ctx; t->w2img = ws + f_w2; t->w2timg = ws + f_w2t;
         t->node_of_host = new std::vector<int>(node_of);
-        // zero-filled: pad rows stay zero for the lifetime of the topology (kernels never write them)
-        auto zalloc = [&](float** p, size_t count) -> int {
-            HD_TRY(dev_alloc(p, count));
-            HIP_TRY(hipMemset(*p, 0, std::max<size_t>(count, 1) * sizeof(float)));
-            return HD_OK;
-        };
-        HD_TRY(zalloc(&t->hbuf, (size_t)M_pad * H)); HD_TRY(zalloc(&t->AB, (size_t)M_pad * 2 * H));
-        HD_TRY(zalloc(&t->AB2, (size_t)M_pad * 2 * H));
-        HD_TRY(zalloc(&t->Tb, (size_t)M_pad * H)); HD_TRY(zalloc(&t->agg, (size_t)M_pad * H));      // small-batch fp32 node chain
-        HD_TRY(zalloc(&t->x0, (size_t)M_pad * 4)); HD_TRY(zalloc(&t->xcur, (size_t)M_pad * 4));
-        HD_TRY(zalloc(&t->part, (size_t)std::max(1, n_parts) * H)); HD_TRY(zalloc(&t->xpart, (size_t)std::max(1, n_parts) * 4));
-        HD_TRY(zalloc(&t->eps, BN * h->D)); HD_TRY(zalloc(&t->zbuf, BN * h->D));
-        HD_TRY(zalloc(&t->ctxbuf, BN * (size_t)std::max(1, h->cfg.context_node_nf)));
-        HD_TRY(zalloc(&t->w2img, (size_t)H * H)); HD_TRY(zalloc(&t->w2timg, (size_t)H * H));
-        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipStreamSynchronize(nullptr));        // the memset ran on the NULL stream; callers launch on any stream
         return HD_OK;
     };
     const int r = build();
@@ -1838,8 +1860,12 @@ extern "C" int hd_sample_loop(hd_handle* h, hd_topology* topo, float* z, const f
     GraphKey key;
     key.raw_x = raw_x; key.raw_h = raw_h; key.has_ctx = context ? 1 : 0; key.mol_shape = mol_shape < 0 ? -1 : mol;
     key.noise_rows = noise_rows; key.T = T; key.s_hi = raw_x ? s_hi : 0; key.seed = seed; key.weights_gen = h->weights_gen; key.sched_gen = h->sched_gen;
+    // The replay state (d_step, d_draw, d_tcur, d_base) belongs to the handle: a replay issued on another stream - another
+    // topology of this handle, or the same one from another caller stream - must have finished before this one touches it.
+    if (h->ev_last_set) HIP_TRY(hipStreamWaitEvent(rs, h->ev_last, 0));
     if (topo->gexec && !(topo->gkey == key)) {
-        HIP_TRY(hipStreamSynchronize(rs));               // a replay of the stale graph may still be running
+        if (h->ev_last_set) HIP_TRY(hipEventSynchronize(h->ev_last));   // a replay of the stale graph may still be running, on any stream
+        HIP_TRY(hipStreamSynchronize(rs));
         hipGraphExecDestroy(topo->gexec);
         topo->gexec = nullptr;
     }
@@ -1874,6 +1900,8 @@ extern "C" int hd_sample_loop(hd_handle* h, hd_topology* topo, float* z, const f
         if (le != hipSuccess) return fail(HD_E_HIP, std::string("hipGraphLaunch: ") + hipGetErrorString(le));
     }
     HIP_TRY(hipMemcpyAsync(z, topo->zbuf, zbytes, hipMemcpyDeviceToDevice, rs));
+    HIP_TRY(hipEventRecord(h->ev_last, rs));
+    h->ev_last_set = true;
     if (rs != s) {
         HIP_TRY(hipEventRecord(h->ev_out, rs));
         HIP_TRY(hipStreamWaitEvent(s, h->ev_out, 0));

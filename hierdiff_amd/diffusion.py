@@ -222,7 +222,10 @@ class DiffusionQM9(_Base):
         once per version of the schedule parameters - and a loss evaluation needs no host round trip."""
         if gammas is not None and key in gammas:
             return torch.as_tensor(gammas[key], dtype=torch.float32, device=t.device).view(-1, 1)
-        if torch.is_grad_enabled():        # training: the schedule network is part of the graph (fp32, like the reference)
+        # training a LEARNED schedule: the network is part of the autograd graph (fp32, like the reference).  A predefined
+        # schedule has no trainable parameter, and an evaluation call needs no graph: both read the table, so that the same
+        # batch gives the same NLL whatever the grad mode
+        if torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.gamma.parameters()):
             return self.gamma(t).view(-1, 1)
         ver = (self.T, str(t.device)) + tuple((p.data_ptr(), p._version) for p in self.gamma.state_dict(keep_vars=True).values())
         if getattr(self, "_gamma_grid_key", None) != ver:

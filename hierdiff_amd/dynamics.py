@@ -9,6 +9,7 @@ include/hierdiff_hip.h; the torch modules below only hold parameters.
 from __future__ import annotations
 
 import ctypes as C
+import hashlib
 import math
 import os
 import weakref
@@ -88,16 +89,12 @@ class Topology:
     """Index tables + activation workspace for one (node_mask, edge_mask) pair (hd_topology)."""
 
     def __init__(self, owner: "EGNN_dynamics_QM9", node_mask: torch.Tensor, edge_mask: Optional[torch.Tensor],
-                 B: int, N: int):
+                 B: int, N: int, host_masks: Optional[Tuple[np.ndarray, Optional[np.ndarray]]] = None):
         lib = _lib.load()
-        nm = node_mask.reshape(B * N).to(torch.bool).cpu().contiguous().numpy().astype(np.uint8)
-        em_ptr = None
-        if edge_mask is not None:
-            em = edge_mask.reshape(B * N * N).to(torch.bool).cpu().contiguous().numpy().astype(np.uint8)
-            em_ptr = em.ctypes.data
+        nm, em = host_masks if host_masks is not None else masks_to_host(node_mask, edge_mask, B, N)
         self._h = C.c_void_p()
-        _lib.check(lib.hd_topology_create(owner._handle(), nm.ctypes.data, em_ptr, B, N, C.byref(self._h)),
-                   "hd_topology_create")
+        _lib.check(lib.hd_topology_create(owner._handle(), nm.ctypes.data, None if em is None else em.ctypes.data, B, N,
+                                          C.byref(self._h)), "hd_topology_create")
         self.B, self.N = B, N
         self._finalizer = weakref.finalize(self, lib.hd_topology_destroy, self._h)
 
@@ -109,6 +106,15 @@ class Topology:
         buf = (C.c_longlong * 6)()
         _lib.check(_lib.load().hd_topology_info(self._h, buf), "hd_topology_info")
         return dict(zip(("B", "N", "nodes", "edges", "tiles", "parts"), (int(v) for v in buf)))
+
+
+def masks_to_host(node_mask: torch.Tensor, edge_mask: Optional[torch.Tensor], B: int, N: int):
+    """(node mask [B*N], edge mask [B*N*N] or None) as host uint8 arrays with ONE device-to-host copy (one sync)."""
+    nm = node_mask.reshape(B * N).to(torch.bool)
+    if edge_mask is None:
+        return nm.cpu().numpy().astype(np.uint8), None
+    both = torch.cat([nm.view(torch.uint8), edge_mask.reshape(B * N * N).to(torch.bool).view(torch.uint8)]).cpu().numpy()
+    return np.ascontiguousarray(both[:B * N]), np.ascontiguousarray(both[B * N:])
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -158,8 +164,10 @@ class EGNN_dynamics_QM9(nn.Module):
         self._hd = None              # (handle, device index)
         self._handle_gen = 0         # bumped whenever a new hd_handle is created (schedule / weights must be re-sent)
         self._weights_key = None
-        self._topo_cache: Dict[Tuple, Topology] = {}
+        self._topo_cache: Dict[Tuple, Tuple] = {}               # by mask tensor identity
+        self._topo_by_content: Dict[Tuple, Topology] = {}       # by mask content
         self.debug_checks = False
+        self.differentiable: Optional[bool] = None      # None: by rule (_wants_autograd)
 
     # ------------------------------------------------------------------ precision of the matrix-core path
     @property
@@ -214,6 +222,7 @@ class EGNN_dynamics_QM9(nn.Module):
 
     def _release(self):
         self._topo_cache.clear()
+        self._topo_by_content.clear()
         if self._hd is not None:
             self._finalizer()
             self._hd = None
@@ -238,21 +247,33 @@ class EGNN_dynamics_QM9(nn.Module):
 
     # ------------------------------------------------------------------ topology
     def topology(self, node_mask: torch.Tensor, edge_mask: Optional[torch.Tensor], B: int, N: int) -> Topology:
-        """Cached per mask tensors (identity + in-place version), as the reference caches its edge
-        lists per (n_nodes, batch_size) in `_edges_dict` (en_dynamics.py:124-143)."""
+        """Index tables + workspace for a pair of masks, cached twice over.  Fast path: the mask TENSORS of an earlier call
+        (storage address + in-place version + shape: the 1001 forwards of a sampling run, and views of one mask tensor - the
+        `.view(bs, n*n)` the reference's forward(batch) makes every step - hit without touching the data; like the reference
+        caches its edge lists per (n_nodes, batch_size) in `_edges_dict`, en_dynamics.py:124-143).  Otherwise - a training
+        loop hands over NEW mask tensors every batch - the key is the masks' CONTENT (one device-to-host copy, which
+        building the tables needs anyway, and a 16-byte digest): batches whose masks repeat share one topology, and a
+        miss costs one allocation, one upload and one memset (hd_topology_create)."""
         self._handle()
-        # keyed on storage address + in-place version + shape (views of one mask tensor - e.g. the `.view(bs, n*n)` the
-        # reference's forward(batch) makes every step - hit the same entry); the cached tensors are kept alive, so an
-        # address cannot be recycled while its entry exists
         sig = lambda m: None if m is None else (m.data_ptr(), m._version, m.numel(), m.dtype, str(m.device))
         key = (sig(node_mask), sig(edge_mask), B, N)
         hit = self._topo_cache.get(key)
         if hit is not None:
             return hit[0]
+        nm, em = masks_to_host(node_mask, edge_mask, B, N)
+        dig = hashlib.blake2b(nm.tobytes() + (b"" if em is None else em.tobytes()), digest_size=16).digest()
+        ckey = (dig, em is None, B, N)
+        topo = self._topo_by_content.get(ckey)
+        if topo is None:
+            if len(self._topo_by_content) >= 8:
+                self._topo_by_content.pop(next(iter(self._topo_by_content)))
+            topo = Topology(self, node_mask, edge_mask, B, N, host_masks=(nm, em))
+            self._topo_by_content[ckey] = topo
+        else:
+            self._topo_by_content[ckey] = self._topo_by_content.pop(ckey)      # most recently used last
         if len(self._topo_cache) >= 8:
             self._topo_cache.pop(next(iter(self._topo_cache)))
-        topo = Topology(self, node_mask, edge_mask, B, N)
-        self._topo_cache[key] = (topo, node_mask, edge_mask)     # holding the tensors pins their ids
+        self._topo_cache[key] = (topo, node_mask, edge_mask)     # holding the tensors pins their addresses
         return topo
 
     # ------------------------------------------------------------------ forward
@@ -264,7 +285,7 @@ class EGNN_dynamics_QM9(nn.Module):
         it is the inference path (hd_egnn_forward)."""
         if xh.device.type != "cuda":
             raise HierDiffHipError("EGNN_dynamics_QM9._forward needs cuda tensors (no CPU fallback)")
-        if torch.is_grad_enabled() and (xh.requires_grad or any(p.requires_grad for p in self.egnn.parameters())):
+        if self._wants_autograd(xh):
             from .training import dynamics_forward_train
             return dynamics_forward_train(self, t, xh, node_mask, edge_mask, context, mol_shape)
         bs, n_nodes, dims = xh.shape
@@ -274,6 +295,18 @@ class EGNN_dynamics_QM9(nn.Module):
         self.sync_weights()
         topo = self.topology(node_mask, edge_mask, bs, n_nodes)
         return self.forward_with_topology(topo, t, xh, context, mol_shape)
+
+    def _wants_autograd(self, xh: torch.Tensor) -> bool:
+        """The differentiable (exact-fp32, training.py) path is taken when autograd is recording AND someone can use the
+        graph: the module is in training mode with trainable parameters, or the input itself requires grad.  An evaluation
+        call (`model.eval()`; validation NLL, sampling) made without an explicit torch.no_grad() therefore still runs the
+        inference kernels of the configured precision - like the reference, whose eval-mode forward is the same arithmetic
+        with or without no_grad.  `self.differentiable = True / False` overrides the rule."""
+        if self.differentiable is not None:
+            return bool(self.differentiable) and torch.is_grad_enabled()
+        if not torch.is_grad_enabled():
+            return False
+        return xh.requires_grad or (self.training and any(p.requires_grad for p in self.egnn.parameters()))
 
     def forward_with_topology(self, topo: Topology, t, xh, context, mol_shape=None) -> torch.Tensor:
         dev = xh.device

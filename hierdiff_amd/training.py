@@ -46,7 +46,6 @@ class _TrainTables:
         self.index = torch.from_numpy(node_of[:self.M].astype(np.int64)).to(device)      # flat index b*N + n
         self.H = H
         self.device = device
-        self._ws = None
 
     # dW2 = G2^T P is a GEMM whose contraction runs over every edge row (K = 223,232 at B=256, N=30 against a 256 x 256
     # result): it is cut into SPLIT_K slabs (one batched GEMM + a sum over slabs) so that the BLAS library has SPLIT_K x
@@ -55,15 +54,34 @@ class _TrainTables:
     SPLIT_K = 32
 
     def workspace(self):
-        if self._ws is None:
+        """Backward workspaces, SHARED by every topology of a (device, width): three [edge rows, H] buffers are 0.7 GB at
+        B = 256, N = 30, H = 256, and a training loop builds a new topology for every batch of masks.  Grow-only; the
+        views handed out cover this topology's rows."""
+        slab = 128 * self.SPLIT_K
+        rows_pad = (self.rows + slab - 1) // slab * slab
+        pool = _WS_POOL.setdefault((str(self.device), self.H), {"rows_pad": 0, "rows": 0, "tiles": 0, "dirty_hi": 0})
+        if pool["rows_pad"] < rows_pad or pool["rows"] < self.rows or pool["tiles"] < self.tiles:
             z = lambda *s: torch.empty(s, device=self.device, dtype=torch.float32)
-            slab = 128 * self.SPLIT_K
-            rows_pad = (self.rows + slab - 1) // slab * slab
-            big = lambda: torch.zeros((rows_pad, self.H), device=self.device, dtype=torch.float32)
-            self._ws = dict(G2=big(), P=big(), G1=z(self.rows, self.H),
-                            escal=z(self.rows, 8), colpart=z(self.tiles, self.H), bapart=z(self.tiles),
-                            b2part=z(self.tiles, self.H), wrdpart=z(self.tiles, 2, self.H))
-        return self._ws
+            pool["rows_pad"], pool["rows"], pool["tiles"] = max(pool["rows_pad"], rows_pad), max(pool["rows"], self.rows), max(pool["tiles"], self.tiles)
+            pool.update(G2=torch.zeros((pool["rows_pad"], self.H), device=self.device, dtype=torch.float32),
+                        P=torch.zeros((pool["rows_pad"], self.H), device=self.device, dtype=torch.float32),
+                        G1=z(pool["rows"], self.H), escal=z(pool["rows"], 8), colpart=z(pool["tiles"], self.H), bapart=z(pool["tiles"]),
+                        b2part=z(pool["tiles"], self.H), wrdpart=z(pool["tiles"], 2, self.H), dirty_hi=0)
+        # The split-K GEMM reads whole slabs, so the rows between this topology's last tile and the end of its last slab must be
+        # zero.  Invariant: rows >= dirty_hi are zero (dirty_hi = the most rows any topology has written since they were cleaned).
+        d = pool["dirty_hi"]
+        if d > self.rows:
+            pool["G2"][self.rows:min(rows_pad, d)].zero_()
+            pool["P"][self.rows:min(rows_pad, d)].zero_()
+            if d <= rows_pad:
+                d = self.rows
+        pool["dirty_hi"] = max(d, self.rows)
+        return dict(G2=pool["G2"][:rows_pad], P=pool["P"][:rows_pad], G1=pool["G1"][:self.rows], escal=pool["escal"][:self.rows],
+                    colpart=pool["colpart"][:self.tiles], bapart=pool["bapart"][:self.tiles], b2part=pool["b2part"][:self.tiles],
+                    wrdpart=pool["wrdpart"][:self.tiles])
+
+
+_WS_POOL: dict = {}
 
 
 def _tables(dyn: EGNN_dynamics_QM9, topo: Topology, device) -> _TrainTables:

@@ -107,6 +107,7 @@ def test_training_loss_gradients_on_reference_fixtures(name):
     ref.mean().backward()
     model = build_diffusion(sd_np, int(fx["hidden_nf"]), int(fx["n_layers"]), T=T, precision="fp32")
     model.train(training)
+    model.dynamics.differentiable = True          # gradients of the EVALUATION-mode loss too (by rule only training mode records)
     replay = dict(t_int=fx["t_int"], eps=fx["eps"], gammas={k: fx[k] for k in gam})
     if not training:
         replay["eps0"] = fx["eps0"]
@@ -182,3 +183,28 @@ def test_training_step_with_learned_schedule_and_optimizer():
     assert np.isfinite(last) and last < first, (first, last)
     loss = model.training_step(batch, 0)            # the un-replayed entry point (own draws)
     assert torch.isfinite(loss) and loss.requires_grad
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_eval_mode_nll_does_not_depend_on_grad_mode(precision):
+    """an evaluation call made WITHOUT torch.no_grad() (this test runs with autograd recording) takes the
+    inference kernels of the configured precision - it neither raises in the bf16 modes nor switches the schedule from the
+    float64 table to the on-device fp32 network - and returns the bits of the same call under no_grad."""
+    from hierdiff_amd.weights import synthetic_state_dict
+    H, L = 64, 2
+    model = build_diffusion(synthetic_state_dict(9, 0, H, L, 2, True, 34, 0.5), H, L, T=1000, precision=precision).eval()
+    assert torch.is_grad_enabled() and any(p.requires_grad for p in model.dynamics.parameters())
+    nm, em = orc.canonical_masks([6, 4, 7, 5])
+    B, N = nm.shape[:2]
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(B, N, 3, generator=g) * nm
+    x = x - (x.sum(1, keepdim=True) / nm.sum(1, keepdim=True)) * nm
+    h = torch.cat([torch.randint(0, 5, (B, N, 5), generator=g).float(), torch.randn(B, N, 3, generator=g)], dim=2) * nm
+    replay = dict(t_int=torch.tensor([[3.], [170.], [500.], [1000.]]), eps=torch.randn(B, N, 11, generator=g) * nm,
+                  eps0=torch.randn(B, N, 11, generator=g) * nm)
+    args = (x.to(DEV), h.to(DEV), nm.to(DEV), em.to(DEV))
+    with_grad = model.nll(*args, **replay)
+    assert not with_grad.requires_grad
+    with torch.no_grad():
+        without = model.nll(*args, **replay)
+    assert torch.isfinite(with_grad).all() and torch.equal(with_grad, without)
