@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_bwd(EdgeBwdArgs a) {
                     float pre = w.a[u][j] + w.b[u][j];               // same operation order as the forward kernel
                     pre = __builtin_fmaf(radial, wr4[j], pre);
                     pre = __builtin_fmaf(d0, wd4[j], pre);
-                    P[4 * u + j] = silu_f(pre);
+                    P[4 * u + j] = HD_F32_SILU(pre);
                 }
             } else {
 #pragma unroll
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_bwd(EdgeBwdArgs a) {
                 const float wav = wrd_s[3 * H + 32 * ct + n];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float m = silu_f(acc[ct][r]);
+                    const float m = HD_F32_SILU(acc[ct][r]);
                     dot[r] = __builtin_fmaf(m, wav, dot[r]);
                     sd[r] = __builtin_fmaf(m, gval(gc, r), sd[r]);
                 }
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_bwd(EdgeBwdArgs a) {
             for (int ct = 0; ct < NCT; ++ct) {
                 const float wav = wrd_s[3 * H + 32 * ct + n];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) dot[r] = __builtin_fmaf(silu_f(acc[ct][r]), wav, dot[r]);
+                for (int r = 0; r < 16; ++r) dot[r] = __builtin_fmaf(HD_F32_SILU(acc[ct][r]), wav, dot[r]);
                 __builtin_amdgcn_sched_barrier(0);
             }
             const float rowdot = row_reduce(dot);                     // phi of row rho(my_slot)
