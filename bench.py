@@ -61,6 +61,19 @@ def lib_sha256() -> str:
         return hashlib.sha256(fh.read()).hexdigest()
 
 
+def kernel_source_sha256() -> str:
+    """sha256 over the kernel sources the library is built from (csrc/*, include/*.h, the build flags): identifies the
+    kernels independently of where and when hipcc produced the binary."""
+    import hashlib
+    from hierdiff_amd import build as _b
+    h = hashlib.sha256()
+    for path in sorted(_b.DEPS):
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def edge_flops_per_launch(n_edges: int, H: int) -> float:
     """Algorithmic FLOPs of one edge-kernel launch (one sub-MLP over all valid edges), SURVEY.md
     section 8d: per edge 2H^2 (second Linear) + 2H (attention / coordinate head dot) + 5H (factorised
@@ -90,14 +103,18 @@ def load_counters(precision: str, shape) -> dict:
         if tuple(c.get("shape", [])) != tuple(shape):
             reasons.append(f"{rel}: collected on shape {c.get('shape')}")
             continue
-        if c.get("lib_sha256") != lib_sha256():
-            reasons.append(f"{rel}: collected on library {str(c.get('lib_sha256'))[:12]}, loaded {lib_sha256()[:12]}")
+        # the summary names the binary it was collected on AND the kernel sources that binary was built from; a rebuild of
+        # the same sources (the driver builds in its own container) is the same kernels
+        if c.get("lib_sha256") != lib_sha256() and c.get("kernel_source_sha256") != kernel_source_sha256():
+            reasons.append(f"{rel}: collected on library {str(c.get('lib_sha256'))[:12]} / kernel sources "
+                           f"{str(c.get('kernel_source_sha256'))[:12]}, loaded {lib_sha256()[:12]} / {kernel_source_sha256()[:12]}")
             continue
         out = dict(c.get("edge_kernel", {}).get(precision, {}))
         if not out:
             continue
         out["replayed_from"] = rel
-        out["lib_sha256"] = c["lib_sha256"]
+        out["lib_sha256"] = c.get("lib_sha256", "")
+        out["kernel_source_sha256"] = c.get("kernel_source_sha256", "")
         return out
     return {"stale": "; ".join(reasons) or "no counter summary under profiles/"}
 
@@ -189,6 +206,7 @@ def timed_headline(model, precision, args, dev, rank, world, dist):
             if traffic:
                 # replayed bytes (committed PMC pass on this very library) over this kernel's live average duration
                 replay = {"replayed_from": pmc["replayed_from"], "lib_sha256": pmc["lib_sha256"][:16],
+                          "kernel_source_sha256": pmc["kernel_source_sha256"][:16],
                           "hbm_bytes_per_launch": traffic, "hbm_gbps": round(traffic / avg_s / 1e9, 1),
                           "hbm_frac": round(traffic / avg_s / 1e9 / HBM_PEAK_GBPS, 4)}
                 for k in ("mfma_busy", "valu_issue_frac", "wait_inst_frac", "wait_any_frac"):

@@ -310,10 +310,10 @@ class Edge_denoise(nn.Module):
         edge_mask = batch['edge_mask'].to(dev, torch.float32).reshape(bs * n * n, -1)
         adj = batch['search_adj_matrix'].detach().cpu().to(torch.float32).clone()     # the tree bookkeeping lives on the host
         val = torch.sum(adj.reshape(bs * n, n), dim=-1, keepdim=True).to(dev)
-        valid = [int(i[0]) for i in nm_host.reshape(bs * n, -1).nonzero()]
-        rowsum = adj.reshape(bs * n, n).sum(-1)
-        discovered = [i for i in valid if rowsum[i] > 0]
-        undiscovered = [i for i in valid if rowsum[i] == 0]
+        valid = nm_host.reshape(bs * n).numpy() != 0
+        rowsum = adj.reshape(bs * n, n).sum(-1).numpy()
+        discovered = [int(i) for i in np.nonzero(valid & (rowsum > 0))[0]]
+        undiscovered = [int(i) for i in np.nonzero(valid & (rowsum == 0))[0]]
         adj = adj - torch.diag_embed(torch.diagonal(adj, dim1=1, dim2=2))
         h, x, eff = self._embed_and_full(h, x, adj.reshape(bs * n * n, 1), node_mask, edge_mask, bs, n)
         have_edges = bool(adj.sum() > 0)

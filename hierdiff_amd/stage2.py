@@ -111,6 +111,7 @@ class E_GCL(nn.Module):
                                  recurrent=int(bool(recurrent)), coords_range=float(coords_range))
         self._hd = None
         self._weights_key = None
+        self._plist = None
         self._graphs: Dict[Tuple, _Graph] = {}          # by content of the edge list
         self._graph_ids: Dict[Tuple, Tuple] = {}        # by tensor identity (fast path)
 
@@ -136,10 +137,12 @@ class E_GCL(nn.Module):
 
     def _sync_weights(self):
         h = self._handle()
-        key = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if self._plist is None:                  # the module-tree walk of .parameters() costs more than a beam-sized layer
+            self._plist = list(self.parameters())
+        key = tuple((p.data_ptr(), p._version) for p in self._plist)
         if key == self._weights_key:
             return
-        blob = torch.cat([p.detach().reshape(-1).to(torch.float32) for p in self.parameters()]).contiguous()
+        blob = torch.cat([p.detach().reshape(-1).to(torch.float32) for p in self._plist]).contiguous()
         lib = _lib.load()
         if blob.numel() != lib.hd_egcl_weight_count(h):
             raise HierDiffHipError(f"parameter count {blob.numel()} != library layout {lib.hd_egcl_weight_count(h)}")
@@ -149,6 +152,7 @@ class E_GCL(nn.Module):
 
     def _apply(self, fn, *a, **k):
         self._weights_key = None
+        self._plist = None
         return super()._apply(fn, *a, **k)
 
     def _graph(self, row, col, M) -> _Graph:

@@ -25,6 +25,8 @@ import glob
 import json
 import os
 import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sys
 
 
 def per_kernel(path):
@@ -47,6 +49,7 @@ def main():
     out = {"source": f"rocprofv3 passes of scratch/round_profiles.sh (raw CSVs: profiles/{tag}_*_pmc_*.csv, profiles/{tag}_*_sq.csv, "
                      f"profiles/{tag}_*_T50_kernel_stats.csv); bench.py --timesteps 3 (counters) / 50 (kernel stats), B=256 N=30 H=256 L=6",
            "shape": [256, 30, 256, 6],
+           "kernel_source_sha256": __import__("bench").kernel_source_sha256(),
            # the library the passes ran on: bench.py replays these figures only while this very file is loaded
            "lib_sha256": __import__("hashlib").sha256(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                                                                       "hierdiff_amd", "lib", "libhierdiff_hip.so"), "rb").read()).hexdigest(),
