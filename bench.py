@@ -341,6 +341,21 @@ def other_configs(args, dev) -> dict:
         # the reference's shipped job: batch_size 2 (conf/sample/default.yaml:1-2), graph replay
         blk["b2_latency_T1000_B2_N30_L6"] = dict(full(2, timeit(lambda: host(m6.sample_from_masks(nm2, None, None))), 6),
                                                  launch="hipGraph replay (cached)")
+        # ... and the whole shipped job, `sample_batches(batch_size=2, num_batches=16)` with sizes drawn from the GEOM histogram
+        # (diffusion_qm9.py:397-436): the 32 independent molecules run as one device batch (DiffusionQM9.merge_batches),
+        # bit-identical to the reference's loop order of 16 device batches, which is timed beside it in fp32
+        def job(merge):
+            m6.merge_batches = merge
+            torch.manual_seed(2022)
+            return m6.sample_batches(2, 16, dev)
+        dt_job = timeit(lambda: job(256))
+        blk["shipped_job_16_batches_of_2_L6"] = {"s_per_job": round(dt_job, 4), "molecules_per_s": round(32 / dt_job, 2), "timesteps": 1000,
+                                                 "how": "one device batch of 32 (merge_batches)"}
+        if prec == "fp32":
+            dt_loop = timeit(lambda: job(0))
+            blk["shipped_job_16_batches_of_2_L6"].update(s_per_job_as_16_device_batches=round(dt_loop, 4),
+                                                         speedup_from_merging=round(dt_loop / dt_job, 2))
+        m6.merge_batches = 256
         blk["headline_L9_B256_N30"] = short(256, timeit(lambda: m9s.sample_from_masks(nm256, None, None), reps=2), Ts)
         # opt-in: the same batch as two halves on two HIP streams (hierdiff_amd.TwoStreamSampler, bit-identical results)
         two = TwoStreamSampler(m6s)

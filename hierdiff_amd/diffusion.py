@@ -152,6 +152,9 @@ class DiffusionQM9(_Base):
         self.noise_mode = "philox"      # "philox": in-kernel counter RNG; "torch": torch.randn draws
         self.seed = 2022
         self.use_graph = True
+        # sample_batches: molecules of consecutive batches run as ONE device batch of at most this many (0: one device batch
+        # per call of the reference's loop).  Samples are bit-identical either way (a sample depends on its global id only).
+        self.merge_batches = 256
         self.debug_checks = False       # True re-enables the reference's host-synchronising asserts
         self.schedule_gammas = None     # optional [T+1] gamma grid overriding the network (replay a run)
         # "fp64" (default): the schedule network is evaluated once in float64 on the host and rounded - the same table on
@@ -616,13 +619,6 @@ class DiffusionQM9(_Base):
         """diffusion_qm9.py:347-395: list of {'x': [n_i,3], 'h': [n_i,8], ('context': [n_i,1])} on the CPU."""
         device = torch.device(device)
         sample_n = self.nodes_dist.sample(num_samples)
-        n_max = max(sample_n)
-        sizes = torch.tensor(sample_n)
-        ar = torch.arange(n_max)
-        node_mask = (ar[None, :] < sizes[:, None]).unsqueeze(-1)
-        if context is not None:
-            context = torch.zeros([num_samples, n_max, 1]).to(device) + context
-        node_mask = node_mask.to(device)
         pocket = None
         if pocket_cond is not None:
             if not self.pocket:
@@ -630,6 +626,22 @@ class DiffusionQM9(_Base):
             pocket = (pocket_cond[1].to(device, torch.float32),
                       self.pocket_embed(pocket_cond[0].to(device).long()).to(torch.float32),
                       pocket_cond[2].to(device).bool(), pocket_cond[3].to(device).bool())
+        return self._sample_sizes(sample_n, device, None if context is None else [context] * num_samples,
+                                  sample_id_base, pocket)
+
+    def _sample_sizes(self, sample_n, device, contexts, sample_id_base, pocket=None):
+        """One device batch for the molecule sizes `sample_n` (global sample ids sample_id_base + i); `contexts`: one scalar
+        (or [1]-broadcastable value) per molecule or None.  Masks as diffusion_qm9.py:349-353, result slicing as :388-395."""
+        num_samples = len(sample_n)
+        n_max = max(sample_n)
+        sizes = torch.tensor(sample_n)
+        ar = torch.arange(n_max)
+        node_mask = (ar[None, :] < sizes[:, None]).unsqueeze(-1)
+        context = None
+        if contexts is not None:
+            col = torch.stack([torch.as_tensor(c, dtype=torch.float32).reshape(-1)[:1].cpu() for c in contexts]).reshape(num_samples, 1, 1)
+            context = (torch.zeros([num_samples, n_max, 1]) + col).to(device)
+        node_mask = node_mask.to(device)
         x, h = self.sample_from_masks(node_mask, None, context, sample_id_base=sample_id_base, pocket=pocket)
         x, h = x.cpu(), h.cpu()
         xs = [x[i, :sample_n[i]].clone() for i in range(num_samples)]
@@ -642,7 +654,29 @@ class DiffusionQM9(_Base):
     def sample_batches(self, batch_size, num_batches, device, context_range=None, protein_data_all=None,
                        sample_id_base: int = 0):
         """diffusion_qm9.py:397-436, incl. the protein branch (`protein_data_all`: list of dicts with
-        'residue_type', 'coord', 'pocket_name', 'ligand_name')."""
+        'residue_type', 'coord', 'pocket_name', 'ligand_name').
+
+        The reference runs the batches one after the other (its shipped job is 16 batches of 2 molecules,
+        conf/sample/default.yaml:1-2).  Molecules are independent, and here a sample's bits depend only on its global id
+        (counter RNG keyed by the id, per-molecule tiles, batch-size-independent kernels), so consecutive batches are run
+        as one device batch of at most `self.merge_batches` molecules: same results, bit for bit, as the loop
+        (tests/test_gpu_configs.py::test_merged_sample_batches_equal_the_loop), at the throughput of the larger batch.
+        The molecule sizes are drawn batch by batch exactly as the loop draws them.  Not merged: the protein branch,
+        `noise_mode == "torch"` (torch.randn draws depend on the batch shape), `merge_batches = 0`.  One difference that
+        is not a sample's own: the NaN guard (en_dynamics.py:109-111) zeroes the velocity of the whole DEVICE batch."""
+        device = torch.device(device)
+        if protein_data_all is None and self.merge_batches and self.noise_mode == "philox" and num_batches > 1:
+            sizes, ctxs = [], []
+            for i in range(num_batches):
+                sizes.extend(self.nodes_dist.sample(batch_size))
+                if context_range is not None:
+                    ctxs.extend([context_range[i % len(context_range)]] * batch_size)
+            per = max(int(batch_size), int(self.merge_batches) // int(batch_size) * int(batch_size))
+            results = []
+            for lo in range(0, len(sizes), per):
+                hi = min(lo + per, len(sizes))
+                results.extend(self._sample_sizes(sizes[lo:hi], device, ctxs[lo:hi] if ctxs else None, sample_id_base + lo))
+            return results, []
         protein_cond_all = None
         if protein_data_all is not None:
             protein_cond_all = pocket_tensors(protein_data_all)

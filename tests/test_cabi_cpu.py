@@ -253,3 +253,28 @@ def test_loss_gamma_grid_equals_rowwise_evaluation():
         if hasattr(model.gamma, "l2"):                          # with autograd the network itself is in the graph
             with torch.enable_grad():
                 assert model._gamma_rows(t_int / T, "gamma_t", None).requires_grad
+
+
+def test_sample_batches_merges_consecutive_batches_host_side():
+    """Host logic of `DiffusionQM9.sample_batches` (diffusion_qm9.py:397-436): the molecule sizes are drawn batch by batch
+    exactly as the reference's loop draws them, consecutive batches form device batches of at most `merge_batches`
+    molecules (whole batches only), global sample ids and the per-batch context value follow the loop's order.  The
+    device half is tests/test_gpu_configs.py::test_merged_sample_batches_equal_the_loop."""
+    import torch
+    from hierdiff_amd import DiffusionQM9, default_config
+    m = DiffusionQM9(default_config(hidden_nf=32, n_layers=1, timesteps=4))
+    torch.manual_seed(7)
+    loop_sizes = [n for _ in range(5) for n in m.nodes_dist.sample(3)]
+    calls = []
+    m._sample_sizes = lambda sizes, dev, ctx, base, pocket=None: (calls.append((list(sizes), ctx, base)) or [{"x": None}] * len(sizes))
+    torch.manual_seed(7)
+    res, names = m.sample_batches(3, 5, "cpu", context_range=[0.5, 1.5], sample_id_base=100)
+    assert names == [] and len(res) == 15 and len(calls) == 1
+    assert calls[0][0] == loop_sizes and calls[0][2] == 100
+    assert calls[0][1] == [0.5] * 3 + [1.5] * 3 + [0.5] * 3 + [1.5] * 3 + [0.5] * 3
+    calls.clear()
+    m.merge_batches = 7                                   # two whole batches of 3 per device batch
+    torch.manual_seed(7)
+    m.sample_batches(3, 5, "cpu", sample_id_base=100)
+    assert [c[0] for c in calls] == [loop_sizes[0:6], loop_sizes[6:12], loop_sizes[12:15]]
+    assert [c[2] for c in calls] == [100, 106, 112] and all(c[1] is None for c in calls)

@@ -538,3 +538,33 @@ def test_bench_rccl_path_at_world_one(tmp_path):
                   "vs_baseline", "dtype", "data", "config", "roofline"):
             assert k in line, k
         assert line["roofline"]["bound"] == "mfma" and 0.0 < line["roofline"]["frac"] < 1.0
+
+
+# ----------------------------------------------------------------------------- (l) the reference's shipped job: many small batches
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_merged_sample_batches_equal_the_loop(precision):
+    """`sample_batches(batch_size=2, num_batches=16)` is the reference's shipped job (conf/sample/default.yaml:1-2,
+    diffusion_qm9.py:397-436: 16 calls of sample(2)).  Here the 32 molecules run as one device batch (`merge_batches`);
+    every molecule equals, bit for bit, what the reference's loop order produces (`merge_batches = 0`): sizes drawn batch
+    by batch from the same generator state, global sample ids, a context value per batch.  Also with a merge limit that
+    cuts the job into device batches of 6 and with a width that takes the column-split small-batch kernels."""
+    H, L, T = 128, 2, 15
+    for ctx_nf, ctx_range in ((0, None), (1, [-0.4, 1.5, 4.9])):
+        m = build_diffusion(_syn(H, L, C_=ctx_nf, seed=91, gain=0.02), H, L, C_=ctx_nf, T=T, precision=precision).eval()
+        outs = []
+        for merge in (0, 256, 6):
+            m.merge_batches = merge
+            torch.manual_seed(1234)                                   # the node-count draws of nodes_dist
+            res, names = m.sample_batches(2, 16, DEV, context_range=ctx_range, sample_id_base=500)
+            assert len(res) == 32 and names == []
+            outs.append(res)
+        for other in outs[1:]:
+            for a, b in zip(outs[0], other):
+                assert a["x"].shape == b["x"].shape and torch.isfinite(a["x"]).all()
+                assert torch.equal(a["x"], b["x"]) and torch.equal(a["h"], b["h"])
+                if ctx_nf:
+                    assert torch.equal(a["context"], b["context"])
+        if ctx_nf:                                                    # batch i carries context_range[i % 3] on every row
+            for i, r in enumerate(outs[1]):
+                assert float((r["context"] - ctx_range[(i // 2) % 3]).abs().max()) == 0.0
