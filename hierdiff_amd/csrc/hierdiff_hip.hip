@@ -1725,6 +1725,67 @@ extern "C" int hd_linear(int device, const float* x, int M, int K, int ldx, cons
     return HD_OK;
 }
 
+// ----------------------------------------------------------------------------- training GEMM (k_tgemm.hpp)
+
+extern "C" int hd_gemm_f32(int device, int M, int N, int K, const float* A, long long a_m_stride, long long a_k_stride,
+                           const float* B, long long b_k_stride, long long b_n_stride, float* C, int ldc, const float* bias,
+                           int epi, const float* aux, const float* row_mask, float* C2, int split_k, float* ws,
+                           float* colsum, void* stream) {
+    if (!A || !B || !C) return fail(HD_E_INVALID, "hd_gemm_f32: null tensor");
+    if (M < 0 || N < 0 || K < 0 || ldc < N) return fail(HD_E_INVALID, "hd_gemm_f32: bad shape");
+    if ((a_m_stride != 1 && a_k_stride != 1) || (b_k_stride != 1 && b_n_stride != 1))
+        return fail(HD_E_INVALID, "hd_gemm_f32: each operand needs one unit stride");
+    if (epi < TG_EPI_BIAS || epi > TG_EPI_MUL_DSILU) return fail(HD_E_INVALID, "hd_gemm_f32: epi must be 0..3");
+    if ((epi == TG_EPI_BIAS_SILU2 && !C2) || ((epi == TG_EPI_RESID_MASK || epi == TG_EPI_MUL_DSILU) && !aux))
+        return fail(HD_E_INVALID, "hd_gemm_f32: the epilogue's second tensor is missing");
+    if (split_k < 1) split_k = 1;
+    if (split_k > 1 && (!ws || epi != TG_EPI_BIAS)) return fail(HD_E_INVALID, "hd_gemm_f32: split-K needs a workspace and the plain epilogue");
+    if (colsum && (split_k < 2 || a_m_stride != 1 || a_k_stride == 1)) return fail(HD_E_INVALID, "hd_gemm_f32: column sums ride on a split-K GEMM with an m-contiguous A");
+    if (hd_device_count() <= device || device < 0) return fail(HD_E_HIP, "hd_gemm_f32: no such HIP device (is a GPU visible?)");
+    if (M == 0 || N == 0) return HD_OK;
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t s = (hipStream_t)stream;
+    const bool a_kc = a_k_stride == 1, b_kc = b_k_stride == 1;      // k-contiguous source: transposed on its way into LDS
+    TGemmArgs g;
+    std::memset(&g, 0, sizeof(g));
+    g.A = A; g.B = B; g.C = C; g.C2 = C2; g.bias = bias; g.aux = aux; g.rmask = row_mask;
+    g.sam = a_m_stride; g.sak = a_k_stride; g.sbk = b_k_stride; g.sbn = b_n_stride;
+    g.M = M; g.N = N; g.K = K; g.ldc = ldc; g.epi = epi;
+    // split-K slabs are whole K chunks, so that a slab boundary never cuts a float4
+    int kslab = std::max(K, 1);
+    const bool splitting = split_k > 1;               // partial results through ws + k_tgemm_reduce, even if one slab is left
+    if (splitting) {
+        kslab = ((K + split_k - 1) / split_k + TG_BK - 1) / TG_BK * TG_BK;
+        if (kslab < TG_BK) kslab = TG_BK;
+        split_k = std::max(1, (K + kslab - 1) / kslab);
+    }
+    g.kslab = kslab;
+    g.ws = splitting ? ws : nullptr;
+    g.colsum_ws = (splitting && colsum) ? ws + (size_t)split_k * M * N : nullptr;
+    auto aligned = [](const float* p, long long ld) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && (ld & 3) == 0; };
+    g.avec = aligned(A, a_kc ? a_m_stride : a_k_stride) ? 1 : 0;
+    g.bvec = aligned(B, b_kc ? b_n_stride : b_k_stride) ? 1 : 0;
+    const dim3 grid((M + TG_BM - 1) / TG_BM, (N + TG_BN - 1) / TG_BN, split_k), block(256);
+    // FAST: full tiles, whole K chunks per slab, 16-byte aligned rows - no bounds checks, no branches around the loads
+    const bool fast = g.avec && g.bvec && M % TG_BM == 0 && N % TG_BN == 0 && K % TG_BK == 0 && K > 0;
+    auto launch = [&](auto Fast) {
+        constexpr bool F = decltype(Fast)::value;
+        if (a_kc && b_kc) hipLaunchKernelGGL((k_tgemm<true, true, F>), grid, block, 0, s, g);
+        else if (a_kc) hipLaunchKernelGGL((k_tgemm<true, false, F>), grid, block, 0, s, g);
+        else if (b_kc) hipLaunchKernelGGL((k_tgemm<false, true, F>), grid, block, 0, s, g);
+        else hipLaunchKernelGGL((k_tgemm<false, false, F>), grid, block, 0, s, g);
+    };
+    if (fast) launch(std::true_type{}); else launch(std::false_type{});
+    if (splitting) {
+        TGemmReduceArgs r;
+        r.ws = ws; r.colsum_ws = g.colsum_ws; r.bias = bias; r.C = C; r.colsum = colsum; r.M = M; r.N = N; r.ldc = ldc; r.nz = split_k;
+        const long long total = (long long)M * N + (colsum ? M : 0);
+        hipLaunchKernelGGL(k_tgemm_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, r);
+    }
+    HIP_TRY(hipGetLastError());
+    return HD_OK;
+}
+
 // ----------------------------------------------------------------------------- sampling maths
 
 static NoiseSrc make_noise(const float* raw_x, const float* raw_h, int rows, uint64_t seed, uint64_t base,

@@ -1,0 +1,285 @@
+// General exact-fp32 GEMM of the TRAINING path (k_tgemm): the node-level Linears around an edge layer, forward and both
+// backward directions, and the dense reduction over all edge rows dW2 = G2^T P (hierdiff_amd/training.py; reference:
+// the nn.Linear modules of egnn_new.py:9-33,74-89 under torch.autograd, diffusion_qm9.py:774-777).  Included through kernels.hpp.
+//
+//     C[m][n] = epi( sum_k A(m, k) B(k, n) ),   A(m, k) = A[m sam + k sak],   B(k, n) = B[k sbk + n sbn]
+//
+// with one unit stride per operand, so that one kernel serves
+//     forward   Y  = X W^T + b     A = X  (k contiguous),  B(k, n) = W[n][k] (k contiguous)
+//     backward  dX = dY W          A = dY (k contiguous),  B(k, n) = W[k][n] (n contiguous)
+//     backward  dW = dY^T X        A(m, k) = dY[k][m] (m contiguous),  B(k, n) = X[k][n] (n contiguous), k = node / edge rows,
+//                                  cut into gridDim.z slabs of kslab rows (split-K: per-slab partial results in `ws`, summed in
+//                                  slab order by k_tgemm_reduce - deterministic, no atomics), the bias gradient
+//                                  db[m] = sum_k dY[k][m] riding along as column sums of the A tiles.
+// Workgroup tile 64 x 128, K chunks of 32 double-buffered through LDS as [row][k] (row stride 36 floats: a lane's four k
+// values are one conflict-free ds_read_b128 whatever the source layout; m- / n-contiguous sources are transposed on the LDS
+// write, conflict-free through a quad swizzle), four wavefronts of 32 x 64 (two v_mfma_f32_32x32x2_f32 accumulators), global
+// loads two to three chunks ahead in registers, the LDS fragments of the next chunk requested before the MFMAs of the
+// current one, one barrier per chunk, two workgroups per CU (55 KB of LDS).  Sources that are not 16-byte aligned (the embedding Linears, K = 9
+// or 10) take scalar loads.  Exact fp32 like every other kernel of the training path; the order of the k sum differs from
+// the BLAS library's, i.e. results agree with it to fp32 round-off.
+#pragma once
+#include "common.hpp"
+
+enum { TG_EPI_BIAS = 0, TG_EPI_BIAS_SILU2 = 1, TG_EPI_RESID_MASK = 2, TG_EPI_MUL_DSILU = 3 };
+
+struct TGemmArgs {
+    const float* A;
+    const float* B;
+    float* C;               // [M][ldc]
+    float* C2;              // BIAS_SILU2: silu(C)
+    const float* bias;      // [N] or null
+    const float* aux;       // RESID_MASK: residual R [M][ldc]; MUL_DSILU: pre-activation [M][ldc]
+    const float* rmask;     // RESID_MASK: [M] row mask or null
+    float* ws;              // split-K: [z][M][N] partial results (null: one slab, epilogue applied here)
+    float* colsum_ws;       // non-null: [z][M] partial sums over k of A(m, k) (written by the n-tile-0 workgroups)
+    long long sam, sak, sbk, sbn;
+    int M, N, K, ldc, kslab, epi, avec, bvec;
+};
+
+constexpr int TG_BM = 64, TG_BN = 128, TG_BK = 32;
+
+// d/dx [x sigmoid(x)] = s (1 + x (1 - s))
+HD_DEVINL float dsilu_f(float x) {
+    const float s = sigmoid_f(x);
+    return s * __builtin_fmaf(x, 1.0f - s, 1.0f);
+}
+
+// FAST: every tile is full and every row 16-byte aligned (M % 64 == 0, N % 128 == 0, slabs of whole chunks) - all node-level
+// and edge-row shapes of the production widths.  Its loads carry no bounds checks and no branches: hipcc assumes that
+// nothing is in flight behind a control-flow join and answers a load inside an `if` with s_waitcnt vmcnt(0) at the join, which
+// exposes the full L2 / HBM latency once per chunk (measured: 35 us for a 7,680 x 256 x 256 product whichever prefetch
+// distance was written down).  The general form (embedding Linears with K = 9 / 10 columns, ragged row counts) keeps the checks.
+template <bool A_KC, bool B_KC, bool FAST>
+__global__ __launch_bounds__(256, 2) void k_tgemm(TGemmArgs g) {
+    // LDS: [row][k] with k contiguous, row stride 36 floats (conflict-free ds_read_b128 of a lane's four k values)
+    constexpr int LDK = TG_BK + 4;
+    __shared__ __attribute__((aligned(16))) float As[2][TG_BM * LDK];
+    __shared__ __attribute__((aligned(16))) float Bs[2][TG_BN * LDK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1, hh = lane >> 5, n = lane & 31;
+    const int m0 = blockIdx.x * TG_BM, n0 = blockIdx.y * TG_BN;
+    const int kbeg = blockIdx.z * g.kslab, kend = min(g.K, kbeg + g.kslab);
+    const int nchunk = (kend - kbeg + TG_BK - 1) / TG_BK;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+
+    // one float4 of a tile: `row` along the operand's strided axis, `x` along its contiguous one (limit xend)
+    auto ld4 = [&](const float* base, long long stride, int row, int x, int xend, bool vec) -> f32x4 {
+        const float* p = base + (long long)row * stride + x;
+        if constexpr (FAST) return *reinterpret_cast<const f32x4*>(p);
+        f32x4 v = z4;
+        if (vec && x + 3 < xend) v = *reinterpret_cast<const f32x4*>(p);
+        else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (x + j < xend) v[j] = p[j];
+        }
+        return v;
+    };
+    // ---- global -> registers: A two float4 per thread and chunk, B four
+    auto load_chunk = [&](int c, f32x4 (&ra)[2], f32x4 (&rb)[4]) {
+        const int k0 = kbeg + c * TG_BK;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int idx = tid + 256 * u;
+            if constexpr (!FAST) ra[u] = z4;
+            if constexpr (A_KC) {
+                const int m = m0 + (idx >> 3), k = k0 + 4 * (idx & 7);
+                if (FAST || (m < g.M && k < kend)) ra[u] = ld4(g.A, g.sam, m, k, kend, g.avec);
+            } else {
+                const int k = k0 + (idx >> 4), m = m0 + 4 * (idx & 15);
+                if (FAST || (k < kend && m < g.M)) ra[u] = ld4(g.A, g.sak, k, m, g.M, g.avec);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = tid + 256 * u;
+            if constexpr (!FAST) rb[u] = z4;
+            if constexpr (B_KC) {
+                const int nn = n0 + (idx >> 3), k = k0 + 4 * (idx & 7);
+                if (FAST || (nn < g.N && k < kend)) rb[u] = ld4(g.B, g.sbn, nn, k, kend, g.bvec);
+            } else {
+                const int k = k0 + (idx >> 5), nn = n0 + 4 * (idx & 31);
+                if (FAST || (k < kend && nn < g.N)) rb[u] = ld4(g.B, g.sbk, k, nn, g.N, g.bvec);
+            }
+        }
+    };
+    // ---- registers -> LDS: k-contiguous sources as they come (one ds_write_b128), m- / n-contiguous ones transposed.
+    // The eight k quads of a row are permuted by sw(row) = (row >> 4) & 3 (quad ^ sw): the transposing writes of the 16
+    // lanes that share a k then hit 16 different banks (16 (row/4 & 3) + 4 (quad ^ sw)) instead of four, and the
+    // ds_read_b128 of 16 consecutive rows stay conflict-free (sw is constant over them).
+    auto sw = [](int row) { return (row >> 4) & 3; };
+    auto store_chunk = [&](int buf, const f32x4 (&ra)[2], const f32x4 (&rb)[4]) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int idx = tid + 256 * u;
+            if constexpr (A_KC) {
+                const int row = idx >> 3;
+                *reinterpret_cast<f32x4*>(&As[buf][row * LDK + 4 * ((idx & 7) ^ sw(row))]) = ra[u];
+            } else {
+                const int k = idx >> 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int row = 4 * (idx & 15) + j;
+                    As[buf][row * LDK + 4 * ((k >> 2) ^ sw(row)) + (k & 3)] = ra[u][j];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = tid + 256 * u;
+            if constexpr (B_KC) {
+                const int row = idx >> 3;
+                *reinterpret_cast<f32x4*>(&Bs[buf][row * LDK + 4 * ((idx & 7) ^ sw(row))]) = rb[u];
+            } else {
+                const int k = idx >> 5;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int row = 4 * (idx & 31) + j;
+                    Bs[buf][row * LDK + 4 * ((k >> 2) ^ sw(row)) + (k & 3)] = rb[u][j];
+                }
+            }
+        }
+    };
+
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    // lane (row n, half hh) feeds k = 16 hh + 4 q + j to instruction (q, j) of a chunk - the same map for both operands.
+    // The twelve fragments of chunk c+1 are requested BEFORE the MFMAs of chunk c (two fragment sets): left alone hipcc sinks
+    // every LDS read next to the MFMA that uses it and exposes the LDS latency sixteen times per chunk, and with the reads
+    // behind the barrier instead all eight wavefronts of a CU queue at the LDS at once (MFMA-busy 0.51 measured; 0.62 in this
+    // form, dW2 = G2^T P at 88 TFLOP/s).  Giving the two co-resident workgroups different issue priorities (s_setprio by
+    // wavefront-slot parity) changed nothing.
+    struct Frag { f32x4 a[4], b0[4], b1[4]; };
+    const int arow = 32 * wr + n, brow = 64 * wc + n;
+    auto read_frags = [&](int buf, Frag& f) {
+        const float* ap = &As[buf][arow * LDK];
+        const float* bp = &Bs[buf][brow * LDK];
+        const float* bq = bp + 32 * LDK;
+        const int sa = sw(arow), sb0 = sw(brow), sb1 = sw(brow + 32);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f.a[q] = *reinterpret_cast<const f32x4*>(ap + 4 * ((4 * hh + q) ^ sa));
+            f.b0[q] = *reinterpret_cast<const f32x4*>(bp + 4 * ((4 * hh + q) ^ sb0));
+            f.b1[q] = *reinterpret_cast<const f32x4*>(bq + 4 * ((4 * hh + q) ^ sb1));
+        }
+    };
+    auto mfmas = [&](const Frag& f) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[q][j], f.b0[q][j], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[q][j], f.b1[q][j], acc1, 0, 0, 0);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    f32x4 csum = z4;                                        // colsum_ws: this thread's share of sum_k A(m, k) (A m-contiguous)
+    const bool do_colsum = !A_KC && g.colsum_ws != nullptr && blockIdx.y == 0;
+
+    // Pipeline, one barrier per chunk, everything of period two (LDS buffers, fragment sets, global staging sets), so the
+    // loop is unrolled by two.  Step c:  store chunk c+1 (global data requested two steps ago) into buffer (c+1)&1 - last
+    // read for the fragments of chunk c-1, which every wavefront holds in registers since before its MFMAs of step c-1 -
+    // barrier, request the fragments of chunk c+1, request the global data of chunk c+3, then the 32 MFMAs of chunk c on
+    // the fragment set filled during step c-1.  No load sits behind a branch (a chunk index past the slab re-reads the last
+    // chunk and is never stored); the branches around LDS stores / fragment reads contain no global loads.
+    f32x4 ga0[2], gb0[4], ga1[2], gb1[4];
+    Frag f0, f1;
+    const int last = max(nchunk - 1, 0);
+    if (nchunk > 0) {
+        load_chunk(0, ga0, gb0);
+        load_chunk(min(1, last), ga1, gb1);
+        store_chunk(0, ga0, gb0);
+        if (do_colsum) csum += ga0[0] + ga0[1];
+        __syncthreads();
+        read_frags(0, f0);
+        load_chunk(min(2, last), ga0, gb0);
+    }
+    for (int c = 0; c < nchunk; c += 2) {
+        // fragments f0 = chunk c; staging set 1 = chunk c+1; set 0 = chunk c+2 (in flight)
+        const bool more1 = c + 1 < nchunk;
+        if (more1) {
+            store_chunk(1, ga1, gb1);
+            if (do_colsum) csum += ga1[0] + ga1[1];
+        }
+        __syncthreads();
+        if (more1) read_frags(1, f1);
+        load_chunk(min(c + 3, last), ga1, gb1);
+        mfmas(f0);
+        if (!more1) break;
+        // fragments f1 = chunk c+1; set 0 = chunk c+2; set 1 = chunk c+3 (in flight)
+        const bool more2 = c + 2 < nchunk;
+        if (more2) {
+            store_chunk(0, ga0, gb0);
+            if (do_colsum) csum += ga0[0] + ga0[1];
+        }
+        __syncthreads();
+        if (more2) read_frags(0, f0);
+        load_chunk(min(c + 4, last), ga0, gb0);
+        mfmas(f1);
+    }
+
+    if (do_colsum) {                                        // sum over the 16 thread rows of the loader grid, in row order
+        __syncthreads();                                    // every wavefront is out of the chunk loop
+        float* red = &Bs[0][0];                             // [16][64]
+        *reinterpret_cast<f32x4*>(red + (tid >> 4) * 64 + 4 * (tid & 15)) = csum;
+        __syncthreads();
+        if (tid < 64 && m0 + tid < g.M) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) s += red[k * 64 + tid];
+            g.colsum_ws[(size_t)blockIdx.z * g.M + m0 + tid] = s;
+        }
+    }
+
+    // ---- epilogue.  acc[r]: row m0 + 32 wr + rho(r), rho(r) = (r & 3) + 8 (r >> 2) + 4 hh; column n0 + 64 wc + 32 cn + n
+    const bool split = g.ws != nullptr;
+#pragma unroll
+    for (int cn = 0; cn < 2; ++cn) {
+        const int col = n0 + 64 * wc + 32 * cn + n;
+        if (col >= g.N) continue;
+        const float bias = (!split && g.bias) ? g.bias[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + 32 * wr + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            if (row >= g.M) continue;
+            float v = (cn == 0 ? acc0[r] : acc1[r]);
+            if (split) { g.ws[((size_t)blockIdx.z * g.M + row) * g.N + col] = v; continue; }
+            v += bias;
+            const size_t o = (size_t)row * g.ldc + col;
+            if (g.epi == TG_EPI_BIAS_SILU2) { g.C[o] = v; g.C2[o] = silu_f(v); }
+            else if (g.epi == TG_EPI_RESID_MASK) { v += g.aux[o]; if (g.rmask) v *= g.rmask[row]; g.C[o] = v; }
+            else if (g.epi == TG_EPI_MUL_DSILU) g.C[o] = v * dsilu_f(g.aux[o]);
+            else g.C[o] = v;
+        }
+    }
+}
+
+// C[m][n] = sum_z ws[z][m][n] (+ bias[n]), slabs in ascending order; blocks beyond the matrix finish the column sums:
+// colsum[m] = sum_z colsum_ws[z][m]
+struct TGemmReduceArgs {
+    const float* ws;
+    const float* colsum_ws;
+    const float* bias;
+    float* C;
+    float* colsum;
+    int M, N, ldc, nz;
+};
+
+__global__ __launch_bounds__(256) void k_tgemm_reduce(TGemmReduceArgs g) {
+    const long long total = (long long)g.M * g.N;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < total) {
+        float s = 0.f;
+        for (int z = 0; z < g.nz; ++z) s += g.ws[(size_t)z * total + i];
+        const int m = (int)(i / g.N), n = (int)(i - (long long)m * g.N);
+        if (g.bias) s += g.bias[n];
+        g.C[(size_t)m * g.ldc + n] = s;
+    } else if (g.colsum && i - total < g.M) {
+        const int m = (int)(i - total);
+        float s = 0.f;
+        for (int z = 0; z < g.nz; ++z) s += g.colsum_ws[(size_t)z * g.M + m];
+        g.colsum[m] = s;
+    }
+}

@@ -34,7 +34,14 @@ class PositiveLinear(torch.nn.Module):
             torch.nn.init.uniform_(self.bias, -bound, bound)
 
     def forward(self, x):
-        return F.linear(x, F.softplus(self.weight), self.bias)
+        w = F.softplus(self.weight)
+        if x.is_cuda and x.dim() == 2 and (self.in_features == 1 or self.out_features == 1):
+            # the schedule network's layers are 1 -> 1, 1 -> 1024 and 1024 -> 1: on the GPU (training-mode loss) an outer
+            # product and a row dot, not GEMMs for the BLAS library.  The CPU forms (float64 table, the float32 replay of
+            # the reference's evaluation) keep F.linear, i.e. the reference's own arithmetic.
+            y = x * w.t() if self.in_features == 1 else (x * w).sum(dim=1, keepdim=True)
+            return y if self.bias is None else y + self.bias
+        return F.linear(x, w, self.bias)
 
 
 class GammaNetwork(torch.nn.Module):

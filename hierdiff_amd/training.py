@@ -11,8 +11,11 @@ Split of the work, by what is hot:
     `hd_edge_layer_forward` (the sampler's k_edge) and `hd_edge_layer_backward` (k_edge_bwd: per-edge activations are
     recomputed tile by tile, never stored by the forward pass), wrapped as ONE autograd Function;
   * the node-level Linears around it (embedding, the two halves of the first edge Linear, node MLP, output layer) are
-    plain dense GEMMs on [nodes, H] matrices: torch.matmul (the BLAS library) under ordinary autograd; so are the three
-    dense reductions over the materialised per-edge gradients (dW2 = G2^T P etc.).
+    dense GEMMs on [nodes, H] matrices and run on this library's own exact-fp32 GEMM (`hd_gemm_f32`, csrc/k_tgemm.hpp)
+    in all three directions - Y = X W^T + b, dX = dY W, dW = dY^T X (split-K, deterministic, the bias gradient riding
+    along) - wrapped as the autograd Functions `_Linear` and `_NodeMLP` (the node MLP with its SiLU, residual and mask
+    fused into the GEMM epilogues); so is the one dense reduction over all edge rows, dW2 = G2^T P.  No BLAS-library
+    kernel is left in a training step.
 Arithmetic is exact fp32 (`precision = "fp32"`), like the reference's training forward (its apex O2 mode is a
 trainer-level choice outside this path).  Multi-GPU: one process per GPU, gradients averaged with one flat all-reduce
 (`hierdiff_amd.sharding.allreduce_gradients`, RCCL under backend "nccl").
@@ -47,36 +50,19 @@ class _TrainTables:
         self.H = H
         self.device = device
 
-    # dW2 = G2^T P is a GEMM whose contraction runs over every edge row (K = 223,232 at B=256, N=30 against a 256 x 256
-    # result): it is cut into SPLIT_K slabs (one batched GEMM + a sum over slabs) so that the BLAS library has SPLIT_K x
-    # the workgroups to fill the chip with.  The workspaces are rounded up to whole slabs; the rows behind the last tile
-    # are zeroed once here and never written by the kernels.
-    SPLIT_K = 32
-
     def workspace(self):
         """Backward workspaces, SHARED by every topology of a (device, width): three [edge rows, H] buffers are 0.7 GB at
         B = 256, N = 30, H = 256, and a training loop builds a new topology for every batch of masks.  Grow-only; the
-        views handed out cover this topology's rows."""
-        slab = 128 * self.SPLIT_K
-        rows_pad = (self.rows + slab - 1) // slab * slab
-        pool = _WS_POOL.setdefault((str(self.device), self.H), {"rows_pad": 0, "rows": 0, "tiles": 0, "dirty_hi": 0})
-        if pool["rows_pad"] < rows_pad or pool["rows"] < self.rows or pool["tiles"] < self.tiles:
+        views handed out cover this topology's rows (the kernels write every row of every tile, and the dense reduction
+        dW2 = G2^T P reads exactly those rows)."""
+        pool = _WS_POOL.setdefault((str(self.device), self.H), {"rows": 0, "tiles": 0})
+        if pool["rows"] < self.rows or pool["tiles"] < self.tiles:
             z = lambda *s: torch.empty(s, device=self.device, dtype=torch.float32)
-            pool["rows_pad"], pool["rows"], pool["tiles"] = max(pool["rows_pad"], rows_pad), max(pool["rows"], self.rows), max(pool["tiles"], self.tiles)
-            pool.update(G2=torch.zeros((pool["rows_pad"], self.H), device=self.device, dtype=torch.float32),
-                        P=torch.zeros((pool["rows_pad"], self.H), device=self.device, dtype=torch.float32),
-                        G1=z(pool["rows"], self.H), escal=z(pool["rows"], 8), colpart=z(pool["tiles"], self.H), bapart=z(pool["tiles"]),
-                        b2part=z(pool["tiles"], self.H), wrdpart=z(pool["tiles"], 2, self.H), dirty_hi=0)
-        # The split-K GEMM reads whole slabs, so the rows between this topology's last tile and the end of its last slab must be
-        # zero.  Invariant: rows >= dirty_hi are zero (dirty_hi = the most rows any topology has written since they were cleaned).
-        d = pool["dirty_hi"]
-        if d > self.rows:
-            pool["G2"][self.rows:min(rows_pad, d)].zero_()
-            pool["P"][self.rows:min(rows_pad, d)].zero_()
-            if d <= rows_pad:
-                d = self.rows
-        pool["dirty_hi"] = max(d, self.rows)
-        return dict(G2=pool["G2"][:rows_pad], P=pool["P"][:rows_pad], G1=pool["G1"][:self.rows], escal=pool["escal"][:self.rows],
+            pool["rows"], pool["tiles"] = max(pool["rows"], self.rows), max(pool["tiles"], self.tiles)
+            pool.update(G2=z(pool["rows"], self.H), P=z(pool["rows"], self.H), G1=z(pool["rows"], self.H), escal=z(pool["rows"], 8),
+                        colpart=z(pool["tiles"], self.H), bapart=z(pool["tiles"]), b2part=z(pool["tiles"], self.H),
+                        wrdpart=z(pool["tiles"], 2, self.H))
+        return dict(G2=pool["G2"][:self.rows], P=pool["P"][:self.rows], G1=pool["G1"][:self.rows], escal=pool["escal"][:self.rows],
                     colpart=pool["colpart"][:self.tiles], bapart=pool["bapart"][:self.tiles], b2part=pool["b2part"][:self.tiles],
                     wrdpart=pool["wrdpart"][:self.tiles])
 
@@ -90,6 +76,115 @@ def _tables(dyn: EGNN_dynamics_QM9, topo: Topology, device) -> _TrainTables:
         tr = _TrainTables(topo, dyn._cfg.hidden_nf, device)
         topo._train = tr
     return tr
+
+
+# ----------------------------------------------------------------------------- dense GEMMs (hd_gemm_f32)
+
+_EPI_BIAS, _EPI_BIAS_SILU2, _EPI_RESID_MASK, _EPI_MUL_DSILU = 0, 1, 2, 3
+
+
+def _rows(t: torch.Tensor) -> torch.Tensor:
+    """2-D fp32 view with unit column stride (any row stride)."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.stride(1) == 1 or t.shape[1] == 1 and t.stride(0) >= 1 else t.contiguous()
+
+
+def _gemm(M, N, K, A, sam, sak, B, sbk, sbn, C, bias=None, epi=_EPI_BIAS, aux=None, rmask=None, C2=None, split=1,
+          colsum=None):
+    dev = C.device
+    ws = None
+    if split > 1:
+        ws = torch.empty(split * (M * N + M), device=dev, dtype=torch.float32)
+    p = lambda t: None if t is None else t.data_ptr()
+    _lib.check(_lib.load().hd_gemm_f32(dev.index or 0, M, N, K, A.data_ptr(), sam, sak, B.data_ptr(), sbk, sbn, C.data_ptr(),
+                                       C.stride(0), p(bias), epi, p(aux), p(rmask), p(C2), split, p(ws), p(colsum), _stream(dev)),
+               "hd_gemm_f32")
+    return C
+
+
+def _linear_fwd(x, W, b, epi=_EPI_BIAS, aux=None, rmask=None):
+    """epi(x W^T + b): returns C (and SiLU(C) for _EPI_BIAS_SILU2)."""
+    M, K = x.shape
+    N = W.shape[0]
+    C = torch.empty((M, N), device=x.device, dtype=torch.float32)
+    C2 = torch.empty_like(C) if epi == _EPI_BIAS_SILU2 else None
+    _gemm(M, N, K, x, x.stride(0), 1, W, 1, W.stride(0), C, bias=b, epi=epi, aux=aux, rmask=rmask, C2=C2)
+    return (C, C2) if C2 is not None else C
+
+
+def _linear_dx(g, W, epi=_EPI_BIAS, aux=None):
+    """epi(g W): [M, K] for g [M, N], W [N, K]."""
+    M, N = g.shape
+    K = W.shape[1]
+    C = torch.empty((M, K), device=g.device, dtype=torch.float32)
+    return _gemm(M, K, N, g, g.stride(0), 1, W, W.stride(0), 1, C, epi=epi, aux=aux)
+
+
+def _split_for(m_out, n_out, k):
+    """Slabs of a dW = dY^T X GEMM: enough workgroups to fill the chip (the result is only 8 - 16 tiles), at least eight
+    K chunks per slab, and a workspace (slabs x result) that stays a few times the operands' size."""
+    tiles = ((m_out + 63) // 64) * ((n_out + 127) // 128)
+    return int(max(2, min(64, (512 + tiles - 1) // tiles, k // 256)))
+
+
+def _linear_dw(g, x, want_db, rows=None):
+    """dW = g^T x [N, K] (and db = column sums of g) over the first `rows` rows, split-K in slab order."""
+    rows = g.shape[0] if rows is None else rows
+    N, K = g.shape[1], x.shape[1]
+    dW = torch.empty((N, K), device=g.device, dtype=torch.float32)
+    db = torch.empty((N,), device=g.device, dtype=torch.float32) if want_db else None
+    _gemm(N, K, rows, g, 1, g.stride(0), x, x.stride(0), 1, dW, split=_split_for(N, K, rows), colsum=db)
+    return dW, db
+
+
+class _Linear(torch.autograd.Function):
+    """y = x W^T + b on hd_gemm_f32 (torch.nn.functional.linear's contract for 2-D x)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        x, W = _rows(x.detach()), _rows(W.detach())
+        ctx.save_for_backward(x, W)
+        ctx.has_b = b is not None
+        return _linear_fwd(x, W, None if b is None else b.detach().contiguous())
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, W = ctx.saved_tensors
+        g = _rows(gy)
+        dx = _linear_dx(g, W) if ctx.needs_input_grad[0] else None
+        dW, db = (None, None)
+        if ctx.needs_input_grad[1] or (ctx.has_b and ctx.needs_input_grad[2]):
+            dW, db = _linear_dw(g, x, ctx.has_b)
+        return dx, dW, db
+
+
+class _NodeMLP(torch.autograd.Function):
+    """h' = (h + W4 SiLU(W3 [h ; agg] + b3) + b4) mask (egnn_new.py:57-69): two GEMMs forward (SiLU, residual and mask in
+    their epilogues), four backward (SiLU' in the epilogue of dT = g W4)."""
+
+    @staticmethod
+    def forward(ctx, h, agg, W3, b3, W4, b4, nm):
+        X = torch.cat([h.detach(), agg.detach()], dim=1)
+        W3, W4 = _rows(W3.detach()), _rows(W4.detach())
+        pre, T = _linear_fwd(X, W3, b3.detach().contiguous(), _EPI_BIAS_SILU2)
+        hn = torch.empty((h.shape[0], W4.shape[0]), device=h.device, dtype=torch.float32)
+        hres = h.detach().contiguous()
+        _gemm(h.shape[0], W4.shape[0], W4.shape[1], T, T.stride(0), 1, W4, 1, W4.stride(0), hn, bias=b4.detach().contiguous(),
+              epi=_EPI_RESID_MASK, aux=hres, rmask=nm)
+        ctx.save_for_backward(X, pre, T, W3, W4, nm)
+        return hn
+
+    @staticmethod
+    def backward(ctx, ghn):
+        X, pre, T, W3, W4, nm = ctx.saved_tensors
+        H = W4.shape[0]
+        g = ghn * nm.unsqueeze(1)
+        dW4, db4 = _linear_dw(g, T, True)
+        dpre = _linear_dx(g, W4, _EPI_MUL_DSILU, aux=pre)       # (g W4) * SiLU'(pre)
+        dW3, db3 = _linear_dw(dpre, X, True)
+        dX = _linear_dx(dpre, W3)
+        return dX[:, :H] + g, dX[:, H:], dW3, db3, dW4, db4, None
 
 
 class _EdgeLayer(torch.autograd.Function):
@@ -133,9 +228,8 @@ class _EdgeLayer(torch.autograd.Function):
             ws["P"].data_ptr(), ws["G1"].data_ptr(), ws["escal"].data_ptr(), ws["colpart"].data_ptr(), ws["bapart"].data_ptr(),
             ws["b2part"].data_ptr(), ws["wrdpart"].data_ptr(), dAB.data_ptr(), dx.data_ptr(), dx0.data_ptr(), _stream(dev)),
             "hd_edge_layer_backward")
-        # the one dense reduction over all edge rows: dL/dW2[c][k] = sum_e G2[e][c] P[e][k], split-K through the BLAS library
-        S = tr.SPLIT_K
-        dW2 = torch.bmm(ws["G2"].view(S, -1, tr.H).transpose(1, 2), ws["P"].view(S, -1, tr.H)).sum(0)      # [H, H]
+        # the one dense reduction over all edge rows: dL/dW2[c][k] = sum_e G2[e][c] P[e][k] (K = edge rows, split-K in slab order)
+        dW2, _ = _linear_dw(ws["G2"], ws["P"], False, rows=tr.rows)                                           # [H, H]
         # everything else left the kernels as per-tile partial sums
         db2 = ws["b2part"].sum(0)
         dwrd = ws["wrdpart"].sum(0)                            # [2, H]: sum_e {radial, d0}_e G1[e][:]
@@ -172,14 +266,16 @@ def dynamics_forward_train(dyn: EGNN_dynamics_QM9, t, xh, node_mask, edge_mask, 
         cols.append(tt.reshape(1, 1).expand(M, 1) if tt.numel() == 1 else tt[idx // N].unsqueeze(1))
     if dyn.context_node_nf > 0:
         cols.append(context.to(dev, torch.float32).reshape(B * N, dyn.context_node_nf)[idx])
-    h = F.linear(torch.cat(cols, dim=1), egnn.embedding.weight, egnn.embedding.bias)
+    h = _Linear.apply(torch.cat(cols, dim=1), egnn.embedding.weight, egnn.embedding.bias)
     x4 = F.pad(x_in, (0, 1))
     x04 = x4
     zero_wa = torch.zeros(H, device=dev)
+    nm1 = nm.reshape(-1).contiguous()
 
     def edge_layer(coord, lin0, lin2, wa, ba, xb):
         W1 = lin0.weight
-        AB = torch.cat([F.linear(h, W1[:, :H], lin0.bias), F.linear(h, W1[:, H:2 * H])], dim=1)
+        # [A | B] = h [W1a ; W1b]^T + [b1 | 0]: one GEMM over the stacked halves of the first edge Linear
+        AB = _Linear.apply(h, torch.cat([W1[:, :H], W1[:, H:2 * H]], dim=0), torch.cat([lin0.bias, zero_wa]))
         wrd = W1[:, 2 * H:2 * H + 2].t()
         return _EdgeLayer.apply(dyn, topo, tr, coord, AB, xb, x04, wrd, lin2.weight, lin2.bias, wa, ba)
 
@@ -193,12 +289,12 @@ def dynamics_forward_train(dyn: EGNN_dynamics_QM9, t, xh, node_mask, edge_mask, 
             else:
                 wa, ba = zero_wa, None
             agg = edge_layer(False, g.edge_mlp[0], g.edge_mlp[2], wa, ba, xb)
-            h = (h + g.node_mlp(torch.cat([h, agg], dim=1))) * nm
+            h = _NodeMLP.apply(h, agg, g.node_mlp[0].weight, g.node_mlp[0].bias, g.node_mlp[2].weight, g.node_mlp[2].bias, nm1)
         e = blk.gcl_equiv
         xagg = edge_layer(True, e.coord_mlp[0], e.coord_mlp[2], e.coord_mlp[4].weight.reshape(-1), None, xb)
         x4 = (xb + xagg) * nm
         h = h * nm
-    hout = F.linear(h, egnn.embedding_out.weight, egnn.embedding_out.bias) * nm
+    hout = _Linear.apply(h, egnn.embedding_out.weight, egnn.embedding_out.bias) * nm
     x_final = x4[:, :3]
     if mol_shape is not None:
         fixed = ((idx % N) >= int(mol_shape)).unsqueeze(1)

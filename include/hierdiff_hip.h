@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define HD_ABI_VERSION 4
+#define HD_ABI_VERSION 5
 
 #define HD_OK 0
 #define HD_E_INVALID (-1)      /* bad argument / unsupported configuration */
@@ -231,6 +231,20 @@ int hd_egcl_forward(hd_egcl* g, hd_egcl_graph* t, const float* h, const float* x
  * heads, Linear + SiLU + Linear [+ Sigmoid]).  One fmaf chain over k per output element. */
 int hd_linear(int device, const float* x, int M, int K, int ldx, const float* W, const float* b, int N, int act,
               float* y, int ldy, void* stream);
+
+/* General exact-fp32 GEMM of the training path (csrc/k_tgemm.hpp): C [M][ldc] = epi(sum_k A(m,k) B(k,n)) with
+ * A(m,k) = A[m a_m_stride + k a_k_stride], B(k,n) = B[k b_k_stride + n b_n_stride], one unit stride per operand - the
+ * node-level nn.Linear modules of the EGNN (egnn_new.py:17-33,76-89,172-173) under autograd: forward Y = X W^T + b,
+ * backward dX = dY W and dW = dY^T X (diffusion_qm9.py:774-777 -> torch.autograd), and the dense reduction over all edge rows
+ * dW2 = G2^T P of hd_edge_layer_backward.  epi: 0 C = acc + bias; 1 C = acc + bias, C2 = SiLU(C); 2 C = (aux + acc + bias) *
+ * row_mask[m] (row_mask may be NULL); 3 C = acc * SiLU'(aux).  bias [N] or NULL.  split_k > 1 (epi 0 only): K is cut into
+ * slabs whose partial results go to ws ([slabs][M][N] floats, + [slabs][M] when colsum is given) and are added in slab order
+ * (deterministic); colsum [M] then receives sum_k A(m,k) (the bias gradient of dW = dY^T X; A must be m-contiguous).  The
+ * slab count actually used is ceil(K / (32 * ceil(K / split_k / 32))) <= split_k. */
+int hd_gemm_f32(int device, int M, int N, int K, const float* A, long long a_m_stride, long long a_k_stride,
+                const float* B, long long b_k_stride, long long b_n_stride, float* C, int ldc, const float* bias,
+                int epi, const float* aux, const float* row_mask, float* C2, int split_k, float* ws,
+                float* colsum, void* stream);
 
 /* Host implementation of the library's normal generator (same bits as the device one up to libm
  * round-off); used by tests and by callers that want to reproduce a draw on the CPU. */

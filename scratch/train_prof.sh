@@ -16,7 +16,7 @@ f = glob.glob('/tmp/tr/**/p_kernel_stats.csv', recursive=True)
 rows = list(csv.DictReader(open(f[0])))
 tot = sum(float(r['TotalDurationNs']) for r in rows)
 print("total kernel time %.1f ms over the whole script (2 warm-up + 5 timed training steps + 5 no-grad forwards)" % (tot / 1e6))
-for r in rows[:22]:
+for r in rows[:30]:
     print(f"{r['Name'][:70]:70s} calls {int(r['Calls']):5d} avg {float(r['AverageNs'])/1e3:8.1f} us  {float(r['Percentage']):5.1f}%")
 PY
 } > gpurun_out/train_prof.log 2>&1
