@@ -66,6 +66,7 @@ SIGNATURES = {
     "hd_linear": (C.c_int, [C.c_int, _FP, C.c_int, C.c_int, C.c_int, _FP, _FP, C.c_int, C.c_int, _FP, C.c_int, _VP]),
     "hd_gemm_f32": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _FP, C.c_longlong, C.c_longlong, _FP, C.c_longlong, C.c_longlong,
                               _FP, C.c_int, _FP, C.c_int, _FP, _FP, _FP, C.c_int, _FP, _FP, _VP]),
+    "hd_colsum_f32": (C.c_int, [C.c_int, C.c_int, C.c_int, _VP, _VP, _VP, _FP, _VP]),
     "hd_philox_normal_host": (C.c_float, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]),
     "hd_profile_enable": (C.c_int, [_VP, C.c_int]),
     "hd_profile_read": (C.c_int, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),

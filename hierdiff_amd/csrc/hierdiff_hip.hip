@@ -1786,6 +1786,27 @@ extern "C" int hd_gemm_f32(int device, int M, int N, int K, const float* A, long
     return HD_OK;
 }
 
+extern "C" int hd_colsum_f32(int device, int rows, int n, const float* const* src, const int* width, float* const* dst,
+                             float* ws, void* stream) {
+    if (n < 1 || n > 4 || !src || !width || !dst || !ws) return fail(HD_E_INVALID, "hd_colsum_f32: 1..4 arrays, a workspace");
+    if (rows < 0) return fail(HD_E_INVALID, "hd_colsum_f32: rows < 0");
+    if (hd_device_count() <= device || device < 0) return fail(HD_E_HIP, "hd_colsum_f32: no such HIP device (is a GPU visible?)");
+    HIP_TRY(hipSetDevice(device));
+    ColSumArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.rows = rows; a.n = n; a.ws = ws;
+    for (int i = 0; i < n; ++i) {
+        if (!src[i] || !dst[i] || width[i] < 1) return fail(HD_E_INVALID, "hd_colsum_f32: null array / width < 1");
+        a.src[i] = src[i]; a.dst[i] = dst[i]; a.width[i] = width[i]; a.off[i + 1] = a.off[i] + width[i];
+    }
+    const int total = a.off[n];
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_colsum_stage1, dim3((total + 63) / 64, CS_CHUNKS), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_colsum_stage2, dim3((total + 255) / 256), dim3(256), 0, s, a);
+    HIP_TRY(hipGetLastError());
+    return HD_OK;
+}
+
 // ----------------------------------------------------------------------------- sampling maths
 
 static NoiseSrc make_noise(const float* raw_x, const float* raw_h, int rows, uint64_t seed, uint64_t base,

@@ -283,3 +283,45 @@ __global__ __launch_bounds__(256) void k_tgemm_reduce(TGemmReduceArgs g) {
         g.colsum[m] = s;
     }
 }
+
+// Column sums of up to four [rows][width] arrays in two launches (the per-tile partial sums hd_edge_layer_backward leaves behind:
+// db2, d(w_a), d(w_r) / d(w_d), d(b_a)): stage 1 sums CS_CHUNKS row ranges into ws [CS_CHUNKS][total width], stage 2 adds the
+// ranges in ascending order - deterministic.
+constexpr int CS_CHUNKS = 32;
+struct ColSumArgs {
+    const float* src[4];
+    float* dst[4];
+    int width[4], off[5];      // off[i] = first global column of array i; off[n] = total width
+    float* ws;
+    int rows, n;
+};
+
+__global__ __launch_bounds__(256) void k_colsum_stage1(ColSumArgs a) {
+    __shared__ float red[4][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    const int total = a.off[a.n];
+    const int per = (a.rows + CS_CHUNKS - 1) / CS_CHUNKS;
+    const int r0 = blockIdx.y * per, r1 = min(a.rows, r0 + per);
+    float s = 0.f;
+    if (col < total) {
+        int i = 0;
+        while (i + 1 < a.n && col >= a.off[i + 1]) ++i;
+        const float* p = a.src[i] + (col - a.off[i]);
+        const int w = a.width[i];
+        for (int r = r0 + rl; r < r1; r += 4) s += p[(size_t)r * w];
+    }
+    red[rl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rl == 0 && col < total) a.ws[(size_t)blockIdx.y * total + col] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void k_colsum_stage2(ColSumArgs a) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    const int total = a.off[a.n];
+    if (col >= total) return;
+    float s = 0.f;
+    for (int c = 0; c < CS_CHUNKS; ++c) s += a.ws[(size_t)c * total + col];
+    int i = 0;
+    while (i + 1 < a.n && col >= a.off[i + 1]) ++i;
+    a.dst[i][col - a.off[i]] = s;
+}

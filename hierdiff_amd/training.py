@@ -230,11 +230,20 @@ class _EdgeLayer(torch.autograd.Function):
             "hd_edge_layer_backward")
         # the one dense reduction over all edge rows: dL/dW2[c][k] = sum_e G2[e][c] P[e][k] (K = edge rows, split-K in slab order)
         dW2, _ = _linear_dw(ws["G2"], ws["P"], False, rows=tr.rows)                                           # [H, H]
-        # everything else left the kernels as per-tile partial sums
-        db2 = ws["b2part"].sum(0)
-        dwrd = ws["wrdpart"].sum(0)                            # [2, H]: sum_e {radial, d0}_e G1[e][:]
-        dwa = ws["colpart"].sum(0)
-        dba = ws["bapart"].sum().view(1) if has_ba else None
+        # everything else left the kernels as per-tile partial sums: one two-launch column sum over the four arrays
+        H = tr.H
+        red = torch.empty(4 * H + 1, device=dev, dtype=torch.float32)
+        db2, dwrd, dwa, dba = red[:H], red[H:3 * H].view(2, H), red[3 * H:4 * H], red[4 * H:]
+        srcs = [ws["b2part"], ws["wrdpart"], ws["colpart"]] + ([ws["bapart"]] if has_ba else [])
+        dsts = [db2, dwrd, dwa] + ([dba] if has_ba else [])
+        widths = [H, 2 * H, H] + ([1] if has_ba else [])
+        n = len(srcs)
+        csws = torch.empty(32 * sum(widths), device=dev, dtype=torch.float32)
+        _lib.check(lib.hd_colsum_f32(dev.index or 0, tr.tiles, n, (C.c_void_p * n)(*[t.data_ptr() for t in srcs]),
+                                     (C.c_int * n)(*widths), (C.c_void_p * n)(*[t.data_ptr() for t in dsts]),
+                                     csws.data_ptr(), _stream(dev)), "hd_colsum_f32")
+        if not has_ba:
+            dba = None
         return (None, None, None, None, dAB[:tr.M], dx[:tr.M], dx0[:tr.M], dwrd, dW2, db2, dwa, dba)
 
 

@@ -246,6 +246,13 @@ int hd_gemm_f32(int device, int M, int N, int K, const float* A, long long a_m_s
                 int epi, const float* aux, const float* row_mask, float* C2, int split_k, float* ws,
                 float* colsum, void* stream);
 
+/* Column sums of n <= 4 device arrays src[i] [rows][width[i]] into dst[i] [width[i]] in two launches, rows added in a fixed
+ * order (32 ascending row ranges, then the ranges ascending): the reductions hd_edge_layer_backward leaves to its caller
+ * (db2, d(wa), d(w_r) / d(w_d), d(ba) from the per-tile partial sums).  src / width / dst are HOST arrays of n entries;
+ * ws: 32 * sum(width) device floats. */
+int hd_colsum_f32(int device, int rows, int n, const float* const* src, const int* width, float* const* dst, float* ws,
+                  void* stream);
+
 /* Host implementation of the library's normal generator (same bits as the device one up to libm
  * round-off); used by tests and by callers that want to reproduce a draw on the CPU. */
 float hd_philox_normal_host(uint64_t seed, uint64_t sample_id, uint32_t draw, uint32_t index);

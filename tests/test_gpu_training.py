@@ -305,3 +305,28 @@ def test_training_step_launches_no_blas_library_kernel():
     assert any("k_tgemm" in n for n in names), names[:40]
     bad = [n for n in names if n.startswith("Cijk_") or "rocblas" in n.lower() or "hipblas" in n.lower()]
     assert not bad, bad
+
+
+def test_colsum_f32_matches_a_float64_column_sum_and_is_deterministic():
+    """hd_colsum_f32 (the per-tile partial sums of hd_edge_layer_backward -> db2, d(w_r)/d(w_d), d(wa), d(ba)): up to four arrays of
+    different widths in one call, against float64 column sums; same bits on every call; ragged row counts."""
+    import ctypes as C
+    from hierdiff_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(9)
+    for rows in (1, 31, 6976):
+        arrs = [torch.randn(rows, w, generator=g).to(DEV) for w in (256, 512, 256, 1)]
+        for n in (4, 3, 1):
+            outs = []
+            for rep in range(2):
+                dst = [torch.full((a.shape[1],), float("nan"), device=DEV) for a in arrs[:n]]
+                ws = torch.empty(32 * sum(a.shape[1] for a in arrs[:n]), device=DEV)
+                _lib.check(lib.hd_colsum_f32(0, rows, n, (C.c_void_p * n)(*[a.data_ptr() for a in arrs[:n]]),
+                                             (C.c_int * n)(*[a.shape[1] for a in arrs[:n]]),
+                                             (C.c_void_p * n)(*[d.data_ptr() for d in dst]), ws.data_ptr(), 0), "hd_colsum_f32")
+                torch.cuda.synchronize()
+                outs.append(dst)
+            for a, d0, d1 in zip(arrs[:n], outs[0], outs[1]):
+                ref = a.double().sum(0)
+                assert float((d0.double() - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max())) * max(1, rows) ** 0.5
+                assert torch.equal(d0, d1)
