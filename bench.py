@@ -348,14 +348,27 @@ def other_configs(args, dev) -> dict:
             m6.merge_batches = merge
             torch.manual_seed(2022)
             return m6.sample_batches(2, 16, dev)
-        dt_job = timeit(lambda: job(256))
+        dt_job = timeit(lambda: job(4096))
         blk["shipped_job_16_batches_of_2_L6"] = {"s_per_job": round(dt_job, 4), "molecules_per_s": round(32 / dt_job, 2), "timesteps": 1000,
                                                  "how": "one device batch of 32 (merge_batches)"}
         if prec == "fp32":
             dt_loop = timeit(lambda: job(0))
             blk["shipped_job_16_batches_of_2_L6"].update(s_per_job_as_16_device_batches=round(dt_loop, 4),
                                                          speedup_from_merging=round(dt_loop / dt_job, 2))
-        m6.merge_batches = 256
+        m6.merge_batches = 4096
+        # a GEOM-sized job of several batches (config 3's sizes: 4 batches of 256): merged into one device batch (up to
+        # DiffusionQM9.merge_edges = 900,000 edges, four headline batches) the edge kernel runs at its full tile rate
+        def geom_job(merge):
+            m6.merge_batches = merge
+            torch.manual_seed(2022)
+            return m6.sample_batches(256, 4, dev)
+        dt_g = timeit(lambda: geom_job(4096))
+        blk["geom_job_4_batches_of_256_L6"] = {"s_per_job": round(dt_g, 4), "molecules_per_s": round(1024 / dt_g, 2), "timesteps": 1000,
+                                               "how": "merged device batches (merge_batches / merge_edges)"}
+        if prec == "fp32":
+            dt_gl = timeit(lambda: geom_job(0))
+            blk["geom_job_4_batches_of_256_L6"].update(s_per_job_as_4_device_batches=round(dt_gl, 4), speedup_from_merging=round(dt_gl / dt_g, 2))
+        m6.merge_batches = 4096
         blk["headline_L9_B256_N30"] = short(256, timeit(lambda: m9s.sample_from_masks(nm256, None, None), reps=2), Ts)
         # opt-in: the same batch as two halves on two HIP streams (hierdiff_amd.TwoStreamSampler, bit-identical results)
         two = TwoStreamSampler(m6s)

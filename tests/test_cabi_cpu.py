@@ -278,3 +278,16 @@ def test_sample_batches_merges_consecutive_batches_host_side():
     m.sample_batches(3, 5, "cpu", sample_id_base=100)
     assert [c[0] for c in calls] == [loop_sizes[0:6], loop_sizes[6:12], loop_sizes[12:15]]
     assert [c[2] for c in calls] == [100, 106, 112] and all(c[1] is None for c in calls)
+    calls.clear()
+    m.merge_batches = 2048                                # the edge limit cuts instead: whole batches, greedily
+    per_batch = [sum(n * (n - 1) for n in loop_sizes[3 * i:3 * i + 3]) for i in range(5)]
+    m.merge_edges = per_batch[0] + per_batch[1] + 1
+    torch.manual_seed(7)
+    m.sample_batches(3, 5, "cpu", sample_id_base=0)
+    got = [len(c[0]) // 3 for c in calls]
+    assert sum(got) == 5 and got[0] >= 2
+    lo = 0
+    for nb in got:                                        # every device batch is within the limit unless it is a single batch
+        e = sum(per_batch[lo:lo + nb])
+        assert nb == 1 or e <= m.merge_edges
+        lo += nb

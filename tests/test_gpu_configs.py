@@ -547,18 +547,19 @@ def test_merged_sample_batches_equal_the_loop(precision):
     """`sample_batches(batch_size=2, num_batches=16)` is the reference's shipped job (conf/sample/default.yaml:1-2,
     diffusion_qm9.py:397-436: 16 calls of sample(2)).  Here the 32 molecules run as one device batch (`merge_batches`);
     every molecule equals, bit for bit, what the reference's loop order produces (`merge_batches = 0`): sizes drawn batch
-    by batch from the same generator state, global sample ids, a context value per batch.  Also with a merge limit that
-    cuts the job into device batches of 6 and with a width that takes the column-split small-batch kernels."""
+    by batch from the same generator state, global sample ids, a context value per batch.  Also with merge limits (molecules, edges) that
+    cut the job into several device batches and with a width that takes the column-split small-batch kernels."""
     H, L, T = 128, 2, 15
     for ctx_nf, ctx_range in ((0, None), (1, [-0.4, 1.5, 4.9])):
         m = build_diffusion(_syn(H, L, C_=ctx_nf, seed=91, gain=0.02), H, L, C_=ctx_nf, T=T, precision=precision).eval()
         outs = []
-        for merge in (0, 256, 6):
-            m.merge_batches = merge
+        for merge, edges in ((0, 225_000), (256, 225_000), (6, 225_000), (2048, 700)):
+            m.merge_batches, m.merge_edges = merge, edges
             torch.manual_seed(1234)                                   # the node-count draws of nodes_dist
             res, names = m.sample_batches(2, 16, DEV, context_range=ctx_range, sample_id_base=500)
             assert len(res) == 32 and names == []
             outs.append(res)
+        assert len(outs) == 4
         for other in outs[1:]:
             for a, b in zip(outs[0], other):
                 assert a["x"].shape == b["x"].shape and torch.isfinite(a["x"]).all()
