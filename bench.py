@@ -164,7 +164,7 @@ def timed_headline(model, precision, args, dev, rank, world, dist):
     if dist is not None:
         dist.barrier()
     if use_events:
-        _lib.check(lib.hd_profile_enable(handle, 1 | (max(1, args.event_stride) << 8)), "hd_profile_enable")
+        _lib.check(lib.hd_profile_enable(handle, 3 | (max(1, args.event_stride) << 8)), "hd_profile_enable")
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for k in range(args.steps):
@@ -223,6 +223,24 @@ def timed_headline(model, precision, args, dev, rank, world, dist):
                 roofline["vs_fp32_mfma_peak"] = round(achieved / MFMA_PEAK_TFLOPS["fp32"], 4)
                 roofline["note"] = (f"contraction on {m} bf16 MFMAs per product ({precision}); achieved counts algorithmic "
                                     "flops, executed_* the issued MFMA flops; vs_fp32_mfma_peak = achieved / 157.3")
+        if cnt[1] > 0:
+            # the node side (family 1: the fused k_node_f32 / k_node launches, or k_gemm_r16 below HD_FUSE_MIN_ROWS): algorithmic
+            # flops of all node-level Linears of a forward (f_n = S 6H^2 + (S+1) 4H^2 per node and block)
+            # over the launches that carry them
+            node_s = ms[1] / cnt[1] * 1e-3
+            launches_per_fwd = cnt[1] / max(1, cnt[0]) * (L * (S + 1))
+            node_fl = L * info["nodes"] * (S * 6.0 * H * H + (S + 1) * 4.0 * H * H) / max(1.0, launches_per_fwd)
+            peak = MFMA_PEAK_TFLOPS[precision]
+            m = MFMAS_PER_PRODUCT[precision]
+            if roofline is not None:
+                roofline["node_kernel"] = {"kernel": "k_node_f32" if precision == "fp32" else f"k_node ({precision})",
+                                           "achieved": round(node_fl / node_s / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
+                                           "frac": round(node_fl / node_s / 1e12 / peak, 4),
+                                           "executed_frac": round(m * node_fl / node_s / 1e12 / peak, 4),
+                                           "avg_launch_us": round(node_s * 1e6, 2), "launches": int(cnt[1]),
+                                           "launches_per_forward": round(launches_per_fwd, 2),
+                                           "flops_per_launch_avg": node_fl,
+                                           "share_of_forward": round(ms[1] / max(1e-9, ms[0] + ms[1] + ms[2]), 4)}
     n_fwd = T + 1
     mols = world * B * args.steps
     fwd_fl = forward_flops(info["edges"], info["nodes"], H, L, S, 9)
