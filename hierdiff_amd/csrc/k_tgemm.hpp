@@ -75,31 +75,28 @@ __global__ __launch_bounds__(256, 2) void k_tgemm(TGemmArgs g) {
         }
         return v;
     };
-    // ---- global -> registers: A two float4 per thread and chunk, B four
-    auto load_chunk = [&](int c, f32x4 (&ra)[2], f32x4 (&rb)[4]) {
+    // ---- one 16-byte piece of a chunk (pieces 0, 1: the A tile; 2 .. 5: the B tile), global -> registers
+    auto load_piece = [&](int c, int u, f32x4& r) {
         const int k0 = kbeg + c * TG_BK;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        if (u < 2) {
             const int idx = tid + 256 * u;
-            if constexpr (!FAST) ra[u] = z4;
+            if constexpr (!FAST) r = z4;
             if constexpr (A_KC) {
                 const int m = m0 + (idx >> 3), k = k0 + 4 * (idx & 7);
-                if (FAST || (m < g.M && k < kend)) ra[u] = ld4(g.A, g.sam, m, k, kend, g.avec);
+                if (FAST || (m < g.M && k < kend)) r = ld4(g.A, g.sam, m, k, kend, g.avec);
             } else {
                 const int k = k0 + (idx >> 4), m = m0 + 4 * (idx & 15);
-                if (FAST || (k < kend && m < g.M)) ra[u] = ld4(g.A, g.sak, k, m, g.M, g.avec);
+                if (FAST || (k < kend && m < g.M)) r = ld4(g.A, g.sak, k, m, g.M, g.avec);
             }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int idx = tid + 256 * u;
-            if constexpr (!FAST) rb[u] = z4;
+        } else {
+            const int idx = tid + 256 * (u - 2);
+            if constexpr (!FAST) r = z4;
             if constexpr (B_KC) {
                 const int nn = n0 + (idx >> 3), k = k0 + 4 * (idx & 7);
-                if (FAST || (nn < g.N && k < kend)) rb[u] = ld4(g.B, g.sbn, nn, k, kend, g.bvec);
+                if (FAST || (nn < g.N && k < kend)) r = ld4(g.B, g.sbn, nn, k, kend, g.bvec);
             } else {
                 const int k = k0 + (idx >> 5), nn = n0 + 4 * (idx & 31);
-                if (FAST || (k < kend && nn < g.N)) rb[u] = ld4(g.B, g.sbk, k, nn, g.N, g.bvec);
+                if (FAST || (k < kend && nn < g.N)) r = ld4(g.B, g.sbk, k, nn, g.N, g.bvec);
             }
         }
     };
@@ -108,34 +105,31 @@ __global__ __launch_bounds__(256, 2) void k_tgemm(TGemmArgs g) {
     // lanes that share a k then hit 16 different banks (16 (row/4 & 3) + 4 (quad ^ sw)) instead of four, and the
     // ds_read_b128 of 16 consecutive rows stay conflict-free (sw is constant over them).
     auto sw = [](int row) { return (row >> 4) & 3; };
-    auto store_chunk = [&](int buf, const f32x4 (&ra)[2], const f32x4 (&rb)[4]) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
+    auto store_piece = [&](int buf, int u, const f32x4& v) {
+        if (u < 2) {
             const int idx = tid + 256 * u;
             if constexpr (A_KC) {
                 const int row = idx >> 3;
-                *reinterpret_cast<f32x4*>(&As[buf][row * LDK + 4 * ((idx & 7) ^ sw(row))]) = ra[u];
+                *reinterpret_cast<f32x4*>(&As[buf][row * LDK + 4 * ((idx & 7) ^ sw(row))]) = v;
             } else {
                 const int k = idx >> 4;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int row = 4 * (idx & 15) + j;
-                    As[buf][row * LDK + 4 * ((k >> 2) ^ sw(row)) + (k & 3)] = ra[u][j];
+                    As[buf][row * LDK + 4 * ((k >> 2) ^ sw(row)) + (k & 3)] = v[j];
                 }
             }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int idx = tid + 256 * u;
+        } else {
+            const int idx = tid + 256 * (u - 2);
             if constexpr (B_KC) {
                 const int row = idx >> 3;
-                *reinterpret_cast<f32x4*>(&Bs[buf][row * LDK + 4 * ((idx & 7) ^ sw(row))]) = rb[u];
+                *reinterpret_cast<f32x4*>(&Bs[buf][row * LDK + 4 * ((idx & 7) ^ sw(row))]) = v;
             } else {
                 const int k = idx >> 5;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int row = 4 * (idx & 31) + j;
-                    Bs[buf][row * LDK + 4 * ((k >> 2) ^ sw(row)) + (k & 3)] = rb[u][j];
+                    Bs[buf][row * LDK + 4 * ((k >> 2) ^ sw(row)) + (k & 3)] = v[j];
                 }
             }
         }
@@ -145,84 +139,69 @@ __global__ __launch_bounds__(256, 2) void k_tgemm(TGemmArgs g) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
     // lane (row n, half hh) feeds k = 16 hh + 4 q + j to instruction (q, j) of a chunk - the same map for both operands.
-    // The twelve fragments of chunk c+1 are requested BEFORE the MFMAs of chunk c (two fragment sets): left alone hipcc sinks
-    // every LDS read next to the MFMA that uses it and exposes the LDS latency sixteen times per chunk, and with the reads
-    // behind the barrier instead all eight wavefronts of a CU queue at the LDS at once (MFMA-busy 0.51 measured; 0.62 in this
-    // form, dW2 = G2^T P at 88 TFLOP/s).  Giving the two co-resident workgroups different issue priorities (s_setprio by
-    // wavefront-slot parity) changed nothing.
-    struct Frag { f32x4 a[4], b0[4], b1[4]; };
+    // A chunk's twelve fragments: piece r = 3 q + {0: A, 1: B columns 0-31, 2: B columns 32-63 of the wavefront's 64}.
+    struct Frag { f32x4 v[12]; };
     const int arow = 32 * wr + n, brow = 64 * wc + n;
-    auto read_frags = [&](int buf, Frag& f) {
-        const float* ap = &As[buf][arow * LDK];
-        const float* bp = &Bs[buf][brow * LDK];
-        const float* bq = bp + 32 * LDK;
-        const int sa = sw(arow), sb0 = sw(brow), sb1 = sw(brow + 32);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            f.a[q] = *reinterpret_cast<const f32x4*>(ap + 4 * ((4 * hh + q) ^ sa));
-            f.b0[q] = *reinterpret_cast<const f32x4*>(bp + 4 * ((4 * hh + q) ^ sb0));
-            f.b1[q] = *reinterpret_cast<const f32x4*>(bq + 4 * ((4 * hh + q) ^ sb1));
-        }
-    };
-    auto mfmas = [&](const Frag& f) {
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[q][j], f.b0[q][j], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[q][j], f.b1[q][j], acc1, 0, 0, 0);
-            }
-        __builtin_amdgcn_sched_barrier(0);
+    auto read_frag = [&](int buf, int r, f32x4& dst) {
+        const int q = r / 3, w = r % 3;
+        const int row = w == 0 ? arow : (w == 1 ? brow : brow + 32);
+        const float* base = w == 0 ? &As[buf][row * LDK] : &Bs[buf][row * LDK];
+        dst = *reinterpret_cast<const f32x4*>(base + 4 * ((4 * hh + q) ^ sw(row)));
     };
     f32x4 csum = z4;                                        // colsum_ws: this thread's share of sum_k A(m, k) (A m-contiguous)
     const bool do_colsum = !A_KC && g.colsum_ws != nullptr && blockIdx.y == 0;
 
-    // Pipeline, one barrier per chunk, everything of period two (LDS buffers, fragment sets, global staging sets), so the
-    // loop is unrolled by two.  Step c:  store chunk c+1 (global data requested two steps ago) into buffer (c+1)&1 - last
-    // read for the fragments of chunk c-1, which every wavefront holds in registers since before its MFMAs of step c-1 -
-    // barrier, request the fragments of chunk c+1, request the global data of chunk c+3, then the 32 MFMAs of chunk c on
-    // the fragment set filled during step c-1.  No load sits behind a branch (a chunk index past the slab re-reads the last
-    // chunk and is never stored); the branches around LDS stores / fragment reads contain no global loads.
-    f32x4 ga0[2], gb0[4], ga1[2], gb1[4];
-    Frag f0, f1;
+    // Pipeline: one barrier per chunk; LDS buffers, fragment sets and global staging sets all of period two (the loop is
+    // unrolled by two).  Step c issues, BETWEEN the 32 MFMAs of chunk c (fragment set c&1, filled during step c-1):
+    //   the six global loads of chunk c+3 (staging set (c+1)&1, whose chunk c+1 went to LDS during step c-1),
+    //   the twelve fragment reads of chunk c+1 from buffer (c+1)&1 (stored during step c-1, published by the barrier),
+    //   the six LDS stores of chunk c+2 (staging set c&1, requested during step c-1) into buffer c&1 - last read for the
+    //   fragments of chunk c, which every wavefront holds in registers since before the barrier that ended step c-1.
+    // Every memory instruction is issued in the 64-cycle shadow of an MFMA (a sched_barrier after each pair pins the order:
+    // left alone hipcc sinks the LDS reads next to their uses - i.e. behind the barrier, where all eight wavefronts of the CU
+    // then queue at the LDS with the matrix pipe idle: MFMA-busy 0.51 - and hoists the stores in front of the MFMAs: 0.62).
+    // No load sits behind a branch: chunk indices past the slab are clamped (they re-read / re-store the last chunk, whose
+    // copy is never used).
+    f32x4 gs[2][6];
+    Frag fr[2];
     const int last = max(nchunk - 1, 0);
-    if (nchunk > 0) {
-        load_chunk(0, ga0, gb0);
-        load_chunk(min(1, last), ga1, gb1);
-        store_chunk(0, ga0, gb0);
-        if (do_colsum) csum += ga0[0] + ga0[1];
+    auto step = [&](auto Par, int c) {
+        constexpr int P = decltype(Par)::value;             // parity of c
+        const int cl = min(c + 3, last);
+        static_for<0, 32>([&](auto Ic) {
+            constexpr int i = decltype(Ic)::value;
+            constexpr int q = i / 8, j = (i / 2) % 4;
+            if constexpr ((i & 1) == 0) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fr[P].v[3 * q][j], fr[P].v[3 * q + 1][j], acc0, 0, 0, 0);
+            else acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fr[P].v[3 * q][j], fr[P].v[3 * q + 2][j], acc1, 0, 0, 0);
+            if constexpr (i < 6) load_piece(cl, i, gs[P ^ 1][i]);
+            else if constexpr (i < 18) read_frag(P ^ 1, i - 6, fr[P ^ 1].v[i - 6]);
+            else if constexpr (i >= 20 && i < 26) store_piece(P, i - 20, gs[P][i - 20]);
+            if constexpr (i < 26) __builtin_amdgcn_sched_barrier(0);
+        });
+        if (do_colsum && c + 2 < nchunk) csum += gs[P][0] + gs[P][1];
         __syncthreads();
-        read_frags(0, f0);
-        load_chunk(min(2, last), ga0, gb0);
+    };
+    if (nchunk > 0) {
+        // chunks 0 and 1 to LDS, chunk 2 requested, fragments of chunk 0 in registers
+        static_for<0, 6>([&](auto Uc) { load_piece(0, decltype(Uc)::value, gs[0][decltype(Uc)::value]); });
+        static_for<0, 6>([&](auto Uc) { load_piece(min(1, last), decltype(Uc)::value, gs[1][decltype(Uc)::value]); });
+        static_for<0, 6>([&](auto Uc) { store_piece(0, decltype(Uc)::value, gs[0][decltype(Uc)::value]); });
+        if (do_colsum) csum += gs[0][0] + gs[0][1];
+        static_for<0, 6>([&](auto Uc) { store_piece(1, decltype(Uc)::value, gs[1][decltype(Uc)::value]); });
+        if (do_colsum && 1 < nchunk) csum += gs[1][0] + gs[1][1];
+        static_for<0, 6>([&](auto Uc) { load_piece(min(2, last), decltype(Uc)::value, gs[0][decltype(Uc)::value]); });
+        __syncthreads();
+        static_for<0, 12>([&](auto Rc) { read_frag(0, decltype(Rc)::value, fr[0].v[decltype(Rc)::value]); });
+        __syncthreads();                                    // everybody holds its fragments of chunk 0: step 0 may overwrite buffer 0
     }
     for (int c = 0; c < nchunk; c += 2) {
-        // fragments f0 = chunk c; staging set 1 = chunk c+1; set 0 = chunk c+2 (in flight)
-        const bool more1 = c + 1 < nchunk;
-        if (more1) {
-            store_chunk(1, ga1, gb1);
-            if (do_colsum) csum += ga1[0] + ga1[1];
-        }
-        __syncthreads();
-        if (more1) read_frags(1, f1);
-        load_chunk(min(c + 3, last), ga1, gb1);
-        mfmas(f0);
-        if (!more1) break;
-        // fragments f1 = chunk c+1; set 0 = chunk c+2; set 1 = chunk c+3 (in flight)
-        const bool more2 = c + 2 < nchunk;
-        if (more2) {
-            store_chunk(0, ga0, gb0);
-            if (do_colsum) csum += ga0[0] + ga0[1];
-        }
-        __syncthreads();
-        if (more2) read_frags(0, f0);
-        load_chunk(min(c + 4, last), ga0, gb0);
-        mfmas(f1);
+        step(std::integral_constant<int, 0>{}, c);
+        if (c + 1 >= nchunk) break;
+        step(std::integral_constant<int, 1>{}, c + 1);
     }
 
     if (do_colsum) {                                        // sum over the 16 thread rows of the loader grid, in row order
-        __syncthreads();                                    // every wavefront is out of the chunk loop
-        float* red = &Bs[0][0];                             // [16][64]
+        float* red = &Bs[0][0];                             // [16][64]; the chunk loop ended with a barrier
         *reinterpret_cast<f32x4*>(red + (tid >> 4) * 64 + 4 * (tid & 15)) = csum;
         __syncthreads();
         if (tid < 64 && m0 + tid < g.M) {
