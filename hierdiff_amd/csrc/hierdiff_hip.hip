@@ -1765,7 +1765,12 @@ extern "C" int hd_gemm_f32(int device, int M, int N, int K, const float* A, long
     auto aligned = [](const float* p, long long ld) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && (ld & 3) == 0; };
     g.avec = aligned(A, a_kc ? a_m_stride : a_k_stride) ? 1 : 0;
     g.bvec = aligned(B, b_kc ? b_n_stride : b_k_stride) ? 1 : 0;
-    const dim3 grid((M + TG_BM - 1) / TG_BM, (N + TG_BN - 1) / TG_BN, split_k), block(256);
+    dim3 grid((M + TG_BM - 1) / TG_BM, (N + TG_BN - 1) / TG_BN, split_k);
+    const dim3 block(256);
+    if (splitting) {                                   // 1-D, XCD-aware: the tiles of a slab share an XCD's L2 (k_tgemm.hpp)
+        g.nx = grid.x; g.ny = grid.y; g.nz = split_k;
+        grid = dim3(g.nx * g.ny * 8 * ((split_k + 7) / 8));
+    }
     // FAST: full tiles, whole K chunks per slab, 16-byte aligned rows - no bounds checks, no branches around the loads
     const bool fast = g.avec && g.bvec && M % TG_BM == 0 && N % TG_BN == 0 && K % TG_BK == 0 && K > 0;
     auto launch = [&](auto Fast) {

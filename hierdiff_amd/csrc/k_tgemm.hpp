@@ -35,6 +35,7 @@ struct TGemmArgs {
     float* colsum_ws;       // non-null: [z][M] partial sums over k of A(m, k) (written by the n-tile-0 workgroups)
     long long sam, sak, sbk, sbn;
     int M, N, K, ldc, kslab, epi, avec, bvec;
+    int nx, ny, nz;         // nz > 0: 1-D XCD-aware launch of nx x ny tiles x nz slabs (split-K)
 };
 
 constexpr int TG_BM = 64, TG_BN = 128, TG_BK = 32;
@@ -58,8 +59,18 @@ __global__ __launch_bounds__(256, 2) void k_tgemm(TGemmArgs g) {
     __shared__ __attribute__((aligned(16))) float Bs[2][TG_BN * LDK];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1, hh = lane >> 5, n = lane & 31;
-    const int m0 = blockIdx.x * TG_BM, n0 = blockIdx.y * TG_BN;
-    const int kbeg = blockIdx.z * g.kslab, kend = min(g.K, kbeg + g.kslab);
+    // Split-K launches are 1-D and XCD-aware (workgroup id % 8 = XCD): the tiles of one K slab - which read the same rows of
+    // both operands - run on ONE XCD and share its L2 (a plain 3-D grid deals the eight 64 x 128 tiles of a 256 x 256 result
+    // to eight different XCDs: every slab is then fetched from HBM / Infinity Cache up to four times).
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (g.nz > 0) {
+        const int id = blockIdx.x, xcd = id & 7, j = id >> 3, tiles = g.nx * g.ny, t = j % tiles;
+        bz = (j / tiles) * 8 + xcd;
+        if (bz >= g.nz) return;
+        bx = t % g.nx; by = t / g.nx;
+    }
+    const int m0 = bx * TG_BM, n0 = by * TG_BN;
+    const int kbeg = bz * g.kslab, kend = min(g.K, kbeg + g.kslab);
     const int nchunk = (kend - kbeg + TG_BK - 1) / TG_BK;
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
 
@@ -149,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void k_tgemm(TGemmArgs g) {
         dst = *reinterpret_cast<const f32x4*>(base + 4 * ((4 * hh + q) ^ sw(row)));
     };
     f32x4 csum = z4;                                        // colsum_ws: this thread's share of sum_k A(m, k) (A m-contiguous)
-    const bool do_colsum = !A_KC && g.colsum_ws != nullptr && blockIdx.y == 0;
+    const bool do_colsum = !A_KC && g.colsum_ws != nullptr && by == 0;
 
     // Pipeline: one barrier per chunk; LDS buffers, fragment sets and global staging sets all of period two (the loop is
     // unrolled by two).  Step c issues, BETWEEN the 32 MFMAs of chunk c (fragment set c&1, filled during step c-1):
@@ -208,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void k_tgemm(TGemmArgs g) {
             float s = 0.f;
 #pragma unroll
             for (int k = 0; k < 16; ++k) s += red[k * 64 + tid];
-            g.colsum_ws[(size_t)blockIdx.z * g.M + m0 + tid] = s;
+            g.colsum_ws[(size_t)bz * g.M + m0 + tid] = s;
         }
     }
 
@@ -224,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void k_tgemm(TGemmArgs g) {
             const int row = m0 + 32 * wr + (r & 3) + 8 * (r >> 2) + 4 * hh;
             if (row >= g.M) continue;
             float v = (cn == 0 ? acc0[r] : acc1[r]);
-            if (split) { g.ws[((size_t)blockIdx.z * g.M + row) * g.N + col] = v; continue; }
+            if (split) { g.ws[((size_t)bz * g.M + row) * g.N + col] = v; continue; }
             v += bias;
             const size_t o = (size_t)row * g.ldc + col;
             if (g.epi == TG_EPI_BIAS_SILU2) { g.C[o] = v; g.C2[o] = silu_f(v); }
