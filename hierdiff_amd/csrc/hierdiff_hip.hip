@@ -960,6 +960,14 @@ extern "C" int hd_debug_edge_trace(hd_handle* h, long long* out, int max_wg) {
     return n;
 }
 
+// stamps of the last k_node_f32 launch: [workgroup < 512][8 waves][HD_NTRACE_STAMPS] (scratch/node_trace.py)
+extern "C" int hd_debug_node_trace(long long* out, int max_ll) {
+    hipDeviceSynchronize();
+    const int n = std::min(max_ll, 512 * 8 * HD_NTRACE_STAMPS);
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(hd_ntrace), sizeof(long long) * n) != hipSuccess) return 0;
+    return n;
+}
+
 template <int PREC>
 static bool launch_edge_ablated(hd_handle* h, const EdgeArgs& a, hipStream_t s) {
     const int lds = edge_lds_bytes<256>(PREC == 2);

@@ -371,6 +371,17 @@ __global__ __launch_bounds__(64 * NW, 1) void k_node(NodeArgs a) {
     const u32x4* W4l = reinterpret_cast<const u32x4*>(a.W4img) + lane;
     const u32x4* AB0l = reinterpret_cast<const u32x4*>(a.ABimg[0]) + lane;
     if constexpr (UPD) M1::prefetch(br1, W3l, ct0, 0);
+    // biases of every phase, requested at kernel entry (a load at its point of use is an exposed L2 round trip per phase)
+    float b3v[CT], b4v[CT], abv[NAB][2 * CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        b3v[c] = UPD ? a.b3[32 * (ct0 + c) + n] : 0.f;
+        b4v[c] = UPD ? a.b4[32 * (ct0 + c) + n] : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < NAB; ++q)
+#pragma unroll
+        for (int c = 0; c < 2 * CT; ++c) abv[q][c] = a.ABbias[q][(c / CT) * H + 32 * (ct0 + c % CT) + n];
 
     // ---- phase 0: X -> LDS (bf16 head/tail).  NT/32 threads per row, each moving every (NT/32)-th float4 of
     // the row, so a thread needs one pstart pair and all its loads are independent of each other.
@@ -431,7 +442,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_node(NodeArgs a) {
             f32x16 acc[CT];
 #pragma unroll
             for (int c = 0; c < CT; ++c) {
-                const float b = a.b3[32 * (ct0 + c) + n];
+                const float b = b3v[c];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[c][r] = b;
             }
@@ -458,7 +469,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_node(NodeArgs a) {
             for (int r = 0; r < 16; ++r) mk[r] = a.nmask[row0 + (r & 3) + 8 * (r >> 2) + 4 * hh];
 #pragma unroll
             for (int c = 0; c < CT; ++c) {
-                const float b = a.b4[32 * (ct0 + c) + n];
+                const float b = b4v[c];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     acc[c][r] = b;
@@ -497,7 +508,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_node(NodeArgs a) {
         f32x16 acc[2 * CT];
 #pragma unroll
         for (int c = 0; c < 2 * CT; ++c) {
-            const float b = a.ABbias[q][(c / CT) * H + 32 * (ct0 + c % CT) + n];
+            const float b = abv[q][c];
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[c][r] = b;
         }
@@ -529,6 +540,19 @@ __global__ __launch_bounds__(64 * NW, 1) void k_node(NodeArgs a) {
         }
     }
 }
+
+// Measurement build only: per-wave cycle stamps of the LAST k_node_f32 launch (hd_debug_node_trace, scratch/node_trace.py).
+#ifdef HD_DEBUG_KERNELS
+#define HD_NTRACE_STAMPS 12
+__device__ long long hd_ntrace[512 * 8 * HD_NTRACE_STAMPS];
+#define HD_NSTAMP(k)                                                                                                   \
+    do {                                                                                                               \
+        const long long ts_ = __builtin_readcyclecounter();                                                            \
+        if (lane == 0 && blockIdx.x < 512) hd_ntrace[((size_t)blockIdx.x * 8 + wave) * HD_NTRACE_STAMPS + (k)] = ts_;    \
+    } while (0)
+#else
+#define HD_NSTAMP(k) do { } while (0)
+#endif
 
 // ----------------------------------------------------------------------------- fused node update, exact fp32
 // The same launch structure as k_node (one launch per node update: neighbour-sum reduction, node MLP, residual, the next
@@ -617,6 +641,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_node_f32(NodeArgs a) {
         rt = start + idx;
     }
     const int row0 = rt * 32;
+    HD_NSTAMP(0);
 
     typedef NodeMmaF<KX / 32, CT, CT, PF12, NCT> M1;            // X W3^T      (UPD only)
     typedef NodeMmaF<H / 32, CT, CT, PF12, NCT> M2;             // T W4^T      (UPD only)
@@ -629,6 +654,17 @@ __global__ __launch_bounds__(64 * NW, 1) void k_node_f32(NodeArgs a) {
     const u32x4* W4l = reinterpret_cast<const u32x4*>(a.W4img) + lane;
     const u32x4* AB0l = reinterpret_cast<const u32x4*>(a.ABimg[0]) + lane;
     if constexpr (UPD) M1::prefetch(br1, W3l, ct0, 0);
+    // biases of every phase, requested at kernel entry (a load at its point of use is an exposed L2 round trip per phase)
+    float b3v[CT], b4v[CT], abv[NAB][2 * CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        b3v[c] = UPD ? a.b3[32 * (ct0 + c) + n] : 0.f;
+        b4v[c] = UPD ? a.b4[32 * (ct0 + c) + n] : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < NAB; ++q)
+#pragma unroll
+        for (int c = 0; c < 2 * CT; ++c) abv[q][c] = a.ABbias[q][(c / CT) * H + 32 * (ct0 + c % CT) + n];
 
     // ---- phase 0: X -> LDS.  NT/32 threads per row, each moving every (NT/32)-th float4 of the row.
     {
@@ -673,6 +709,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_node_f32(NodeArgs a) {
         }
     }
 
+    HD_NSTAMP(1);
     if constexpr (UPD) {
         // ---- phase 1: T = silu(X W3^T + b3)
         {
@@ -684,17 +721,20 @@ __global__ __launch_bounds__(64 * NW, 1) void k_node_f32(NodeArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
             __syncthreads();                                         // X complete
+            HD_NSTAMP(2);
             M2::prefetch(br2, W4l, ct0, 0);
             M1::run(acc, br1, X + n * LDX + 16 * hh, W3l, ct0, 0);
+            HD_NSTAMP(3);
 #pragma unroll
             for (int c = 0; c < CT; ++c) {
-                const float b = a.b3[32 * (ct0 + c) + n];
+                const float b = b3v[c];
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     T[((r & 3) + 8 * (r >> 2) + 4 * hh) * LDH + 32 * (ct0 + c) + n] = silu_f(acc[c][r] + b);
             }
         }
         __syncthreads();
+        HD_NSTAMP(4);
         // ---- phase 2: h' = (h + T W4^T + b4) * mask
         {
             f32x16 acc[CT];
@@ -710,10 +750,11 @@ __global__ __launch_bounds__(64 * NW, 1) void k_node_f32(NodeArgs a) {
                 }
             M3::prefetch(br3, AB0l, ct0, NCT);
             M2::run(acc, br2, T + n * LDH + 16 * hh, W4l, ct0, 0);
+            HD_NSTAMP(5);
             // every wave is done reading X once it is past its own M1::run AND the barrier above: h' may overwrite region 0
 #pragma unroll
             for (int c = 0; c < CT; ++c) {
-                const float b = a.b4[32 * (ct0 + c) + n];
+                const float b = b4v[c];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int R = (r & 3) + 8 * (r >> 2) + 4 * hh;
@@ -733,6 +774,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_node_f32(NodeArgs a) {
         }
     }
 
+    HD_NSTAMP(6);
     // ---- phase 3: AB_q = h' [W1a | W1b]^T + bias, two H-wide halves per wavefront, staged through region 1
 #pragma unroll
     for (int q = 0; q < NAB; ++q) {
@@ -747,12 +789,13 @@ __global__ __launch_bounds__(64 * NW, 1) void k_node_f32(NodeArgs a) {
             if (!UPD) __syncthreads();                               // h tile complete
         }
         M3::run(acc, br3, Nn + n * LDH + 16 * hh, ABl, ct0, NCT);
+        HD_NSTAMP(7 + 2 * q);
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             if (half || q) __syncthreads();                 // previous staging tile fully stored
 #pragma unroll
             for (int c = 0; c < CT; ++c) {
-                const float b = a.ABbias[q][half * H + 32 * (ct0 + c) + n];
+                const float b = abv[q][half * CT + c];
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     T[((r & 3) + 8 * (r >> 2) + 4 * hh) * LDH + 32 * (ct0 + c) + n] = acc[half * CT + c][r] + b;
@@ -767,5 +810,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_node_f32(NodeArgs a) {
                         *reinterpret_cast<const f32x4*>(T + r * LDH + 4 * c4);
             }
         }
+        HD_NSTAMP(8 + 2 * q);
     }
+    HD_NSTAMP(11);
 }
