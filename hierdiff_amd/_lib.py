@@ -20,7 +20,7 @@ class HdConfig(C.Structure):
         ("hidden_nf", C.c_int32), ("n_layers", C.c_int32), ("inv_sublayers", C.c_int32),
         ("attention", C.c_int32), ("tanh", C.c_int32), ("condition_time", C.c_int32),
         ("norm_constant", C.c_float), ("normalization_factor", C.c_float), ("coords_range", C.c_float),
-        ("precision", C.c_int32),
+        ("precision", C.c_int32), ("aggregation_mean", C.c_int32),
     ]
 
 
@@ -73,7 +73,7 @@ SIGNATURES = {
     "hd_debug_edge_trace": (C.c_int, [_VP, C.c_void_p, C.c_int]),
 }
 
-ABI_VERSION = 5          # HD_ABI_VERSION of include/hierdiff_hip.h
+ABI_VERSION = 6          # HD_ABI_VERSION of include/hierdiff_hip.h
 _lib: Optional[C.CDLL] = None
 
 

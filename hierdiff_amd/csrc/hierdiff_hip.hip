@@ -140,6 +140,12 @@ struct hd_topology {
 
 // ----------------------------------------------------------------------------- small helpers
 
+// divisor of the neighbour sums: normalization_factor ('sum'), or the number of edge-list entries per receiving node ('mean':
+// the reference's list holds all N x N pairs of a molecule, so every node counts the padded N; egnn_new.py:283-288)
+static inline float agg_norm(const hd_config& c, const hd_topology* t) {
+    return c.aggregation_mean ? (float)t->N : c.normalization_factor;
+}
+
 extern "C" int hd_version(void) { return HD_ABI_VERSION; }
 extern "C" const char* hd_last_error(void) { return g_err.c_str(); }
 
@@ -193,7 +199,7 @@ extern "C" int hd_create(const hd_config* cfg, int device, hd_handle** out) {
     if (F < 1) return fail(HD_E_INVALID, "hd_create: in_node_nf must leave at least one feature column");
     if (cfg->context_node_nf < 0) return fail(HD_E_INVALID, "hd_create: context_node_nf < 0");
     if (cfg->precision < 0 || cfg->precision > 2) return fail(HD_E_INVALID, "hd_create: precision must be 0 (fp32), 1 (bf16x3) or 2 (bf16x6)");
-    if (!(cfg->normalization_factor != 0.0f)) return fail(HD_E_INVALID, "hd_create: normalization_factor == 0");
+    if (!cfg->aggregation_mean && !(cfg->normalization_factor != 0.0f)) return fail(HD_E_INVALID, "hd_create: normalization_factor == 0");
     if (hd_device_count() <= device || device < 0)
         return fail(HD_E_HIP, "hd_create: no such HIP device (is a GPU visible?)");
     HIP_TRY(hipSetDevice(device));
@@ -1156,7 +1162,7 @@ static int forward_impl(hd_handle* h, hd_topology* t, const float* xh, const flo
             NodeArgs a;
             std::memset(&a, 0, sizeof(a));
             a.h_in = t->hbuf; a.h_out = t->hbuf; a.part = t->part; a.pstart = t->pstart; a.nmask = t->nmask;
-            a.norm = c.normalization_factor; a.M = M;
+            a.norm = agg_norm(c, t); a.M = M;
             return a;
         };
         auto set_ab = [&](NodeArgs& a, int q, const LayerW& nw, float* dst) {
@@ -1170,7 +1176,7 @@ static int forward_impl(hd_handle* h, hd_topology* t, const float* xh, const flo
         auto r16_args = [&]() {
             R16Args g;
             std::memset(&g, 0, sizeof(g));
-            g.A = t->hbuf; g.lda = H; g.K1 = H; g.K = H; g.M = M; g.n_img = 1; g.nmask = t->nmask; g.norm = c.normalization_factor;
+            g.A = t->hbuf; g.lda = H; g.K1 = H; g.K = H; g.M = M; g.n_img = 1; g.nmask = t->nmask; g.norm = agg_norm(c, t);
             return g;
         };
         auto ab_r16 = [&](int nab, const LayerW* const* nxt, float* const* dst) {       // AB_q = h [W1a | W1b]_q^T + [b1 | 0]
@@ -1234,7 +1240,7 @@ static int forward_impl(hd_handle* h, hd_topology* t, const float* xh, const flo
                     ProfScope ps(h, s, 2);
                     XupdArgs x;
                     x.part = t->xpart; x.pstart = t->pstart; x.nmask = t->nmask; x.xcur = t->xcur;
-                    x.norm = c.normalization_factor; x.M = M;
+                    x.norm = agg_norm(c, t); x.M = M;
                     hipLaunchKernelGGL(k_xupd, dim3((M + 255) / 256), dim3(256), 0, s, x);
                     ab_cur = t->AB2;                        // next block's first GCL (written with the last node update)
                 }
@@ -1355,7 +1361,7 @@ extern "C" int hd_edge_layer_forward(hd_handle* h, hd_topology* t, int coord, co
     e.use_tanh = c.tanh; e.n_tiles = t->n_tiles; e.n_wg = t->n_wg;
     HD_TRY(edge(h, coord != 0, e, s));
     AggArgs ag;
-    ag.part = coord ? t->xpart : t->part; ag.pstart = t->pstart; ag.agg = out; ag.norm = c.normalization_factor;
+    ag.part = coord ? t->xpart : t->part; ag.pstart = t->pstart; ag.agg = out; ag.norm = agg_norm(c, t);
     ag.M = M; ag.H = ow;
     const long long total = (long long)M * (ow / 4);
     hipLaunchKernelGGL(k_agg, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ag);
@@ -1400,7 +1406,7 @@ extern "C" int hd_edge_layer_backward(hd_handle* h, hd_topology* t, int coord, c
     std::memset(&a, 0, sizeof(a));
     a.AB = AB; a.wrd = wrd; a.b2 = b2; a.wa = wa; a.ei = t->ei; a.ej = t->ej; a.eseg = t->eseg; a.xcur = x; a.x0 = x0;
     a.ba_ptr = ba; a.norm_constant = c.norm_constant; a.coords_range = c.coords_range / (float)c.n_layers;
-    a.inv_norm = 1.0f / c.normalization_factor; a.attention = c.attention; a.use_tanh = c.tanh; a.n_tiles = t->n_tiles;
+    a.inv_norm = 1.0f / agg_norm(c, t); a.attention = c.attention; a.use_tanh = c.tanh; a.n_tiles = t->n_tiles;
     a.gin = gout; a.G2 = G2; a.escal = escal; a.colpart = colpart; a.bapart = bapart; a.Pout = P; a.G1 = G1;
     a.b2part = b2part; a.wrdpart = wrdpart;
     a.Wimg = t->w2img;

@@ -140,8 +140,8 @@ class EGNN_dynamics_QM9(nn.Module):
             raise NotImplementedError(f"mode {mode!r}: only 'egnn_dynamics' is on the sampling hot path")
         if sin_embedding:
             raise NotImplementedError("sin_embedding=True is config-off in the reference (ddpmgblur.yaml:35)")
-        if aggregation_method != 'sum':
-            raise NotImplementedError("aggregation_method must be 'sum' (ddpmgblur.yaml:37)")
+        if aggregation_method not in ('sum', 'mean'):
+            raise ValueError(f"aggregation_method {aggregation_method!r}: 'sum' or 'mean' (egnn_new.py:269-289)")
         if not (act_fn == "silu" or isinstance(act_fn, nn.SiLU)):
             raise NotImplementedError("act_fn must be 'silu'")
         if n_dims != 3:
@@ -160,7 +160,9 @@ class EGNN_dynamics_QM9(nn.Module):
                              attention=int(bool(attention)), tanh=int(bool(tanh)),
                              condition_time=int(bool(condition_time)), norm_constant=float(norm_constant),
                              normalization_factor=float(normalization_factor), coords_range=30.0,
-                             precision=PRECISIONS[os.environ.get("HIERDIFF_PRECISION", DEFAULT_PRECISION)])
+                             precision=PRECISIONS[os.environ.get("HIERDIFF_PRECISION", DEFAULT_PRECISION)],
+                             aggregation_mean=int(aggregation_method == 'mean'))
+        self.aggregation_method = aggregation_method
         self._hd = None              # (handle, device index)
         self._handle_gen = 0         # bumped whenever a new hd_handle is created (schedule / weights must be re-sent)
         self._weights_key = None

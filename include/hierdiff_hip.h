@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define HD_ABI_VERSION 5
+#define HD_ABI_VERSION 6
 
 #define HD_OK 0
 #define HD_E_INVALID (-1)      /* bad argument / unsupported configuration */
@@ -52,8 +52,8 @@ typedef struct hd_handle hd_handle;
 typedef struct hd_topology hd_topology;
 
 /* Mirrors EGNN_dynamics_QM9's constructor arguments (en_dynamics.py:9-13) that are on the path.
- * Unsupported values (mode != egnn_dynamics, sin_embedding, aggregation 'mean', act_fn != silu)
- * are rejected by the Python wrapper before this struct is built. */
+ * Unsupported values (mode != egnn_dynamics, sin_embedding, act_fn != silu) are rejected by the Python wrapper
+ * before this struct is built. */
 typedef struct hd_config {
     int32_t in_node_nf;          /* node features INCLUDING the time column, excluding context */
     int32_t context_node_nf;
@@ -76,6 +76,11 @@ typedef struct hd_config {
                                         6 bf16 MFMAs per product, fp32 accumulation - truncation <= 2^-26 per product,
                                         below the rounding of the fp32 accumulation itself; everything else as in
                                         mode 0 (hidden_nf < 128 runs mode 0's kernels) */
+    int32_t aggregation_mean;    /* 0: aggregation_method 'sum' - neighbour sums / normalization_factor (egnn_new.py:280-282);
+                                    1: 'mean' (:283-288) - sums / number of edge-list entries of the receiving node.  The
+                                       reference's edge list holds all N x N pairs of a molecule, masked or not
+                                       (en_dynamics.py:124-143), so that count is the padded N of the call for every node
+                                       and normalization_factor is unused */
 } hd_config;
 
 int hd_version(void);

@@ -66,7 +66,7 @@ def import_reference():
 
 
 def make_cfg(hidden_nf, n_layers, context_node_nf=0, normalization_factor=10, inv_sublayers=2, pocket=False,
-             node_coarse_type="prop", noise_schedule="learned", loss_type="vlb", timesteps=1000):
+             node_coarse_type="prop", noise_schedule="learned", loss_type="vlb", timesteps=1000, aggregation_method="sum"):
     return AttrDict(
         pocket=pocket, node_coarse_type=node_coarse_type, loss_type=loss_type, hcontinous=True,
         noise_schedule=noise_schedule, timesteps=timesteps, norm_values=[1.0, 1.0, 1.0],
@@ -77,15 +77,17 @@ def make_cfg(hidden_nf, n_layers, context_node_nf=0, normalization_factor=10, in
                           hidden_nf=hidden_nf, act_fn="silu", n_layers=n_layers, attention=True,
                           condition_time=True, tanh=True, mode="egnn_dynamics", norm_constant=0,
                           inv_sublayers=inv_sublayers, sin_embedding=False,
-                          normalization_factor=normalization_factor, aggregation_method="sum"),
+                          normalization_factor=normalization_factor, aggregation_method=aggregation_method),
         analyze=os.path.join(REF, "conf/analyze/GEOM.yaml"),
     )
 
 
 def build_reference(DiffusionQM9, hidden_nf, n_layers, context_node_nf=0, seed=0, coord_gain=0.001, pocket=False,
-                    node_coarse_type="prop", noise_schedule="learned", loss_type="vlb", timesteps=1000):
+                    node_coarse_type="prop", noise_schedule="learned", loss_type="vlb", timesteps=1000,
+                    aggregation_method="sum"):
     cfg = make_cfg(hidden_nf, n_layers, context_node_nf, pocket=pocket, node_coarse_type=node_coarse_type,
-                   noise_schedule=noise_schedule, loss_type=loss_type, timesteps=timesteps)
+                   noise_schedule=noise_schedule, loss_type=loss_type, timesteps=timesteps,
+                   aggregation_method=aggregation_method)
     with contextlib.redirect_stdout(io.StringIO()):
         model = DiffusionQM9(cfg)
     fin = (8 if node_coarse_type == "prop" else 3) + 1
@@ -96,7 +98,7 @@ def build_reference(DiffusionQM9, hidden_nf, n_layers, context_node_nf=0, seed=0
     model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd_np.items()})
     model.eval()
     ocfg = orc.DynCfg(in_node_nf=fin, context_node_nf=context_node_nf, hidden_nf=hidden_nf,
-                      n_layers=n_layers, normalization_factor=10.0)
+                      n_layers=n_layers, normalization_factor=10.0, aggregation_method=aggregation_method)
     return model, orc.as_torch_sd(sd_np), ocfg
 
 
@@ -175,6 +177,38 @@ def fixture_forward(DiffusionQM9, name, n_list, hidden_nf, n_layers, seed, coord
                     check(f"{name} trace {short} h", a.numpy(), inter[short + "_h"])
                     check(f"{name} trace {short} x", b.numpy(), inter[short + "_x"])
             out.update({"trace_" + k: v for k, v in inter.items()})
+    save(name, **out)
+
+
+def fixture_forward_mean(DiffusionQM9, name, n_list, hidden_nf, n_layers, seed, coord_gain, n_max=None):
+    """F19: EGNN_dynamics_QM9._forward with aggregation_method='mean' (egnn_new.py:283-288; config-off in ddpmgblur.yaml:37,
+    kept for completeness of the constructor surface): neighbour sums divided by the number of edge-list entries per node -
+    the padded N of the call, since get_adj_matrix lists all N x N pairs (en_dynamics.py:124-143) - on ragged canonical
+    masks and on a general edge mask, plus a conditional call with fixed nodes."""
+    model, sd, ocfg = build_reference(DiffusionQM9, hidden_nf, n_layers, 0, seed, coord_gain, aggregation_method="mean")
+    assert model.dynamics.egnn.aggregation_method == "mean"
+    xh, nm, em = orc.random_inputs(n_list, 8, seed=seed + 100, n_max=n_max)
+    B, N = xh.shape[:2]
+    rng = np.random.Generator(np.random.PCG64(seed + 7))
+    em_gen = em.clone().view(B, N, N)                         # a general mask: a fifth of the valid edges removed
+    drop = torch.from_numpy(rng.random((B, N, N)) < 0.2)
+    em_gen = (em_gen.bool() & ~drop).view(em.shape).to(em.dtype)
+    out = {"xh": xh.numpy(), "node_mask": nm.numpy(), "edge_mask": em.numpy(), "edge_mask_general": em_gen.numpy(),
+           "n_list": np.array(n_list), "hidden_nf": hidden_nf, "n_layers": n_layers, "weight_seed": seed,
+           "coord_gain": coord_gain}
+    with torch.no_grad():
+        trow = torch.linspace(0.1, 0.9, B).view(B, 1)
+        out["t_rows"] = trow.numpy()
+        for tag, mask, mol in (("canonical", em, None), ("general", em_gen, None), ("fixed_nodes", em, N - 2)):
+            ref = model.dynamics._forward(trow, xh.clone(), nm, mask, None, mol)
+            got = orc.dynamics_forward(sd, ocfg, trow, xh, nm, mask, None, mol, prefix="dynamics.egnn.")
+            check(f"{name}[{tag}]", got.numpy(), ref.numpy())
+            out["out_" + tag] = ref.numpy()
+        out["mol_shape_fixed"] = N - 2
+        # what 'mean' amounts to on this edge list: the 'sum' arithmetic with normalization_factor = N
+        ocfg_n = orc.DynCfg(in_node_nf=ocfg.in_node_nf, hidden_nf=hidden_nf, n_layers=n_layers, normalization_factor=float(N))
+        same = orc.dynamics_forward(sd, ocfg_n, trow, xh, nm, em, None, None, prefix="dynamics.egnn.")
+        assert torch.equal(same, orc.dynamics_forward(sd, ocfg, trow, xh, nm, em, None, None, prefix="dynamics.egnn."))
     save(name, **out)
 
 
@@ -709,6 +743,9 @@ def main():
     run(fixture_poly2_l2, "f12_poly2_l2_h32_l2", 32, 2, 16, 6, [7, 3, 8, 5, 6])
     run(fixture_elem, "f13_elem_h64_l2", 64, 2, 17, 3, [6, 9, 4, 7])
     run(fixture_pocket_loss, "f14_pocket_loss_h64_l2", 64, 2, 18, [7, 4, 6, 5], [9, 12, 5, 12])
+    # round 3: aggregation_method = 'mean'
+    run(fixture_forward_mean, "f19_mean_h64_l2", [9, 1, 4, 7, 2, 6], 64, 2, 21, 1.0, n_max=11)
+    run(fixture_forward_mean, "f19_mean_h256_l3", [8, 5, 3, 7], 256, 3, 22, 1.0)
 
 
 if __name__ == "__main__":

@@ -4,7 +4,7 @@ L=$PWD/hierdiff_amd/lib
 out=gpurun_out/ab_node.log; mkdir -p gpurun_out; : > $out
 for rep in 1 2; do
   for lib in "$@"; do
-    for cfg in "fp32 256" "bf16x6 256" "bf16x3 256" "fp32 64" "fp32 2" "bf16x3 64"; do
+    for cfg in "fp32 256" "bf16x6 256" "bf16x3 256"; do
       echo "== $lib $cfg rep $rep" >> $out
       HIERDIFF_LIB=$L/$lib.so bash scratch/prof.sh $cfg 2>&1 | grep "k_node\|r16\|ms/forward" >> $out
     done

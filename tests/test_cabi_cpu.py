@@ -28,7 +28,7 @@ def test_header_symbols_all_exported(lib):
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.hd_version() == _lib.ABI_VERSION == 5
+    assert lib.hd_version() == _lib.ABI_VERSION == 6
 
 
 def test_no_gpu_fails_loudly(lib):
@@ -113,10 +113,13 @@ def test_nodes_distribution_follows_histogram():
 
 def test_unsupported_modes_raise():
     from hierdiff_amd import EGNN_dynamics_QM9
-    for kw in (dict(mode="gnn_dynamics"), dict(sin_embedding=True), dict(aggregation_method="mean"),
-               dict(act_fn="relu"), dict(hidden_nf=48)):
+    for kw in (dict(mode="gnn_dynamics"), dict(sin_embedding=True), dict(act_fn="relu"), dict(hidden_nf=48)):
         with pytest.raises(NotImplementedError):
             EGNN_dynamics_QM9(9, 0, 3, **kw)
+    with pytest.raises(ValueError):
+        EGNN_dynamics_QM9(9, 0, 3, aggregation_method="max")
+    m = EGNN_dynamics_QM9(9, 0, 3, aggregation_method="mean")            # round 3: supported (fixture F19)
+    assert m._cfg.aggregation_mean == 1 and EGNN_dynamics_QM9(9, 0, 3)._cfg.aggregation_mean == 0
 
 
 def test_sample_results_wire_format(tmp_path):

@@ -78,6 +78,29 @@ def test_forward_golden(name, precision):
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
+@pytest.mark.parametrize("name", ["f19_mean_h64_l2", "f19_mean_h256_l3"])
+def test_mean_aggregation_golden(name, precision):
+    """F19: aggregation_method='mean' (egnn_new.py:283-288) - neighbour sums divided by the edge-list entries per node (the padded
+    N) instead of normalization_factor - on canonical / general edge masks and with fixed nodes, in every precision mode."""
+    fx = load(name)
+    sd_np, _, _ = fixture_model(fx)
+    dyn = build_dynamics(sd_np, int(fx["hidden_nf"]), int(fx["n_layers"]), aggregation_method="mean")
+    dyn.precision = precision
+    xh, nm, t = (torch.from_numpy(fx[k]).to(DEV) for k in ("xh", "node_mask", "t_rows"))
+    for tag, mask, mol in (("canonical", "edge_mask", None), ("general", "edge_mask_general", None),
+                           ("fixed_nodes", "edge_mask", int(fx["mol_shape_fixed"]))):
+        out = dyn._forward(t, xh, nm, torch.from_numpy(fx[mask]).to(DEV), None, mol)
+        assert_parity(out.cpu().numpy(), fx["out_" + tag], f"{name} {tag}")
+    # 'mean' on the reference's all-pairs edge list is the 'sum' arithmetic with normalization_factor = padded N: same bits
+    dyn_n = build_dynamics(sd_np, int(fx["hidden_nf"]), int(fx["n_layers"]), normalization_factor=xh.shape[1])
+    dyn_n.precision = precision
+    em = torch.from_numpy(fx["edge_mask"]).to(DEV)
+    assert torch.equal(dyn._forward(t, xh, nm, em, None, None), dyn_n._forward(t, xh, nm, em, None, None))
+    dyn_s = build_dynamics(sd_np, int(fx["hidden_nf"]), int(fx["n_layers"]))          # 'sum' / 10 must not reproduce it
+    assert rel_l2(dyn_s._forward(t, xh, nm, em, None, None).cpu().numpy(), fx["out_canonical"]) > 1e-3
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("name", ["f3_cond_h256_l3", "f3_cond_h32_l2"])
 def test_conditional_step_golden(name, precision):
     fx = load(name)

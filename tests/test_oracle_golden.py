@@ -32,6 +32,25 @@ def test_forward_matches_reference(name):
     assert np.all(out.numpy()[~fx["node_mask"][..., 0]] == 0.0)
 
 
+@pytest.mark.parametrize("name", ["f19_mean_h64_l2", "f19_mean_h256_l3"])
+def test_mean_aggregation_matches_reference(name):
+    """F19: aggregation_method='mean' (egnn_new.py:283-288) on canonical and general edge masks and with fixed nodes."""
+    import dataclasses
+    fx = load(name)
+    _, sd, cfg = fixture_model(fx)
+    cfg = dataclasses.replace(cfg, aggregation_method="mean")
+    xh, nm, t = (torch.from_numpy(fx[k]) for k in ("xh", "node_mask", "t_rows"))
+    with torch.no_grad():
+        for tag, mask, mol in (("canonical", "edge_mask", None), ("general", "edge_mask_general", None),
+                               ("fixed_nodes", "edge_mask", int(fx["mol_shape_fixed"]))):
+            out = orc.dynamics_forward(sd, cfg, t, xh, nm, torch.from_numpy(fx[mask]), None, mol, prefix="dynamics.egnn.")
+            assert_parity(out.numpy(), fx["out_" + tag], f"{name} {tag}", 2e-6, 2e-5)
+        # the 'sum' arithmetic must NOT reproduce it (the fixture would pin nothing otherwise)
+        other = orc.dynamics_forward(sd, dataclasses.replace(cfg, aggregation_method="sum"), t, xh, nm,
+                                     torch.from_numpy(fx["edge_mask"]), None, None, prefix="dynamics.egnn.")
+        assert rel_l2(other.numpy(), fx["out_canonical"]) > 1e-3
+
+
 def test_trace_matches_reference():
     fx = load("f7_h32_l2")
     _, sd, cfg = fixture_model(fx)
