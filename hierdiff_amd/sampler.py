@@ -45,6 +45,55 @@ def load_reference_state_dict(path: str, trust_checkpoint: bool = False) -> Dict
     return {(k[len("model."):] if k.startswith("model.") else k): v for k, v in sd.items()}
 
 
+def _attr(node):
+    """yaml mapping -> AttrDict, recursively (what DiffusionQM9 reads its OmegaConf node through)."""
+    from .diffusion import AttrDict
+    if isinstance(node, dict):
+        return AttrDict({k: _attr(v) for k, v in node.items()})
+    if isinstance(node, list):
+        return [_attr(v) for v in node]
+    if isinstance(node, str):
+        # PyYAML (YAML 1.1) reads `1e-4` as a string, OmegaConf - what the reference loads the file with - as a float
+        import re
+        if re.fullmatch(r"[-+]?(\d+\.?\d*|\.\d+)[eE][-+]?\d+", node):
+            return float(node)
+    return node
+
+
+def load_model_config(path: str):
+    """The reference's own model YAML (`endiffusion/conf/model/ddpmgblur.yaml`: `_target_` + a `cfg:` block, which Hydra hands
+    to `DiffusionQM9.__init__` as `cfg`, sampler.py:20-22) -> the AttrDict this package's DiffusionQM9 takes.  `analyze` (the
+    node-count histogram, `conf/analyze/GEOM.yaml`) is resolved the way a Hydra run does - relative to the directory that holds
+    `conf/` - and falls back to the built-in copy of that histogram when the file is not there."""
+    import yaml
+    with open(path) as fh:
+        doc = yaml.safe_load(fh)
+    if not isinstance(doc, dict):
+        raise ValueError(f"{path}: not a mapping")
+    target = doc.get("_target_")
+    if target is not None and not str(target).endswith("DiffusionQM9"):
+        raise ValueError(f"{path}: _target_ {target!r} is not the coarse-grained diffusion model")
+    cfg = _attr(doc.get("cfg", doc))
+    for key in ("dynamics", "timesteps", "noise_schedule", "node_coarse_type"):
+        if key not in cfg:
+            raise ValueError(f"{path}: missing key {key!r} (expected the layout of conf/model/ddpmgblur.yaml)")
+    an = cfg.get("analyze")
+    if isinstance(an, str) and not os.path.isabs(an):
+        here = os.path.dirname(os.path.abspath(path))
+        tried = [os.path.join(base, an) for base in (os.path.dirname(os.path.dirname(here)), os.path.dirname(here), here, os.getcwd())]
+        found = [p for p in tried if os.path.isfile(p)]
+        cfg["analyze"] = found[0] if found else None
+    return cfg
+
+
+def load_sample_config(path: str) -> Tuple[int, int]:
+    """`conf/sample/default.yaml` -> (batch_size, num_batches), the keyword arguments of `sample_batches` (sampler.py:38)."""
+    import yaml
+    with open(path) as fh:
+        doc = yaml.safe_load(fh) or {}
+    return int(doc["batch_size"]), int(doc["num_batches"])
+
+
 def write_results(path: str, results: List[dict], test_names: Optional[list] = None) -> None:
     """The reference's output file: one pickle holding the tuple (results, test_names) (sampler.py:39-41)."""
     with open(path, "wb") as f:
@@ -74,7 +123,13 @@ def main(argv=None) -> int:
     ap.add_argument("--trust-checkpoint", action="store_true",
                     help="allow the unrestricted unpickler for checkpoints that weights_only=True rejects")
     ap.add_argument("--seed", type=int, default=2022)
+    ap.add_argument("--model-config", default=None,
+                    help="the reference's model YAML (conf/model/ddpmgblur.yaml); overrides --hidden-nf / --n-layers / --timesteps")
+    ap.add_argument("--sample-config", default=None,
+                    help="the reference's sample YAML (conf/sample/default.yaml: batch_size, num_batches)")
     args = ap.parse_args(argv)
+    if args.sample_config:
+        args.batch_size, args.num_batches = load_sample_config(args.sample_config)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -87,8 +142,14 @@ def main(argv=None) -> int:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     ctx_nf = 1 if args.context else 0
-    model = DiffusionQM9(default_config(hidden_nf=args.hidden_nf, n_layers=args.n_layers, context_node_nf=ctx_nf,
-                                        timesteps=args.timesteps))
+    if args.model_config:
+        cfg = load_model_config(args.model_config)
+        if ctx_nf:
+            cfg.dynamics.context_node_nf = ctx_nf
+        model = DiffusionQM9(cfg)
+    else:
+        model = DiffusionQM9(default_config(hidden_nf=args.hidden_nf, n_layers=args.n_layers, context_node_nf=ctx_nf,
+                                            timesteps=args.timesteps))
     if rank == 0 and args.checkpoint:
         model.load_state_dict(load_reference_state_dict(args.checkpoint, args.trust_checkpoint))
     model = model.to(dev)

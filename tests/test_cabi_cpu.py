@@ -152,6 +152,94 @@ def test_sample_results_wire_format(tmp_path):
     assert np.array_equal(m.state_dict()["dynamics.egnn.embedding.weight"].numpy(), syn["dynamics.egnn.embedding.weight"])
 
 
+MODEL_YAML = """\
+_target_: train_module.diffusion_qm9.DiffusionQM9
+cfg:
+  pocket: False
+  node_coarse_type: prop
+  loss_type: 'vlb'
+  hcontinous: true
+  noise_schedule: 'learned'
+  timesteps: {T}
+  norm_values: [1., 1., 1.]
+  norm_biases: [null,0.,0.]
+  parametrization: 'eps'
+  include_charges: True
+  dataset: "qm9"
+  conditioning: []
+  data_augmentation: False
+  pre_noise:
+    noise_schedule: 'learned'
+    timesteps: {T}
+    precision: 1e-4
+  dynamics:
+    in_node_nf: 0
+    context_node_nf: 0
+    n_dims: 3
+    hidden_nf: {H}
+    act_fn: "silu"
+    n_layers: {L}
+    attention: true
+    condition_time: true
+    tanh: true
+    mode: "egnn_dynamics"
+    norm_constant: 0
+    inv_sublayers: 2
+    sin_embedding: False
+    normalization_factor: 10
+    aggregation_method: "sum"
+  analyze: conf/analyze/GEOM.yaml
+"""
+
+
+def write_reference_style_conf(root, H=32, L=1, T=4, batch_size=3, num_batches=2, with_analyze=True):
+    """A config tree with the layout and keys of the reference's `endiffusion/conf` (model/ddpmgblur.yaml, sample/default.yaml,
+    analyze/GEOM.yaml), written by the test: values are this test's, the schema is what Hydra hands to DiffusionQM9."""
+    conf = root / "conf"
+    (conf / "model").mkdir(parents=True)
+    (conf / "sample").mkdir()
+    (conf / "model" / "ddpmgblur.yaml").write_text(MODEL_YAML.format(H=H, L=L, T=T))
+    (conf / "sample" / "default.yaml").write_text(f"batch_size: {batch_size}\nnum_batches: {num_batches}\n")
+    if with_analyze:
+        (conf / "analyze").mkdir()
+        (conf / "analyze" / "GEOM.yaml").write_text("5: 10\n3: 30\n8: 60\n")
+    return conf
+
+
+def test_cli_reads_reference_yaml_configs(tmp_path):
+    """`--model-config` / `--sample-config`: the reference's own YAML files (conf/model/ddpmgblur.yaml, conf/sample/default.yaml)
+    build the same model as the keyword route; `analyze` resolves like a Hydra run and falls back to the built-in histogram."""
+    from hierdiff_amd import DiffusionQM9, default_config
+    from hierdiff_amd.sampler import load_model_config, load_sample_config
+    conf = write_reference_style_conf(tmp_path, H=32, L=1, T=7)
+    cfg = load_model_config(str(conf / "model" / "ddpmgblur.yaml"))
+    assert cfg.timesteps == 7 and cfg.dynamics.hidden_nf == 32 and cfg.dynamics.aggregation_method == "sum"
+    assert cfg.norm_biases == [None, 0.0, 0.0] and cfg.pre_noise.precision == 1e-4          # OmegaConf's reading of `1e-4`
+    assert cfg.analyze == str(conf / "analyze" / "GEOM.yaml")
+    assert load_sample_config(str(conf / "sample" / "default.yaml")) == (3, 2)
+    m = DiffusionQM9(cfg)
+    ref = DiffusionQM9(default_config(hidden_nf=32, n_layers=1, timesteps=7))
+    assert list(m.state_dict().keys()) == list(ref.state_dict().keys()) and m.T == 7
+    assert m.nodes_dist.n_nodes == [5, 3, 8]                               # YAML key order, like the reference's dict
+    torch.manual_seed(0)
+    assert set(m.nodes_dist.sample(200)) <= {3, 5, 8}
+    # without the analyze file: the built-in GEOM histogram
+    conf2 = write_reference_style_conf(tmp_path / "b", with_analyze=False)
+    cfg2 = load_model_config(str(conf2 / "model" / "ddpmgblur.yaml"))
+    assert cfg2.analyze is None and max(DiffusionQM9(cfg2).nodes_dist.sample(500)) > 8
+    # the reference's own files, where the build container has them (never on the GPU box)
+    ref_yaml = "/root/reference/endiffusion/conf/model/ddpmgblur.yaml"
+    if os.path.exists(ref_yaml):
+        c = load_model_config(ref_yaml)
+        assert c.dynamics.hidden_nf == 256 and c.dynamics.n_layers == 6 and c.timesteps == 1000
+        assert c.analyze.endswith("conf/analyze/GEOM.yaml") and os.path.isfile(c.analyze)
+        assert load_sample_config("/root/reference/endiffusion/conf/sample/default.yaml") == (2, 16)
+    with pytest.raises(ValueError):
+        bad = tmp_path / "bad.yaml"
+        bad.write_text("_target_: something.Else\ncfg: {}\n")
+        load_model_config(str(bad))
+
+
 def test_no_register_spills_in_production_kernels():
     """The edge kernels hide loads from hipcc (inline-asm loads released by hand-counted waits); a VGPR spill next to
     one would save a destination before its data has landed.  The build records hipcc's resource remarks and refuses

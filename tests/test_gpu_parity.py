@@ -536,6 +536,26 @@ def test_cli_sampler_writes_reference_wire_format(tmp_path):
     assert all(torch.equal(a["x"], b["x"]) and torch.equal(a["h"], b["h"]) for a, b in zip(results, again))
 
 
+def test_cli_sampler_from_reference_yaml_configs(tmp_path):
+    """The CLI pointed at a config tree laid out like the reference's `endiffusion/conf` gives the molecules of the keyword route."""
+    import pickle
+    from hierdiff_amd import sampler
+    from hierdiff_amd.weights import synthetic_state_dict
+    from tests.test_cabi_cpu import write_reference_style_conf
+    conf = write_reference_style_conf(tmp_path, H=32, L=1, T=4, batch_size=3, num_batches=2, with_analyze=False)
+    syn = synthetic_state_dict(9, 0, 32, 1, 2, True, 12, 1.0)
+    ck = tmp_path / "diffusion.ckpt"
+    torch.save({"state_dict": {"model." + k: torch.from_numpy(v.copy()) for k, v in syn.items()}}, ck)
+    a, b = tmp_path / "a.pkl", tmp_path / "b.pkl"
+    assert sampler.main(["--checkpoint", str(ck), "--out", str(a), "--model-config", str(conf / "model" / "ddpmgblur.yaml"),
+                         "--sample-config", str(conf / "sample" / "default.yaml")]) == 0
+    assert sampler.main(["--checkpoint", str(ck), "--out", str(b), "--batch-size", "3", "--num-batches", "2",
+                         "--hidden-nf", "32", "--n-layers", "1", "--timesteps", "4"]) == 0
+    ra, rb = pickle.load(open(a, "rb"))[0], pickle.load(open(b, "rb"))[0]
+    assert len(ra) == len(rb) == 6
+    assert all(torch.equal(p["x"], q["x"]) and torch.equal(p["h"], q["h"]) for p, q in zip(ra, rb))
+
+
 @pytest.mark.parametrize("precision", PRECISIONS)
 def test_pocket_conditioned_chain_golden(precision):
     """F8 (diffusion_qm9.py:362-382): residue nodes ride along as fixed rows behind the molecule."""
