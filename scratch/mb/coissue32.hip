@@ -15,6 +15,13 @@ __device__ __forceinline__ void valu(float (&v)[8]) {
         if constexpr (KIND == 1) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(v[i & 7]) : "v"(v[(i + 1) & 7]));
         if constexpr (KIND == 3) asm volatile("v_exp_f32 %0, %0" : "+v"(v[i & 7]));
         if constexpr (KIND == 7) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(v[i & 7]) : "v"(v[(i + 1) & 7]));
+        // KIND 11: packed fp32 (two lanes' worth of FMAs per instruction: NV packed = 2 NV scalar FMAs), on register pairs
+        if constexpr (KIND == 11) {
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            f32x2& p = *reinterpret_cast<f32x2*>(&v[(2 * i) & 6]);
+            const f32x2 q = *reinterpret_cast<const f32x2*>(&v[(2 * i + 2) & 6]);
+            asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(p) : "v"(q));
+        }
         if constexpr (KIND == 9) {
             if ((i % 6) == 2) asm volatile("v_exp_f32 %0, %0" : "+v"(v[i & 7]));
             else if ((i % 6) == 5) asm volatile("v_rcp_f32 %0, %0" : "+v"(v[i & 7]));
@@ -79,6 +86,7 @@ int main() {
         sweep<9, true>("silu mix", out, in, g);
         sweep<3, true>("v_exp_f32", out, in, g);
         sweep<7, true>("v_cndmask", out, in, g);
+        sweep<11, true>("v_pk_fma_f32", out, in, g);     // compare NV packed with 2 NV of v_fma_f32
     }
     return 0;
 }
