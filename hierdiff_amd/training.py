@@ -188,20 +188,30 @@ class _NodeMLP(torch.autograd.Function):
 
 
 class _EdgeLayer(torch.autograd.Function):
-    """out = neighbour sum of the edge model of one GCL ([M, H]) or EquivariantUpdate ([M, 4], xyz0); see
-    include/hierdiff_hip.h `hd_edge_layer_forward` / `hd_edge_layer_backward`."""
+    """out = neighbour sum of the edge model of one GCL ([M, H]) or EquivariantUpdate ([M, 4], xyz0), from the node features:
+    the factorised first edge Linear [A | B] = h [W1a ; W1b]^T + [b1 | 0] (one GEMM over the stacked halves of `W1`
+    [H, 2H + 2]; its last two columns are the distance weights w_r, w_d) and the edge kernels of include/hierdiff_hip.h
+    `hd_edge_layer_forward` / `hd_edge_layer_backward`.  One Function for both, so that the gradient of `W1` is assembled once
+    (three strided copies) instead of through autograd's slice / cat / transpose nodes (a zero-filled [H, 2H + 2] tensor, a copy
+    and an accumulation per slice: ~10 small launches per edge layer)."""
 
     @staticmethod
-    def forward(ctx, dyn, topo, tr, coord, AB, x4, x04, wrd, W2, b2, wa, ba):
+    def forward(ctx, dyn, topo, tr, coord, h, W1, b1, zero_h, x4, x04, W2, b2, wa, ba):
         lib = _lib.load()
-        AB, x4, x04, wrd, W2, b2, wa = (v.detach().contiguous() for v in (AB, x4, x04, wrd, W2, b2, wa))
+        H = tr.H
+        W1d = W1.detach()
+        hd = _rows(h.detach())
+        Wst = torch.cat([W1d[:, :H], W1d[:, H:2 * H]], dim=0)                     # [2H, H]
+        AB = _linear_fwd(hd, Wst, torch.cat([b1.detach(), zero_h]))
+        wrd = W1d[:, 2 * H:2 * H + 2].t().contiguous()                             # [2, H]
+        x4, x04, W2, b2, wa = (v.detach().contiguous() for v in (x4, x04, W2, b2, wa))
         ba_c = None if ba is None else ba.detach().contiguous()
         out = torch.empty((max(1, tr.M), 4 if coord else tr.H), device=AB.device, dtype=torch.float32)
         _lib.check(lib.hd_edge_layer_forward(dyn._handle(), topo.ptr, int(coord), AB.data_ptr(), x4.data_ptr(), x04.data_ptr(),
                                              wrd.data_ptr(), W2.data_ptr(), b2.data_ptr(), wa.data_ptr(),
                                              None if ba_c is None else ba_c.data_ptr(), out.data_ptr(), _stream(AB.device)),
                    "hd_edge_layer_forward")
-        ctx.save_for_backward(AB, x4, x04, wrd, W2, b2, wa, *([] if ba_c is None else [ba_c]))
+        ctx.save_for_backward(AB, x4, x04, wrd, W2, b2, wa, hd, Wst, *([] if ba_c is None else [ba_c]))
         ctx.misc = (dyn, topo, tr, coord, ba_c is not None)
         return out[:tr.M]
 
@@ -209,8 +219,8 @@ class _EdgeLayer(torch.autograd.Function):
     def backward(ctx, gout):
         dyn, topo, tr, coord, has_ba = ctx.misc
         saved = ctx.saved_tensors
-        AB, x4, x04, wrd, W2, b2, wa = saved[:7]
-        ba = saved[7] if has_ba else None
+        AB, x4, x04, wrd, W2, b2, wa, hd, Wst = saved[:9]
+        ba = saved[9] if has_ba else None
         lib = _lib.load()
         ws = tr.workspace()
         dev = AB.device
@@ -244,7 +254,15 @@ class _EdgeLayer(torch.autograd.Function):
                                      csws.data_ptr(), _stream(dev)), "hd_colsum_f32")
         if not has_ba:
             dba = None
-        return (None, None, None, None, dAB[:tr.M], dx[:tr.M], dx0[:tr.M], dwrd, dW2, db2, dwa, dba)
+        # through the first edge Linear: dh = dAB [W1a ; W1b], d[W1a ; W1b] = dAB^T h (+ db1), and W1's gradient in its own layout
+        gAB = dAB[:tr.M]
+        dh = _linear_dx(gAB, Wst)
+        dWst, dbst = _linear_dw(gAB, hd, True)
+        dW1 = torch.empty((H, 2 * H + 2), device=dev, dtype=torch.float32)
+        dW1[:, :H].copy_(dWst[:H])
+        dW1[:, H:2 * H].copy_(dWst[H:])
+        dW1[:, 2 * H:].copy_(dwrd.t())
+        return (None, None, None, None, dh, dW1, dbst[:H], None, dx[:tr.M], dx0[:tr.M], dW2, db2, dwa, dba)
 
 
 def dynamics_forward_train(dyn: EGNN_dynamics_QM9, t, xh, node_mask, edge_mask, context, mol_shape=None) -> torch.Tensor:
@@ -282,11 +300,7 @@ def dynamics_forward_train(dyn: EGNN_dynamics_QM9, t, xh, node_mask, edge_mask, 
     nm1 = nm.reshape(-1).contiguous()
 
     def edge_layer(coord, lin0, lin2, wa, ba, xb):
-        W1 = lin0.weight
-        # [A | B] = h [W1a ; W1b]^T + [b1 | 0]: one GEMM over the stacked halves of the first edge Linear
-        AB = _Linear.apply(h, torch.cat([W1[:, :H], W1[:, H:2 * H]], dim=0), torch.cat([lin0.bias, zero_wa]))
-        wrd = W1[:, 2 * H:2 * H + 2].t()
-        return _EdgeLayer.apply(dyn, topo, tr, coord, AB, xb, x04, wrd, lin2.weight, lin2.bias, wa, ba)
+        return _EdgeLayer.apply(dyn, topo, tr, coord, h, lin0.weight, lin0.bias, zero_wa, xb, x04, lin2.weight, lin2.bias, wa, ba)
 
     for i in range(L):
         blk = getattr(egnn, f"e_block_{i}")
