@@ -1,0 +1,103 @@
+"""Randomised parity sweep: the HIP dynamics forward against the CPU oracle on random model shapes, batch compositions, edge masks
+and options (the fixed cases live in tests/; this is the wide net).  usage: fuzz_parity.py [cases] [seed]"""
+import sys, time, numpy as np, torch
+sys.path.insert(0, '.')
+from oracle import egnn_oracle as orc
+from hierdiff_amd import EGNN_dynamics_QM9
+from hierdiff_amd.weights import synthetic_state_dict
+DEV = "cuda:0"
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+rng = np.random.Generator(np.random.PCG64(int(sys.argv[2]) if len(sys.argv) > 2 else 7))
+def rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / max(float(b.norm()), 1e-30))
+worst = {"fp32": 0.0, "bf16x6": 0.0, "bf16x3": 0.0}
+fails = 0
+t0 = time.time()
+for case in range(cases):
+    H = int(rng.choice([32, 64, 128, 256]))
+    L = int(rng.integers(1, 4)); S = int(rng.integers(1, 4))
+    att, tanh = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    C_ = int(rng.choice([0, 0, 1, 2]))
+    agg = str(rng.choice(["sum", "sum", "mean"]))
+    nc = float(rng.choice([0.0, 1.0])); nf = float(rng.choice([1.0, 10.0, 100.0]))
+    B = int(rng.integers(1, 9)); nmax = int(rng.choice([3, 8, 17, 30, 48, 70]))
+    n_list = [int(rng.integers(1, nmax + 1)) for _ in range(B)]
+    pad = nmax + int(rng.integers(0, 3))
+    sd_np = synthetic_state_dict(9, C_, H, L, S, att, 1000 + case, float(rng.choice([0.001, 1.0])))
+    cfg = orc.DynCfg(in_node_nf=9, context_node_nf=C_, hidden_nf=H, n_layers=L, inv_sublayers=S, attention=att, tanh=tanh,
+                     norm_constant=nc, normalization_factor=nf, aggregation_method=agg)
+    xh, nm, em = orc.random_inputs(n_list, 8, 2000 + case, pad)
+    N = xh.shape[1]
+    kind = int(rng.integers(0, 3))
+    if kind == 1:                                   # random holes (asymmetric) + a few self edges
+        emb = em.view(B, N, N).bool().clone()
+        emb &= torch.from_numpy(rng.random((B, N, N)) > 0.25)
+        for b in range(B):
+            if n_list[b] > 1 and rng.random() < 0.5: emb[b, 0, 0] = True
+        em = emb.view(em.shape).to(em.dtype)
+    elif kind == 2:                                 # two blocks per molecule
+        emb = em.view(B, N, N).bool().clone()
+        for b in range(B):
+            k = n_list[b] // 2
+            emb[b, :k, k:] = False; emb[b, k:, :k] = False
+        em = emb.view(em.shape).to(em.dtype)
+    ctx = torch.from_numpy(rng.standard_normal((B, N, C_)).astype(np.float32)) if C_ else None
+    mol = None if rng.random() < 0.6 else int(rng.integers(1, N + 1))
+    t = torch.from_numpy(rng.random((B, 1)).astype(np.float32)) if rng.random() < 0.7 else torch.tensor([float(rng.random())])
+    with torch.no_grad():
+        ref = orc.dynamics_forward(orc.as_torch_sd(sd_np), cfg, t, xh, nm, em, ctx, mol, prefix="dynamics.egnn.")
+    dyn = EGNN_dynamics_QM9(9, C_, 3, hidden_nf=H, n_layers=L, attention=att, tanh=tanh, norm_constant=nc, inv_sublayers=S,
+                            normalization_factor=nf, aggregation_method=agg)
+    dyn.load_numpy_state_dict(sd_np, prefix="dynamics."); dyn = dyn.to(DEV)
+    line = f"case {case:3d} H={H:3d} L={L} S={S} att={int(att)} tanh={int(tanh)} C={C_} agg={agg:4s} nc={nc} nf={nf:5.1f} n={n_list} N={N} mask={kind} mol={mol}"
+    for prec in ("fp32", "bf16x6", "bf16x3"):
+        dyn.precision = prec
+        with torch.no_grad():
+            out = dyn._forward(t.to(DEV), xh.to(DEV), nm.to(DEV), em.to(DEV), None if ctx is None else ctx.to(DEV), mol).cpu()
+        r = rel(out, ref)
+        worst[prec] = max(worst[prec], r)
+        bad = (not torch.isfinite(out).all()) or r > 1e-4 or bool((out[~nm[..., 0]] != 0).any())
+        line += f"  {prec} {r:.1e}{' FAIL' if bad else ''}"
+        fails += int(bad)
+    print(line, flush=True)
+print(f"{cases} cases in {time.time() - t0:.0f} s, failures {fails}, worst rel-L2 {worst}")
+
+# ---- phase 2: short sampling chains (z_T, T posterior steps, decode) with injected normals and the oracle's schedule grid
+from hierdiff_amd import DiffusionQM9, default_config
+chains = max(1, cases // 4)
+wc = 0.0
+t1 = time.time()
+for case in range(chains):
+    H = int(rng.choice([32, 64, 128])); L = int(rng.integers(1, 3)); T = int(rng.integers(2, 7))
+    C_ = int(rng.choice([0, 0, 1]))
+    B = int(rng.integers(1, 7)); nmax = int(rng.choice([4, 9, 20, 33]))
+    n_list = [int(rng.integers(1, nmax + 1)) for _ in range(B)]
+    fix = bool(rng.random() < 0.3)
+    sd_np = synthetic_state_dict(9, C_, H, L, 2, True, 3000 + case, float(rng.choice([0.02, 1.0])))
+    sd = orc.as_torch_sd(sd_np)
+    cfg = orc.DynCfg(in_node_nf=9, context_node_nf=C_, hidden_nf=H, n_layers=L, normalization_factor=10.0)
+    nm, em = orc.canonical_masks(n_list)
+    N = nm.shape[1]
+    ctx = torch.full((B, N, 1), float(rng.uniform(-0.4, 4.9))) if C_ else None
+    nb = 1 if fix else B
+    raws = [(torch.from_numpy(rng.standard_normal((nb, N, 3)).astype(np.float32)),
+             torch.from_numpy(rng.standard_normal((nb, N, 8)).astype(np.float32))) for _ in range(T + 2)]
+    grid = orc.schedule_table(sd, T)["gamma"]
+    with torch.no_grad():
+        rx, rh = orc.sample_chain(sd, cfg, T, nm, em, ctx, raws, fix_noise=fix, gamma_grid=torch.from_numpy(grid))
+    m = DiffusionQM9(default_config(hidden_nf=H, n_layers=L, context_node_nf=C_, timesteps=T))
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v).copy()) for k, v in sd_np.items()})
+    m = m.to(DEV); m.schedule_gammas = grid
+    line = f"chain {case:3d} H={H:3d} L={L} T={T} C={C_} fix_noise={int(fix)} n={n_list}"
+    for prec in ("fp32", "bf16x6", "bf16x3"):
+        m.dynamics.precision = prec
+        x, h = m.sample_from_masks(nm.to(DEV), em.to(DEV), None if ctx is None else ctx.to(DEV), fix_noise=fix, raw_noises=raws)
+        nmf = nm.float()
+        r = max(rel(x.cpu() * nmf, rx * nmf), rel(h.cpu(), rh))
+        bad = r > (1e-3 if prec == "bf16x3" else 2e-4) or not torch.isfinite(x).all()
+        wc = max(wc, r); fails += int(bad)
+        line += f"  {prec} {r:.1e}{' FAIL' if bad else ''}"
+    print(line, flush=True)
+print(f"{chains} chains in {time.time() - t1:.0f} s, failures so far {fails}, worst rel-L2 {wc:.2e}")
+sys.exit(1 if fails else 0)

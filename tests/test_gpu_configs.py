@@ -569,3 +569,16 @@ def test_merged_sample_batches_equal_the_loop(precision):
         if ctx_nf:                                                    # batch i carries context_range[i % 3] on every row
             for i, r in enumerate(outs[1]):
                 assert float((r["context"] - ctx_range[(i // 2) % 3]).abs().max()) == 0.0
+
+
+def test_randomised_parity_sweep():
+    """The wide net next to the fixed cases: scratch/fuzz_parity.py - random model shapes / options / batch compositions / edge masks
+    for the forward (all three precision modes) and short sampling chains, against the CPU oracle (a 400 + 100 case run of the same
+    script: profiles/r03_fuzz_parity.log)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    proc = subprocess.run([sys.executable, os.path.join(root, "scratch", "fuzz_parity.py"), "48", "5"], cwd=root,
+                          capture_output=True, text=True, timeout=600)
+    tail = "\n".join(proc.stdout.splitlines()[-6:])
+    assert proc.returncode == 0, tail + proc.stderr[-2000:]
+    assert "failures 0" in tail and "failures so far 0" in tail, tail
