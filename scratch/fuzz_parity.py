@@ -80,19 +80,29 @@ for case in range(chains):
     nm, em = orc.canonical_masks(n_list)
     N = nm.shape[1]
     ctx = torch.full((B, N, 1), float(rng.uniform(-0.4, 4.9))) if C_ else None
+    pocket = None
+    if C_ == 0 and not fix and rng.random() < 0.4:          # fixed pocket nodes riding behind the molecule (diffusion_qm9.py:362-382)
+        P = int(rng.integers(1, 40))
+        p_n = [int(rng.integers(1, P + 1)) for _ in range(B)]
+        p_nm = torch.from_numpy((np.arange(P)[None, :] < np.array(p_n)[:, None]).astype(np.float32)).unsqueeze(-1)
+        p_em = (p_nm * p_nm.transpose(1, 2)) * (1.0 - torch.eye(P)[None])
+        p_pos = torch.from_numpy(rng.standard_normal((B, P, 3)).astype(np.float32)) * p_nm
+        p_feat = torch.from_numpy(rng.standard_normal((B, P, 8)).astype(np.float32)) * p_nm
+        pocket = (p_pos, p_feat, p_nm, p_em)
     nb = 1 if fix else B
     raws = [(torch.from_numpy(rng.standard_normal((nb, N, 3)).astype(np.float32)),
              torch.from_numpy(rng.standard_normal((nb, N, 8)).astype(np.float32))) for _ in range(T + 2)]
     grid = orc.schedule_table(sd, T)["gamma"]
     with torch.no_grad():
-        rx, rh = orc.sample_chain(sd, cfg, T, nm, em, ctx, raws, fix_noise=fix, gamma_grid=torch.from_numpy(grid))
+        rx, rh = orc.sample_chain(sd, cfg, T, nm, em, ctx, raws, fix_noise=fix, gamma_grid=torch.from_numpy(grid), pocket=pocket)
     m = DiffusionQM9(default_config(hidden_nf=H, n_layers=L, context_node_nf=C_, timesteps=T))
     m.load_state_dict({k: torch.from_numpy(np.asarray(v).copy()) for k, v in sd_np.items()})
     m = m.to(DEV); m.schedule_gammas = grid
-    line = f"chain {case:3d} H={H:3d} L={L} T={T} C={C_} fix_noise={int(fix)} n={n_list}"
+    line = f"chain {case:3d} H={H:3d} L={L} T={T} C={C_} fix_noise={int(fix)} pocket={0 if pocket is None else pocket[0].shape[1]} n={n_list}"
+    pk = None if pocket is None else tuple(v.to(DEV) for v in pocket)
     for prec in ("fp32", "bf16x6", "bf16x3"):
         m.dynamics.precision = prec
-        x, h = m.sample_from_masks(nm.to(DEV), em.to(DEV), None if ctx is None else ctx.to(DEV), fix_noise=fix, raw_noises=raws)
+        x, h = m.sample_from_masks(nm.to(DEV), em.to(DEV), None if ctx is None else ctx.to(DEV), fix_noise=fix, raw_noises=raws, pocket=pk)
         nmf = nm.float()
         r = max(rel(x.cpu() * nmf, rx * nmf), rel(h.cpu(), rh))
         bad = r > (1e-3 if prec == "bf16x3" else 2e-4) or not torch.isfinite(x).all()
