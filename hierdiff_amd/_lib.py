@@ -27,7 +27,7 @@ class HdConfig(C.Structure):
 class HdEgclConfig(C.Structure):
     _fields_ = [("hidden_nf", C.c_int32), ("edges_in_d", C.c_int32), ("context_nf", C.c_int32), ("attention", C.c_int32),
                 ("tanh", C.c_int32), ("coord_update", C.c_int32), ("edge_update", C.c_int32), ("recurrent", C.c_int32),
-                ("coords_range", C.c_float)]
+                ("coords_range", C.c_float), ("geo", C.c_int32)]
 
 
 # name -> (restype, argtypes); mirrors include/hierdiff_hip.h one to one

@@ -1667,7 +1667,7 @@ extern "C" int hd_egcl_forward(hd_egcl* g, hd_egcl_graph* t, const float* h, con
             EgclPreArgs a;
             a.AB = t->AB; a.T1 = wide ? t->T1 : nullptr; a.ea = wide ? nullptr : edge_attr; a.w_e = W + g->w_e; a.w_r = W + g->w_r;
             a.w_c = W + g->w_c; a.hin = t->hin; a.x = t->x4; a.row = t->row; a.col = t->col; a.P = t->P; a.geo = t->geo;
-            a.E = E; a.H = H; a.De = De; a.ctx = ctx;
+            a.E = E; a.H = H; a.De = De; a.ctx = ctx; a.geo_mode = c.geo;
             hipLaunchKernelGGL(k_egcl_pre, blocks((long long)E * (H / 4)), dim3(256), 0, s, a);
         }
         egcl_gemm(g, EPI_BIAS_SILU, false, gemm_args(t->P, H, H, H, nullptr, g->w2_img, g->b2, t->M1, H, E, H, nullptr), s);

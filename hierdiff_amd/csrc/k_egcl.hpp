@@ -25,7 +25,7 @@ struct EgclPreArgs {
     const int* col;
     float* P;               // [E][H]
     float* geo;             // [E][4] = {cdiff_x, cdiff_y, cdiff_z, radial}
-    int E, H, De, ctx;
+    int E, H, De, ctx, geo_mode;      // geo_mode: the message model's distance input is 1 / radial^2 (gcl.py:170-175)
 };
 
 __global__ void k_egcl_pre(EgclPreArgs a) {
@@ -47,7 +47,7 @@ __global__ void k_egcl_pre(EgclPreArgs a) {
                 *reinterpret_cast<const f32x4*>(a.AB + (size_t)c * 2 * a.H + a.H + k);
     const f32x4 wr = *reinterpret_cast<const f32x4*>(a.w_r + k);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) pre[j] = __builtin_fmaf(radial, wr[j], pre[j]);
+    for (int j = 0; j < 4; ++j) pre[j] = __builtin_fmaf(a.geo_mode ? 1.0f / (radial * radial) : radial, wr[j], pre[j]);
     if (a.T1) pre += *reinterpret_cast<const f32x4*>(a.T1 + (size_t)e * a.H + k);
     for (int d = 0; d < (a.T1 ? 0 : a.De); ++d) {
         const float v = a.ea[(size_t)e * a.De + d];

@@ -5,7 +5,7 @@ same constructor, same `state_dict` keys (mes_mlp.0.weight, edge_mlp.0.weight, n
 att_mlp.0.weight, ...), same `forward(h, edge_index, coord, edge_attr, node_attr, node_mask, edge_mask)` and return value.
 The arithmetic runs in libhierdiff_hip.so (`hd_egcl_forward`, exact fp32 MFMA GEMMs over edge / node rows + row kernels);
 the torch modules below only hold parameters.  Inference only (value); no CPU fallback.
-Not supported (config-off in the reference's stage-2 models): geo=True, agg='mean', node_attr, angle_net, act_fn != SiLU.
+Not supported (config-off in the reference's stage-2 models): agg='mean', node_attr, angle_net (dead code in the reference), act_fn != SiLU.
 """
 from __future__ import annotations
 
@@ -83,8 +83,8 @@ class E_GCL(nn.Module):
             raise NotImplementedError("E_GCL on MI355X: input_nf == output_nf == hidden_nf (as in edge_denoise.py:35-43)")
         if hidden_nf not in (32, 64, 128, 256):
             raise NotImplementedError("hidden_nf must be one of 32, 64, 128, 256")
-        if geo or angle_net or nodes_att_dim or agg != 'sum' or not isinstance(act_fn, nn.SiLU):
-            raise NotImplementedError("geo / angle_net / node_attr / agg='mean' / act_fn != SiLU are config-off in the reference")
+        if angle_net or nodes_att_dim or agg != 'sum' or not isinstance(act_fn, nn.SiLU):
+            raise NotImplementedError("angle_net / node_attr / agg='mean' / act_fn != SiLU are config-off in the reference")
         if not (edges_in_d == hidden_nf or 0 <= edges_in_d < 32):
             raise NotImplementedError("edges_in_d must be hidden_nf or < 32")
         if edge_update and edges_in_d != hidden_nf:
@@ -108,7 +108,7 @@ class E_GCL(nn.Module):
             self.att_mlp = nn.Sequential(nn.Linear(H, 1), nn.Sigmoid())
         self._cfg = HdEgclConfig(hidden_nf=H, edges_in_d=edges_in_d, context_nf=context_nf, attention=int(bool(attention)),
                                  tanh=int(bool(tanh)), coord_update=int(bool(coord_update)), edge_update=int(bool(edge_update)),
-                                 recurrent=int(bool(recurrent)), coords_range=float(coords_range))
+                                 recurrent=int(bool(recurrent)), coords_range=float(coords_range), geo=int(bool(geo)))
         self._hd = None
         self._weights_key = None
         self._plist = None

@@ -205,7 +205,7 @@ int hd_edge_layer_backward(hd_handle* h, hd_topology* topo, int coord, const flo
 /* ---- Stage-2 layer: E_GCL forward (/root/reference/models/egnn/gcl.py:9-205), exact fp32.
  * The layer of the edge-denoise / refine models: messages from [h_row; h_col; radial; edge_attr; context], optional
  * attention gate, coordinate update and node update aggregated over the RECEIVING index `col`, optional update of the
- * H-wide edge features.  geo = False, agg = 'sum', node_attr = None, act_fn = SiLU. */
+ * H-wide edge features.  agg = 'sum', node_attr = None, act_fn = SiLU. */
 typedef struct hd_egcl hd_egcl;
 typedef struct hd_egcl_graph hd_egcl_graph;
 typedef struct hd_egcl_config {        /* E_GCL.__init__ arguments (gcl.py:19) */
@@ -214,6 +214,8 @@ typedef struct hd_egcl_config {        /* E_GCL.__init__ arguments (gcl.py:19) *
     int32_t context_nf;
     int32_t attention, tanh, coord_update, edge_update, recurrent;
     float coords_range;
+    int32_t geo;                       /* 1: the message model sees 1 / radial^2 instead of radial (gcl.py:170-175); the coordinate and
+                                          edge models keep radial.  An edge list with self edges then carries inf / NaN, as in the reference */
 } hd_egcl_config;
 int hd_egcl_create(const hd_egcl_config* cfg, int device, hd_egcl** out);
 int hd_egcl_destroy(hd_egcl* g);

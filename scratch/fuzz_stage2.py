@@ -20,6 +20,7 @@ for case in range(cases):
     ctx = int(rng.choice([0, 0, 2]))
     att, eu = bool(rng.integers(0, 2)), bool(rng.integers(0, 2)) and wide
     cu, rec, tanh = bool(rng.integers(0, 2)), bool(rng.random() < 0.8), bool(rng.integers(0, 2))
+    geo = bool(rng.random() < 0.25)
     M = int(rng.integers(2, 40))
     kind = int(rng.integers(0, 3))
     if kind == 0:                                   # dense blocks
@@ -27,12 +28,16 @@ for case in range(cases):
         ar = torch.arange(n)
         row = ar.repeat_interleave(n).repeat(bs) + (torch.arange(bs) * n).repeat_interleave(n * n)
         col = ar.repeat(n).repeat(bs) + (torch.arange(bs) * n).repeat_interleave(n * n)
+    if geo and kind != 1: kind = 1                  # 1 / radial^2: no self edges (inf in the reference too)
+    if kind == 0:
+        pass
     else:                                           # sparse random edges (kind 2: with repeats and self edges)
         E = int(rng.integers(1, 4 * M))
         row = torch.from_numpy(rng.integers(0, M, size=E)); col = torch.from_numpy(rng.integers(0, M, size=E))
         if kind == 1:
             keep = row != col
-            if keep.sum() == 0: keep[0] = True
+            if keep.sum() == 0:
+                col[0] = (row[0] + 1) % M; keep[0] = True
             row, col = row[keep], col[keep]
     E = row.numel()
     masked = bool(rng.integers(0, 2)); has_em = bool(rng.integers(0, 2))
@@ -41,18 +46,18 @@ for case in range(cases):
     h = torch.from_numpy(rng.standard_normal((M, H + ctx)).astype(np.float32))
     x = torch.from_numpy(rng.standard_normal((M, 3)).astype(np.float32))
     ea = torch.from_numpy(rng.standard_normal((E, De)).astype(np.float32))
-    cfg = orc.EGCLCfg(hidden_nf=H, edges_in_d=De, context_nf=ctx, attention=att, tanh=tanh, coord_update=cu, edge_update=eu, recurrent=rec)
+    cfg = orc.EGCLCfg(hidden_nf=H, edges_in_d=De, context_nf=ctx, attention=att, tanh=tanh, coord_update=cu, edge_update=eu, recurrent=rec, geo=geo)
     layers = 2 if eu else 1
     hr, xr, er = h, x, ea
     hg, xg, eg = h.to(DEV), x.to(DEV), ea.to(DEV)
-    line = f"case {case:3d} H={H:3d} De={De:3d} ctx={ctx} att={int(att)} eu={int(eu)} cu={int(cu)} rec={int(rec)} tanh={int(tanh)} M={M:2d} E={E:4d} graph={kind} nm={int(masked)} em={int(has_em)}"
+    line = f"case {case:3d} H={H:3d} De={De:3d} ctx={ctx} att={int(att)} eu={int(eu)} cu={int(cu)} rec={int(rec)} tanh={int(tanh)} geo={int(geo)} M={M:2d} E={E:4d} graph={kind} nm={int(masked)} em={int(has_em)}"
     try:
         for li in range(layers):
             sd_np = synthetic_egcl_state_dict(H, De, ctx, att, eu, 7000 + 10 * case + li, coord_gain=0.3)
             with torch.no_grad():
                 out_r = orc.e_gcl_forward(orc.as_torch_sd(sd_np), cfg, hr, row, col, xr, er, nm, em)
             m = E_GCL(H, H, H, context_nf=ctx, edges_in_d=De, attention=att, tanh=tanh, coords_range=30, edge_update=eu,
-                      coord_update=cu, recurrent=rec)
+                      coord_update=cu, recurrent=rec, geo=geo)
             own = set(m.state_dict().keys())            # (no coord_mlp without coord_update)
             m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd_np.items() if k in own})
             m = m.to(DEV)
@@ -61,8 +66,15 @@ for case in range(cases):
             hr, xr = out_r[0], out_r[1]
             hg, xg = out_g[0], out_g[1]
             if eu: er, eg = out_r[2], out_g[2]
-        r = max(rel(hg.cpu(), hr), rel(xg.cpu(), xr), rel(eg.cpu(), er) if eu else 0.0)
-        bad = r > 1e-4 or not torch.isfinite(hg).all()
+        if not (torch.isfinite(hr).all() and torch.isfinite(xr).all()):
+            # the REFERENCE arithmetic is non-finite here (geo: 1 / radial^2 of coincident points, e.g. two masked nodes that a
+            # previous layer moved to the origin): the HIP layer must be non-finite in the same rows, nothing else is comparable
+            r = 0.0
+            bad = bool((torch.isfinite(hg.cpu()).all(dim=1) != torch.isfinite(hr).all(dim=1)).any())
+            line += "  [reference non-finite]"
+        else:
+            r = max(rel(hg.cpu(), hr), rel(xg.cpu(), xr), rel(eg.cpu(), er) if eu else 0.0)
+            bad = r > 1e-4 or not torch.isfinite(hg).all()
     except Exception as exc:                        # an unsupported combination must say so, not crash later
         r, bad = float("nan"), not isinstance(exc, NotImplementedError)
         line += f"  [{type(exc).__name__}: {str(exc)[:80]}]"

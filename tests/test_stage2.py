@@ -7,7 +7,8 @@ import torch
 from oracle import egnn_oracle as orc
 from tests.helpers import assert_parity, load
 
-FIXTURES = ["f15_egcl_full_h64", "f15_egcl_full_h256", "f15_egcl_focal_h64", "f15_egcl_edge_h64", "f15_egcl_ctx_h64"]
+FIXTURES = ["f15_egcl_full_h64", "f15_egcl_full_h256", "f15_egcl_focal_h64", "f15_egcl_edge_h64", "f15_egcl_ctx_h64",
+            "f15_egcl_geo_h64"]
 
 
 def _case(fx):
@@ -15,7 +16,7 @@ def _case(fx):
     H, De, ctx = int(fx["hidden_nf"]), int(fx["edges_in_d"]), int(fx["context_nf"])
     att, eu = bool(int(fx["attention"])), bool(int(fx["edge_update"]))
     sd_np = synthetic_egcl_state_dict(H, De, ctx, att, eu, int(fx["weight_seed"]), coord_gain=0.3)
-    cfg = orc.EGCLCfg(hidden_nf=H, edges_in_d=De, context_nf=ctx, attention=att, edge_update=eu)
+    cfg = orc.EGCLCfg(hidden_nf=H, edges_in_d=De, context_nf=ctx, attention=att, edge_update=eu, geo=bool(int(fx.get("geo", 0))))
     nm = torch.from_numpy(fx["node_mask"]) if int(fx["masked"]) else None
     em = torch.from_numpy(fx["edge_mask"]) if int(fx["has_edge_mask"]) else None
     return sd_np, cfg, nm, em
@@ -45,7 +46,8 @@ def test_module_mirrors_reference_layout():
     m.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic_egcl_state_dict(64, 64, 0, True, True, 1).items()})
     m2 = E_GCL(64, 64, 64, edges_in_d=1, attention=False, tanh=True, coords_range=30, edge_update=False)
     assert "edge_mlp.0.weight" not in m2.state_dict() and m2.state_dict()["mes_mlp.0.weight"].shape == (64, 130)
-    for kw in (dict(geo=True), dict(agg="mean"), dict(angle_net=True), dict(edges_in_d=40)):
+    assert E_GCL(64, 64, 64, edges_in_d=64, geo=True)._cfg.geo == 1          # round 3: supported (fixture f15_egcl_geo_h64)
+    for kw in (dict(agg="mean"), dict(angle_net=True), dict(edges_in_d=40)):
         with pytest.raises(NotImplementedError):
             E_GCL(64, 64, 64, **kw)
     with pytest.raises(NotImplementedError):
@@ -64,7 +66,7 @@ def test_hip_layer_golden(name):
     sd_np, cfg, nm, em = _case(fx)
     dev = "cuda:0"
     m = E_GCL(cfg.hidden_nf, cfg.hidden_nf, cfg.hidden_nf, context_nf=cfg.context_nf, edges_in_d=cfg.edges_in_d,
-              attention=cfg.attention, tanh=True, coords_range=30, edge_update=cfg.edge_update)
+              attention=cfg.attention, tanh=True, coords_range=30, edge_update=cfg.edge_update, geo=cfg.geo)
     m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd_np.items()})
     m = m.to(dev)
     row, col = torch.from_numpy(fx["row"]).long().to(dev), torch.from_numpy(fx["col"]).long().to(dev)
