@@ -132,8 +132,10 @@ class DiffusionQM9(_Base):
         self.parametrization = _get(cfg, "parametrization")
         self.norm_values = list(_get(cfg, "norm_values"))
         self.norm_biases = list(_get(cfg, "norm_biases"))
-        if [float(v) for v in self.norm_values] != [1.0, 1.0, 1.0] or (self.norm_biases[1] or 0.0) != 0.0:
-            raise NotImplementedError("only norm_values [1,1,1] / norm_biases [None,0,0] (ddpmgblur.yaml:10-11)")
+        # data scaling (diffusion_qm9.py:103-104, 165-179; production: [1,1,1] / [None,0,0], ddpmgblur.yaml:10-11).  The library's
+        # decode kernel returns normalised x / h; `_final_decode` applies `unnormalize` when the values are not the unit ones.
+        self._unit_norm = [float(v) for v in self.norm_values] == [1.0, 1.0, 1.0] and \
+            all(float(b or 0.0) == 0.0 for b in self.norm_biases)
         self.register_buffer('buffer', torch.zeros(1))
         if _get(cfg, "noise_schedule") != 'learned':
             self.check_issues_norm_values()
@@ -516,6 +518,9 @@ class DiffusionQM9(_Base):
             self._lib_handle(), topo.ptr, z0.data_ptr(), eps.data_ptr(), c3.ctypes.data_as(C.POINTER(C.c_float)),
             _ptr(raw_x), _ptr(raw_h), nb, self.seed, philox[0] if philox else 0, philox[1] if philox else 0,
             int(fix_noise), x.data_ptr(), h.data_ptr(), _stream(dev)), "hd_final_decode")
+        if not self._unit_norm:         # `unnormalize` (:174-179); h is already masked: (h nv1 + nb1) mask = h_masked nv1 + nb1 mask
+            x = x * float(self.norm_values[0])
+            h = h * float(self.norm_values[1]) + float(self.norm_biases[1] or 0.0) * node_mask.reshape(B, N, 1).to(h.dtype)
         return x, h
 
     def sample_normal(self, mu, sigma, node_mask, fix_noise=False):

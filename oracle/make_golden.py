@@ -66,11 +66,12 @@ def import_reference():
 
 
 def make_cfg(hidden_nf, n_layers, context_node_nf=0, normalization_factor=10, inv_sublayers=2, pocket=False,
-             node_coarse_type="prop", noise_schedule="learned", loss_type="vlb", timesteps=1000, aggregation_method="sum"):
+             node_coarse_type="prop", noise_schedule="learned", loss_type="vlb", timesteps=1000, aggregation_method="sum",
+             norm_values=(1.0, 1.0, 1.0), norm_biases=(None, 0.0, 0.0)):
     return AttrDict(
         pocket=pocket, node_coarse_type=node_coarse_type, loss_type=loss_type, hcontinous=True,
-        noise_schedule=noise_schedule, timesteps=timesteps, norm_values=[1.0, 1.0, 1.0],
-        norm_biases=[None, 0.0, 0.0], parametrization="eps", include_charges=True, dataset="qm9",
+        noise_schedule=noise_schedule, timesteps=timesteps, norm_values=list(norm_values),
+        norm_biases=list(norm_biases), parametrization="eps", include_charges=True, dataset="qm9",
         data_augmentation=False,
         pre_noise=AttrDict(noise_schedule=noise_schedule, timesteps=timesteps, precision=1e-4),
         dynamics=AttrDict(in_node_nf=0, context_node_nf=context_node_nf, n_dims=3,
@@ -84,10 +85,10 @@ def make_cfg(hidden_nf, n_layers, context_node_nf=0, normalization_factor=10, in
 
 def build_reference(DiffusionQM9, hidden_nf, n_layers, context_node_nf=0, seed=0, coord_gain=0.001, pocket=False,
                     node_coarse_type="prop", noise_schedule="learned", loss_type="vlb", timesteps=1000,
-                    aggregation_method="sum"):
+                    aggregation_method="sum", norm_values=(1.0, 1.0, 1.0), norm_biases=(None, 0.0, 0.0)):
     cfg = make_cfg(hidden_nf, n_layers, context_node_nf, pocket=pocket, node_coarse_type=node_coarse_type,
                    noise_schedule=noise_schedule, loss_type=loss_type, timesteps=timesteps,
-                   aggregation_method=aggregation_method)
+                   aggregation_method=aggregation_method, norm_values=norm_values, norm_biases=norm_biases)
     with contextlib.redirect_stdout(io.StringIO()):
         model = DiffusionQM9(cfg)
     fin = (8 if node_coarse_type == "prop" else 3) + 1
@@ -209,6 +210,105 @@ def fixture_forward_mean(DiffusionQM9, name, n_list, hidden_nf, n_layers, seed, 
         ocfg_n = orc.DynCfg(in_node_nf=ocfg.in_node_nf, hidden_nf=hidden_nf, n_layers=n_layers, normalization_factor=float(N))
         same = orc.dynamics_forward(sd, ocfg_n, trow, xh, nm, em, None, None, prefix="dynamics.egnn.")
         assert torch.equal(same, orc.dynamics_forward(sd, ocfg, trow, xh, nm, em, None, None, prefix="dynamics.egnn."))
+    save(name, **out)
+
+
+def fixture_norm(DiffusionQM9, name, hidden_nf, n_layers, seed, coord_gain, T, n_list, norm_values, norm_biases):
+    """F20: non-unit norm_values / norm_biases (diffusion_qm9.py:103-104, 165-179, 481-493, 675-699; EDM-style data scaling,
+    [1,1,1] / [None,0,0] in ddpmgblur.yaml): (a) a T-step DiffusionQM9.sample chain with recorded noise - the final
+    `unnormalize`; (b) the validation and the training value of `nll` on raw data with the reference's own draws recorded."""
+    model, sd, ocfg = build_reference(DiffusionQM9, hidden_nf, n_layers, 0, seed, coord_gain, norm_values=norm_values,
+                                      norm_biases=norm_biases)
+    assert list(model.norm_values) == list(norm_values)
+    model.nodes_dist.sample = lambda n: list(n_list)
+    B, N = len(n_list), max(n_list)
+    nm, em = orc.canonical_masks(n_list)
+    rng = np.random.Generator(np.random.PCG64(seed + 11))
+    # ---- (a) sampling chain
+    T_full = model.T
+    model.T = T
+    raws = [(torch.from_numpy(rng.standard_normal((B, N, 3)).astype(np.float32)),
+             torch.from_numpy(rng.standard_normal((B, N, 8)).astype(np.float32))) for _ in range(T + 2)]
+    queue = [r for pair in raws for r in pair]
+    orig_randn = torch.randn
+
+    def fake_randn(size, device=None, **kw):
+        r = queue.pop(0)
+        assert tuple(r.shape) == tuple(size), (r.shape, size)
+        return r.clone()
+    torch.randn = fake_randn
+    seen = []          # the schedule values of the run itself (fp32 evaluation depends on the batch shape, see fixture_chain)
+    hook = model.gamma.register_forward_hook(lambda m, a, o: seen.append((float(a[0][0, 0]), float(o[0, 0]))))
+    try:
+        with torch.no_grad():
+            res = model.sample(B, "cpu")
+    finally:
+        torch.randn = orig_randn
+        hook.remove()
+    assert not queue
+    gamma_grid = np.full(T + 1, np.nan, np.float32)
+    for tau, gv in seen:
+        gamma_grid[int(round(tau * T))] = gv
+    assert not np.isnan(gamma_grid).any()
+    x_got, h_got = orc.sample_chain(sd, ocfg, T, nm, em, None, raws, gamma_grid=torch.from_numpy(gamma_grid),
+                                    norm_values=norm_values, norm_biases=norm_biases)
+    x_ref = np.zeros((B, N, 3), np.float32)
+    h_ref = np.zeros((B, N, 8), np.float32)
+    for b, r in enumerate(res):
+        x_ref[b, :n_list[b]] = r["x"].numpy()
+        h_ref[b, :n_list[b]] = r["h"].numpy()
+    nmf = nm.float().numpy()
+    check(f"{name} chain x", x_got.numpy() * nmf, x_ref, tol=2e-5)
+    check(f"{name} chain h", h_got.numpy(), h_ref, tol=2e-5)
+    out = dict(n_list=np.array(n_list), chain_x=x_ref, chain_h=h_ref, T_chain=T, gamma_grid=gamma_grid,
+               raw_x=np.stack([r[0].numpy() for r in raws]), raw_h=np.stack([r[1].numpy() for r in raws]),
+               norm_values=np.array(norm_values, np.float32), norm_biases=np.array([0.0 if v is None else v for v in norm_biases], np.float32),
+               hidden_nf=hidden_nf, n_layers=n_layers, weight_seed=seed, coord_gain=coord_gain)
+    # ---- (b) nll on raw data, evaluation and training mode
+    model.T = T_full
+    g = torch.Generator().manual_seed(seed + 300)
+    x = torch.randn(B, N, 3, generator=g) * nm * norm_values[0]
+    x = x - (x.sum(1, keepdim=True) / nm.sum(1, keepdim=True)) * nm
+    h_int = torch.randint(0, 5, (B, N, 5), generator=g).float()
+    h = torch.cat([h_int, torch.randn(B, N, 3, generator=g)], dim=2) * nm
+    out.update(x=x.numpy(), h=h.numpy(), T=T_full)
+    for training in (False, True):
+        model.train(training)
+        draws, tdraw = [], []
+        orig = model.sample_combined_position_feature_noise
+
+        def recording(**kw):
+            z = orig(**kw)
+            draws.append(z.clone())
+            return z
+        model.sample_combined_position_feature_noise = recording
+        real_randint = torch.randint
+
+        def rec_randint(*a, **k):
+            t = torch.tensor([0, 1, 500, 1000, 37][:B]).view(B, 1) if training else real_randint(*a, **k)
+            tdraw.append(t.clone())
+            return t.clone()
+        torch.randint = rec_randint
+        torch.manual_seed(seed + 301)
+        try:
+            with torch.no_grad():
+                loss = model.nll(x, h, nm, em.view(B, N * N), None)
+        finally:
+            torch.randint = real_randint
+            model.sample_combined_position_feature_noise = orig
+        t_int = tdraw[0].view(B, 1)
+        with torch.no_grad():
+            gam = {"gamma_s": model.gamma((t_int - 1) / model.T), "gamma_t": model.gamma(t_int / model.T),
+                   "gamma_0": model.gamma(torch.zeros(B, 1)), "gamma_T": model.gamma(torch.ones(B, 1))}
+            got, _ = orc.nll_forward(sd, ocfg, model.T, x, h, nm, em, None, t_int, draws[0], draws[1] if not training else None,
+                                     training=training, gammas=gam, norm_values=norm_values, norm_biases=norm_biases)
+        tag = "train" if training else "eval"
+        check(f"{name} nll {tag}", got.numpy(), loss.numpy(), tol=5e-6)
+        out.update({f"{tag}_t_int": t_int.numpy(), f"{tag}_eps": draws[0].numpy(), f"{tag}_nll": loss.numpy(),
+                    **{f"{tag}_{k}": v.numpy() for k, v in gam.items()}})
+        if not training:
+            out["eval_eps0"] = draws[1].numpy()
+    model.eval()
     save(name, **out)
 
 
@@ -743,6 +843,8 @@ def main():
     run(fixture_poly2_l2, "f12_poly2_l2_h32_l2", 32, 2, 16, 6, [7, 3, 8, 5, 6])
     run(fixture_elem, "f13_elem_h64_l2", 64, 2, 17, 3, [6, 9, 4, 7])
     run(fixture_pocket_loss, "f14_pocket_loss_h64_l2", 64, 2, 18, [7, 4, 6, 5], [9, 12, 5, 12])
+    # round 3: non-unit norm_values / norm_biases
+    run(fixture_norm, "f20_norm_h64_l2", 64, 2, 24, 1.0, 3, [9, 4, 7, 6, 8], (2.0, 4.0, 10.0), (None, 1.5, 0.5))
     # round 3: aggregation_method = 'mean'
     run(fixture_forward_mean, "f19_mean_h64_l2", [9, 1, 4, 7, 2, 6], 64, 2, 21, 1.0, n_max=11)
     run(fixture_forward_mean, "f19_mean_h256_l3", [8, 5, 3, 7], 256, 3, 22, 1.0)

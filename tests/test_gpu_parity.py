@@ -673,6 +673,46 @@ def test_nll_forward_golden(name, precision):
     assert torch.isfinite(a).all() and torch.equal(a, b)
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_norm_values_chain_and_nll_golden(precision):
+    """F20: non-unit norm_values / norm_biases - `unnormalize` behind the library's decode kernel (sampling chain with the reference's
+    noise and schedule values replayed) and `nll` on raw data in evaluation and training mode."""
+    from hierdiff_amd import DiffusionQM9, default_config
+    fx = load("f20_norm_h64_l2")
+    sd_np, _, _ = fixture_model(fx)
+    nv = [float(v) for v in fx["norm_values"]]
+    nb = [None] + [float(v) for v in fx["norm_biases"][1:]]
+    n_list = [int(v) for v in fx["n_list"]]
+    nm, em = orc.canonical_masks(n_list)
+
+    def build(T):
+        cfg = default_config(hidden_nf=int(fx["hidden_nf"]), n_layers=int(fx["n_layers"]), timesteps=T)
+        cfg.norm_values, cfg.norm_biases = nv, nb
+        m = DiffusionQM9(cfg)
+        m.load_state_dict({k: torch.from_numpy(np.asarray(v).copy()) for k, v in sd_np.items()})
+        m.dynamics.precision = precision
+        return m.to(DEV)
+    T = int(fx["T_chain"])
+    model = build(T)
+    model.schedule_gammas = fx["gamma_grid"]
+    raws = [(torch.from_numpy(fx["raw_x"][i]), torch.from_numpy(fx["raw_h"][i])) for i in range(T + 2)]
+    x, h = model.sample_from_masks(nm.to(DEV), em.to(DEV), None, raw_noises=raws)
+    nmf = nm.float().numpy()
+    tol = 1e-3 if precision == "bf16x3" else 1e-4           # three chained steps of an untrained net amplify the per-forward error
+    assert_parity(x.cpu().numpy() * nmf, fx["chain_x"], "F20 chain x", tol, 10 * tol)
+    assert_parity(h.cpu().numpy(), fx["chain_h"], "F20 chain h", tol, 10 * tol)
+    model = build(int(fx["T"]))
+    xr, hr = torch.from_numpy(fx["x"]).to(DEV), torch.from_numpy(fx["h"]).to(DEV)
+    for tag, training in (("eval", False), ("train", True)):
+        model.train(training)
+        gam = {k: fx[f"{tag}_{k}"] for k in ("gamma_s", "gamma_t", "gamma_0", "gamma_T")}
+        replay = dict(t_int=fx[f"{tag}_t_int"], eps=fx[f"{tag}_eps"], gammas=gam)
+        if not training:
+            replay["eps0"] = fx["eval_eps0"]
+        loss = model.nll(xr, hr, nm.to(DEV), em.to(DEV), None, **replay)
+        np.testing.assert_allclose(loss.cpu().numpy(), fx[f"{tag}_nll"], rtol=1e-4, atol=1e-3)
+
+
 def test_c_abi_error_codes_and_messages():
     """Error behaviour of the boundary (include/hierdiff_hip.h): negative codes + hd_last_error(), no aborts;
     the Python mirror turns them into HierDiffHipError / ValueError."""

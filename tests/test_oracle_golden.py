@@ -286,3 +286,32 @@ def test_long_chain_schedule_deviation_end_to_end():
     rx, rh = rel_l2(x.numpy() * nmf, fx["x"]), rel_l2(h.numpy(), fx["h"])
     print(f"end of the T=1000 trajectory, float64 schedule table vs the reference's fp32 one: x {rx:.2e} h {rh:.2e}")
     assert rx < 1e-2 and rh < 1e-2
+
+
+def test_norm_values_chain_and_nll_match_reference():
+    """F20: non-unit norm_values / norm_biases (EDM-style data scaling; [1,1,1] / [None,0,0] in production) - the final `unnormalize` of a
+    sampling chain and the value of `nll` on raw data (normalize, integer-feature scale, volume term), evaluation and training mode."""
+    fx = load("f20_norm_h64_l2")
+    _, sd, cfg = fixture_model(fx)
+    nv = [float(v) for v in fx["norm_values"]]
+    nb = [None] + [float(v) for v in fx["norm_biases"][1:]]
+    n_list = [int(v) for v in fx["n_list"]]
+    nm, em = orc.canonical_masks(n_list)
+    T = int(fx["T_chain"])
+    raws = [(torch.from_numpy(fx["raw_x"][i]), torch.from_numpy(fx["raw_h"][i])) for i in range(T + 2)]
+    with torch.no_grad():
+        x, h = orc.sample_chain(sd, cfg, T, nm, em, None, raws, gamma_grid=torch.from_numpy(fx["gamma_grid"]), norm_values=nv,
+                                norm_biases=nb)
+        x1, h1 = orc.sample_chain(sd, cfg, T, nm, em, None, raws, gamma_grid=torch.from_numpy(fx["gamma_grid"]))
+    nmf = nm.float().numpy()
+    assert_parity(x.numpy() * nmf, fx["chain_x"], "F20 chain x", 2e-5, 2e-4)
+    assert_parity(h.numpy(), fx["chain_h"], "F20 chain h", 2e-5, 2e-4)
+    assert rel_l2(x1.numpy() * nmf, fx["chain_x"]) > 0.1           # the unit values must not reproduce it
+    for tag, training in (("eval", False), ("train", True)):
+        gam = {k: torch.from_numpy(fx[f"{tag}_{k}"]) for k in ("gamma_s", "gamma_t", "gamma_0", "gamma_T")}
+        with torch.no_grad():
+            got, _ = orc.nll_forward(sd, cfg, int(fx["T"]), fx["x"], fx["h"], nm, em, None, fx[f"{tag}_t_int"], fx[f"{tag}_eps"],
+                                     fx["eval_eps0"] if not training else None, training=training, gammas=gam, norm_values=nv,
+                                     norm_biases=nb)
+        np.testing.assert_allclose(got.numpy(), fx[f"{tag}_nll"], rtol=5e-6, atol=1e-4)
+
