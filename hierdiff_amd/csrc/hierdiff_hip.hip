@@ -853,7 +853,9 @@ static void launch_gemm(int epi, bool cat, const GemmArgs& g, hipStream_t s) {
     const int nrt = (g.M + 32 * WM - 1) / (32 * WM), nct = g.Nc / (32 * WN * CN);
     dim3 grid(8 * ((nrt + 7) / 8) * nct);
     dim3 block(WM * WN * 64);
-    if (cat && epi == EPI_BIAS) hipLaunchKernelGGL((k_gemm<WM, WN, CN, EPI_BIAS, true>), grid, block, 0, s, g);
+    if (cat && epi == EPI_RANK1_SILU) hipLaunchKernelGGL((k_gemm<WM, WN, CN, EPI_RANK1_SILU, true>), grid, block, 0, s, g);
+    else if (epi == EPI_BIAS_MASK) hipLaunchKernelGGL((k_gemm<WM, WN, CN, EPI_BIAS_MASK, false>), grid, block, 0, s, g);
+    else if (cat && epi == EPI_BIAS) hipLaunchKernelGGL((k_gemm<WM, WN, CN, EPI_BIAS, true>), grid, block, 0, s, g);
     else if (cat) hipLaunchKernelGGL((k_gemm<WM, WN, CN, EPI_BIAS_SILU, true>), grid, block, 0, s, g);
     else if (epi == EPI_BIAS_SILU) hipLaunchKernelGGL((k_gemm<WM, WN, CN, EPI_BIAS_SILU, false>), grid, block, 0, s, g);
     else if (epi == EPI_BIAS) hipLaunchKernelGGL((k_gemm<WM, WN, CN, EPI_BIAS, false>), grid, block, 0, s, g);
@@ -1414,6 +1416,7 @@ extern "C" int hd_edge_layer_backward(hd_handle* h, hd_topology* t, int coord, c
     a.Wimg = t->w2timg;
     launch_edge_bwd(h, coord != 0, 1, a, t->n_wg, s);
     CsrSumArgs cs;
+    std::memset(&cs, 0, sizeof(cs));
     cs.G = G1; cs.out = dAB; cs.M = M; cs.H = H; cs.ldo = 2 * H;
     const long long total = (long long)M * (H / 4);
     cs.ptr = t->rptr; cs.rows = t->rrows; cs.col0 = 0;
@@ -1611,7 +1614,8 @@ extern "C" int hd_egcl_graph_create(hd_egcl* g, const int* row, const int* col, 
         const size_t Mp = t->Mp, Ep = t->Ep;
         HD_TRY(zalloc(&t->hin, Mp * H)); HD_TRY(zalloc(&t->hres, Mp * H)); HD_TRY(zalloc(&t->x4, Mp * 4)); HD_TRY(zalloc(&t->AB, Mp * 2 * H));
         HD_TRY(zalloc(&t->agg, Mp * H)); HD_TRY(zalloc(&t->xagg, Mp * 4)); HD_TRY(zalloc(&t->Tn, Mp * H));
-        HD_TRY(zalloc(&t->ea, Ep * H)); HD_TRY(zalloc(&t->T1, Ep * H)); HD_TRY(zalloc(&t->P, Ep * H)); HD_TRY(zalloc(&t->M1, Ep * H));
+        HD_TRY(zalloc(&t->T1, Ep * H));         // (t->ea: the caller's edge_attr is read in place since round 3)
+        HD_TRY(zalloc(&t->P, Ep * H)); HD_TRY(zalloc(&t->M1, Ep * H));
         HD_TRY(zalloc(&t->C1, Ep * H)); HD_TRY(zalloc(&t->geo, Ep * 4)); HD_TRY(zalloc(&t->trans, Ep * 4));
         std::vector<float> ones(Mp, 1.0f);
         HD_TRY(dev_upload(&t->ones, ones));
@@ -1660,8 +1664,7 @@ extern "C" int hd_egcl_forward(hd_egcl* g, hd_egcl_graph* t, const float* h, con
     egcl_gemm(g, EPI_BIAS, false, gemm_args(t->hin, H, H, H, nullptr, g->ab_img, g->ab_bias, t->AB, 2 * H, M, 2 * H, nullptr), s);
     if (E > 0) {
         if (wide) {
-            HIP_TRY(hipMemcpyAsync(t->ea, edge_attr, (size_t)E * H * sizeof(float), hipMemcpyDeviceToDevice, s));
-            egcl_gemm(g, EPI_BIAS, false, gemm_args(t->ea, H, H, H, nullptr, g->w1e_img, g->zero_bias, t->T1, H, E, H, nullptr), s);
+            egcl_gemm(g, EPI_BIAS, false, gemm_args(edge_attr, H, H, H, nullptr, g->w1e_img, g->zero_bias, t->T1, H, E, H, nullptr), s);
         }
         {
             EgclPreArgs a;
@@ -1688,13 +1691,11 @@ extern "C" int hd_egcl_forward(hd_egcl* g, hd_egcl_graph* t, const float* h, con
     }
     {   // sums over incoming edges (receiving index = col), ascending edge order
         CsrSumArgs cs;
+        std::memset(&cs, 0, sizeof(cs));
         cs.ptr = t->cptr; cs.rows = t->crows; cs.M = M; cs.col0 = 0;
         cs.G = t->M1; cs.out = t->agg; cs.H = H; cs.ldo = H;
-        hipLaunchKernelGGL(k_csr_sum, blocks((long long)M * (H / 4)), dim3(256), 0, s, cs);
-        if (c.coord_update) {
-            cs.G = t->trans; cs.out = t->xagg; cs.H = 4; cs.ldo = 4;
-            hipLaunchKernelGGL(k_csr_sum, blocks((long long)M), dim3(256), 0, s, cs);
-        }
+        cs.G2 = c.coord_update ? t->trans : nullptr; cs.out2 = t->xagg;      // the [E][4] translations in the same launch
+        hipLaunchKernelGGL(k_csr_sum, blocks((long long)M * (H / 4 + (c.coord_update ? 1 : 0))), dim3(256), 0, s, cs);
     }
     // node model: h_new = (h + node_mlp([h | agg])) (* node_mask)
     const float* nm = node_mask ? node_mask : t->ones;
@@ -1703,16 +1704,13 @@ extern "C" int hd_egcl_forward(hd_egcl* g, hd_egcl_graph* t, const float* h, con
     egcl_gemm(g, EPI_RESID_MASK, false, gemm_args(t->Tn, H, H, H, nullptr, g->wn2_img, g->bn2, t->hres, H, M, H, nm), s);
     if (c.edge_update && E > 0) {
         // edge_mlp: E1 = SiLU([edge_feat | edge_attr] We1^T + radial w_er + be1);  edge_attr' = (E1 We2^T + be2) * edge_mask
-        egcl_gemm(g, EPI_BIAS, true, gemm_args(t->M1, H, H, 2 * H, t->ea, g->we1_img, g->be1, t->C1, H, E, H, nullptr), s);
-        EgclEwArgs a;
-        a.X = t->C1; a.w = W + g->w_er; a.geo = t->geo; a.emask = nullptr; a.E = E; a.H = H;
-        hipLaunchKernelGGL((k_egcl_ew<0>), blocks((long long)E * (H / 4)), dim3(256), 0, s, a);
-        egcl_gemm(g, EPI_BIAS, false, gemm_args(t->C1, H, H, H, nullptr, g->we2_img, g->be2, t->P, H, E, H, nullptr), s);
-        if (edge_mask) {
-            a.X = t->P; a.emask = edge_mask;
-            hipLaunchKernelGGL((k_egcl_ew<1>), blocks((long long)E * (H / 4)), dim3(256), 0, s, a);
-        }
-        HIP_TRY(hipMemcpyAsync(edge_attr_out, t->P, (size_t)E * H * sizeof(float), hipMemcpyDeviceToDevice, s));
+        // (round 3: the radial column + SiLU and the final mask ride in the GEMM epilogues, and the second GEMM writes the caller's
+        // tensor - rows >= E are never stored: four stream operations less per layer, same expressions element by element)
+        GemmArgs e1 = gemm_args(t->M1, H, H, 2 * H, edge_attr, g->we1_img, g->be1, t->C1, H, E, H, nullptr);
+        e1.rowv = t->geo + 3; e1.rowv_stride = 4; e1.colv = W + g->w_er;
+        egcl_gemm(g, EPI_RANK1_SILU, true, e1, s);
+        egcl_gemm(g, edge_mask ? EPI_BIAS_MASK : EPI_BIAS, false,
+                  gemm_args(t->C1, H, H, H, nullptr, g->we2_img, g->be2, edge_attr_out, H, E, H, edge_mask), s);
     }
     {
         EgclNodeOutArgs a;

@@ -411,14 +411,21 @@ struct CsrSumArgs {
     const int* rows;        // [E]
     float* out;             // [M_pad][ldo]
     int M, H, ldo, col0;
+    const float* G2;        // optional second operand [E_pad][4] (stage 2: the per-edge translations), summed by one more
+    float* out2;            // thread per node into [M_pad][4]; NULL = not present
 };
 
 __global__ void k_csr_sum(CsrSumArgs a) {
-    const int q = a.H >> 2;
+    const int q = a.H >> 2, qt = q + (a.G2 ? 1 : 0);
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const int i = idx / q, c4 = idx - i * q;
+    const int i = idx / qt, c4 = idx - i * qt;
     if (i >= a.M) return;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (c4 == q) {
+        for (int p = a.ptr[i]; p < a.ptr[i + 1]; ++p) v += *reinterpret_cast<const f32x4*>(a.G2 + (size_t)a.rows[p] * 4);
+        *reinterpret_cast<f32x4*>(a.out2 + (size_t)i * 4) = v;
+        return;
+    }
     for (int p = a.ptr[i]; p < a.ptr[i + 1]; ++p) v += *reinterpret_cast<const f32x4*>(a.G + (size_t)a.rows[p] * a.H + 4 * c4);
     *reinterpret_cast<f32x4*>(a.out + (size_t)i * a.ldo + a.col0 + 4 * c4) = v;
 }

@@ -57,16 +57,21 @@ __global__ void k_node_init(InitArgs a) {
 // The K index inside a chunk is permuted (lane half h owns k = 16h..16h+15) so that both
 // operands are fetched with one ds_read_b128 per four MFMAs; weights are pre-packed in that image.
 
-enum { EPI_BIAS = 0, EPI_BIAS_SILU = 1, EPI_RESID_MASK = 2 };
+enum { EPI_BIAS = 0, EPI_BIAS_SILU = 1, EPI_RESID_MASK = 2,
+       EPI_BIAS_MASK = 3,        // (acc + bias) * nmask[row]                                   (stage 2: new edge attributes * edge_mask)
+       EPI_RANK1_SILU = 4 };     // silu(rowv[row * rowv_stride] * colv[col] + (acc + bias))    (stage 2: the radial column of edge_mlp.0)
 
 struct GemmArgs {
     const float* A;       // [M_pad][lda], columns k < K1
     const float* A2;      // CAT: [M_pad][K - K1], columns k >= K1 (the aggregated neighbour messages)
     const float* Bimg;    // packed weight image
     const float* bias;    // [Nc]
-    const float* nmask;   // [M_pad] (EPI_RESID_MASK)
+    const float* nmask;   // [M_pad] (EPI_RESID_MASK, EPI_BIAS_MASK)
     float* C;             // [M_pad][ldc]
     int lda, ldc, K1, K, M, Nc;
+    const float* rowv;    // EPI_RANK1_SILU: per-row scalar at rowv[row * rowv_stride] ...
+    const float* colv;    // ... times the per-column vector colv[Nc]
+    int rowv_stride;
 };
 
 
@@ -121,6 +126,7 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm(GemmArgs g) {
             int idx = tid + u * NT;
             int r = idx >> 3, sg = idx & 7;
             int row = row0 + r;
+            if (row >= g.M) row = g.M - 1;          // rows past the end are never stored: read a valid one (A may be the caller's tensor)
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (!CAT || k0 < g.K1) v = *reinterpret_cast<const f32x4*>(g.A + (size_t)row * g.lda + k0 + 4 * sg);
             else v = *reinterpret_cast<const f32x4*>(g.A2 + (size_t)row * (g.K - g.K1) + (k0 - g.K1) + 4 * sg);
@@ -209,6 +215,13 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm(GemmArgs g) {
                 for (int j = 0; j < 4; ++j) v[j] = silu_f(v[j]);
             }
             if (EPI == EPI_RESID_MASK) v = (*dst + v) * g.nmask[row];
+            if (EPI == EPI_BIAS_MASK) v = v * g.nmask[row];
+            if (EPI == EPI_RANK1_SILU) {            // k_egcl_ew<0>'s expression, element by element
+                const float rv = g.rowv[(size_t)row * g.rowv_stride];
+                const f32x4 cw = *reinterpret_cast<const f32x4*>(g.colv + col);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = silu_f(__builtin_fmaf(rv, cw[j], v[j]));
+            }
             *dst = v;
         }
     }
