@@ -577,7 +577,7 @@ def test_randomised_parity_sweep():
     script: profiles/r03_fuzz_parity.log)."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    proc = subprocess.run([sys.executable, os.path.join(root, "scratch", "fuzz_parity.py"), "48", "5"], cwd=root,
+    proc = subprocess.run([sys.executable, os.path.join(root, "scratch", "fuzz_parity.py"), "32", "5"], cwd=root,
                           capture_output=True, text=True, timeout=600)
     lines = proc.stdout.splitlines()
     tail = "\n".join(lines[-6:])

@@ -337,7 +337,7 @@ def test_randomised_gradient_sweep():
     script: profiles/r03_fuzz_parity.log)."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    proc = subprocess.run([sys.executable, os.path.join(root, "scratch", "fuzz_grads.py"), "24", "9"], cwd=root,
+    proc = subprocess.run([sys.executable, os.path.join(root, "scratch", "fuzz_grads.py"), "16", "9"], cwd=root,
                           capture_output=True, text=True, timeout=600)
     tail = "\n".join(proc.stdout.splitlines()[-4:])
     assert proc.returncode == 0, tail + proc.stderr[-2000:]

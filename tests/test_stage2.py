@@ -123,7 +123,7 @@ def test_randomised_layer_sweep():
     script: profiles/r03_fuzz_parity.log)."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    proc = subprocess.run([sys.executable, os.path.join(root, "scratch", "fuzz_stage2.py"), "60", "21"], cwd=root,
+    proc = subprocess.run([sys.executable, os.path.join(root, "scratch", "fuzz_stage2.py"), "40", "21"], cwd=root,
                           capture_output=True, text=True, timeout=600)
     tail = "\n".join(proc.stdout.splitlines()[-4:])
     assert proc.returncode == 0, tail + proc.stderr[-2000:]
