@@ -572,12 +572,12 @@ def test_merged_sample_batches_equal_the_loop(precision):
 
 
 def test_randomised_parity_sweep():
-    """The wide net next to the fixed cases: scratch/fuzz_parity.py - random model shapes / options / batch compositions / edge masks
+    """The wide net next to the fixed cases: tests/fuzz_parity.py - random model shapes / options / batch compositions / edge masks
     for the forward (all three precision modes) and short sampling chains, against the CPU oracle (a 400 + 100 case run of the same
     script: profiles/r03_fuzz_parity.log)."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    proc = subprocess.run([sys.executable, os.path.join(root, "scratch", "fuzz_parity.py"), "32", "5"], cwd=root,
+    proc = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_parity.py"), "32", "5"], cwd=root,
                           capture_output=True, text=True, timeout=600)
     lines = proc.stdout.splitlines()
     tail = "\n".join(lines[-6:])

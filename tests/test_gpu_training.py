@@ -333,11 +333,11 @@ def test_colsum_f32_matches_a_float64_column_sum_and_is_deterministic():
 
 
 def test_randomised_gradient_sweep():
-    """The wide net next to the fixed cases: scratch/fuzz_grads.py on random shapes / options / masks (a 120-case run of the same
+    """The wide net next to the fixed cases: tests/fuzz_grads.py on random shapes / options / masks (a 120-case run of the same
     script: profiles/r03_fuzz_parity.log)."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    proc = subprocess.run([sys.executable, os.path.join(root, "scratch", "fuzz_grads.py"), "16", "9"], cwd=root,
+    proc = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_grads.py"), "16", "9"], cwd=root,
                           capture_output=True, text=True, timeout=600)
     tail = "\n".join(proc.stdout.splitlines()[-4:])
     assert proc.returncode == 0, tail + proc.stderr[-2000:]

@@ -119,11 +119,11 @@ def test_hip_stack_vs_oracle_beam_sized():
 
 @pytest.mark.gpu
 def test_randomised_layer_sweep():
-    """scratch/fuzz_stage2.py: random graphs / widths / options of the stage-2 layer against the oracle (a 300-case run of the same
+    """tests/fuzz_stage2.py: random graphs / widths / options of the stage-2 layer against the oracle (a 300-case run of the same
     script: profiles/r03_fuzz_parity.log)."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    proc = subprocess.run([sys.executable, os.path.join(root, "scratch", "fuzz_stage2.py"), "40", "21"], cwd=root,
+    proc = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_stage2.py"), "40", "21"], cwd=root,
                           capture_output=True, text=True, timeout=600)
     tail = "\n".join(proc.stdout.splitlines()[-4:])
     assert proc.returncode == 0, tail + proc.stderr[-2000:]
