@@ -1,0 +1,67 @@
+"""The data-parallel optimisation step around `DiffusionQM9.training_step`, without Lightning.
+
+What the reference's trainer does per batch (`endiffusion/conf/trainer/default.yaml`: strategy ddp, gradient_clip_val 2,
+gradient_clip_algorithm norm, accumulate_grad_batches 1; `conf/optim/adamw.yaml`: AdamW lr 4e-4, weight_decay 4e-8;
+`conf/scheduler/step.yaml`: StepLR step_size 15, gamma 0.1, stepped once per epoch; `train_module/diffusion_qm9.py:774-777`):
+
+    loss = model.training_step(batch)      # forward + loss on this rank's shard of the batch
+    loss.backward()
+    <DDP: gradients averaged over ranks>   # here: ONE flat all-reduce (hierdiff_amd.sharding.allreduce_gradients, RCCL over xGMI)
+    clip_grad_norm_(parameters, 2.0)
+    optimizer.step()
+
+One process per GPU (`python -m torch.distributed.run --nproc-per-node N ...`); at world size 1, or without an initialised
+process group, the all-reduce is skipped.  This module holds no training loop policy beyond that step: data loading, logging and
+checkpointing stay with the caller.
+"""
+from __future__ import annotations
+
+from typing import Dict, Iterable, Optional
+
+import torch
+
+from .sharding import allreduce_gradients
+
+
+def configure_optimizers(model: torch.nn.Module, lr: float = 4.0e-4, weight_decay: float = 4.0e-8, step_size: int = 15,
+                         gamma: float = 0.1):
+    """(AdamW, StepLR) with the reference's values (conf/optim/adamw.yaml, conf/scheduler/step.yaml)."""
+    opt = torch.optim.AdamW(model.parameters(), lr=lr, weight_decay=weight_decay)
+    return opt, torch.optim.lr_scheduler.StepLR(opt, step_size=step_size, gamma=gamma)
+
+
+def _world() -> int:
+    import torch.distributed as dist
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def ddp_step(model, batch: Dict[str, torch.Tensor], optimizer: torch.optim.Optimizer, clip_val: Optional[float] = 2.0) -> Dict[str, float]:
+    """One optimisation step on this rank's batch; returns {"loss", "grad_norm"} (the norm BEFORE clipping, like Lightning's
+    track_grad_norm: 2).  Every rank must call it the same number of times (the all-reduce is collective)."""
+    model.train()
+    optimizer.zero_grad(set_to_none=True)
+    loss = model.training_step(batch, 0)
+    loss.backward()
+    if _world() > 1:
+        allreduce_gradients(model, average=True)
+    params = [p for p in model.parameters() if p.grad is not None]
+    if clip_val is not None:
+        norm = torch.nn.utils.clip_grad_norm_(params, float(clip_val))
+    else:
+        norm = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(p.grad) for p in params]))
+    optimizer.step()
+    return {"loss": float(loss.detach()), "grad_norm": float(norm)}
+
+
+def fit_epoch(model, batches: Iterable[Dict[str, torch.Tensor]], optimizer, scheduler=None, clip_val: Optional[float] = 2.0,
+              device: Optional[torch.device] = None):
+    """`ddp_step` over an iterable of reference-style batch dicts (keys positions, atom_mask, edge_mask, node_feature ...), the
+    scheduler stepped once at the end (StepLR counts epochs).  Returns the list of per-step dicts."""
+    log = []
+    for batch in batches:
+        if device is not None:
+            batch = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
+        log.append(ddp_step(model, batch, optimizer, clip_val))
+    if scheduler is not None:
+        scheduler.step()
+    return log

@@ -342,3 +342,42 @@ def test_randomised_gradient_sweep():
     tail = "\n".join(proc.stdout.splitlines()[-4:])
     assert proc.returncode == 0, tail + proc.stderr[-2000:]
     assert "failures 0" in tail, tail
+
+
+def test_trainer_ddp_step_equals_the_manual_sequence():
+    """hierdiff_amd.trainer.ddp_step on the real model (world size 1: no process group, the all-reduce is skipped): forward + backward
+    on the HIP path, clip_grad_norm_(2), AdamW with the reference's values - bit-equal to the same sequence written out."""
+    from hierdiff_amd import DiffusionQM9, default_config
+    from hierdiff_amd.trainer import configure_optimizers, ddp_step
+    from hierdiff_amd.weights import synthetic_state_dict
+    H, L, B, N = 64, 2, 6, 9
+    sd = synthetic_state_dict(9, 0, H, L, 2, True, 31, 0.5)
+    g = torch.Generator().manual_seed(2)
+    nm = torch.ones(B, N, 1, dtype=torch.bool); nm[2, 5:] = False; nm[4, 3:] = False
+    em = (nm.float() @ nm.float().transpose(1, 2)).bool() & ~torch.eye(N, dtype=torch.bool)[None]
+    x = torch.randn(B, N, 3, generator=g) * nm
+    x = x - (x.sum(1, keepdim=True) / nm.sum(1, keepdim=True)) * nm
+    h = torch.cat([torch.randint(0, 5, (B, N, 5), generator=g).float(), torch.randn(B, N, 3, generator=g)], 2) * nm
+    batch = {"positions": x.to(DEV), "atom_mask": nm.to(DEV), "edge_mask": em.to(DEV), "node_feature": h.to(DEV)}
+
+    def fresh():
+        m = DiffusionQM9(default_config(hidden_nf=H, n_layers=L))
+        m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+        return m.to(DEV).train()
+    a, b = fresh(), fresh()
+    opt_a, _ = configure_optimizers(a)
+    opt_b, _ = configure_optimizers(b)
+    for step in range(2):
+        torch.manual_seed(100 + step)                       # the loss draws t and eps from torch's generator
+        out = ddp_step(a, batch, opt_a, clip_val=2.0)
+        torch.manual_seed(100 + step)
+        opt_b.zero_grad(set_to_none=True)
+        loss = b.training_step(batch, 0)
+        loss.backward()
+        norm = torch.nn.utils.clip_grad_norm_([p for p in b.parameters() if p.grad is not None], 2.0)
+        opt_b.step()
+        assert out["loss"] == float(loss.detach()) and out["grad_norm"] == float(norm) and np.isfinite(out["loss"])
+    for (ka, pa), (kb, pb) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert ka == kb and torch.equal(pa, pb), ka
+    moved = sum(float((pa.cpu() - torch.from_numpy(sd[k])).abs().max()) > 0 for k, pa in a.state_dict().items() if k in sd and k != "buffer")
+    assert moved > 10, "the optimiser must have moved the weights"

@@ -125,3 +125,65 @@ def test_world2_gradient_allreduce(tmp_path):
         b = torch.zeros(shp) if k == 3 else torch.randn(shp, generator=gens[1])
         want = (a + b) / 2
         assert torch.allclose(r[0]["grads"][k], want, atol=1e-7) and torch.equal(r[0]["grads"][k], r[1]["grads"][k]), k
+
+
+class _ToyModel(torch.nn.Module):
+    """Stands in for DiffusionQM9 in the CPU tier (the real training_step needs a GPU): same `training_step(batch, idx) -> loss`."""
+
+    def __init__(self):
+        super().__init__()
+        self.lin = torch.nn.Linear(6, 3)
+
+    def training_step(self, batch, batch_idx=0):
+        return ((self.lin(batch["x"]) - batch["y"]) ** 2).mean()
+
+
+def _step_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hierdiff_amd.trainer import configure_optimizers, fit_epoch
+    torch.manual_seed(5)                                   # identical initial weights on every rank (what the broadcast gives)
+    model = _ToyModel()
+    opt, sched = configure_optimizers(model)
+    g = torch.Generator().manual_seed(40 + rank)          # every rank its own shard of the global batch
+    batches = [{"x": torch.randn(8, 6, generator=g) * 30, "y": torch.randn(8, 3, generator=g)} for _ in range(3)]
+    log = fit_epoch(model, batches, opt, sched, clip_val=2.0)
+    torch.save({"w": model.lin.weight.detach().clone(), "b": model.lin.bias.detach().clone(), "log": log,
+                "lr": opt.param_groups[0]["lr"]}, os.path.join(out_dir, f"s{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.autograd          # (tests run under torch.no_grad() unless marked: tests/conftest.py)
+def test_world2_ddp_step_matches_single_process_on_the_global_batch(tmp_path):
+    """hierdiff_amd.trainer: loss.backward -> one flat gradient all-reduce (mean) -> clip_grad_norm_(2) -> AdamW.step, the
+    reference trainer's per-batch sequence (conf/trainer/default.yaml, conf/optim/adamw.yaml).  Two ranks on two shards end with
+    the same weights as one process that averages the two shards' gradients itself."""
+    world, port = 2, _free_port()
+    mp.spawn(_step_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(tmp_path / f"s{k}.pt") for k in range(world)]
+    assert torch.equal(r[0]["w"], r[1]["w"]) and torch.equal(r[0]["b"], r[1]["b"])
+    assert all(a["grad_norm"] == b["grad_norm"] for a, b in zip(r[0]["log"], r[1]["log"]))     # norm of the AVERAGED gradient
+    assert max(a["grad_norm"] for a in r[0]["log"]) > 2.0, "the test must exercise the clipping"
+    # single-process restatement
+    from hierdiff_amd.trainer import configure_optimizers
+    torch.manual_seed(5)
+    model = _ToyModel()
+    opt, sched = configure_optimizers(model)
+    assert opt.defaults["lr"] == 4.0e-4 and opt.defaults["weight_decay"] == 4.0e-8 and sched.step_size == 15 and sched.gamma == 0.1
+    gens = [torch.Generator().manual_seed(40 + k) for k in range(world)]
+    for _ in range(3):
+        shards = [{"x": torch.randn(8, 6, generator=g) * 30, "y": torch.randn(8, 3, generator=g)} for g in gens]
+        opt.zero_grad(set_to_none=True)
+        grads = []
+        for sh in shards:
+            model.zero_grad(set_to_none=True)
+            model.training_step(sh).backward()
+            grads.append([p.grad.clone() for p in model.parameters()])
+        for p, ga, gb in zip(model.parameters(), *grads):
+            p.grad = (ga + gb) / 2
+        torch.nn.utils.clip_grad_norm_(list(model.parameters()), 2.0)
+        opt.step()
+    assert torch.allclose(model.lin.weight, r[0]["w"], atol=1e-7) and torch.allclose(model.lin.bias, r[0]["b"], atol=1e-7)
+    assert r[0]["lr"] == 4.0e-4                       # StepLR: unchanged after one epoch of fifteen
