@@ -69,6 +69,20 @@ class _EquivariantBlockParams(nn.Module):
         self.add_module("gcl_equiv", _EquivariantUpdateParams(hidden_nf, 2))
 
 
+class _GNNParams(nn.Module):
+    """egnn_new.py:208-231 (mode 'gnn_dynamics'): GCLs without edge attributes, outputs [velocity | h]."""
+
+    def __init__(self, in_node_nf: int, hidden_nf: int, out_node_nf: int, n_layers: int, attention: bool):
+        super().__init__()
+        self.embedding = nn.Linear(in_node_nf, hidden_nf)
+        self.embedding_out = nn.Linear(hidden_nf, out_node_nf)
+        for i in range(n_layers):
+            self.add_module("gcl_%d" % i, _GCLParams(hidden_nf, 0, attention))
+
+    def forward(self, *a, **k):
+        raise NotImplementedError("parameters only; the arithmetic lives in libhierdiff_hip.so")
+
+
 class _EGNNParams(nn.Module):
     """egnn_new.py:155-190"""
 
@@ -136,8 +150,8 @@ class EGNN_dynamics_QM9(nn.Module):
                  attention=False, condition_time=True, tanh=False, mode='egnn_dynamics', norm_constant=0,
                  inv_sublayers=2, sin_embedding=False, normalization_factor=100, aggregation_method='sum'):
         super().__init__()
-        if mode != 'egnn_dynamics':
-            raise NotImplementedError(f"mode {mode!r}: only 'egnn_dynamics' is on the sampling hot path")
+        if mode not in ('egnn_dynamics', 'gnn_dynamics'):
+            raise Exception("Wrong mode %s" % mode)                  # en_dynamics.py:96-97
         if sin_embedding:
             raise NotImplementedError("sin_embedding=True is config-off in the reference (ddpmgblur.yaml:35)")
         if aggregation_method not in ('sum', 'mean'):
@@ -149,6 +163,10 @@ class EGNN_dynamics_QM9(nn.Module):
         if hidden_nf not in (32, 64, 128, 256):
             raise NotImplementedError("hidden_nf must be one of 32, 64, 128, 256")
         self.mode = mode
+        if mode == 'gnn_dynamics':
+            self._init_gnn(in_node_nf, context_node_nf, n_dims, hidden_nf, n_layers, attention, condition_time,
+                           normalization_factor, aggregation_method)
+            return
         self.egnn = _EGNNParams(in_node_nf + context_node_nf, hidden_nf, n_layers, inv_sublayers, bool(attention))
         self.in_node_nf = in_node_nf
         self.context_node_nf = context_node_nf
@@ -171,9 +189,84 @@ class EGNN_dynamics_QM9(nn.Module):
         self.debug_checks = False
         self.differentiable: Optional[bool] = None      # None: by rule (_wants_autograd)
 
+    # ------------------------------------------------------------------ mode 'gnn_dynamics' (en_dynamics.py:24-29, 91-94)
+    # The non-equivariant variant: GNN (egnn_new.py:208-242) over the node inputs [x | h | t], GCLs without edge attributes, the
+    # first three output columns are the velocity.  The reference calls it WITHOUT an edge mask (en_dynamics.py:93), so the
+    # messages run over all N x N pairs of a molecule - self pairs and padded nodes included - and only the rows are masked.
+    # It runs on the same kernels: an internal egnn-mode engine with ONE block of n_layers GCLs, the coordinates fed as features
+    # (its own coordinates are zero, so the two distance columns it adds to the first edge Linear - zero weights - and its
+    # coordinate layer - zero weights - contribute exact zeros), an all-ones edge mask (which makes every node of the batch an
+    # active node of the layout while the row mask stays the node mask), and the engine's output columns read as
+    # [unused | velocity | h].  Inference only: the sampler loop of the library and the training path are egnn_dynamics'.
+    def _init_gnn(self, in_node_nf, context_node_nf, n_dims, hidden_nf, n_layers, attention, condition_time, normalization_factor,
+                  aggregation_method):
+        if context_node_nf:
+            raise NotImplementedError("mode 'gnn_dynamics' with context: the reference strips context columns its GNN never "
+                                      "produced (en_dynamics.py:28, 99-101) and returns a tensor of the wrong width")
+        self.gnn = _GNNParams(in_node_nf + context_node_nf + 3, hidden_nf, 3 + in_node_nf, n_layers, bool(attention))
+        self.in_node_nf, self.context_node_nf, self.n_dims, self.condition_time = in_node_nf, context_node_nf, n_dims, condition_time
+        self.aggregation_method = aggregation_method
+        self._edges_dict = {}
+        self.debug_checks = False
+        self.differentiable = None
+        self._hd, self._handle_gen, self._weights_key, self._topo_cache, self._topo_by_content = None, 0, None, {}, {}
+        engine = EGNN_dynamics_QM9(in_node_nf + 3, 0, n_dims, hidden_nf=hidden_nf, n_layers=1, attention=attention,
+                                   condition_time=condition_time, tanh=False, norm_constant=1, inv_sublayers=n_layers,
+                                   normalization_factor=normalization_factor, aggregation_method=aggregation_method)
+        for p in engine.parameters():
+            p.requires_grad_(False)
+        object.__setattr__(self, "_engine", engine)          # not a submodule: its tensors are derived, not part of the state_dict
+        self._engine_key = None
+
+    def _sync_gnn_engine(self):
+        key = tuple((p.data_ptr(), p._version) for p in self.gnn.parameters())
+        if key == self._engine_key:
+            return
+        eg, gn = self._engine.egnn, self.gnn
+        H = gn.embedding.weight.shape[0]
+        with torch.no_grad():
+            eg.embedding.weight.copy_(gn.embedding.weight); eg.embedding.bias.copy_(gn.embedding.bias)
+            eg.embedding_out.weight.copy_(gn.embedding_out.weight); eg.embedding_out.bias.copy_(gn.embedding_out.bias)
+            blk = eg.e_block_0
+            for i in range(len([k for k in gn._modules if k.startswith("gcl_")])):
+                src, dst = getattr(gn, f"gcl_{i}"), getattr(blk, f"gcl_{i}")
+                dst.edge_mlp[0].weight.zero_()
+                dst.edge_mlp[0].weight[:, :2 * H].copy_(src.edge_mlp[0].weight)     # the two distance columns stay zero
+                dst.edge_mlp[0].bias.copy_(src.edge_mlp[0].bias)
+                for a, b in ((dst.edge_mlp[2], src.edge_mlp[2]), (dst.node_mlp[0], src.node_mlp[0]), (dst.node_mlp[2], src.node_mlp[2])):
+                    a.weight.copy_(b.weight); a.bias.copy_(b.bias)
+                if hasattr(src, "att_mlp"):
+                    dst.att_mlp[0].weight.copy_(src.att_mlp[0].weight); dst.att_mlp[0].bias.copy_(src.att_mlp[0].bias)
+            for p in blk.gcl_equiv.parameters():
+                p.zero_()
+        self._engine_key = key
+
+    def _forward_gnn(self, t, xh, node_mask, edge_mask, context):
+        if torch.is_grad_enabled() and (xh.requires_grad or (self.training and any(p.requires_grad for p in self.gnn.parameters()))) \
+                and self.differentiable is not False:
+            raise NotImplementedError("mode 'gnn_dynamics' is inference only here: call it under torch.no_grad() / model.eval()")
+        bs, n_nodes, dims = xh.shape
+        if dims - self.n_dims != self.in_node_nf - (1 if self.condition_time else 0):
+            raise ValueError(f"xh has {dims - self.n_dims} feature columns, model expects "
+                             f"{self.in_node_nf - (1 if self.condition_time else 0)}")
+        self._sync_gnn_engine()
+        nm = node_mask.reshape(bs, n_nodes, 1)
+        with torch.no_grad():
+            xh_m = xh.detach().to(torch.float32) * nm.to(torch.float32)
+            feed = torch.cat([torch.zeros_like(xh_m[:, :, :self.n_dims]), xh_m], dim=2)        # [coordinates = 0 | x | h]
+            all_pairs = torch.ones((bs, n_nodes, n_nodes), dtype=torch.bool, device=xh.device)
+            out = self._engine._forward(t, feed, nm, all_pairs, None, None)
+            vel, h_final = out[:, :, self.n_dims:2 * self.n_dims], out[:, :, 2 * self.n_dims:]
+            vel = torch.where(torch.isnan(vel).any(), torch.zeros_like(vel), vel)              # en_dynamics.py:109-111, no host sync
+            nmf = nm.to(torch.float32)
+            vel = vel - (vel.sum(1, keepdim=True) / nmf.sum(1, keepdim=True)) * nmf            # remove_mean_with_mask (:116)
+            return torch.cat([vel, h_final], dim=2)
+
     # ------------------------------------------------------------------ precision of the matrix-core path
     @property
     def precision(self) -> str:
+        if self.mode == 'gnn_dynamics':
+            return self._engine.precision
         return {v: k for k, v in PRECISIONS.items()}[self._cfg.precision]
 
     @precision.setter
@@ -184,6 +277,9 @@ class EGNN_dynamics_QM9(nn.Module):
         rounding of the fp32 accumulation, everything else as in "fp32"."""
         if name not in PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(PRECISIONS)}")
+        if self.mode == 'gnn_dynamics':
+            self._engine.precision = name
+            return
         if PRECISIONS[name] != self._cfg.precision:
             self._release()
             self._cfg.precision = PRECISIONS[name]
@@ -202,9 +298,12 @@ class EGNN_dynamics_QM9(nn.Module):
 
     # ------------------------------------------------------------------ handle / weights
     def _device(self) -> torch.device:
-        return self.egnn.embedding.weight.device
+        return (self.gnn if self.mode == 'gnn_dynamics' else self.egnn).embedding.weight.device
 
     def _handle(self) -> C.c_void_p:
+        if self.mode == 'gnn_dynamics':
+            raise NotImplementedError("mode 'gnn_dynamics': only `_forward` runs on the library (the sampler loop and the training "
+                                      "path are egnn_dynamics')")
         dev = self._device()
         if dev.type != "cuda":
             raise HierDiffHipError("EGNN_dynamics_QM9 runs only on an MI355X: move the module to a cuda device "
@@ -287,6 +386,8 @@ class EGNN_dynamics_QM9(nn.Module):
         it is the inference path (hd_egnn_forward)."""
         if xh.device.type != "cuda":
             raise HierDiffHipError("EGNN_dynamics_QM9._forward needs cuda tensors (no CPU fallback)")
+        if self.mode == 'gnn_dynamics':
+            return self._forward_gnn(t, xh, node_mask, edge_mask, context)
         if self._wants_autograd(xh):
             from .training import dynamics_forward_train
             return dynamics_forward_train(self, t, xh, node_mask, edge_mask, context, mol_shape)
@@ -349,6 +450,9 @@ class EGNN_dynamics_QM9(nn.Module):
     def _apply(self, fn, *a, **k):
         # .to()/.cuda() replace parameter storage: force a re-pack on the next call
         self._weights_key = None
+        if self.mode == 'gnn_dynamics':
+            self._engine._apply(fn, *a, **k)
+            self._engine_key = None
         return super()._apply(fn, *a, **k)
 
     def load_numpy_state_dict(self, sd: Dict[str, np.ndarray], prefix: str = "") -> None:

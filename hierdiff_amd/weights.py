@@ -103,6 +103,44 @@ def synthetic_dynamics_state_dict(in_node_nf: int, context_node_nf: int, hidden_
     return out
 
 
+def gnn_param_shapes(in_node_nf: int, context_node_nf: int, hidden_nf: int, n_layers: int,
+                     attention: bool = False) -> "OrderedDict[str, Tuple[int, ...]]":
+    """Ordered (name -> shape) of EGNN_dynamics_QM9's parameters in mode 'gnn_dynamics' (en_dynamics.py:24-29; GNN, egnn_new.py:208-231:
+    node inputs [x | h (incl. time) | context], GCLs without edge attributes, outputs [velocity (3) | h (in_node_nf)])."""
+    H = hidden_nf
+    fin = in_node_nf + context_node_nf + 3
+    shapes: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+    shapes["gnn.embedding.weight"] = (H, fin)
+    shapes["gnn.embedding.bias"] = (H,)
+    shapes["gnn.embedding_out.weight"] = (3 + in_node_nf, H)
+    shapes["gnn.embedding_out.bias"] = (3 + in_node_nf,)
+    for i in range(n_layers):
+        g = f"gnn.gcl_{i}."
+        shapes[g + "edge_mlp.0.weight"] = (H, 2 * H)
+        shapes[g + "edge_mlp.0.bias"] = (H,)
+        shapes[g + "edge_mlp.2.weight"] = (H, H)
+        shapes[g + "edge_mlp.2.bias"] = (H,)
+        shapes[g + "node_mlp.0.weight"] = (H, 2 * H)
+        shapes[g + "node_mlp.0.bias"] = (H,)
+        shapes[g + "node_mlp.2.weight"] = (H, H)
+        shapes[g + "node_mlp.2.bias"] = (H,)
+        if attention:
+            shapes[g + "att_mlp.0.weight"] = (1, H)
+            shapes[g + "att_mlp.0.bias"] = (1,)
+    return shapes
+
+
+def synthetic_gnn_state_dict(in_node_nf: int, context_node_nf: int, hidden_nf: int, n_layers: int, attention: bool = False,
+                             seed: int = 0) -> "OrderedDict[str, np.ndarray]":
+    """nn.Linear-style fan-in-scaled uniform weights for every tensor of the 'gnn_dynamics' mode, keyed by name."""
+    shapes = gnn_param_shapes(in_node_nf, context_node_nf, hidden_nf, n_layers, attention)
+    out: "OrderedDict[str, np.ndarray]" = OrderedDict()
+    for name, shape in shapes.items():
+        wshape = shape if name.endswith(".weight") else shapes[name[:-4] + "weight"]
+        out[name] = _uniform(name, seed, shape, 1.0 / math.sqrt(wshape[1]))
+    return out
+
+
 def synthetic_gamma_state_dict(seed: int = 0) -> "OrderedDict[str, np.ndarray]":
     """PositiveLinear-style init: kaiming-uniform(a=sqrt(5)) - 2 (noise_model.py:92-96)."""
     out: "OrderedDict[str, np.ndarray]" = OrderedDict()

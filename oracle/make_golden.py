@@ -312,6 +312,42 @@ def fixture_norm(DiffusionQM9, name, hidden_nf, n_layers, seed, coord_gain, T, n
     save(name, **out)
 
 
+def fixture_gnn(DiffusionQM9, name, n_list, hidden_nf, n_layers, seed, attention, aggregation_method, normalization_factor, n_max=None):
+    """F21: EGNN_dynamics_QM9._forward in mode 'gnn_dynamics' (en_dynamics.py:24-29, 91-94; GNN egnn_new.py:208-242; config-off in
+    ddpmgblur.yaml:32): ragged molecules padded beyond the largest one - the reference passes no edge mask there, so padded nodes
+    and self pairs send messages - per-row and scalar t."""
+    from models.module.en_dynamics import EGNN_dynamics_QM9 as Ref  # type: ignore
+    from hierdiff_amd.weights import synthetic_gnn_state_dict
+    ref = Ref(9, 0, 3, hidden_nf=hidden_nf, n_layers=n_layers, attention=attention, mode="gnn_dynamics",
+              normalization_factor=normalization_factor, aggregation_method=aggregation_method)
+    sd_np = synthetic_gnn_state_dict(9, 0, hidden_nf, n_layers, attention, seed)
+    assert list(sd_np.keys()) == list(ref.state_dict().keys())
+    ref.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd_np.items()})
+    ref.eval()
+    ocfg = orc.DynCfg(in_node_nf=9, hidden_nf=hidden_nf, n_layers=n_layers, attention=attention,
+                      normalization_factor=float(normalization_factor), aggregation_method=aggregation_method)
+    xh, nm, em = orc.random_inputs(n_list, 8, seed=seed + 100, n_max=n_max)
+    B = xh.shape[0]
+    sd = orc.as_torch_sd(sd_np)
+    out = {"xh": xh.numpy(), "node_mask": nm.numpy(), "n_list": np.array(n_list), "hidden_nf": hidden_nf, "n_layers": n_layers,
+           "weight_seed": seed, "attention": int(attention), "aggregation_mean": int(aggregation_method == "mean"),
+           "normalization_factor": float(normalization_factor)}
+    with torch.no_grad():
+        trow = torch.linspace(0.05, 0.95, B).view(B, 1)
+        r = ref._forward(trow, xh.clone(), nm, em, None)
+        check(f"{name}[row t]", orc.gnn_dynamics_forward(sd, ocfg, trow, xh, nm).numpy(), r.numpy())
+        out["t_rows"], out["out_row_t"] = trow.numpy(), r.numpy()
+        t1 = torch.tensor([0.37])
+        r = ref._forward(t1, xh.clone(), nm, em, None)
+        check(f"{name}[scalar t]", orc.gnn_dynamics_forward(sd, ocfg, t1, xh, nm).numpy(), r.numpy())
+        out["t_scalar"], out["out_scalar_t"] = t1.numpy(), r.numpy()
+        # the padded nodes do matter in this mode: the same molecules without padding give other numbers
+        if n_max is not None and n_max > max(n_list):
+            xs, nms, ems = orc.random_inputs(n_list, 8, seed=seed + 100, n_max=None)
+            assert xs.shape[1] < xh.shape[1]
+    save(name, **out)
+
+
 def fixture_conditional(DiffusionQM9, name, hidden_nf, n_layers, seed, coord_gain):
     """F3 (BASELINE config 5): context feature, fixed trailing nodes (mol_shape < N),
     block-diagonal edge mask, fix_noise -> one sample_p_zs_given_zt."""
@@ -845,6 +881,9 @@ def main():
     run(fixture_pocket_loss, "f14_pocket_loss_h64_l2", 64, 2, 18, [7, 4, 6, 5], [9, 12, 5, 12])
     # round 3: non-unit norm_values / norm_biases
     run(fixture_norm, "f20_norm_h64_l2", 64, 2, 24, 1.0, 3, [9, 4, 7, 6, 8], (2.0, 4.0, 10.0), (None, 1.5, 0.5))
+    # round 3: mode = 'gnn_dynamics'
+    run(fixture_gnn, "f21_gnn_h64_l3", [9, 1, 4, 7, 2, 6], 64, 3, 27, True, "sum", 10, n_max=11)
+    run(fixture_gnn, "f21_gnn_h256_l2_mean", [8, 5, 3, 7], 256, 2, 28, False, "mean", 100, n_max=9)
     # round 3: aggregation_method = 'mean'
     run(fixture_forward_mean, "f19_mean_h64_l2", [9, 1, 4, 7, 2, 6], 64, 2, 21, 1.0, n_max=11)
     run(fixture_forward_mean, "f19_mean_h256_l3", [8, 5, 3, 7], 256, 3, 22, 1.0)

@@ -138,5 +138,36 @@ for case in range(splits):
             ok &= bool(torch.equal(xs[i - a, :k], xw[i, :k]) and torch.equal(hs[i - a, :k], hw[i, :k]))
     fails += int(not ok)
     print(f"split {case:3d} H={H:3d} L={L} T={T} {prec:6s} n={n_list} cuts={cuts} base={base}  {'bit-identical' if ok else 'FAIL'}", flush=True)
-print(f"{splits} batch splits in {time.time() - t2:.0f} s, failures in total {fails}")
+print(f"{splits} batch splits in {time.time() - t2:.0f} s, failures so far {fails}")
+
+# ---- phase 4: mode 'gnn_dynamics' (no edge mask in the reference: padded nodes and self pairs send messages)
+from hierdiff_amd.weights import synthetic_gnn_state_dict
+gnns = max(1, cases // 8)
+t3 = time.time()
+wg = 0.0
+for case in range(gnns):
+    H = int(rng.choice([32, 64, 128, 256])); L = int(rng.integers(1, 5))
+    att = bool(rng.integers(0, 2)); agg = str(rng.choice(["sum", "mean"])); nf = float(rng.choice([1.0, 10.0, 100.0]))
+    B = int(rng.integers(1, 7)); nmax = int(rng.choice([2, 6, 15, 31]))
+    n_list = [int(rng.integers(1, nmax + 1)) for _ in range(B)]
+    sd_np = synthetic_gnn_state_dict(9, 0, H, L, att, 9000 + case)
+    cfg = orc.DynCfg(in_node_nf=9, hidden_nf=H, n_layers=L, attention=att, normalization_factor=nf, aggregation_method=agg)
+    xh, nm, em = orc.random_inputs(n_list, 8, 9500 + case, nmax + int(rng.integers(0, 4)))
+    t = torch.from_numpy(rng.random((B, 1)).astype(np.float32))
+    with torch.no_grad():
+        ref = orc.gnn_dynamics_forward(orc.as_torch_sd(sd_np), cfg, t, xh, nm)
+    dyn = EGNN_dynamics_QM9(9, 0, 3, hidden_nf=H, n_layers=L, attention=att, mode="gnn_dynamics", normalization_factor=nf,
+                            aggregation_method=agg)
+    dyn.load_numpy_state_dict(sd_np); dyn = dyn.to(DEV).eval()
+    line = f"gnn {case:3d} H={H:3d} L={L} att={int(att)} agg={agg:4s} nf={nf:5.1f} n={n_list} N={xh.shape[1]}"
+    for prec in ("fp32", "bf16x6", "bf16x3"):
+        dyn.precision = prec
+        with torch.no_grad():
+            out = dyn._forward(t.to(DEV), xh.to(DEV), nm.to(DEV), em.to(DEV), None).cpu()
+        r = rel(out, ref); wg = max(wg, r)
+        bad = r > 1e-4 or not torch.isfinite(out).all() or bool((out[~nm[..., 0]] != 0).any())
+        fails += int(bad)
+        line += f"  {prec} {r:.1e}{' FAIL' if bad else ''}"
+    print(line, flush=True)
+print(f"{gnns} gnn_dynamics cases in {time.time() - t3:.0f} s, worst rel-L2 {wg:.2e}, failures in total {fails}")
 sys.exit(1 if fails else 0)

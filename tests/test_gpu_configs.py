@@ -584,4 +584,5 @@ def test_randomised_parity_sweep():
     assert proc.returncode == 0, tail + proc.stderr[-2000:]
     assert any("cases in" in ln and "failures 0," in ln for ln in lines), tail        # forward phase
     assert any("chains in" in ln and "failures so far 0" in ln for ln in lines), tail   # chains
-    assert "failures in total 0" in lines[-1], tail                                    # batch splits / padding
+    assert any("batch splits in" in ln and "failures so far 0" in ln for ln in lines), tail   # batch splits / padding
+    assert "failures in total 0" in lines[-1], tail                                    # gnn_dynamics

@@ -713,6 +713,42 @@ def test_norm_values_chain_and_nll_golden(precision):
         np.testing.assert_allclose(loss.cpu().numpy(), fx[f"{tag}_nll"], rtol=1e-4, atol=1e-3)
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
+@pytest.mark.parametrize("name", ["f21_gnn_h64_l3", "f21_gnn_h256_l2_mean"])
+def test_gnn_dynamics_golden(name, precision):
+    """F21: mode 'gnn_dynamics' on the library's kernels (an internal egnn-mode engine: coordinates fed as features, all-pairs edge
+    mask so that padded nodes and self pairs send messages as in the reference, which passes no edge mask there)."""
+    from hierdiff_amd import EGNN_dynamics_QM9
+    from tests.test_oracle_golden import _gnn_case
+    fx = load(name)
+    sd_np, cfg = _gnn_case(fx)
+    dyn = EGNN_dynamics_QM9(9, 0, 3, hidden_nf=cfg.hidden_nf, n_layers=cfg.n_layers, attention=cfg.attention, mode="gnn_dynamics",
+                            normalization_factor=cfg.normalization_factor, aggregation_method=cfg.aggregation_method)
+    assert list(dyn.state_dict().keys()) == list(sd_np.keys())
+    dyn.load_numpy_state_dict(sd_np)
+    dyn = dyn.to(DEV).eval()
+    dyn.precision = precision
+    xh, nm = torch.from_numpy(fx["xh"]).to(DEV), torch.from_numpy(fx["node_mask"]).to(DEV)
+    B, N = xh.shape[:2]
+    em = torch.zeros(B, N * N, dtype=torch.bool, device=DEV)          # whatever the caller passes: the reference ignores it in this mode
+    out = dyn._forward(torch.from_numpy(fx["t_rows"]).to(DEV), xh, nm, em, None)
+    assert_parity(out.cpu().numpy(), fx["out_row_t"], name + " row t")
+    out = dyn._forward(torch.from_numpy(fx["t_scalar"]).to(DEV), xh, nm, em, None)
+    assert_parity(out.cpu().numpy(), fx["out_scalar_t"], name + " scalar t")
+    assert np.all(out.cpu().numpy()[~fx["node_mask"][..., 0]] == 0.0)
+    # new weights are picked up (the engine's copy is keyed on the parameters' versions)
+    with torch.no_grad():
+        dyn.gnn.embedding_out.bias.add_(1.0)
+    out2 = dyn._forward(torch.from_numpy(fx["t_scalar"]).to(DEV), xh, nm, em, None)
+    assert not torch.equal(out, out2)
+    # inference only; the sampler loop / training path stay egnn_dynamics'
+    dyn.train()
+    with torch.enable_grad(), pytest.raises(NotImplementedError):
+        dyn._forward(torch.from_numpy(fx["t_scalar"]).to(DEV), xh, nm, em, None)
+    with pytest.raises(NotImplementedError):
+        dyn.sync_weights()
+
+
 def test_c_abi_error_codes_and_messages():
     """Error behaviour of the boundary (include/hierdiff_hip.h): negative codes + hd_last_error(), no aborts;
     the Python mirror turns them into HierDiffHipError / ValueError."""

@@ -315,3 +315,28 @@ def test_norm_values_chain_and_nll_match_reference():
                                      norm_biases=nb)
         np.testing.assert_allclose(got.numpy(), fx[f"{tag}_nll"], rtol=5e-6, atol=1e-4)
 
+
+def _gnn_case(fx):
+    from hierdiff_amd.weights import synthetic_gnn_state_dict
+    H, L, att = int(fx["hidden_nf"]), int(fx["n_layers"]), bool(int(fx["attention"]))
+    sd_np = synthetic_gnn_state_dict(9, 0, H, L, att, int(fx["weight_seed"]))
+    cfg = orc.DynCfg(in_node_nf=9, hidden_nf=H, n_layers=L, attention=att, normalization_factor=float(fx["normalization_factor"]),
+                     aggregation_method="mean" if int(fx["aggregation_mean"]) else "sum")
+    return sd_np, cfg
+
+
+@pytest.mark.parametrize("name", ["f21_gnn_h64_l3", "f21_gnn_h256_l2_mean"])
+def test_gnn_dynamics_matches_reference(name):
+    """F21: mode 'gnn_dynamics' (en_dynamics.py:24-29, 91-94; GNN egnn_new.py:208-242) - no edge mask in the reference's call, so padded
+    nodes and self pairs send messages."""
+    fx = load(name)
+    sd_np, cfg = _gnn_case(fx)
+    sd = orc.as_torch_sd(sd_np)
+    xh, nm = torch.from_numpy(fx["xh"]), torch.from_numpy(fx["node_mask"])
+    with torch.no_grad():
+        out = orc.gnn_dynamics_forward(sd, cfg, torch.from_numpy(fx["t_rows"]), xh, nm)
+        assert_parity(out.numpy(), fx["out_row_t"], name + " row t", 2e-6, 2e-5)
+        out = orc.gnn_dynamics_forward(sd, cfg, torch.from_numpy(fx["t_scalar"]), xh, nm)
+        assert_parity(out.numpy(), fx["out_scalar_t"], name + " scalar t", 2e-6, 2e-5)
+    assert np.all(out.numpy()[~fx["node_mask"][..., 0]] == 0.0)
+
