@@ -451,6 +451,16 @@ class DiffusionQM9(_Base):
         zx = zx - (zx.sum(1, keepdim=True) / nm.sum(1, keepdim=True)) * nm
         return torch.cat([zx, raw_h * nm], dim=2)
 
+    def _combine_raw(self, raw, node_mask, B):
+        """z_T from an injected (randn_x [b,N,3], randn_h [b,N,F]) pair: masked, x centred (diffusion_qm9.py:445-456), b = 1 broadcast."""
+        dev = node_mask.device
+        nm = node_mask.to(torch.float32)
+        rx, rh = (r.to(dev, torch.float32) for r in raw)
+        zx = rx * nm
+        zx = zx - (zx.sum(1, keepdim=True) / nm.sum(1, keepdim=True)) * nm
+        z = torch.cat([zx, rh * nm], dim=2)
+        return z.expand(B, -1, -1).contiguous() if z.shape[0] == 1 and B > 1 else z.contiguous()
+
     @torch.no_grad()
     def sample_p_zs_given_zt(self, s, t, zt, node_mask, edge_mask, context, fix_noise=False, mol_shape=None,
                              raw_noise: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
@@ -582,7 +592,21 @@ class DiffusionQM9(_Base):
         nb = 1 if fix_noise else B
         T = self.T
         z = torch.empty((B, N, D), device=dev, dtype=torch.float32)
-        if raw_noises is not None:
+        gnn = getattr(self.dynamics, "mode", "egnn_dynamics") == "gnn_dynamics"
+        if gnn and (pocket is not None or z_init is not None):
+            raise NotImplementedError("mode 'gnn_dynamics': plain sampling only (no pocket, no z_init)")
+        if gnn and raw_noises is not None:
+            # step by step (the fused loop evaluates the egnn network): injected draws in the reference's order
+            assert len(raw_noises) == T + 2, "need T+2 raw noise pairs"
+            z = self._combine_raw(raw_noises[0], node_mask, B)
+            gg = None if self.schedule_gammas is None else torch.as_tensor(np.asarray(self.schedule_gammas), dtype=torch.float32)
+            for i, s_ in enumerate(reversed(range(0, T))):
+                s_array = torch.full((B, 1), fill_value=s_, device=dev)
+                gm = None if gg is None else (gg[s_].expand(B, 1), gg[s_ + 1].expand(B, 1))
+                z = self.sample_p_zs_given_zt(s_array / T, (s_array + 1) / T, z, node_mask, edge_mask, context, fix_noise=fix_noise,
+                                              mol_shape=N, raw_noise=raw_noises[1 + i], gammas=gm)
+            final_raw = tuple(r.to(dev, torch.float32).contiguous() for r in raw_noises[T + 1])
+        elif raw_noises is not None:
             assert len(raw_noises) == T + 2, "need T+2 raw noise pairs"
             rx = [r[0].to(dev, torch.float32).contiguous() for r in raw_noises]
             rh = [r[1].to(dev, torch.float32).contiguous() for r in raw_noises]
@@ -592,7 +616,7 @@ class DiffusionQM9(_Base):
             step_h = torch.stack(rh[1:T + 1]).contiguous()
             z = run_loop(z, step_x, step_h, step_x.shape[1], 0, 0)
             final_raw = (rx[T + 1], rh[T + 1])
-        elif self.noise_mode == "torch":
+        elif self.noise_mode == "torch" or gnn:
             z = self.sample_combined_position_feature_noise(nb, N, node_mask)
             if nb == 1 and B > 1:
                 z = z.expand(B, -1, -1).contiguous()
@@ -614,7 +638,7 @@ class DiffusionQM9(_Base):
             final_raw = "philox"
         self._check_mean_zero(z[:, :, :self.n_dims], node_mask)
         zeros = torch.zeros((B, 1), device=dev)
-        eps = self.dynamics.forward_with_topology(topo, zeros, z, ctx, None)
+        eps = self.phi(z, zeros, node_mask, edge_mask, context) if gnn else self.dynamics.forward_with_topology(topo, zeros, z, ctx, None)
         coef3 = tabs["decode"].numpy()
         if final_raw == "philox":
             x, hfeat = self._final_decode(z, eps, node_mask, edge_mask, coef3, fix_noise, None,

@@ -197,7 +197,8 @@ class EGNN_dynamics_QM9(nn.Module):
     # (its own coordinates are zero, so the two distance columns it adds to the first edge Linear - zero weights - and its
     # coordinate layer - zero weights - contribute exact zeros), an all-ones edge mask (which makes every node of the batch an
     # active node of the layout while the row mask stays the node mask), and the engine's output columns read as
-    # [unused | velocity | h].  Inference only: the sampler loop of the library and the training path are egnn_dynamics'.
+    # [unused | velocity | h].  Inference only; DiffusionQM9 samples with it through its step-by-step loop (the library's fused
+    # sampler loop and the training path are egnn_dynamics').
     def _init_gnn(self, in_node_nf, context_node_nf, n_dims, hidden_nf, n_layers, attention, condition_time, normalization_factor,
                   aggregation_method):
         if context_node_nf:
@@ -217,6 +218,14 @@ class EGNN_dynamics_QM9(nn.Module):
             p.requires_grad_(False)
         object.__setattr__(self, "_engine", engine)          # not a submodule: its tensors are derived, not part of the state_dict
         self._engine_key = None
+        # the sampler's own arithmetic (noise, posterior step, decode: hd_noise / hd_posterior_step / hd_final_decode) needs a handle
+        # and tile tables of THIS module's [B, N, 3 + F] layout, not of the engine's widened one: a minimal egnn-mode twin provides
+        # them (its network is never evaluated)
+        arith = EGNN_dynamics_QM9(in_node_nf, 0, n_dims, hidden_nf=32, n_layers=1, attention=False, condition_time=condition_time,
+                                  inv_sublayers=1, normalization_factor=1)
+        for p in arith.parameters():
+            p.requires_grad_(False)
+        object.__setattr__(self, "_arith", arith)
 
     def _sync_gnn_engine(self):
         key = tuple((p.data_ptr(), p._version) for p in self.gnn.parameters())
@@ -302,8 +311,7 @@ class EGNN_dynamics_QM9(nn.Module):
 
     def _handle(self) -> C.c_void_p:
         if self.mode == 'gnn_dynamics':
-            raise NotImplementedError("mode 'gnn_dynamics': only `_forward` runs on the library (the sampler loop and the training "
-                                      "path are egnn_dynamics')")
+            return self._arith._handle()             # sampler arithmetic only; the network runs through `_forward`
         dev = self._device()
         if dev.type != "cuda":
             raise HierDiffHipError("EGNN_dynamics_QM9 runs only on an MI355X: move the module to a cuda device "
@@ -334,6 +342,11 @@ class EGNN_dynamics_QM9(nn.Module):
 
     def sync_weights(self, force: bool = False) -> None:
         """(Re)pack the parameters into the HIP handle when they changed since the last call."""
+        if self.mode == 'gnn_dynamics':
+            self._sync_gnn_engine()
+            self._arith.sync_weights(force)
+            self._handle_gen = self._arith._handle_gen
+            return
         h = self._handle()
         key = tuple((p.data_ptr(), p._version) for p in self.egnn.parameters())
         if not force and key == self._weights_key:
@@ -355,6 +368,8 @@ class EGNN_dynamics_QM9(nn.Module):
         loop hands over NEW mask tensors every batch - the key is the masks' CONTENT (one device-to-host copy, which
         building the tables needs anyway, and a 16-byte digest): batches whose masks repeat share one topology, and a
         miss costs one allocation, one upload and one memset (hd_topology_create)."""
+        if self.mode == 'gnn_dynamics':
+            return self._arith.topology(node_mask, edge_mask, B, N)
         self._handle()
         sig = lambda m: None if m is None else (m.data_ptr(), m._version, m.numel(), m.dtype, str(m.device))
         key = (sig(node_mask), sig(edge_mask), B, N)
@@ -452,6 +467,7 @@ class EGNN_dynamics_QM9(nn.Module):
         self._weights_key = None
         if self.mode == 'gnn_dynamics':
             self._engine._apply(fn, *a, **k)
+            self._arith._apply(fn, *a, **k)
             self._engine_key = None
         return super()._apply(fn, *a, **k)
 

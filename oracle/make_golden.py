@@ -67,7 +67,7 @@ def import_reference():
 
 def make_cfg(hidden_nf, n_layers, context_node_nf=0, normalization_factor=10, inv_sublayers=2, pocket=False,
              node_coarse_type="prop", noise_schedule="learned", loss_type="vlb", timesteps=1000, aggregation_method="sum",
-             norm_values=(1.0, 1.0, 1.0), norm_biases=(None, 0.0, 0.0)):
+             norm_values=(1.0, 1.0, 1.0), norm_biases=(None, 0.0, 0.0), mode="egnn_dynamics"):
     return AttrDict(
         pocket=pocket, node_coarse_type=node_coarse_type, loss_type=loss_type, hcontinous=True,
         noise_schedule=noise_schedule, timesteps=timesteps, norm_values=list(norm_values),
@@ -76,7 +76,7 @@ def make_cfg(hidden_nf, n_layers, context_node_nf=0, normalization_factor=10, in
         pre_noise=AttrDict(noise_schedule=noise_schedule, timesteps=timesteps, precision=1e-4),
         dynamics=AttrDict(in_node_nf=0, context_node_nf=context_node_nf, n_dims=3,
                           hidden_nf=hidden_nf, act_fn="silu", n_layers=n_layers, attention=True,
-                          condition_time=True, tanh=True, mode="egnn_dynamics", norm_constant=0,
+                          condition_time=True, tanh=True, mode=mode, norm_constant=0,
                           inv_sublayers=inv_sublayers, sin_embedding=False,
                           normalization_factor=normalization_factor, aggregation_method=aggregation_method),
         analyze=os.path.join(REF, "conf/analyze/GEOM.yaml"),
@@ -346,6 +346,60 @@ def fixture_gnn(DiffusionQM9, name, n_list, hidden_nf, n_layers, seed, attention
             xs, nms, ems = orc.random_inputs(n_list, 8, seed=seed + 100, n_max=None)
             assert xs.shape[1] < xh.shape[1]
     save(name, **out)
+
+
+def fixture_gnn_chain(DiffusionQM9, name, hidden_nf, n_layers, seed, T, n_list):
+    """F21c: DiffusionQM9.sample with dynamics.mode = 'gnn_dynamics' (T patched small, N pinned, noise and schedule values recorded)."""
+    from hierdiff_amd.weights import synthetic_gamma_state_dict, synthetic_gnn_state_dict
+    cfg = make_cfg(hidden_nf, n_layers, 0, mode="gnn_dynamics")
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = DiffusionQM9(cfg)
+    sd_np = {"gamma." + k: v for k, v in synthetic_gamma_state_dict(seed).items()}
+    sd_np.update({"dynamics." + k: v for k, v in synthetic_gnn_state_dict(9, 0, hidden_nf, n_layers, True, seed).items()})
+    sd_np["buffer"] = np.zeros(1, np.float32)
+    assert sorted(sd_np.keys()) == sorted(model.state_dict().keys())
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd_np.items()})
+    model.eval()
+    model.T = T
+    model.nodes_dist.sample = lambda n: list(n_list)
+    B, N = len(n_list), max(n_list)
+    rng = np.random.Generator(np.random.PCG64(seed + 11))
+    raws = [(torch.from_numpy(rng.standard_normal((B, N, 3)).astype(np.float32)),
+             torch.from_numpy(rng.standard_normal((B, N, 8)).astype(np.float32))) for _ in range(T + 2)]
+    queue = [r for pair in raws for r in pair]
+    orig_randn = torch.randn
+
+    def fake_randn(size, device=None, **kw):
+        r = queue.pop(0)
+        assert tuple(r.shape) == tuple(size), (r.shape, size)
+        return r.clone()
+    torch.randn = fake_randn
+    seen = []
+    hook = model.gamma.register_forward_hook(lambda m, a, o: seen.append((float(a[0][0, 0]), float(o[0, 0]))))
+    try:
+        with torch.no_grad():
+            res = model.sample(B, "cpu")
+    finally:
+        torch.randn = orig_randn
+        hook.remove()
+    assert not queue
+    gamma_grid = np.full(T + 1, np.nan, np.float32)
+    for tau, gv in seen:
+        gamma_grid[int(round(tau * T))] = gv
+    assert not np.isnan(gamma_grid).any()
+    nm, em = orc.canonical_masks(n_list)
+    ocfg = orc.DynCfg(in_node_nf=9, hidden_nf=hidden_nf, n_layers=n_layers, normalization_factor=10.0, mode="gnn_dynamics")
+    x_got, h_got = orc.sample_chain(orc.as_torch_sd(sd_np), ocfg, T, nm, em, None, raws, gamma_grid=torch.from_numpy(gamma_grid))
+    x_ref = np.zeros((B, N, 3), np.float32)
+    h_ref = np.zeros((B, N, 8), np.float32)
+    for b, r in enumerate(res):
+        x_ref[b, :n_list[b]] = r["x"].numpy()
+        h_ref[b, :n_list[b]] = r["h"].numpy()
+    nmf = nm.float().numpy()
+    check(f"{name} x", x_got.numpy() * nmf, x_ref, tol=2e-5)
+    check(f"{name} h", h_got.numpy(), h_ref, tol=2e-5)
+    save(name, n_list=np.array(n_list), x=x_ref, h=h_ref, T=T, gamma_grid=gamma_grid, hidden_nf=hidden_nf, n_layers=n_layers,
+         weight_seed=seed, raw_x=np.stack([r[0].numpy() for r in raws]), raw_h=np.stack([r[1].numpy() for r in raws]))
 
 
 def fixture_conditional(DiffusionQM9, name, hidden_nf, n_layers, seed, coord_gain):
@@ -884,6 +938,7 @@ def main():
     # round 3: mode = 'gnn_dynamics'
     run(fixture_gnn, "f21_gnn_h64_l3", [9, 1, 4, 7, 2, 6], 64, 3, 27, True, "sum", 10, n_max=11)
     run(fixture_gnn, "f21_gnn_h256_l2_mean", [8, 5, 3, 7], 256, 2, 28, False, "mean", 100, n_max=9)
+    run(fixture_gnn_chain, "f21c_gnn_chain_h64_l2", 64, 2, 29, 3, [8, 5, 3, 7])
     # round 3: aggregation_method = 'mean'
     run(fixture_forward_mean, "f19_mean_h64_l2", [9, 1, 4, 7, 2, 6], 64, 2, 21, 1.0, n_max=11)
     run(fixture_forward_mean, "f19_mean_h256_l3", [8, 5, 3, 7], 256, 3, 22, 1.0)

@@ -745,8 +745,37 @@ def test_gnn_dynamics_golden(name, precision):
     dyn.train()
     with torch.enable_grad(), pytest.raises(NotImplementedError):
         dyn._forward(torch.from_numpy(fx["t_scalar"]).to(DEV), xh, nm, em, None)
-    with pytest.raises(NotImplementedError):
-        dyn.sync_weights()
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_gnn_dynamics_sampling_chain_golden(precision):
+    """F21c: DiffusionQM9 built with dynamics.mode = 'gnn_dynamics' samples through its step-by-step loop (network through the gnn
+    `_forward`, posterior step / decode kernels of the library): the reference's own chain with its noise and schedule values."""
+    from hierdiff_amd import DiffusionQM9, default_config
+    from hierdiff_amd.weights import synthetic_gamma_state_dict, synthetic_gnn_state_dict
+    fx = load("f21c_gnn_chain_h64_l2")
+    H, L, seed, T = int(fx["hidden_nf"]), int(fx["n_layers"]), int(fx["weight_seed"]), int(fx["T"])
+    cfg = default_config(hidden_nf=H, n_layers=L, timesteps=T)
+    cfg.dynamics.mode = "gnn_dynamics"
+    model = DiffusionQM9(cfg)
+    sd_np = {"gamma." + k: v for k, v in synthetic_gamma_state_dict(seed).items()}
+    sd_np.update({"dynamics." + k: v for k, v in synthetic_gnn_state_dict(9, 0, H, L, True, seed).items()})
+    sd_np["buffer"] = np.zeros(1, np.float32)
+    assert sorted(model.state_dict().keys()) == sorted(sd_np.keys())
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v).copy()) for k, v in sd_np.items()})
+    model = model.to(DEV).eval()
+    model.dynamics.precision = precision
+    model.schedule_gammas = fx["gamma_grid"]
+    nm, em = orc.canonical_masks([int(v) for v in fx["n_list"]])
+    raws = [(torch.from_numpy(fx["raw_x"][i]), torch.from_numpy(fx["raw_h"][i])) for i in range(T + 2)]
+    x, h = model.sample_from_masks(nm.to(DEV), em.to(DEV), None, raw_noises=raws)
+    tol = 1e-3 if precision == "bf16x3" else 1e-4
+    assert_parity(x.cpu().numpy() * nm.float().numpy(), fx["x"], "F21c x", tol, 10 * tol)
+    assert_parity(h.cpu().numpy(), fx["h"], "F21c h", tol, 10 * tol)
+    # the public entry point (torch-generator noise in this mode): finite molecules of the drawn sizes
+    torch.manual_seed(3)
+    res = model.sample(4, DEV)
+    assert len(res) == 4 and all(torch.isfinite(r["x"]).all() and r["x"].shape[1] == 3 and r["h"].shape[1] == 8 for r in res)
 
 
 def test_c_abi_error_codes_and_messages():

@@ -340,3 +340,19 @@ def test_gnn_dynamics_matches_reference(name):
         assert_parity(out.numpy(), fx["out_scalar_t"], name + " scalar t", 2e-6, 2e-5)
     assert np.all(out.numpy()[~fx["node_mask"][..., 0]] == 0.0)
 
+
+def test_gnn_dynamics_sampling_chain_matches_reference():
+    """F21c: DiffusionQM9.sample with dynamics.mode = 'gnn_dynamics' (three steps, the reference's noise and schedule values)."""
+    from hierdiff_amd.weights import synthetic_gamma_state_dict, synthetic_gnn_state_dict
+    fx = load("f21c_gnn_chain_h64_l2")
+    H, L, seed, T = int(fx["hidden_nf"]), int(fx["n_layers"]), int(fx["weight_seed"]), int(fx["T"])
+    sd_np = {"gamma." + k: v for k, v in synthetic_gamma_state_dict(seed).items()}
+    sd_np.update({"dynamics." + k: v for k, v in synthetic_gnn_state_dict(9, 0, H, L, True, seed).items()})
+    cfg = orc.DynCfg(in_node_nf=9, hidden_nf=H, n_layers=L, normalization_factor=10.0, mode="gnn_dynamics")
+    nm, em = orc.canonical_masks([int(v) for v in fx["n_list"]])
+    raws = [(torch.from_numpy(fx["raw_x"][i]), torch.from_numpy(fx["raw_h"][i])) for i in range(T + 2)]
+    with torch.no_grad():
+        x, h = orc.sample_chain(orc.as_torch_sd(sd_np), cfg, T, nm, em, None, raws, gamma_grid=torch.from_numpy(fx["gamma_grid"]))
+    assert_parity(x.numpy() * nm.float().numpy(), fx["x"], "F21c x", 2e-5, 2e-4)
+    assert_parity(h.numpy(), fx["h"], "F21c h", 2e-5, 2e-4)
+
