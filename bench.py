@@ -536,6 +536,30 @@ def next_rows(dev) -> dict:
     return out
 
 
+def launcher_command(n_gpus: int, argv, port: int) -> list:
+    """The command line `python bench.py --gpus N ...` re-executes itself as when no launcher environment is present:
+    torch.distributed.run, one node, one rank per GPU, rendezvous on 127.0.0.1 (the container hostname may not resolve)."""
+    rest = [a for a in argv if a != "--force-launcher"]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(n_gpus)}",
+            "--master-addr", "127.0.0.1", "--master-port", str(int(port)), os.path.abspath(__file__)] + rest
+
+
+def free_port() -> int:
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n_gpus: int, argv) -> int:
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL across processes needs it on this driver
+    cmd = launcher_command(n_gpus, argv, free_port())
+    print("bench.py: no launcher environment, starting " + " ".join(cmd), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
 NOTES = {"fp32": "exact fp32 MFMA (v_mfma_f32_32x32x2_f32), the reference's arithmetic",
          "bf16x6": "fp32-accurate: per-edge H x H contraction on a three-way bf16 split (24 significant bits), 6 bf16 MFMAs per "
                    "product, fp32 accumulate; node-level GEMMs exact fp32",
@@ -565,6 +589,8 @@ def main() -> None:
                     help="under the launcher at world size 1: do not initialise torch.distributed")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket edge-kernel launches with HIP events in the timed region")
+    ap.add_argument("--force-launcher", action="store_true",
+                    help="start the ranks through torch.distributed.run even for --gpus 1 (the N > 1 code path on one GPU)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -572,9 +598,10 @@ def main() -> None:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus > 1 launch with: python -m torch.distributed.run --nnodes=1 "
-                         "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    if (args.gpus > 1 or args.force_launcher) and "RANK" not in os.environ:
+        # called plainly (`python bench.py --gpus N`): start the ranks ourselves, one process per GPU, exactly as the
+        # driver's launcher form does; rank 0's JSON line is this process's output and its exit code ours
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None

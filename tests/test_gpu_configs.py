@@ -540,6 +540,17 @@ def test_bench_rccl_path_at_world_one(tmp_path):
         assert line["roofline"]["bound"] == "mfma" and 0.0 < line["roofline"]["frac"] < 1.0
 
 
+def test_bench_self_launches_its_ranks(tmp_path):
+    """`python bench.py --gpus N` with no launcher environment starts its own ranks through torch.distributed.run
+    (bench.self_launch).  On this box's one GPU the same path is taken with --force-launcher at N = 1: the child runs under the
+    launcher (RCCL initialised, weights broadcast), the parent hands its JSON line and exit code through."""
+    args = ["--gpus", "1", "--force-launcher", "--steps", "1", "--warmup", "1", "--timesteps", "100", "--precision", "fp32",
+            "--no-configs", "--no-cpu-baseline"]
+    line = _run_bench(args, False, tmp_path, "self-launch")
+    assert line["rccl_ranks"] == 1 and line["rccl"]["backend"] == "nccl" and line["n_gpus"] == 1
+    assert len(line["rank_elapsed_s"]) == 1 and line["value"] > 0
+
+
 # ----------------------------------------------------------------------------- (l) the reference's shipped job: many small batches
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3"])

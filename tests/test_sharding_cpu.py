@@ -187,3 +187,33 @@ def test_world2_ddp_step_matches_single_process_on_the_global_batch(tmp_path):
         opt.step()
     assert torch.allclose(model.lin.weight, r[0]["w"], atol=1e-7) and torch.allclose(model.lin.bias, r[0]["b"], atol=1e-7)
     assert r[0]["lr"] == 4.0e-4                       # StepLR: unchanged after one epoch of fifteen
+
+
+def test_bench_self_launch_command_line(monkeypatch):
+    """`python bench.py --gpus 2` with no RANK in the environment must not exit on argument handling: it re-executes itself
+    under torch.distributed.run with one rank per GPU on 127.0.0.1 (bench.launcher_command / self_launch); under the
+    launcher (RANK set) it does not launch again."""
+    import importlib
+    import os
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, repo)
+    bench = importlib.import_module("bench")
+    cmd = bench.launcher_command(2, ["--gpus", "2", "--steps", "3", "--warmup", "1", "--force-launcher"], 29511)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=2" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29511"
+    i = cmd.index(os.path.join(repo, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "2", "--steps", "3", "--warmup", "1"]          # the flag that forced the launch is dropped
+    # main(): --gpus 2 without a launcher environment goes through self_launch with the untouched argument list
+    seen = {}
+    monkeypatch.setattr(bench, "self_launch", lambda n, argv: seen.update(n=n, argv=list(argv)) or 0)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "3"])
+    try:
+        bench.main()
+    except SystemExit as e:
+        assert e.code == 0
+    assert seen == {"n": 2, "argv": ["--gpus", "2", "--steps", "3"]}
+    assert 1024 < bench.free_port() < 65536
