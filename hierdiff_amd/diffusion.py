@@ -659,21 +659,33 @@ class DiffusionQM9(_Base):
             pocket = (pocket_cond[1].to(device, torch.float32),
                       self.pocket_embed(pocket_cond[0].to(device).long()).to(torch.float32),
                       pocket_cond[2].to(device).bool(), pocket_cond[3].to(device).bool())
-        return self._sample_sizes(sample_n, device, None if context is None else [context] * num_samples,
-                                  sample_id_base, pocket)
+        ctx = None
+        if context is not None:
+            # `zeros([num_samples, n_max, 1]) + context` (:352): a scalar, or any tensor that broadcasts against that shape
+            # (e.g. one value per sample as [num_samples, 1, 1]); anything else raises here as it does there
+            ctx = torch.zeros([num_samples, max(sample_n), 1]) + torch.as_tensor(context, dtype=torch.float32).cpu()
+            if ctx.shape != (num_samples, max(sample_n), 1):
+                raise ValueError(f"context of shape {tuple(torch.as_tensor(context).shape)} does not broadcast to "
+                                 f"[{num_samples}, {max(sample_n)}, 1]")
+        return self._sample_sizes(sample_n, device, None, sample_id_base, pocket, context_full=ctx)
 
-    def _sample_sizes(self, sample_n, device, contexts, sample_id_base, pocket=None):
+    def _sample_sizes(self, sample_n, device, contexts, sample_id_base, pocket=None, context_full=None):
         """One device batch for the molecule sizes `sample_n` (global sample ids sample_id_base + i); `contexts`: one scalar
-        (or [1]-broadcastable value) per molecule or None.  Masks as diffusion_qm9.py:349-353, result slicing as :388-395."""
+        per molecule (merged batches: the value of the batch a molecule belongs to) or None; `context_full`: the
+        [num_samples, n_max, 1] tensor of `sample()` instead.  Masks as diffusion_qm9.py:349-353, result slicing as :388-395."""
         num_samples = len(sample_n)
         n_max = max(sample_n)
         sizes = torch.tensor(sample_n)
         ar = torch.arange(n_max)
         node_mask = (ar[None, :] < sizes[:, None]).unsqueeze(-1)
         context = None
-        if contexts is not None:
-            col = torch.stack([torch.as_tensor(c, dtype=torch.float32).reshape(-1)[:1].cpu() for c in contexts]).reshape(num_samples, 1, 1)
-            context = (torch.zeros([num_samples, n_max, 1]) + col).to(device)
+        if context_full is not None:
+            context = context_full.to(device)
+        elif contexts is not None:
+            cols = [torch.as_tensor(c, dtype=torch.float32).reshape(-1).cpu() for c in contexts]
+            if any(c.numel() != 1 for c in cols):
+                raise ValueError("merged batches take one global context value per batch (context_range entries)")
+            context = (torch.zeros([num_samples, n_max, 1]) + torch.stack(cols).reshape(num_samples, 1, 1)).to(device)
         node_mask = node_mask.to(device)
         x, h = self.sample_from_masks(node_mask, None, context, sample_id_base=sample_id_base, pocket=pocket)
         x, h = x.cpu(), h.cpu()
@@ -695,10 +707,18 @@ class DiffusionQM9(_Base):
         as one device batch of at most `self.merge_batches` molecules / `self.merge_edges` directed edges: same results, bit for bit, as the loop
         (tests/test_gpu_configs.py::test_merged_sample_batches_equal_the_loop), at the throughput of the larger batch.
         The molecule sizes are drawn batch by batch exactly as the loop draws them.  Not merged: the protein branch,
-        `noise_mode == "torch"` (torch.randn draws depend on the batch shape), `merge_batches = 0`.  One difference that
+        `noise_mode == "torch"` (torch.randn draws depend on the batch shape), `merge_batches = 0`, and the two
+        configurations whose results depend on a batch's padded width (below).  One difference that
         is not a sample's own: the NaN guard (en_dynamics.py:109-111) zeroes the velocity of the whole DEVICE batch."""
         device = torch.device(device)
-        if protein_data_all is None and self.merge_batches and self.noise_mode == "philox" and num_batches > 1:
+        # Not merged either: mode 'gnn_dynamics' (torch.randn draws whatever noise_mode says, messages over padded nodes) and
+        # aggregation_method 'mean' (the divisor is the padded N of the call) - both depend on the padded width of the batch a
+        # molecule sits in - and context_range entries that are not one scalar per batch.
+        width_dependent = (getattr(self.dynamics, "mode", "egnn_dynamics") == "gnn_dynamics"
+                           or getattr(self.dynamics, "aggregation_method", "sum") == "mean")
+        scalar_ctx = context_range is None or all(torch.as_tensor(c).numel() == 1 for c in context_range)
+        if (protein_data_all is None and self.merge_batches and self.noise_mode == "philox" and num_batches > 1
+                and not width_dependent and scalar_ctx):
             sizes, ctxs = [], []
             for i in range(num_batches):
                 sizes.extend(self.nodes_dist.sample(batch_size))

@@ -55,7 +55,9 @@ class _TrainTables:
         B = 256, N = 30, H = 256, and a training loop builds a new topology for every batch of masks.  Grow-only; the
         views handed out cover this topology's rows (the kernels write every row of every tile, and the dense reduction
         dW2 = G2^T P reads exactly those rows)."""
-        pool = _WS_POOL.setdefault((str(self.device), self.H), {"rows": 0, "tiles": 0})
+        # keyed by the launching stream too: two models (or threads) running backward on different streams of one device
+        # must not share these buffers (ADVICE round 3)
+        pool = _WS_POOL.setdefault((str(self.device), self.H, int(_stream(self.device) or 0)), {"rows": 0, "tiles": 0})
         if pool["rows"] < self.rows or pool["tiles"] < self.tiles:
             z = lambda *s: torch.empty(s, device=self.device, dtype=torch.float32)
             pool["rows"], pool["tiles"] = max(pool["rows"], self.rows), max(pool["tiles"], self.tiles)
@@ -90,14 +92,32 @@ def _rows(t: torch.Tensor) -> torch.Tensor:
     return t if t.stride(1) == 1 or t.shape[1] == 1 and t.stride(0) >= 1 else t.contiguous()
 
 
+def _dev_index(dev: torch.device) -> int:
+    return torch.cuda.current_device() if dev.index is None else int(dev.index)
+
+
+_SPLITK_WS: dict = {}
+
+
+def _splitk_workspace(dev: torch.device, n: int) -> torch.Tensor:
+    """Grow-only split-K partial-sum buffer per (device, stream): consumed by the reduce kernel of the same call, on the
+    same stream, before the next GEMM of that stream can write it."""
+    key = (_dev_index(dev), int(_stream(dev) or 0))
+    ws = _SPLITK_WS.get(key)
+    if ws is None or ws.numel() < n:
+        ws = torch.empty(max(n, 2 * ws.numel() if ws is not None else n), device=dev, dtype=torch.float32)
+        _SPLITK_WS[key] = ws
+    return ws
+
+
 def _gemm(M, N, K, A, sam, sak, B, sbk, sbn, C, bias=None, epi=_EPI_BIAS, aux=None, rmask=None, C2=None, split=1,
           colsum=None):
     dev = C.device
     ws = None
     if split > 1:
-        ws = torch.empty(split * (M * N + M), device=dev, dtype=torch.float32)
+        ws = _splitk_workspace(dev, split * (M * N + M))
     p = lambda t: None if t is None else t.data_ptr()
-    _lib.check(_lib.load().hd_gemm_f32(dev.index or 0, M, N, K, A.data_ptr(), sam, sak, B.data_ptr(), sbk, sbn, C.data_ptr(),
+    _lib.check(_lib.load().hd_gemm_f32(_dev_index(dev), M, N, K, A.data_ptr(), sam, sak, B.data_ptr(), sbk, sbn, C.data_ptr(),
                                        C.stride(0), p(bias), epi, p(aux), p(rmask), p(C2), split, p(ws), p(colsum), _stream(dev)),
                "hd_gemm_f32")
     return C
@@ -249,7 +269,7 @@ class _EdgeLayer(torch.autograd.Function):
         widths = [H, 2 * H, H] + ([1] if has_ba else [])
         n = len(srcs)
         csws = torch.empty(32 * sum(widths), device=dev, dtype=torch.float32)
-        _lib.check(lib.hd_colsum_f32(dev.index or 0, tr.tiles, n, (C.c_void_p * n)(*[t.data_ptr() for t in srcs]),
+        _lib.check(lib.hd_colsum_f32(_dev_index(dev), tr.tiles, n, (C.c_void_p * n)(*[t.data_ptr() for t in srcs]),
                                      (C.c_int * n)(*widths), (C.c_void_p * n)(*[t.data_ptr() for t in dsts]),
                                      csws.data_ptr(), _stream(dev)), "hd_colsum_f32")
         if not has_ba:

@@ -363,7 +363,8 @@ def test_sample_batches_merges_consecutive_batches_host_side():
     torch.manual_seed(7)
     loop_sizes = [n for _ in range(5) for n in m.nodes_dist.sample(3)]
     calls = []
-    m._sample_sizes = lambda sizes, dev, ctx, base, pocket=None: (calls.append((list(sizes), ctx, base)) or [{"x": None}] * len(sizes))
+    m._sample_sizes = lambda sizes, dev, ctx, base, pocket=None, context_full=None: (
+        calls.append((list(sizes), ctx, base, context_full)) or [{"x": None}] * len(sizes))
     torch.manual_seed(7)
     res, names = m.sample_batches(3, 5, "cpu", context_range=[0.5, 1.5], sample_id_base=100)
     assert names == [] and len(res) == 15 and len(calls) == 1
@@ -388,3 +389,57 @@ def test_sample_batches_merges_consecutive_batches_host_side():
         e = sum(per_batch[lo:lo + nb])
         assert nb == 1 or e <= m.merge_edges
         lo += nb
+
+
+def test_sample_batches_does_not_merge_width_dependent_configurations():
+    """`aggregation_method='mean'` divides by the padded N of the call and `mode='gnn_dynamics'` sends messages
+    over padded nodes and draws with torch.randn - a molecule's result depends on the padded width of its batch, so these run the
+    reference's loop, batch by batch (no merge); so does a context_range whose entries are not one scalar per batch."""
+    import torch
+    from hierdiff_amd import DiffusionQM9, default_config
+    for kw in (dict(aggregation_method="mean"), dict(mode="gnn_dynamics")):
+        cfg = default_config(hidden_nf=32, n_layers=1, timesteps=4)
+        cfg.dynamics.update(kw)
+        m = DiffusionQM9(cfg)
+        assert m.merge_batches and m.noise_mode == "philox"
+        calls = []
+        m.sample = lambda n, dev, context=None, pocket_cond=None, sample_id_base=0: (calls.append((n, sample_id_base)) or [{"x": None}] * n)
+        m._sample_sizes = lambda *a, **k: (_ for _ in ()).throw(AssertionError("merged"))
+        res, _ = m.sample_batches(3, 4, "cpu", sample_id_base=10)
+        assert calls == [(3, 10), (3, 13), (3, 16), (3, 19)] and len(res) == 12
+    m = DiffusionQM9(default_config(hidden_nf=32, n_layers=1, timesteps=4, context_node_nf=1))
+    calls = []
+    m.sample = lambda n, dev, context=None, pocket_cond=None, sample_id_base=0: (calls.append(context) or [{"x": None}] * n)
+    per_sample = torch.arange(3.0).reshape(3, 1, 1)
+    m.sample_batches(3, 2, "cpu", context_range=[per_sample])
+    assert len(calls) == 2 and all(c is per_sample for c in calls)
+
+
+def test_sample_broadcasts_context_like_the_reference():
+    """`sample(num_samples, device, context)`: `zeros([num_samples, n_max, 1]) + context` (diffusion_qm9.py:352) - a scalar or
+    any tensor broadcastable against that shape, e.g. one value per sample; ADVICE round 3: the per-sample form must not be
+    reduced to its first element."""
+    import pytest
+    import torch
+    from hierdiff_amd import DiffusionQM9, default_config
+    m = DiffusionQM9(default_config(hidden_nf=32, n_layers=1, timesteps=4, context_node_nf=1))
+    seen = {}
+
+    def fake(node_mask, edge_mask, context, sample_id_base=0, pocket=None):
+        seen["ctx"] = context
+        B, N = node_mask.shape[:2]
+        return torch.zeros(B, N, 3), torch.zeros(B, N, 8)
+    m.sample_from_masks = fake
+    torch.manual_seed(3)
+    sizes = m.nodes_dist.sample(4)
+    per_sample = torch.tensor([0.5, 1.5, 2.5, 3.5]).reshape(4, 1, 1)
+    torch.manual_seed(3)
+    out = m.sample(4, "cpu", context=per_sample)
+    assert seen["ctx"].shape == (4, max(sizes), 1)
+    assert torch.equal(seen["ctx"], per_sample.expand(4, max(sizes), 1))
+    assert [float(o["context"][0, 0]) for o in out] == [0.5, 1.5, 2.5, 3.5] and out[1]["context"].shape == (sizes[1], 1)
+    torch.manual_seed(3)
+    m.sample(4, "cpu", context=2.0)
+    assert torch.equal(seen["ctx"], torch.full((4, max(sizes), 1), 2.0))
+    with pytest.raises((ValueError, RuntimeError)):
+        m.sample(4, "cpu", context=torch.zeros(3, 1, 1))

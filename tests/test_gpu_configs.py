@@ -582,6 +582,31 @@ def test_merged_sample_batches_equal_the_loop(precision):
                 assert float((r["context"] - ctx_range[(i // 2) % 3]).abs().max()) == 0.0
 
 
+def test_sample_batches_with_mean_aggregation_runs_the_loop():
+    """with `aggregation_method='mean'` the neighbour-sum divisor is the padded N of the CALL, so a molecule's
+    result depends on the largest molecule of its batch: merging batches of different widths would change it.  `sample_batches`
+    therefore runs the reference's loop for this configuration whatever `merge_batches` says - equal, bit for bit, to
+    `merge_batches = 0` and to calling `sample()` batch by batch."""
+    from hierdiff_amd import DiffusionQM9, default_config
+    H, L, T = 64, 2, 8
+    cfg = default_config(hidden_nf=H, n_layers=L, timesteps=T)
+    cfg.dynamics.aggregation_method = "mean"
+    m = DiffusionQM9(cfg)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v).copy()) for k, v in _syn(H, L, seed=92, gain=0.02).items()})
+    m = m.to(DEV).eval()
+    outs = []
+    for merge in (4096, 0):
+        m.merge_batches = merge
+        torch.manual_seed(77)
+        outs.append(m.sample_batches(3, 5, DEV, sample_id_base=40)[0])
+    torch.manual_seed(77)
+    by_hand = [r for i in range(5) for r in m.sample(3, DEV, sample_id_base=40 + 3 * i)]
+    assert len({r["x"].shape[0] for r in by_hand}) > 1                # ragged sizes: the batches have different widths
+    for a, b, c in zip(outs[0], outs[1], by_hand):
+        assert torch.equal(a["x"], b["x"]) and torch.equal(a["h"], b["h"])
+        assert torch.equal(a["x"], c["x"]) and torch.equal(a["h"], c["h"])
+
+
 def test_randomised_parity_sweep():
     """The wide net next to the fixed cases: tests/fuzz_parity.py - random model shapes / options / batch compositions / edge masks
     for the forward (all three precision modes) and short sampling chains, against the CPU oracle (a 400 + 100 case run of the same
