@@ -6,7 +6,8 @@ Public surface mirrors the reference (qiangbo1222/HierDiff, endiffusion/):
   EnVariationalDiffusion   equivariant_diffusion/en_diffusion.py sample() signature
   GammaNetwork, PredefinedNoiseSchedule, DistributionNodes
 and, of the second stage (top-level models/ of the reference): stage2.E_GCL (models/egnn/gcl.py) and
-edge_denoise.Edge_denoise (models/edge_denoise.py: forward values and sample_AR).
+edge_denoise.Edge_denoise (models/edge_denoise.py: forward VALUES and sample_AR - inference / evaluation only: no backward
+through the stage-2 layers, `forward` raises in training mode with autograd recording).
 The compute lives in lib/libhierdiff_hip.so (include/hierdiff_hip.h); build it with
 `python -m hierdiff_amd.build`.
 """

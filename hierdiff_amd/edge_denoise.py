@@ -198,10 +198,20 @@ class Edge_denoise(nn.Module):
         return self._head(self.edge_predict, torch.cat([h_focal, edge_focal, h_att, dist], dim=-1))
 
     # ------------------------------------------------------------------ reference API
-    @torch.no_grad()
     def forward(self, batch):
         """:61-248: {'focal_loss', 'focal_accuracy', 'edge_loss', 'edge_accuracy', 'node_loss', 'node_accuracy', 'total_loss'}
-        of a training batch (values; the reference differentiates through them, this implementation does not)."""
+        of a training batch.  VALUES ONLY (inference / evaluation): the reference's `forward(batch)` is also its stage-2 training
+        objective (trainmodule/train_edge_denoise_pl.py backpropagates `total_loss`); the HIP layers under this module have no
+        backward, so a call that could be asked for gradients - training mode with autograd recording - raises instead of
+        returning a loss without a grad_fn.  Call it under `torch.no_grad()` or after `.eval()`."""
+        if self.training and torch.is_grad_enabled():
+            raise RuntimeError("hierdiff_amd.Edge_denoise.forward computes loss VALUES only (no backward through the HIP stage-2 "
+                               "layers): call it under torch.no_grad() or in eval mode; stage-2 training is out of scope "
+                               "(SURVEY.md section 8f row 4)")
+        with torch.no_grad():
+            return self._forward_values(batch)
+
+    def _forward_values(self, batch):
         dev = self._device()
         h = batch['node_feat'][0]
         bs, n = h.shape[:2]

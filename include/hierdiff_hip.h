@@ -58,7 +58,11 @@ typedef struct hd_config {
     int32_t in_node_nf;          /* node features INCLUDING the time column, excluding context */
     int32_t context_node_nf;
     int32_t n_dims;              /* must be 3 */
-    int32_t hidden_nf;           /* 32, 64, 128 or 256 */
+    int32_t hidden_nf;           /* 32, 64, 128 or 256 (en_dynamics.py:9 accepts any width; production: 256).  Other multiples of 32
+                                    are rejected by hd_create, not padded: every kernel is instantiated per width - the edge kernels
+                                    keep H/32 accumulators in registers and deal H/32 column tiles to 4 or 8 wavefronts, the chunk
+                                    images are cut into 1 KiB pieces per four wavefronts - and a zero-padded 256-wide network would
+                                    change the summation order of every contraction, i.e. the bits, of a narrower model */
     int32_t n_layers;            /* number of EquivariantBlocks */
     int32_t inv_sublayers;       /* GCLs per block */
     int32_t attention;           /* 0/1 */
@@ -182,8 +186,8 @@ int hd_sample_loop(hd_handle* h, hd_topology* topo, float* z, const float* conte
  * with AB = [A | B] [M][2H] the node-level halves of the first Linear (computed by the caller, e.g. with a library
  * GEMM), x / x0 [M][4] the coordinates at block start / network input, M = active nodes, rows in the topology's
  * compact node order (hd_topology_nodes).  Weights are DEVICE pointers in state_dict layout: wrd [2][H] = the two
- * distance columns of the first Linear, W2 [H][H], b2 [H], wa [H], ba [1] (NULL: no attention bias).  The node-level Linears around an edge layer are plain GEMMs and are
- * not part of this ABI (hierdiff_amd/training.py runs them through the BLAS library and autograd). */
+ * distance columns of the first Linear, W2 [H][H], b2 [H], wa [H], ba [1] (NULL: no attention bias).  The node-level Linears around an edge layer are plain GEMMs:
+ * hierdiff_amd/training.py runs them on hd_gemm_f32 below (forward, dX and split-K dW; no BLAS-library kernel in a step). */
 int hd_topology_nodes(const hd_topology* t, int* node_of /* host, `active nodes` ints: flat index b*N + n */);
 int hd_edge_layer_forward(hd_handle* h, hd_topology* topo, int coord, const float* AB, const float* x,
                           const float* x0, const float* wrd, const float* W2, const float* b2, const float* wa,

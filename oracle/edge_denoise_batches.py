@@ -30,6 +30,17 @@ def random_tree(rng, n: int):
     return [int(v) for v in order], parent, adj
 
 
+def synthetic_array_dict(seed: int, out_node_nf: int, n_arrays: int = 6, in_node_nf: int = 8):
+    """A stand-in for the reference's `array_dict` pickle (models/edge_denoise.py:19-20; conf/model/edge_denoise.yaml points it at
+    a dataset artefact): [list of `n_arrays` fragment property signatures - the first in_node_nf - 1 feature columns a node is matched
+    against, :255-256 -, list of the vocabulary slice ("softmax space", sorted ids < out_node_nf) each signature normalises over]."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    sigs = [rng.integers(0, 4, size=in_node_nf - 1).astype(np.float32) for _ in range(n_arrays)]
+    spaces = [sorted(int(v) for v in rng.choice(out_node_nf, size=int(rng.integers(4, max(5, out_node_nf // 2))), replace=False))
+              for _ in range(n_arrays)]
+    return [sigs, spaces]
+
+
 def _features(rng, n_list, n_pad, stage_list, orders, in_node_nf, context_nf, vocab_size):
     bs = len(n_list)
     width = in_node_nf + context_nf + 1
@@ -47,7 +58,7 @@ def _features(rng, n_list, n_pad, stage_list, orders, in_node_nf, context_nf, vo
     return feat, mask, pos
 
 
-def ar_batch(seed: int, n_list: List[int], stage_list: List[int], in_node_nf=8, context_nf=0, vocab_size=50):
+def ar_batch(seed: int, n_list: List[int], stage_list: List[int], in_node_nf=8, context_nf=0, vocab_size=50, array_dict=None):
     """stage s of a sample = number of nodes already placed: 0 -> nothing discovered (all-zero adjacency), 1 -> the root is
     marked by a self loop (ar_sampling_nosize.py:202), >= 2 -> the tree edges among the first s nodes of the growth order."""
     rng = np.random.Generator(np.random.PCG64(seed))
@@ -63,10 +74,18 @@ def ar_batch(seed: int, n_list: List[int], stage_list: List[int], in_node_nf=8, 
             adj[i, v, parent[v]] = adj[i, parent[v], v] = 1
         emask[i, :n, :n] = 1 - torch.eye(n)
     feat, mask, pos = _features(rng, n_list, n_pad, stage_list, [t[0] for t in trees], in_node_nf, context_nf, vocab_size)
+    if array_dict is not None:
+        # sample_AR matches a node's first in_node_nf - 1 feature columns against the signatures (:255-256, check_array_in_list):
+        # two nodes in three carry an exact signature (the `diff == 0` return), the others stay random (nearest signature)
+        sigs = array_dict[0]
+        for i, n in enumerate(n_list):
+            for v in range(n):
+                if rng.random() < 0.67:
+                    feat[i, v, :in_node_nf - 1] = torch.from_numpy(sigs[int(rng.integers(0, len(sigs)))])
     return {'node_feat': [feat, mask], 'node_pos': pos, 'search_adj_matrix': adj, 'edge_mask': emask}
 
 
-def train_batch(seed: int, n_list: List[int], stage_list: List[int], in_node_nf=8, context_nf=0, vocab_size=50):
+def train_batch(seed: int, n_list: List[int], stage_list: List[int], in_node_nf=8, context_nf=0, vocab_size=50, array_dict=None):
     """One growth step per sample: the first s >= 1 nodes of the growth order are placed, node order[s] is added next."""
     rng = np.random.Generator(np.random.PCG64(seed))
     bs, n_pad = len(n_list), max(n_list)
@@ -102,7 +121,15 @@ def train_batch(seed: int, n_list: List[int], stage_list: List[int], in_node_nf=
         flat, orig = [torch.tensor([]), torch.tensor([])], []
     pad = concat_layers([adj_to_bfs(search[i, :nums[i], :nums[i]], predict_idx[i]) for i in range(bs)], n_pad)
     feat, mask, pos = _features(rng, n_list, n_pad, stage_list, [t[0] for t in trees], in_node_nf, context_nf, vocab_size)
-    return {'node_feat': [feat, mask.bool()], 'node_array': torch.zeros(bs, n_pad, dtype=torch.long), 'node_pos': pos,
+    node_array = torch.zeros(bs, n_pad, dtype=torch.long)
+    if array_dict is not None:
+        # the dataset's per-node signature index (dataset_denoise.py `node_array`); the label of the node to add lies inside the
+        # vocabulary slice of its signature (the reference does `softmax_space.index(label)`, :220)
+        node_array = torch.from_numpy(rng.integers(0, len(array_dict[0]), size=(bs, n_pad))).long()
+        for i in range(bs):
+            space = array_dict[1][int(node_array[i, predict_idx[i]])]
+            label[i] = int(space[int(rng.integers(0, len(space)))])
+    return {'node_feat': [feat, mask.bool()], 'node_array': node_array, 'node_pos': pos,
             'focal': torch.tensor([1 if f in set(focal) else 0 for f in focal_cand]), 'focal_cand': focal_cand,
             'real_focal': [l + i * n_pad for i, l in enumerate(last_ind) if l >= 0],
             'edge_search_pad': pad, 'edge_search_pad_orig': orig, 'edge_search_flat': flat,

@@ -131,8 +131,10 @@ def _mlp(sd, name, x, last_sigmoid=False):
 
 
 @torch.no_grad()
-def forward(sd: Dict[str, torch.Tensor], cfg: EDCfg, batch) -> Dict[str, torch.Tensor]:
-    """Edge_denoise.forward (:61-248) with array_dict = None (full softmax, conf/model/edge_denoise.yaml:12)."""
+def forward(sd: Dict[str, torch.Tensor], cfg: EDCfg, batch, array_dict=None) -> Dict[str, torch.Tensor]:
+    """Edge_denoise.forward (:61-248).  array_dict = None: full softmax (conf/model/edge_denoise.yaml:12); otherwise the loaded
+    [signatures, vocabulary slices] pair: the type loss / accuracy of sample i runs over the slice of its node's signature,
+    `array_dict[1][batch['node_array'][i, predict_idx[i]]]` (:214-231)."""
     h = torch.as_tensor(batch['node_feat'][0], dtype=torch.float32)
     bs, n = h.shape[:2]
     x = torch.as_tensor(batch['node_pos'], dtype=torch.float32).reshape(bs * n, -1)
@@ -218,9 +220,12 @@ def forward(sd: Dict[str, torch.Tensor], cfg: EDCfg, batch) -> Dict[str, torch.T
     h_node = torch.stack([hv[i, predict_idx[i], :] for i in range(bs)])
     npred = _mlp(sd, "node_predict", h_node)
     node_loss, hit = torch.tensor(0.0), 0
+    arr = None if array_dict is None else torch.as_tensor(batch['node_array']).reshape(bs, n)
     for i in range(bs):
-        node_loss = node_loss + F.cross_entropy(npred[i].unsqueeze(0), label[i].reshape(1).long())
-        hit += int(torch.argmax(npred[i]) == label[i])
+        space = list(range(npred.shape[1])) if arr is None else list(array_dict[1][int(arr[i, predict_idx[i]])])
+        tgt = torch.tensor([space.index(int(label[i]))])
+        node_loss = node_loss + F.cross_entropy(npred[i, space].unsqueeze(0), tgt)
+        hit += int(torch.argmax(npred[i, space]) == tgt[0])
     total = cfg.focal_loss * focal_loss + cfg.edge_loss * edge_loss + cfg.node_loss * node_loss
     return {'focal_loss': focal_loss, 'focal_accuracy': torch.tensor(focal_acc), 'edge_loss': edge_loss,
             'edge_accuracy': torch.tensor(edge_acc), 'node_loss': node_loss, 'node_accuracy': torch.tensor(hit / bs),
@@ -228,11 +233,27 @@ def forward(sd: Dict[str, torch.Tensor], cfg: EDCfg, batch) -> Dict[str, torch.T
 
 
 @torch.no_grad()
-def sample_ar(sd: Dict[str, torch.Tensor], cfg: EDCfg, batch):
-    """Edge_denoise.sample_AR (:250-420) with array_dict = None: (edges_result, node_predict, adj_matrix)."""
+def check_array_in_list(array, list_a):
+    """:535-544: index of the first signature equal to `array`, else of the nearest one (squared distance, first minimum)."""
+    array = np.asarray(array)
+    diffs = []
+    for ind, ref in enumerate(list_a):
+        d = ((array - ref) ** 2).sum()
+        diffs.append(d)
+        if d == 0:
+            return ind
+    return diffs.index(min(diffs))
+
+
+def sample_ar(sd: Dict[str, torch.Tensor], cfg: EDCfg, batch, array_dict=None):
+    """Edge_denoise.sample_AR (:250-420): (edges_result, node_predict, adj_matrix); with an array_dict (edges_result,
+    node_predict, vocabulary slice of every sample's chosen node, adj_matrix) (:255-256, :408-417)."""
     h = torch.as_tensor(batch['node_feat'][0], dtype=torch.float32)
     bs, n = h.shape[:2]
     h = h.reshape(bs * n, -1)
+    arr = None
+    if array_dict is not None:
+        arr = np.array([check_array_in_list(a[:-(2 + cfg.context_nf)], array_dict[0]) for a in h.numpy()]).reshape(bs, n)
     x = torch.as_tensor(batch['node_pos'], dtype=torch.float32).reshape(bs * n, -1)
     nm2 = torch.as_tensor(batch['node_feat'][1], dtype=torch.float32)[:, :, 0]
     node_nums = torch.sum(nm2, dim=1).int()
@@ -316,5 +337,8 @@ def sample_ar(sd: Dict[str, torch.Tensor], cfg: EDCfg, batch):
     hv = h.reshape(bs, n, -1)
     h_node = torch.stack([hv[i, edges_result[i][1], :] for i in range(bs)])
     npred = _mlp(sd, "node_predict", h_node)
+    picked = None if arr is None else [list(array_dict[1][int(arr[i, edges_result[i][1]])]) for i in range(bs)]
     edges_result = [e if e[0] >= 0 else [0] for e in edges_result]
+    if picked is not None:
+        return edges_result, npred, picked, adj
     return edges_result, npred, adj

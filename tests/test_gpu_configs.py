@@ -112,6 +112,40 @@ def test_config2_full_length_at_stated_size(precision):
     print(f"config 2 full length [{precision}]: |x| max {float(x.abs().max()):.2f}, |h| max {float(h.abs().max()):.2f}")
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_config2_full_length_vs_oracle(precision):
+    """BASELINE config 2 at its stated LENGTH against the oracle: the complete 1000-step reverse
+    diffusion + decode at N = 30, 9 EGNN layers, H = 256 with injected normals.  A molecule's bits do not depend on its batch
+    neighbours, so TWO molecules pin the chain: (i) the B = 64 run (k_edge_mixed + the small-batch node chain in fp32) and the
+    same two molecules run alone (k_edge_split) are bit-identical, (ii) those two equal the CPU oracle's 1001-forward chain
+    (~1 min on the host) within 1e-3 rel-L2 on the final x and h - the trajectory bar of test_full_length_chain_production_width."""
+    from hierdiff_amd.noise_model import evaluate_gamma
+    H, L, T, B, N = 256, 9, 1000, 64, 30
+    sd_np = _syn(H, L, seed=46, gain=0.02)
+    cfg = orc.DynCfg(hidden_nf=H, n_layers=L)
+    g = torch.Generator().manual_seed(14)
+    raws = [(torch.randn(B, N, 3, generator=g), torch.randn(B, N, 8, generator=g)) for _ in range(T + 2)]
+    model = build_diffusion(sd_np, H, L, T=T, precision=precision)
+    nm = torch.ones(B, N, 1, dtype=torch.bool, device=DEV)
+    x, h = model.sample_from_masks(nm, None, None, raw_noises=raws)
+    assert torch.isfinite(x).all() and torch.isfinite(h).all()
+    pick = [5, 40]
+    raws2 = [(rx[pick].contiguous(), rh[pick].contiguous()) for rx, rh in raws]
+    x2, h2 = model.sample_from_masks(nm[:2].contiguous(), None, None, raw_noises=raws2)
+    assert torch.equal(x2, x[pick]) and torch.equal(h2, h[pick])
+    key = ("cfg2_full", T)
+    if key not in _CACHE:
+        nm2, em2 = orc.canonical_masks([N] * 2)
+        gg = evaluate_gamma(copy.deepcopy(model.gamma).cpu(), (torch.arange(T + 1, dtype=torch.float64) / T).view(-1, 1)).view(-1)
+        with torch.no_grad():
+            _CACHE[key] = orc.sample_chain(orc.as_torch_sd(sd_np), cfg, T, nm2, em2, None, raws2, gamma_grid=gg)
+    xo, ho = _CACHE[key]
+    rx = rel_l2(x2.cpu().numpy(), xo.numpy())
+    rh = rel_l2(h2.cpu().numpy(), ho.numpy())
+    print(f"config 2 full length vs oracle [{precision}]: x {rx:.2e} h {rh:.2e}")
+    assert rx < 1e-3 and rh < 1e-3
+
+
 # ----------------------------------------------------------------------------- (c) config 3: GEOM sizes padded to 48, B=256
 
 def _geom_sizes(B, seed=2022, clip=48):
