@@ -72,21 +72,20 @@ def synthetic_edge_denoise_state_dict(seed: int = 0, coord_gain: float = 0.3, **
     return out
 
 
-def bfs_layers(edges: np.ndarray, n_nodes: int, start: int) -> List[List[List[int]]]:
+def bfs_layers(edges, n_nodes: int, start: int) -> List[List[List[int]]]:
     """Layers of [child, parent] pairs reached breadth-first from `start` over the directed pairs `edges`, farthest layer
     first (data_utils/data_diffuse.py:60-79 `get_bfs_order_new`).  Like the reference it does not terminate on a graph whose
-    `n_nodes` nodes are not all reachable from `start`; callers pass connected trees."""
+    `n_nodes` nodes are not all reachable from `start`; callers pass connected trees.  Per layer the reference scans ALL pairs
+    and files [b, a] for every pair whose source is already seen and whose target is not (a target reached from two sources of
+    the same layer is listed twice); the same pairs in the same edge-list order come out here."""
+    pairs = [(int(a), int(b)) for a, b in edges]
     seen = {int(start)}
     layers: List[List[List[int]]] = []
     while len(seen) < n_nodes:
-        layer, found = [], []
-        for a, b in edges:
-            if int(a) in seen and int(b) not in seen:
-                found.append(int(b))
-                layer.append([int(b), int(a)])
-        if not found:
+        layer = [[b, a] for a, b in pairs if a in seen and b not in seen]
+        if not layer:
             raise ValueError("bfs_layers: the edge set is not connected to `start` (the reference loops forever here)")
-        seen.update(found)
+        seen.update(b for b, _ in layer)
         layers.append(layer)
     layers.reverse()
     return layers
@@ -179,9 +178,13 @@ class Edge_denoise(nn.Module):
     def _walk(self, name, layers, h, x, node_mask):
         """One E_GCL applied along a list of edge layers with edge_attr = squared length (:155-159, :201-205)."""
         dev = h.device
-        for layer in layers:
-            e = torch.tensor(layer, dtype=torch.long).reshape(-1, 2).T.contiguous()
-            ed = e.to(dev)
+        host = [torch.tensor(layer, dtype=torch.long).reshape(-1, 2).T.contiguous() for layer in layers]
+        both = torch.cat(host, dim=1).to(dev)                 # every layer's pairs in ONE host-to-device copy
+        lo = 0
+        for e in host:
+            k = int(e.shape[1])
+            ed = both[:, lo:lo + k]
+            lo += k
             ea = torch.sum((x[ed[0]] - x[ed[1]]) ** 2, dim=1, keepdim=True)
             h, x = self._modules[name](h, [e[0], e[1]], x, edge_attr=ea, node_mask=node_mask)
         return h, x
@@ -335,15 +338,17 @@ class Edge_denoise(nn.Module):
             ef = eff[d0 // n, d0 % n, d1 % n, :].reshape(e0.shape[0], -1)
             for i in range(self.n_layers_focal):
                 h, x, ef = self._modules['gcl_focal_%d' % i](h, [e0, e1], x, edge_attr=ef, node_mask=node_mask)
-            hv, vv = h.view(bs, n, -1), val.view(bs, n, -1)
+            # focal_predict of every discovered node of the beam in ONE head call (the reference calls it per sample, :311-316;
+            # a head's rows are independent - one fmaf chain per output in hd_linear - so the scores are the same bits), one
+            # device-to-host copy, then the per-sample argmax (first maximum, like torch.argmax) on the host
             bins = self.split_nodes(discovered, n, bs)
-            focal = []
+            didx = torch.tensor(discovered, dtype=torch.long, device=dev)
+            score = self._head(self.focal_predict, torch.cat([h[didx], val[didx]], dim=-1)).reshape(-1).cpu().numpy()
+            focal, lo = [], 0
             for i in range(bs):
-                if len(bins[i]) > 0:
-                    score = self._head(self.focal_predict, torch.cat([hv[i, bins[i], :], vv[i, bins[i]]], dim=-1))
-                    focal.append(bins[i][int(torch.argmax(score))] + i * n)
-                else:
-                    focal.append(-1)
+                k = len(bins[i])
+                focal.append(bins[i][int(np.argmax(score[lo:lo + k]))] + i * n if k > 0 else -1)
+                lo += k
         elif len(discovered) == 0:
             focal = [-1] * bs
         else:
@@ -352,7 +357,8 @@ class Edge_denoise(nn.Module):
         circle = [[i * n, i * n] for i in range(bs)]
         if len(discovered) > 0:
             if have_edges:
-                per = [self.adj_matrix_to_edges_bfs(adj[i][:node_nums[i], :node_nums[i]], None, focal[i] % n) if focal[i] >= 0 else []
+                adj_np = adj.numpy()                        # the host tensor's own storage: no per-sample tensor ops below
+                per = [self.adj_matrix_to_edges_bfs(adj_np[i, :node_nums[i], :node_nums[i]], None, focal[i] % n) if focal[i] >= 0 else []
                        for i in range(bs)]
                 h, x = self._walk('gcl_edge', [circle] + self.concat_edges(per, n), h, x, node_mask)
             fr = [f for f in focal if f >= 0]
@@ -370,7 +376,8 @@ class Edge_denoise(nn.Module):
                     edges_result.append([-1, 0])
         else:
             edges_result = [[-1, 0] for _ in range(bs)]
-        per = [self.adj_matrix_to_edges_bfs(adj[i][:node_nums[i], :node_nums[i]], None, edges_result[i][1]) if focal[i] > 0 else []
+        adj_np = adj.numpy()
+        per = [self.adj_matrix_to_edges_bfs(adj_np[i, :node_nums[i], :node_nums[i]], None, edges_result[i][1]) if focal[i] > 0 else []
                for i in range(bs)]
         h, x = self._walk('gcl_denoise', [circle] + self.concat_edges(per, n), h, x, node_mask)
         hv = h.view(bs, n, -1)
@@ -392,11 +399,12 @@ class Edge_denoise(nn.Module):
         return adj_matrix.nonzero().T.tolist()
 
     def adj_matrix_to_edges_bfs(self, adj_matrix, blur_feature, end, priority=False):
-        if adj_matrix.sum() == 0:
+        a = adj_matrix.detach().cpu().numpy() if isinstance(adj_matrix, torch.Tensor) else np.asarray(adj_matrix)
+        r, c = np.nonzero(a)                                   # row-major: the order of torch.nonzero
+        if r.size == 0:
             return [[]]
-        edges = adj_matrix.nonzero().cpu().numpy()
-        nodes = {int(v) for v in edges.reshape(-1)}
-        return bfs_layers(edges, len(nodes), int(end))
+        r, c = r.tolist(), c.tolist()
+        return bfs_layers(zip(r, c), len(set(r) | set(c)), int(end))
 
     def attach_to_adj_matrix(self, adj_matrix, edges):
         for e in edges:

@@ -137,8 +137,13 @@ def test_config2_full_length_vs_oracle(precision):
     if key not in _CACHE:
         nm2, em2 = orc.canonical_masks([N] * 2)
         gg = evaluate_gamma(copy.deepcopy(model.gamma).cpu(), (torch.arange(T + 1, dtype=torch.float64) / T).view(-1, 1)).view(-1)
-        with torch.no_grad():
-            _CACHE[key] = orc.sample_chain(orc.as_torch_sd(sd_np), cfg, T, nm2, em2, None, raws2, gamma_grid=gg)
+        threads = torch.get_num_threads()
+        torch.set_num_threads(min(8, threads))     # 60 x 30 x 30 edge rows per forward: a 128-thread pool is 10 x slower than 8 here
+        try:
+            with torch.no_grad():
+                _CACHE[key] = orc.sample_chain(orc.as_torch_sd(sd_np), cfg, T, nm2, em2, None, raws2, gamma_grid=gg)
+        finally:
+            torch.set_num_threads(threads)
     xo, ho = _CACHE[key]
     rx = rel_l2(x2.cpu().numpy(), xo.numpy())
     rh = rel_l2(h2.cpu().numpy(), ho.numpy())
