@@ -314,9 +314,15 @@ class DiffusionQM9(_Base):
         t_int = torch.as_tensor(t_int, dtype=torch.float32, device=dev).view(B, 1)
         s, t = (t_int - 1) / self.T, t_int / self.T
         t_is_zero = (t_int == 0).float().view(-1)
-        gamma_s, gamma_t = self._gamma_rows(s, "gamma_s", gammas), self._gamma_rows(t, "gamma_t", gammas)
-        gamma_0 = self._gamma_rows(torch.zeros_like(t), "gamma_0", gammas)
-        gamma_T = self._gamma_rows(torch.ones_like(t), "gamma_T", gammas)
+        if (gammas is None and x.is_cuda and torch.is_grad_enabled() and self.training
+                and any(p.requires_grad for p in self.gamma.parameters())):
+            # training a learned schedule: the four schedule values of the loss (diffusion_qm9.py:541-552) from ONE pass of the
+            # network over [s; t; 0; 1] instead of four (each ~125 small launches forward + backward)
+            gamma_s, gamma_t, gamma_0, gamma_T = self.gamma(torch.cat([s, t, torch.zeros_like(t), torch.ones_like(t)], dim=0)).view(4, B, 1)
+        else:
+            gamma_s, gamma_t = self._gamma_rows(s, "gamma_s", gammas), self._gamma_rows(t, "gamma_t", gammas)
+            gamma_0 = self._gamma_rows(torch.zeros_like(t), "gamma_0", gammas)
+            gamma_T = self._gamma_rows(torch.ones_like(t), "gamma_T", gammas)
         if eps is None:
             eps = self.sample_combined_position_feature_noise(B, mol, node_mask)
         eps = torch.as_tensor(eps, dtype=torch.float32, device=dev)

@@ -304,10 +304,28 @@ class Edge_denoise(nn.Module):
             return list(range(width))
         return list(self.array_dict[1][int(array.reshape(bs, n)[i, node])])
 
+    def _layers_frozen(self, on: bool):
+        """Parameters do not change inside one sample_AR / forward call: the E_GCL layers compare their parameter versions with the
+        library's copy once per call instead of once per layer application (~40 per growth step)."""
+        for m in self.modules():
+            if isinstance(m, E_GCL):
+                if on:
+                    m._frozen = False
+                    m._sync_weights()
+                m._frozen = on
+
     @torch.no_grad()
     def sample_AR(self, batch):
         """:250-420: for every partial tree of the batch choose the focal node, the node to attach to it and the type
         logits of that node.  Returns (edges_result, node_predict[, array], adj_matrix) like the reference."""
+        self._device()
+        self._layers_frozen(True)
+        try:
+            return self._sample_ar(batch)
+        finally:
+            self._layers_frozen(False)
+
+    def _sample_ar(self, batch):
         dev = self._device()
         h = batch['node_feat'][0]
         bs, n = h.shape[:2]

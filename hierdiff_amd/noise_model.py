@@ -60,9 +60,17 @@ class GammaNetwork(torch.nn.Module):
         return l1_t + self.l3(torch.sigmoid(self.l2(l1_t)))
 
     def forward(self, t):
-        g0 = self.gamma_tilde(torch.zeros_like(t))
-        g1 = self.gamma_tilde(torch.ones_like(t))
-        gt = self.gamma_tilde(t)
+        if t.is_cuda and t.dim() == 2 and t.shape[1] == 1:
+            # GPU (the training-mode loss of a learned schedule): gamma_tilde is row-wise, so the normalisation points 0 and 1
+            # ride along as two extra rows of ONE evaluation instead of two more evaluations on a [B, 1] column of equal
+            # values (noise_model.py:186-200) - a third of the ~40 small launches per call, and of their backward
+            ends = torch.tensor([[0.0], [1.0]], dtype=t.dtype, device=t.device)
+            g = self.gamma_tilde(torch.cat([t, ends], dim=0))
+            gt, g0, g1 = g[:-2], g[-2:-1], g[-1:]
+        else:
+            g0 = self.gamma_tilde(torch.zeros_like(t))
+            g1 = self.gamma_tilde(torch.ones_like(t))
+            gt = self.gamma_tilde(t)
         return self.gamma_0 + (self.gamma_1 - self.gamma_0) * ((gt - g0) / (g1 - g0))
 
 

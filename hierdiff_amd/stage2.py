@@ -112,6 +112,7 @@ class E_GCL(nn.Module):
         self._hd = None
         self._weights_key = None
         self._plist = None
+        self._frozen = False                            # set by a caller that vouches for unchanged parameters during its own call
         self._graphs: Dict[Tuple, _Graph] = {}          # by content of the edge list
         self._graph_ids: Dict[Tuple, Tuple] = {}        # by tensor identity (fast path)
 
@@ -136,6 +137,8 @@ class E_GCL(nn.Module):
         return self._hd[0]
 
     def _sync_weights(self):
+        if self._frozen and self._weights_key is not None and self._hd is not None:
+            return                                         # inside Edge_denoise.sample_AR / forward: checked once per call
         h = self._handle()
         if self._plist is None:                  # the module-tree walk of .parameters() costs more than a beam-sized layer
             self._plist = list(self.parameters())
@@ -167,7 +170,7 @@ class E_GCL(nn.Module):
             return hit[0]
         r = row.detach().to("cpu", torch.int32).contiguous()
         c = col.detach().to("cpu", torch.int32).contiguous()
-        key = (M, int(r.numel()), hashlib.sha1(r.numpy().tobytes() + c.numpy().tobytes()).hexdigest())
+        key = (M, r.numpy().tobytes(), c.numpy().tobytes())        # the content itself: exact, and cheaper than a digest at beam size
         g = self._graphs.get(key)
         if g is None:
             if len(self._graphs) >= 16:
@@ -196,7 +199,13 @@ class E_GCL(nn.Module):
         self._sync_weights()
         g = self._graph(row, col, M)
         dev = h.device
-        f32 = lambda t: None if t is None else t.detach().to(dev, torch.float32).contiguous()
+
+        def f32(t):
+            if t is None:
+                return None
+            if t.dtype is torch.float32 and t.device == dev and t.is_contiguous() and not t.requires_grad:
+                return t                                   # the common case at beam size: nothing to convert, nothing to allocate
+            return t.detach().to(dev, torch.float32).contiguous()
         hc, xc, ea = f32(h), f32(coord), f32(edge_attr)
         nm = None if node_mask is None else f32(node_mask).reshape(-1)
         em = None if edge_mask is None else f32(edge_mask).reshape(-1)
