@@ -55,6 +55,8 @@ SIGNATURES = {
                                  C.c_uint64, C.c_uint64, C.c_int, _VP]),
     "hd_topology_nodes": (C.c_int, [_VP, _VP]),
     "hd_edge_layer_forward": (C.c_int, [_VP, _VP, C.c_int] + [_FP] * 9 + [_VP]),
+    "hd_edge_layer_forward_p": (C.c_int, [_VP, _VP, C.c_int, C.c_int] + [_FP] * 9 + [_VP]),
+    "hd_dw2_x6": (C.c_int, [C.c_int, C.c_int, C.c_int, _FP, _FP, _FP, C.c_int, _FP, C.c_longlong, _VP]),
     "hd_edge_layer_backward": (C.c_int, [_VP, _VP, C.c_int] + [_FP] * 20 + [_VP]),
     "hd_egcl_create": (C.c_int, [C.POINTER(HdEgclConfig), C.c_int, C.POINTER(_VP)]),
     "hd_egcl_destroy": (C.c_int, [_VP]),
@@ -73,7 +75,7 @@ SIGNATURES = {
     "hd_debug_edge_trace": (C.c_int, [_VP, C.c_void_p, C.c_int]),
 }
 
-ABI_VERSION = 6          # HD_ABI_VERSION of include/hierdiff_hip.h
+ABI_VERSION = 7          # HD_ABI_VERSION of include/hierdiff_hip.h
 _lib: Optional[C.CDLL] = None
 
 

@@ -765,7 +765,7 @@ extern "C" int hd_topology_create(hd_handle* h, const uint8_t* node_mask, const 
     const size_t f_x0 = carve((size_t)M_pad * 4), f_xcur = carve((size_t)M_pad * 4);
     const size_t f_part = carve((size_t)std::max(1, n_parts) * H), f_xpart = carve((size_t)std::max(1, n_parts) * 4);
     const size_t f_eps = carve(BN * h->D), f_z = carve(BN * h->D), f_ctx = carve(BN * (size_t)std::max(1, h->cfg.context_node_nf));
-    const size_t f_w2 = carve((size_t)H * H), f_w2t = carve((size_t)H * H);
+    const size_t f_w2 = carve((size_t)H * H * 3 / 2), f_w2t = carve((size_t)H * H);      // w2img: fp32 image or the 1.5 x bf16x6 one
     auto build = [&]() -> int {
         hipError_t e = hipMalloc(reinterpret_cast<void**>(&t->arena), table_bytes + ws_floats * sizeof(float));
         if (e != hipSuccess) { t->arena = nullptr; return fail(HD_E_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e)); }
@@ -1012,20 +1012,23 @@ static bool launch_edge_ablated(hd_handle* h, const EdgeArgs& a, hipStream_t s) 
 extern "C" int hd_debug_edge_trace(hd_handle*, long long*, int) { return 0; }      // product build: nothing is traced
 #endif
 
+// `mode_override` >= 0 selects the arithmetic of THIS launch (0 fp32, 1 bf16x3, 2 bf16x6) instead of the handle's: the opt-in
+// bf16x6 forward of the training path (hd_edge_layer_forward_p) on a handle whose other kernels stay exact fp32
 template <int H>
-static int launch_edge_h(hd_handle* h, bool coord, const EdgeArgs& a, hipStream_t s) {
+static int launch_edge_h(hd_handle* h, bool coord, const EdgeArgs& a, hipStream_t s, int mode_override = -1) {
     const int lds = edge_lds_bytes<H>();
-    const int prec = h->cfg.precision;
+    const int prec = mode_override >= 0 ? mode_override : h->cfg.precision;
+    const bool x6 = mode_override >= 0 ? (mode_override == 2 && H >= 128) : h->x6;
     const dim3 grid(a.n_wg), block(256);
 #ifdef HD_DEBUG_KERNELS
     if constexpr (H == 256) {
-        if (h->ablate && !coord && (h->x6 ? launch_edge_ablated<2>(h, a, s) : prec == 1 ? launch_edge_ablated<1>(h, a, s) : launch_edge_ablated<0>(h, a, s))) return HD_OK;
+        if (h->ablate && !coord && (x6 ? launch_edge_ablated<2>(h, a, s) : prec == 1 ? launch_edge_ablated<1>(h, a, s) : launch_edge_ablated<0>(h, a, s))) return HD_OK;
     }
 #endif
     if constexpr (H >= 128) {
         // at most 512 tiles: one tile per workgroup, columns split over its four wavefronts (k_edge_split.hpp; bit-identical
         // to k_edge in every precision mode, a quarter of the serial MFMA chain per wavefront)
-        const int mode = h->x6 ? 2 : (prec == 1 ? 1 : 0);
+        const int mode = x6 ? 2 : (prec == 1 ? 1 : 0);
         // measured break-even (profiles/r02_split_sweep.log): between 490 and 654 tiles in the bf16 modes, between 654 and 870
         // in fp32 (the longer MFMA chain has more to gain from the split)
         if (a.n_tiles > 0 && a.n_tiles <= (mode == 0 ? h->split_max_tiles + h->split_max_tiles / 3 : h->split_max_tiles)) {
@@ -1046,7 +1049,7 @@ static int launch_edge_h(hd_handle* h, bool coord, const EdgeArgs& a, hipStream_
     if constexpr (H >= 128) {
         // between one whole-tile workgroup per CU and HD_MIX_MAX_TILES: R * n_cu whole-tile workgroups (every CU the same
         // number) + the remaining tiles as column-split workgroups that back-fill (k_edge_mixed; bit-identical per tile)
-        const int mode = h->x6 ? 2 : (prec == 1 ? 1 : 0);
+        const int mode = x6 ? 2 : (prec == 1 ? 1 : 0);
         const int per_round = 4 * h->n_cu;
         // Measured (profiles/r03_mix_sweep*.log, ms per forward, plain -> mixed): fp32 B = 40 1.89 -> 1.45, 64 1.93 -> 1.88,
         // 96 2.66 -> 2.60, 128 3.29 -> 3.17, 160 4.15 -> 3.89, 192 4.79 -> 4.40, 256 5.41 -> 5.51; the bf16 modes gain only
@@ -1076,7 +1079,7 @@ static int launch_edge_h(hd_handle* h, bool coord, const EdgeArgs& a, hipStream_
         }
     }
     if constexpr (H >= 128) {
-        if (h->x6) {
+        if (x6) {
             const int lds6 = edge_lds_bytes<H>(true);
             if (coord) hipLaunchKernelGGL((k_edge<H, true, 2>), grid, block, lds6, s, a);
             else hipLaunchKernelGGL((k_edge<H, false, 2>), grid, block, lds6, s, a);
@@ -1125,14 +1128,14 @@ static int prepare_kernels(hd_handle* h) {
     }
 }
 
-static int edge(hd_handle* h, bool coord, const EdgeArgs& a, hipStream_t s) {
+static int edge(hd_handle* h, bool coord, const EdgeArgs& a, hipStream_t s, int mode_override = -1) {
     if (a.n_wg == 0) return HD_OK;
     ProfScope ps(h, s, 0);
     switch (h->H) {
-        case 32: return launch_edge_h<32>(h, coord, a, s);
-        case 64: return launch_edge_h<64>(h, coord, a, s);
-        case 128: return launch_edge_h<128>(h, coord, a, s);
-        default: return launch_edge_h<256>(h, coord, a, s);
+        case 32: return launch_edge_h<32>(h, coord, a, s, mode_override);
+        case 64: return launch_edge_h<64>(h, coord, a, s, mode_override);
+        case 128: return launch_edge_h<128>(h, coord, a, s, mode_override);
+        default: return launch_edge_h<256>(h, coord, a, s, mode_override);
     }
 }
 
@@ -1341,10 +1344,12 @@ static int check_train(hd_handle* h, hd_topology* t, const char* who) {
     return HD_OK;
 }
 
-extern "C" int hd_edge_layer_forward(hd_handle* h, hd_topology* t, int coord, const float* AB, const float* x,
-                                     const float* x0, const float* wrd, const float* W2, const float* b2,
-                                     const float* wa, const float* ba, float* out, void* stream) {
+extern "C" int hd_edge_layer_forward_p(hd_handle* h, hd_topology* t, int coord, int precision, const float* AB, const float* x,
+                                       const float* x0, const float* wrd, const float* W2, const float* b2,
+                                       const float* wa, const float* ba, float* out, void* stream) {
     HD_TRY(check_train(h, t, "hd_edge_layer_forward"));
+    if (precision != 0 && precision != 2) return fail(HD_E_INVALID, "hd_edge_layer_forward_p: precision must be 0 (fp32) or 2 (bf16x6)");
+    const bool x6 = precision == 2 && h->H >= 128;          // narrower widths run the exact-fp32 kernels, as in sampling
     if (!AB || !x || !x0 || !wrd || !W2 || !b2 || !wa || !out) return fail(HD_E_INVALID, "hd_edge_layer_forward: null tensor");
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
@@ -1353,7 +1358,8 @@ extern "C" int hd_edge_layer_forward(hd_handle* h, hd_topology* t, int coord, co
     const int ow = coord ? 4 : H;
     HIP_TRY(hipMemsetAsync(out, 0, (size_t)std::max(1, M) * ow * sizeof(float), s));
     if (t->n_wg == 0 || M == 0) return HD_OK;
-    hipLaunchKernelGGL((k_pack_w2<false>), dim3((H * H + 255) / 256), dim3(256), 0, s, W2, t->w2img, H);
+    if (x6) hipLaunchKernelGGL(k_pack_w2_x6, dim3((H * H / 2 + 255) / 256), dim3(256), 0, s, W2, reinterpret_cast<uint32_t*>(t->w2img), H);
+    else hipLaunchKernelGGL((k_pack_w2<false>), dim3((H * H + 255) / 256), dim3(256), 0, s, W2, t->w2img, H);
     EdgeArgs e;
     std::memset(&e, 0, sizeof(e));
     e.AB = AB; e.wrd = wrd; e.W2img = t->w2img; e.b2 = b2; e.wa = wa;
@@ -1361,7 +1367,7 @@ extern "C" int hd_edge_layer_forward(hd_handle* h, hd_topology* t, int coord, co
     e.xcur = x; e.x0 = x0; e.part = coord ? t->xpart : t->part; e.ba = 0.0f; e.ba_ptr = ba;
     e.norm_constant = c.norm_constant; e.coords_range = c.coords_range / (float)c.n_layers; e.attention = c.attention;
     e.use_tanh = c.tanh; e.n_tiles = t->n_tiles; e.n_wg = t->n_wg;
-    HD_TRY(edge(h, coord != 0, e, s));
+    HD_TRY(edge(h, coord != 0, e, s, x6 ? 2 : 0));
     AggArgs ag;
     ag.part = coord ? t->xpart : t->part; ag.pstart = t->pstart; ag.agg = out; ag.norm = agg_norm(c, t);
     ag.M = M; ag.H = ow;
@@ -1369,6 +1375,12 @@ extern "C" int hd_edge_layer_forward(hd_handle* h, hd_topology* t, int coord, co
     hipLaunchKernelGGL(k_agg, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ag);
     HIP_TRY(hipGetLastError());
     return HD_OK;
+}
+
+extern "C" int hd_edge_layer_forward(hd_handle* h, hd_topology* t, int coord, const float* AB, const float* x,
+                                     const float* x0, const float* wrd, const float* W2, const float* b2,
+                                     const float* wa, const float* ba, float* out, void* stream) {
+    return hd_edge_layer_forward_p(h, t, coord, 0, AB, x, x0, wrd, W2, b2, wa, ba, out, stream);
 }
 
 extern "C" int hd_edge_layer_backward(hd_handle* h, hd_topology* t, int coord, const float* AB, const float* x,
@@ -1799,6 +1811,36 @@ extern "C" int hd_gemm_f32(int device, int M, int N, int K, const float* A, long
         const long long total = (long long)M * N + (colsum ? M : 0);
         hipLaunchKernelGGL(k_tgemm_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, r);
     }
+    HIP_TRY(hipGetLastError());
+    return HD_OK;
+}
+
+// dW2 = G2^T P in bf16x6 arithmetic (k_dw2.hpp): one workgroup per slab of edge rows owns the whole H x H result
+extern "C" int hd_dw2_x6(int device, int rows, int H, const float* G2, const float* P, float* dW2, int ldc, float* ws,
+                         long long ws_floats, void* stream) {
+    if (!G2 || !P || !dW2 || !ws) return fail(HD_E_INVALID, "hd_dw2_x6: null tensor");
+    if (H != 128 && H != 256) return fail(HD_E_INVALID, "hd_dw2_x6: H must be 128 or 256 (narrower layers use hd_gemm_f32)");
+    if (rows <= 0 || rows % 32 != 0 || ldc < H) return fail(HD_E_INVALID, "hd_dw2_x6: rows must be a positive multiple of 32 (whole edge tiles), ldc >= H");
+    if (hd_device_count() <= device || device < 0) return fail(HD_E_HIP, "hd_dw2_x6: no such HIP device (is a GPU visible?)");
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t s = (hipStream_t)stream;
+    // as many slabs as the workspace holds, at most one per CU (256) and at least four chunks each
+    int slabs = (int)std::min<long long>(256, ws_floats / ((long long)H * H));
+    slabs = std::max(1, std::min(slabs, rows / 128));
+    if ((long long)slabs * H * H > ws_floats) return fail(HD_E_INVALID, "hd_dw2_x6: workspace smaller than one H x H slab");
+    const int kslab = ((rows / 32 + slabs - 1) / slabs) * 32;
+    slabs = (rows + kslab - 1) / kslab;
+    Dw2Args a;
+    a.G = G2; a.P = P; a.ws = ws; a.rows = rows; a.kslab = kslab;
+    static bool prepared[2] = {false, false};
+    if (H == 256) {
+        if (!prepared[1]) { HIP_TRY(hipFuncSetAttribute((const void*)k_dw2_x6<256>, hipFuncAttributeMaxDynamicSharedMemorySize, dw2_lds_bytes<256>())); prepared[1] = true; }
+        hipLaunchKernelGGL((k_dw2_x6<256>), dim3(slabs), dim3(512), dw2_lds_bytes<256>(), s, a);
+    } else {
+        if (!prepared[0]) { HIP_TRY(hipFuncSetAttribute((const void*)k_dw2_x6<128>, hipFuncAttributeMaxDynamicSharedMemorySize, dw2_lds_bytes<128>())); prepared[0] = true; }
+        hipLaunchKernelGGL((k_dw2_x6<128>), dim3(slabs), dim3(512), dw2_lds_bytes<128>(), s, a);
+    }
+    hipLaunchKernelGGL(k_dw2_reduce, dim3((H * H + 255) / 256), dim3(256), 0, s, ws, dW2, H * H, H, ldc, slabs);
     HIP_TRY(hipGetLastError());
     return HD_OK;
 }

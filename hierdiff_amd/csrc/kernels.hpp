@@ -24,3 +24,4 @@
 #include "k_sampling.hpp"
 #include "k_egcl.hpp"
 #include "k_tgemm.hpp"
+#include "k_dw2.hpp"

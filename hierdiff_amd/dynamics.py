@@ -271,6 +271,23 @@ class EGNN_dynamics_QM9(nn.Module):
             vel = vel - (vel.sum(1, keepdim=True) / nmf.sum(1, keepdim=True)) * nmf            # remove_mean_with_mask (:116)
             return torch.cat([vel, h_final], dim=2)
 
+    # ------------------------------------------------------------------ arithmetic of the TRAINING path
+    @property
+    def training_precision(self) -> str:
+        """"fp32" (default): every kernel of a training step is exact fp32.  "bf16x6" (opt-in): the forward's per-edge H x H
+        contraction and the dense reduction dW2 = G2^T P run on the matrix cores proper in the fp32-ACCURATE three-way bf16 split
+        of the sampler's bf16x6 mode (six MFMAs per product, fp32 accumulation; hidden_nf >= 128) while the two backward
+        stages, the node-level GEMMs and the loss stay exact fp32 - this implementation's counterpart of the reference's
+        mixed-precision training (apex O2, conf/trainer/default.yaml:4-5), without its loss of accuracy: gradients agree with
+        the exact-fp32 step to ~1e-6 (tests/test_gpu_training.py)."""
+        return getattr(self, "_training_precision", "fp32")
+
+    @training_precision.setter
+    def training_precision(self, name: str) -> None:
+        if name not in ("fp32", "bf16x6"):
+            raise ValueError('training_precision must be "fp32" or "bf16x6"')
+        object.__setattr__(self, "_training_precision", name)
+
     # ------------------------------------------------------------------ precision of the matrix-core path
     @property
     def precision(self) -> str:

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define HD_ABI_VERSION 6
+#define HD_ABI_VERSION 7
 
 #define HD_OK 0
 #define HD_E_INVALID (-1)      /* bad argument / unsupported configuration */
@@ -192,6 +192,14 @@ int hd_topology_nodes(const hd_topology* t, int* node_of /* host, `active nodes`
 int hd_edge_layer_forward(hd_handle* h, hd_topology* topo, int coord, const float* AB, const float* x,
                           const float* x0, const float* wrd, const float* W2, const float* b2, const float* wa,
                           const float* ba, float* out, void* stream);
+/* The same forward with the arithmetic of the per-edge H x H contraction chosen per call: precision 0 = exact fp32 (what
+ * hd_edge_layer_forward runs), 2 = "bf16x6" (three-way bf16 split of both operands, six MFMAs per product, fp32 accumulation:
+ * the fp32-ACCURATE mode of the sampler, hd_config.precision; hidden_nf < 128 runs the fp32 kernels).  The opt-in mixed mode of
+ * the training path: the reference trains with apex O2 (endiffusion/conf/trainer/default.yaml:4-5); here the forward contraction
+ * and the dense reduction dW2 (hd_dw2_x6) may run on the matrix cores proper while the backward stages stay exact fp32. */
+int hd_edge_layer_forward_p(hd_handle* h, hd_topology* topo, int coord, int precision, const float* AB, const float* x,
+                            const float* x0, const float* wrd, const float* W2, const float* b2, const float* wa,
+                            const float* ba, float* out, void* stream);
 /* Backward of hd_edge_layer_forward given gout = dL/d(out).  Per-edge activations are recomputed; the caller provides
  * workspaces G2, P, G1 [rows][H], escal [rows][8], colpart, b2part [tiles][H], wrdpart [tiles][2][H], bapart [tiles]
  * (rows / tiles from hd_topology_layout's counts, tiles rounded up to a multiple of 4).  Written: dAB [M][2H],
@@ -256,6 +264,13 @@ int hd_gemm_f32(int device, int M, int N, int K, const float* A, long long a_m_s
                 const float* B, long long b_k_stride, long long b_n_stride, float* C, int ldc, const float* bias,
                 int epi, const float* aux, const float* row_mask, float* C2, int split_k, float* ws,
                 float* colsum, void* stream);
+
+/* dW2 [H][ldc] = G2^T P over `rows` edge rows (G2, P [rows][H] as hd_edge_layer_backward leaves them; rows a multiple of 32,
+ * H = 128 or 256) in bf16x6 arithmetic (csrc/k_dw2.hpp): the fp32-accurate form of the one dense reduction over all edge rows,
+ * ~2.5 x faster than the exact-fp32 split-K product of hd_gemm_f32.  ws: ws_floats >= H * H device floats; the product is cut
+ * into min(256, ws_floats / H^2, rows / 128) slabs whose partial results are added in a fixed order (deterministic). */
+int hd_dw2_x6(int device, int rows, int H, const float* G2, const float* P, float* dW2, int ldc, float* ws,
+              long long ws_floats, void* stream);
 
 /* Column sums of n <= 4 device arrays src[i] [rows][width[i]] into dst[i] [width[i]] in two launches, rows added in a fixed
  * order (32 ascending row ranges, then the ranges ascending): the reductions hd_edge_layer_backward leaves to its caller
