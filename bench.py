@@ -447,7 +447,7 @@ def next_rows(dev) -> dict:
                                                  "loss_value_no_grad_ms": round(dv * 1e3, 2),
                                                  "what": "DiffusionQM9.training_step + backward + AdamW.step, the same batch every step "
                                                          "(its topology is cached); every kernel exact fp32"}
-        # opt-in mixed mode (dynamics.training_precision = "bf16x6"): forward edge contraction + dW2 in the fp32-accurate bf16 split
+        # opt-in mixed mode (dynamics.training_precision = "bf16x6"): the edge layer's four H x H contraction sites in the fp32-accurate bf16 split
         m.dynamics.training_precision = "bf16x6"
         for _ in range(2):
             step()
@@ -458,10 +458,11 @@ def next_rows(dev) -> dict:
         torch.cuda.synchronize(dev)
         d6 = (time.perf_counter() - t0) / 5
         m.dynamics.training_precision = "fp32"
-        out[f"training_step_B{B}_N30_L6_bf16x6_forward_and_dW2"] = {
+        out[f"training_step_B{B}_N30_L6_bf16x6_contractions"] = {
             "ms_per_step": round(d6 * 1e3, 2), "molecules_per_s": round(B / d6, 1),
-            "what": "the same step with training_precision = 'bf16x6': hd_edge_layer_forward_p (precision 2) + hd_dw2_x6; backward "
-                    "stages, node GEMMs and loss exact fp32; gradients within 6e-6 of the oracle's (tests/test_gpu_training.py)"}
+            "what": "the same step with training_precision = 'bf16x6': hd_edge_layer_forward_p / hd_edge_layer_backward_p (precision 2) "
+                    "+ hd_dw2_x6; node GEMMs, first-layer GEMMs and loss exact fp32; gradients within 6e-6 of the oracle's "
+                    "(tests/test_gpu_training.py)"}
         # what a real training loop sees: NEW masks every step, i.e. one hd_topology_create per step - mask copy to the host,
         # layout, one allocation + upload - inside the timed region.  Same WORK in both rows below: one multiset of ragged sizes
         # (12 .. 30 nodes, mean 21), either the same batch every step (topology cached) or the sizes permuted over the batch

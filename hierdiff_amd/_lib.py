@@ -58,6 +58,7 @@ SIGNATURES = {
     "hd_edge_layer_forward_p": (C.c_int, [_VP, _VP, C.c_int, C.c_int] + [_FP] * 9 + [_VP]),
     "hd_dw2_x6": (C.c_int, [C.c_int, C.c_int, C.c_int, _FP, _FP, _FP, C.c_int, _FP, C.c_longlong, _VP]),
     "hd_edge_layer_backward": (C.c_int, [_VP, _VP, C.c_int] + [_FP] * 20 + [_VP]),
+    "hd_edge_layer_backward_p": (C.c_int, [_VP, _VP, C.c_int, C.c_int] + [_FP] * 20 + [_VP]),
     "hd_egcl_create": (C.c_int, [C.POINTER(HdEgclConfig), C.c_int, C.POINTER(_VP)]),
     "hd_egcl_destroy": (C.c_int, [_VP]),
     "hd_egcl_weight_count": (C.c_longlong, [_VP]),

@@ -765,7 +765,7 @@ extern "C" int hd_topology_create(hd_handle* h, const uint8_t* node_mask, const 
     const size_t f_x0 = carve((size_t)M_pad * 4), f_xcur = carve((size_t)M_pad * 4);
     const size_t f_part = carve((size_t)std::max(1, n_parts) * H), f_xpart = carve((size_t)std::max(1, n_parts) * 4);
     const size_t f_eps = carve(BN * h->D), f_z = carve(BN * h->D), f_ctx = carve(BN * (size_t)std::max(1, h->cfg.context_node_nf));
-    const size_t f_w2 = carve((size_t)H * H * 3 / 2), f_w2t = carve((size_t)H * H);      // w2img: fp32 image or the 1.5 x bf16x6 one
+    const size_t f_w2 = carve((size_t)H * H * 3 / 2), f_w2t = carve((size_t)H * H * 3 / 2);      // fp32 images or the 1.5 x bf16x6 ones
     auto build = [&]() -> int {
         hipError_t e = hipMalloc(reinterpret_cast<void**>(&t->arena), table_bytes + ws_floats * sizeof(float));
         if (e != hipSuccess) { t->arena = nullptr; return fail(HD_E_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e)); }
@@ -1306,7 +1306,7 @@ extern "C" int hd_topology_nodes(const hd_topology* t, int* node_of) {
 }
 
 template <int H>
-static int edge_bwd_lds_bytes() { return (2 * 32 * H + 4 * 288) * 4; }      // two weight chunks + per-wave scratch
+static int edge_bwd_lds_bytes(bool x6 = false) { return (2 * (x6 ? 24 : 32) * H + 4 * 288) * 4; }      // two weight chunks + per-wave scratch
 
 template <int H>
 static int prepare_edge_bwd_h() {
@@ -1315,12 +1315,29 @@ static int prepare_edge_bwd_h() {
     HIP_TRY(hipFuncSetAttribute((const void*)k_edge_bwd<H, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIP_TRY(hipFuncSetAttribute((const void*)k_edge_bwd<H, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIP_TRY(hipFuncSetAttribute((const void*)k_edge_bwd<H, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    if constexpr (H >= 128) {
+        const int lds6 = edge_bwd_lds_bytes<H>(true);
+        HIP_TRY(hipFuncSetAttribute((const void*)k_edge_bwd<H, false, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds6));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_edge_bwd<H, false, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds6));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_edge_bwd<H, true, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds6));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_edge_bwd<H, true, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds6));
+    }
     return HD_OK;
 }
 
 template <int H>
-static void launch_edge_bwd_h(bool coord, int stage, const EdgeBwdArgs& a, int n_wg, hipStream_t s) {
+static void launch_edge_bwd_h(bool coord, int stage, bool x6, const EdgeBwdArgs& a, int n_wg, hipStream_t s) {
     const dim3 grid(n_wg), block(256);
+    if constexpr (H >= 128) {
+        if (x6) {
+            const int lds6 = edge_bwd_lds_bytes<H>(true);
+            if (!coord && stage == 0) hipLaunchKernelGGL((k_edge_bwd<H, false, 0, 2>), grid, block, lds6, s, a);
+            else if (!coord) hipLaunchKernelGGL((k_edge_bwd<H, false, 1, 2>), grid, block, lds6, s, a);
+            else if (stage == 0) hipLaunchKernelGGL((k_edge_bwd<H, true, 0, 2>), grid, block, lds6, s, a);
+            else hipLaunchKernelGGL((k_edge_bwd<H, true, 1, 2>), grid, block, lds6, s, a);
+            return;
+        }
+    }
     const int lds = edge_bwd_lds_bytes<H>();
     if (!coord && stage == 0) hipLaunchKernelGGL((k_edge_bwd<H, false, 0>), grid, block, lds, s, a);
     else if (!coord) hipLaunchKernelGGL((k_edge_bwd<H, false, 1>), grid, block, lds, s, a);
@@ -1328,12 +1345,12 @@ static void launch_edge_bwd_h(bool coord, int stage, const EdgeBwdArgs& a, int n
     else hipLaunchKernelGGL((k_edge_bwd<H, true, 1>), grid, block, lds, s, a);
 }
 
-static void launch_edge_bwd(hd_handle* h, bool coord, int stage, const EdgeBwdArgs& a, int n_wg, hipStream_t s) {
+static void launch_edge_bwd(hd_handle* h, bool coord, int stage, bool x6, const EdgeBwdArgs& a, int n_wg, hipStream_t s) {
     switch (h->H) {
-        case 32: launch_edge_bwd_h<32>(coord, stage, a, n_wg, s); break;
-        case 64: launch_edge_bwd_h<64>(coord, stage, a, n_wg, s); break;
-        case 128: launch_edge_bwd_h<128>(coord, stage, a, n_wg, s); break;
-        default: launch_edge_bwd_h<256>(coord, stage, a, n_wg, s); break;
+        case 32: launch_edge_bwd_h<32>(coord, stage, false, a, n_wg, s); break;
+        case 64: launch_edge_bwd_h<64>(coord, stage, false, a, n_wg, s); break;
+        case 128: launch_edge_bwd_h<128>(coord, stage, x6, a, n_wg, s); break;
+        default: launch_edge_bwd_h<256>(coord, stage, x6, a, n_wg, s); break;
     }
 }
 
@@ -1358,7 +1375,7 @@ extern "C" int hd_edge_layer_forward_p(hd_handle* h, hd_topology* t, int coord, 
     const int ow = coord ? 4 : H;
     HIP_TRY(hipMemsetAsync(out, 0, (size_t)std::max(1, M) * ow * sizeof(float), s));
     if (t->n_wg == 0 || M == 0) return HD_OK;
-    if (x6) hipLaunchKernelGGL(k_pack_w2_x6, dim3((H * H / 2 + 255) / 256), dim3(256), 0, s, W2, reinterpret_cast<uint32_t*>(t->w2img), H);
+    if (x6) hipLaunchKernelGGL((k_pack_w2_x6<false>), dim3((H * H / 2 + 255) / 256), dim3(256), 0, s, W2, reinterpret_cast<uint32_t*>(t->w2img), H);
     else hipLaunchKernelGGL((k_pack_w2<false>), dim3((H * H + 255) / 256), dim3(256), 0, s, W2, t->w2img, H);
     EdgeArgs e;
     std::memset(&e, 0, sizeof(e));
@@ -1383,12 +1400,14 @@ extern "C" int hd_edge_layer_forward(hd_handle* h, hd_topology* t, int coord, co
     return hd_edge_layer_forward_p(h, t, coord, 0, AB, x, x0, wrd, W2, b2, wa, ba, out, stream);
 }
 
-extern "C" int hd_edge_layer_backward(hd_handle* h, hd_topology* t, int coord, const float* AB, const float* x,
+extern "C" int hd_edge_layer_backward_p(hd_handle* h, hd_topology* t, int coord, int precision, const float* AB, const float* x,
                                       const float* x0, const float* wrd, const float* W2, const float* b2,
                                       const float* wa, const float* ba, const float* gout, float* G2, float* P, float* G1,
                                       float* escal, float* colpart, float* bapart, float* b2part, float* wrdpart,
                                       float* dAB, float* dx, float* dx0, void* stream) {
     HD_TRY(check_train(h, t, "hd_edge_layer_backward"));
+    if (precision != 0 && precision != 2) return fail(HD_E_INVALID, "hd_edge_layer_backward_p: precision must be 0 (fp32) or 2 (bf16x6)");
+    const bool x6 = precision == 2 && h->H >= 128;
     if (!AB || !x || !x0 || !wrd || !W2 || !b2 || !wa || !gout || !G2 || !P || !G1 || !escal || !colpart || !bapart ||
         !b2part || !wrdpart || !dAB || !dx || !dx0)
         return fail(HD_E_INVALID, "hd_edge_layer_backward: null tensor");
@@ -1414,8 +1433,13 @@ extern "C" int hd_edge_layer_backward(hd_handle* h, hd_topology* t, int coord, c
     // every output row is written by the kernels below (all tiles of the padded table exist; the CSR sums and k_edge_dx
     // cover every active node), so nothing is cleared first; escal[:, 0:4] is only defined (and only read) in coordinate layers
     if (coord) HIP_TRY(hipMemsetAsync(bapart, 0, (size_t)tiles * sizeof(float), s));     // no attention bias in a coordinate layer
-    hipLaunchKernelGGL((k_pack_w2<false>), dim3((H * H + 255) / 256), dim3(256), 0, s, W2, t->w2img, H);
-    hipLaunchKernelGGL((k_pack_w2<true>), dim3((H * H + 255) / 256), dim3(256), 0, s, W2, t->w2timg, H);
+    if (x6) {
+        hipLaunchKernelGGL((k_pack_w2_x6<false>), dim3((H * H / 2 + 255) / 256), dim3(256), 0, s, W2, reinterpret_cast<uint32_t*>(t->w2img), H);
+        hipLaunchKernelGGL((k_pack_w2_x6<true>), dim3((H * H / 2 + 255) / 256), dim3(256), 0, s, W2, reinterpret_cast<uint32_t*>(t->w2timg), H);
+    } else {
+        hipLaunchKernelGGL((k_pack_w2<false>), dim3((H * H + 255) / 256), dim3(256), 0, s, W2, t->w2img, H);
+        hipLaunchKernelGGL((k_pack_w2<true>), dim3((H * H + 255) / 256), dim3(256), 0, s, W2, t->w2timg, H);
+    }
     EdgeBwdArgs a;
     std::memset(&a, 0, sizeof(a));
     a.AB = AB; a.wrd = wrd; a.b2 = b2; a.wa = wa; a.ei = t->ei; a.ej = t->ej; a.eseg = t->eseg; a.xcur = x; a.x0 = x0;
@@ -1424,9 +1448,9 @@ extern "C" int hd_edge_layer_backward(hd_handle* h, hd_topology* t, int coord, c
     a.gin = gout; a.G2 = G2; a.escal = escal; a.colpart = colpart; a.bapart = bapart; a.Pout = P; a.G1 = G1;
     a.b2part = b2part; a.wrdpart = wrdpart;
     a.Wimg = t->w2img;
-    launch_edge_bwd(h, coord != 0, 0, a, t->n_wg, s);
+    launch_edge_bwd(h, coord != 0, 0, x6, a, t->n_wg, s);
     a.Wimg = t->w2timg;
-    launch_edge_bwd(h, coord != 0, 1, a, t->n_wg, s);
+    launch_edge_bwd(h, coord != 0, 1, x6, a, t->n_wg, s);
     CsrSumArgs cs;
     std::memset(&cs, 0, sizeof(cs));
     cs.G = G1; cs.out = dAB; cs.M = M; cs.H = H; cs.ldo = 2 * H;
@@ -1441,6 +1465,15 @@ extern "C" int hd_edge_layer_backward(hd_handle* h, hd_topology* t, int coord, c
     hipLaunchKernelGGL(k_edge_dx, dim3((M + 255) / 256), dim3(256), 0, s, d);
     HIP_TRY(hipGetLastError());
     return HD_OK;
+}
+
+extern "C" int hd_edge_layer_backward(hd_handle* h, hd_topology* t, int coord, const float* AB, const float* x,
+                                      const float* x0, const float* wrd, const float* W2, const float* b2,
+                                      const float* wa, const float* ba, const float* gout, float* G2, float* P, float* G1,
+                                      float* escal, float* colpart, float* bapart, float* b2part, float* wrdpart,
+                                      float* dAB, float* dx, float* dx0, void* stream) {
+    return hd_edge_layer_backward_p(h, t, coord, 0, AB, x, x0, wrd, W2, b2, wa, ba, gout, G2, P, G1, escal, colpart, bapart, b2part,
+                                    wrdpart, dAB, dx, dx0, stream);
 }
 
 // ----------------------------------------------------------------------------- stage-2 layer E_GCL (forward)
@@ -1816,33 +1849,38 @@ extern "C" int hd_gemm_f32(int device, int M, int N, int K, const float* A, long
 }
 
 // dW2 = G2^T P in bf16x6 arithmetic (k_dw2.hpp): one workgroup per slab of edge rows owns the whole H x H result
-extern "C" int hd_dw2_x6(int device, int rows, int H, const float* G2, const float* P, float* dW2, int ldc, float* ws,
-                         long long ws_floats, void* stream) {
-    if (!G2 || !P || !dW2 || !ws) return fail(HD_E_INVALID, "hd_dw2_x6: null tensor");
-    if (H != 128 && H != 256) return fail(HD_E_INVALID, "hd_dw2_x6: H must be 128 or 256 (narrower layers use hd_gemm_f32)");
-    if (rows <= 0 || rows % 32 != 0 || ldc < H) return fail(HD_E_INVALID, "hd_dw2_x6: rows must be a positive multiple of 32 (whole edge tiles), ldc >= H");
-    if (hd_device_count() <= device || device < 0) return fail(HD_E_HIP, "hd_dw2_x6: no such HIP device (is a GPU visible?)");
+static int dw2_impl(const char* who, int device, int rows, int H, const float* G2, const float* P, float* dW2, int ldc,
+                    float* ws, long long ws_floats, void* stream) {
+    if (!G2 || !P || !dW2 || !ws) return fail(HD_E_INVALID, std::string(who) + ": null tensor");
+    if (H != 128 && H != 256) return fail(HD_E_INVALID, std::string(who) + ": H must be 128 or 256 (narrower layers use hd_gemm_f32)");
+    if (rows <= 0 || rows % 32 != 0 || ldc < H) return fail(HD_E_INVALID, std::string(who) + ": rows must be a positive multiple of 32 (whole edge tiles), ldc >= H");
+    if (hd_device_count() <= device || device < 0) return fail(HD_E_HIP, std::string(who) + ": no such HIP device (is a GPU visible?)");
     HIP_TRY(hipSetDevice(device));
     hipStream_t s = (hipStream_t)stream;
     // as many slabs as the workspace holds, at most one per CU (256) and at least four chunks each
     int slabs = (int)std::min<long long>(256, ws_floats / ((long long)H * H));
     slabs = std::max(1, std::min(slabs, rows / 128));
-    if ((long long)slabs * H * H > ws_floats) return fail(HD_E_INVALID, "hd_dw2_x6: workspace smaller than one H x H slab");
+    if ((long long)slabs * H * H > ws_floats) return fail(HD_E_INVALID, std::string(who) + ": workspace smaller than one H x H slab");
     const int kslab = ((rows / 32 + slabs - 1) / slabs) * 32;
     slabs = (rows + kslab - 1) / kslab;
     Dw2Args a;
     a.G = G2; a.P = P; a.ws = ws; a.rows = rows; a.kslab = kslab;
-    static bool prepared[2] = {false, false};
-    if (H == 256) {
-        if (!prepared[1]) { HIP_TRY(hipFuncSetAttribute((const void*)k_dw2_x6<256>, hipFuncAttributeMaxDynamicSharedMemorySize, dw2_lds_bytes<256>())); prepared[1] = true; }
-        hipLaunchKernelGGL((k_dw2_x6<256>), dim3(slabs), dim3(512), dw2_lds_bytes<256>(), s, a);
-    } else {
-        if (!prepared[0]) { HIP_TRY(hipFuncSetAttribute((const void*)k_dw2_x6<128>, hipFuncAttributeMaxDynamicSharedMemorySize, dw2_lds_bytes<128>())); prepared[0] = true; }
-        hipLaunchKernelGGL((k_dw2_x6<128>), dim3(slabs), dim3(512), dw2_lds_bytes<128>(), s, a);
+    static bool prepared = false;
+    if (!prepared) {
+        HIP_TRY(hipFuncSetAttribute((const void*)k_dw2_x6<256>, hipFuncAttributeMaxDynamicSharedMemorySize, dw2_lds_bytes<256>()));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_dw2_x6<128>, hipFuncAttributeMaxDynamicSharedMemorySize, dw2_lds_bytes<128>()));
+        prepared = true;
     }
+    if (H == 256) hipLaunchKernelGGL((k_dw2_x6<256>), dim3(slabs), dim3(512), dw2_lds_bytes<256>(), s, a);
+    else hipLaunchKernelGGL((k_dw2_x6<128>), dim3(slabs), dim3(512), dw2_lds_bytes<128>(), s, a);
     hipLaunchKernelGGL(k_dw2_reduce, dim3((H * H + 255) / 256), dim3(256), 0, s, ws, dW2, H * H, H, ldc, slabs);
     HIP_TRY(hipGetLastError());
     return HD_OK;
+}
+
+extern "C" int hd_dw2_x6(int device, int rows, int H, const float* G2, const float* P, float* dW2, int ldc, float* ws,
+                         long long ws_floats, void* stream) {
+    return dw2_impl("hd_dw2_x6", device, rows, H, G2, P, dW2, ldc, ws, ws_floats, stream);
 }
 
 extern "C" int hd_colsum_f32(int device, int rows, int n, const float* const* src, const int* width, float* const* dst,

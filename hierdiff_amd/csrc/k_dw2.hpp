@@ -163,9 +163,11 @@ __global__ __launch_bounds__(256) void k_dw2_reduce(const float* ws, float* C, i
     C[(size_t)(idx / N) * ldc + idx % N] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
 }
 
-// W [H][H] (state_dict layout, row = output column of the layer) -> chunk image of the bf16x6 edge kernel (pack_edge_w2_x6 on the
-// device: training forwards run on the parameter itself): per 16-wide K chunk [head | middle | tail][H/32 column tiles][64 lanes][8 bf16],
-// lane (hh, n) element i = W[32 ct + n][16 c + 8 hh + i].  One thread per (chunk, tile, lane, element pair).
+// W [H][H] (state_dict layout, row = output column of the layer) -> chunk image of the bf16x6 edge kernels (pack_edge_w2_x6 on the
+// device: training runs on the parameter itself): per 16-wide K chunk [head | middle | tail][H/32 column tiles][64 lanes][8 bf16],
+// lane (hh, n) element i = W[32 ct + n][16 c + 8 hh + i] - or, TRANS (second backward stage, dP = G2 W2), of W^T: W[16 c + 8 hh + i][32 ct + n].
+// One thread per (chunk, tile, lane, element pair).
+template <bool TRANS>
 __global__ void k_pack_w2_x6(const float* W, uint32_t* img, int H) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;            // pair index: ((c * NCT + ct) * 64 + lane) * 4 + ip
     if (idx >= H * H / 2) return;
@@ -174,7 +176,8 @@ __global__ void k_pack_w2_x6(const float* W, uint32_t* img, int H) {
     const int ct = rest % NCT, c = rest / NCT;
     const int col = 32 * ct + (lane & 31), k = 16 * c + 8 * (lane >> 5) + 2 * ip;
     uint32_t h, m, l;
-    bf16_split3(W[(size_t)col * H + k], W[(size_t)col * H + k + 1], h, m, l);
+    if (TRANS) bf16_split3(W[(size_t)k * H + col], W[(size_t)(k + 1) * H + col], h, m, l);
+    else bf16_split3(W[(size_t)col * H + k], W[(size_t)col * H + k + 1], h, m, l);
     const size_t base = ((size_t)c * 3 * NCT + ct) * 256 + lane * 4 + ip;       // in dwords: 512 bf16 = 256 dwords per (piece, tile)
     img[base] = h;
     img[base + (size_t)NCT * 256] = m;

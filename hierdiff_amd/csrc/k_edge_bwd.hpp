@@ -52,9 +52,15 @@ struct EdgeBwdArgs {
 HD_DEVINL float dsilu_from_sigmoid(float x, float s) { return s * __builtin_fmaf(x, 1.0f - s, 1.0f); }
 
 // STAGE 0 = A, 1 = B.  One workgroup = four 32-row tiles (one per wavefront), grid = tiles / 4.
-template <int H, bool COORD, int STAGE>
+// PREC 0: the two H x H contractions (stage A: pre2 = W2 P, stage B: dP = G2 W2) in exact fp32.  PREC 2 (round 4, opt-in
+// `training_precision = "bf16x6"`, H >= 128): both in the fp32-accurate three-way bf16 split of the sampler's edge kernel - operand
+// rows split in registers, weight images [head | middle | tail] per 16-wide K chunk (k_pack_w2_x6), six MFMAs per product on two
+// alternating accumulators, fp32 accumulation; everything around the contraction (first-layer recomputation, SiLU and its
+// derivative, gate / head, the materialised G2 / P / G1 tiles, per-tile partial sums) is the fp32 code of PREC 0.
+template <int H, bool COORD, int STAGE, int PREC = 0>
 __global__ __launch_bounds__(256, 2) void k_edge_bwd(EdgeBwdArgs a) {
-    constexpr int NCT = H / 32, NCH = H / 32, CHF = 32 * H;
+    constexpr int KC = PREC == 2 ? 16 : 32;                        // K chunk width
+    constexpr int NCT = H / 32, NCH = H / KC, CHF = PREC == 2 ? 24 * H : 32 * H;   // CHF: floats per weight chunk image
     extern __shared__ __attribute__((aligned(16))) float smem_b[];
     float* wbuf0 = smem_b;                       // [2][CHF] two K chunks of the weight image (double buffer)
     float* scr = smem_b + 2 * CHF;               // per wave: 32 phi + 96 unit dir + 32 ni + 32 nj + 32 radial + 32 d0 + 32 valid
@@ -98,27 +104,28 @@ __global__ __launch_bounds__(256, 2) void k_edge_bwd(EdgeBwdArgs a) {
     // A operand of K chunk c for this lane's edge row (k = 32c + 16hh + 0..15).  The raw rows are requested one chunk ahead
     // (load_raw, in flight under the MFMAs of the current chunk) and finished behind them (finish_P: first-layer
     // pre-activation + SiLU; stage B: the G2 row as it is).
-    const float* Arow = a.AB + (size_t)ni * (2 * H) + 16 * hh;
-    const float* Brow = a.AB + (size_t)nj * (2 * H) + H + 16 * hh;
-    const float* Grow = a.G2 + (size_t)e * H + 16 * hh;
-    struct Raw { f32x4 a[4]; f32x4 b[4]; };
+    constexpr int NQ = KC / 8;                                     // float4 row pieces per lane and chunk (k = KC c + (KC/2) hh + 0 .. KC/2-1)
+    const float* Arow = a.AB + (size_t)ni * (2 * H) + (KC / 2) * hh;
+    const float* Brow = a.AB + (size_t)nj * (2 * H) + H + (KC / 2) * hh;
+    const float* Grow = a.G2 + (size_t)e * H + (KC / 2) * hh;
+    struct Raw { f32x4 a[NQ]; f32x4 b[NQ]; };
     auto load_raw = [&](int c, Raw& w) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < NQ; ++u) {
             if constexpr (STAGE == 0) {
-                w.a[u] = *reinterpret_cast<const f32x4*>(Arow + 32 * c + 4 * u);
-                w.b[u] = *reinterpret_cast<const f32x4*>(Brow + 32 * c + 4 * u);
+                w.a[u] = *reinterpret_cast<const f32x4*>(Arow + KC * c + 4 * u);
+                w.b[u] = *reinterpret_cast<const f32x4*>(Brow + KC * c + 4 * u);
             } else {
-                w.a[u] = *reinterpret_cast<const f32x4*>(Grow + 32 * c + 4 * u);
+                w.a[u] = *reinterpret_cast<const f32x4*>(Grow + KC * c + 4 * u);
             }
         }
     };
-    auto finish_P = [&](int c, const Raw& w, float (&P)[16]) {
+    auto finish_P = [&](int c, const Raw& w, float (&P)[4 * NQ]) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < NQ; ++u) {
             if constexpr (STAGE == 0) {
-                const f32x4 wr4 = *reinterpret_cast<const f32x4*>(wrd_s + 32 * c + 16 * hh + 4 * u);
-                const f32x4 wd4 = *reinterpret_cast<const f32x4*>(wrd_s + H + 32 * c + 16 * hh + 4 * u);
+                const f32x4 wr4 = *reinterpret_cast<const f32x4*>(wrd_s + KC * c + (KC / 2) * hh + 4 * u);
+                const f32x4 wd4 = *reinterpret_cast<const f32x4*>(wrd_s + H + KC * c + (KC / 2) * hh + 4 * u);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float pre = w.a[u][j] + w.b[u][j];               // same operation order as the forward kernel
@@ -140,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_bwd(EdgeBwdArgs a) {
 
     issue_chunk(0);
     __syncthreads();                                             // wrd_s staged
-    float P[16];
+    float P[4 * NQ];
     Raw raw;
     load_raw(0, raw);
     finish_P(0, raw, P);
@@ -157,28 +164,70 @@ __global__ __launch_bounds__(256, 2) void k_edge_bwd(EdgeBwdArgs a) {
         __syncthreads();                                         // chunk c is complete; nobody reads the other buffer any more
         if (c + 1 < NCH) { issue_chunk(c + 1); load_raw(c + 1, raw); }
         const float* wbuf = wbuf0 + (c & 1) * CHF;
-        // eight groups of (k-quad q, half of the column tiles); the B fragments of group g+1 are requested before the
-        // MFMAs of group g.  sched_barrier keeps hipcc from hoisting more fragment reads than that (it spills otherwise).
-        constexpr int GC = (NCT >= 2) ? NCT / 2 : 1, NG = 4 * (NCT / GC);
-        f32x4 bcur[GC], bnxt[GC];
-        auto load_b = [&](int g, f32x4 (&b)[GC]) {
-            const int q = g / (NCT / GC), c0 = (g % (NCT / GC)) * GC;
+        if constexpr (PREC == 2) {
+            // one k-step of 16 per chunk: the lane's 8 operand values -> head / middle / tail dwords (k order = element order of the
+            // image: lane (hh, n) element i is W[32 ct + n][16 c + 8 hh + i]); per pair of column tiles two groups of six MFMAs on
+            // alternating accumulators, the small terms first (h*L, h*M, m*M | h*H, m*H, l*H), fragments requested a pair ahead
+            u32x4 xh, xm, xl;
 #pragma unroll
-            for (int k = 0; k < GC; ++k) b[k] = *reinterpret_cast<const f32x4*>(wbuf + ((q * NCT + c0 + k) * 64 + lane) * 4);
-        };
-        load_b(0, bcur);
+            for (int u = 0; u < 2; ++u) {
+                uint32_t hi[2], mi[2], lo[2];
+                bf16_split3(P[4 * u], P[4 * u + 1], hi[0], mi[0], lo[0]);
+                bf16_split3(P[4 * u + 2], P[4 * u + 3], hi[1], mi[1], lo[1]);
+                xh[2 * u] = hi[0]; xh[2 * u + 1] = hi[1]; xm[2 * u] = mi[0]; xm[2 * u + 1] = mi[1]; xl[2 * u] = lo[0]; xl[2 * u + 1] = lo[1];
+            }
+            const bf16x8 A_h = __builtin_bit_cast(bf16x8, xh), A_m = __builtin_bit_cast(bf16x8, xm), A_l = __builtin_bit_cast(bf16x8, xl);
+            const bf16x8* wf = reinterpret_cast<const bf16x8*>(wbuf) + lane;          // [piece][ct][64 lanes] x 16 B
+            bf16x8 fcur[6], fnxt[6];
+            auto load_f = [&](int g, bf16x8 (&f)[6]) {
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            const int q = g / (NCT / GC), c0 = (g % (NCT / GC)) * GC;
-            if (g + 1 < NG) load_b(g + 1, bnxt);
+                for (int p = 0; p < 3; ++p) { f[2 * p] = wf[(p * NCT + 2 * g) * 64]; f[2 * p + 1] = wf[(p * NCT + 2 * g + 1) * 64]; }
+            };
+            load_f(0, fcur);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int g = 0; g < NCT / 2; ++g) {
+                if (g + 1 < NCT / 2) load_f(g + 1, fnxt);
+                const int c0 = 2 * g, c1 = 2 * g + 1;
+                acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_h, fcur[4], acc[c0], 0, 0, 0);       // h * L
+                acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_h, fcur[5], acc[c1], 0, 0, 0);
+                acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_h, fcur[2], acc[c0], 0, 0, 0);       // h * M
+                acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_h, fcur[3], acc[c1], 0, 0, 0);
+                acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_m, fcur[2], acc[c0], 0, 0, 0);       // m * M
+                acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_m, fcur[3], acc[c1], 0, 0, 0);
+                acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_h, fcur[0], acc[c0], 0, 0, 0);       // h * H
+                acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_h, fcur[1], acc[c1], 0, 0, 0);
+                acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_m, fcur[0], acc[c0], 0, 0, 0);       // m * H
+                acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_m, fcur[1], acc[c1], 0, 0, 0);
+                acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_l, fcur[0], acc[c0], 0, 0, 0);       // l * H
+                acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_l, fcur[1], acc[c1], 0, 0, 0);
 #pragma unroll
-                for (int k = 0; k < GC; ++k)
-                    acc[c0 + k] = __builtin_amdgcn_mfma_f32_32x32x2f32(P[4 * q + j], bcur[k][j], acc[c0 + k], 0, 0, 0);
-#pragma unroll
-            for (int k = 0; k < GC; ++k) bcur[k] = bnxt[k];
-            __builtin_amdgcn_sched_barrier(0);
+                for (int k = 0; k < 6; ++k) fcur[k] = fnxt[k];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            // eight groups of (k-quad q, half of the column tiles); the B fragments of group g+1 are requested before the
+            // MFMAs of group g.  sched_barrier keeps hipcc from hoisting more fragment reads than that (it spills otherwise).
+            constexpr int GC = (NCT >= 2) ? NCT / 2 : 1, NG = 4 * (NCT / GC);
+            f32x4 bcur[GC], bnxt[GC];
+            auto load_b = [&](int g, f32x4 (&b)[GC]) {
+                const int q = g / (NCT / GC), c0 = (g % (NCT / GC)) * GC;
+    #pragma unroll
+                for (int k = 0; k < GC; ++k) b[k] = *reinterpret_cast<const f32x4*>(wbuf + ((q * NCT + c0 + k) * 64 + lane) * 4);
+            };
+            load_b(0, bcur);
+    #pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const int q = g / (NCT / GC), c0 = (g % (NCT / GC)) * GC;
+                if (g + 1 < NG) load_b(g + 1, bnxt);
+    #pragma unroll
+                for (int j = 0; j < 4; ++j)
+    #pragma unroll
+                    for (int k = 0; k < GC; ++k)
+                        acc[c0 + k] = __builtin_amdgcn_mfma_f32_32x32x2f32(P[4 * q + j], bcur[k][j], acc[c0 + k], 0, 0, 0);
+    #pragma unroll
+                for (int k = 0; k < GC; ++k) bcur[k] = bnxt[k];
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         if (c + 1 < NCH) finish_P(c + 1, raw, P);
         __builtin_amdgcn_sched_barrier(0);

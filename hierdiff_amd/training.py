@@ -253,15 +253,16 @@ class _EdgeLayer(torch.autograd.Function):
         dAB = torch.empty((M, 2 * tr.H), device=dev, dtype=torch.float32)
         dx = torch.empty((M, 4), device=dev, dtype=torch.float32)
         dx0 = torch.empty((M, 4), device=dev, dtype=torch.float32)
-        _lib.check(lib.hd_edge_layer_backward(
-            dyn._handle(), topo.ptr, int(coord), AB.data_ptr(), x4.data_ptr(), x04.data_ptr(), wrd.data_ptr(), W2.data_ptr(),
+        x6 = getattr(dyn, "training_precision", "fp32") == "bf16x6"
+        _lib.check(lib.hd_edge_layer_backward_p(
+            dyn._handle(), topo.ptr, int(coord), 2 if x6 else 0, AB.data_ptr(), x4.data_ptr(), x04.data_ptr(), wrd.data_ptr(), W2.data_ptr(),
             b2.data_ptr(), wa.data_ptr(), None if ba is None else ba.data_ptr(), g.data_ptr(), ws["G2"].data_ptr(),
             ws["P"].data_ptr(), ws["G1"].data_ptr(), ws["escal"].data_ptr(), ws["colpart"].data_ptr(), ws["bapart"].data_ptr(),
             ws["b2part"].data_ptr(), ws["wrdpart"].data_ptr(), dAB.data_ptr(), dx.data_ptr(), dx0.data_ptr(), _stream(dev)),
-            "hd_edge_layer_backward")
+            "hd_edge_layer_backward_p")
         # the one dense reduction over all edge rows: dL/dW2[c][k] = sum_e G2[e][c] P[e][k] (K = edge rows, split-K in slab order)
         if getattr(dyn, "training_precision", "fp32") == "bf16x6" and tr.H in (128, 256):
-            # opt-in: the same reduction on a three-way bf16 split of both operands (hd_dw2_x6: fp32-accurate, ~2.5 x faster)
+            # opt-in: the same reduction on a three-way bf16 split of both operands (hd_dw2_x6: fp32-accurate, every row read once)
             dW2 = torch.empty((tr.H, tr.H), device=dev, dtype=torch.float32)
             slabs = max(1, min(256, tr.rows // 128))
             w6 = _splitk_workspace(dev, slabs * tr.H * tr.H)

@@ -200,6 +200,13 @@ int hd_edge_layer_forward(hd_handle* h, hd_topology* topo, int coord, const floa
 int hd_edge_layer_forward_p(hd_handle* h, hd_topology* topo, int coord, int precision, const float* AB, const float* x,
                             const float* x0, const float* wrd, const float* W2, const float* b2, const float* wa,
                             const float* ba, float* out, void* stream);
+/* hd_edge_layer_backward (below) with the arithmetic of its two H x H contractions - stage A recomputes pre2 = W2 P, stage B forms
+ * dP = G2 W2 - chosen per call like hd_edge_layer_forward_p: 0 exact fp32, 2 bf16x6 (hidden_nf >= 128).  Everything around the
+ * contractions (recomputed first layer, SiLU and its derivative, gate / head, G2 / P / G1, per-tile partial sums) is fp32 either way. */
+int hd_edge_layer_backward_p(hd_handle* h, hd_topology* topo, int coord, int precision, const float* AB, const float* x,
+                             const float* x0, const float* wrd, const float* W2, const float* b2, const float* wa,
+                             const float* ba, const float* gout, float* G2, float* P, float* G1, float* escal, float* colpart,
+                             float* bapart, float* b2part, float* wrdpart, float* dAB, float* dx, float* dx0, void* stream);
 /* Backward of hd_edge_layer_forward given gout = dL/d(out).  Per-edge activations are recomputed; the caller provides
  * workspaces G2, P, G1 [rows][H], escal [rows][8], colpart, b2part [tiles][H], wrdpart [tiles][2][H], bapart [tiles]
  * (rows / tiles from hd_topology_layout's counts, tiles rounded up to a multiple of 4).  Written: dAB [M][2H],
@@ -271,7 +278,6 @@ int hd_gemm_f32(int device, int M, int N, int K, const float* A, long long a_m_s
  * into min(256, ws_floats / H^2, rows / 128) slabs whose partial results are added in a fixed order (deterministic). */
 int hd_dw2_x6(int device, int rows, int H, const float* G2, const float* P, float* dW2, int ldc, float* ws,
               long long ws_floats, void* stream);
-
 /* Column sums of n <= 4 device arrays src[i] [rows][width[i]] into dst[i] [width[i]] in two launches, rows added in a fixed
  * order (32 ascending row ranges, then the ranges ascending): the reductions hd_edge_layer_backward leaves to its caller
  * (db2, d(wa), d(w_r) / d(w_d), d(ba) from the per-tile partial sums).  src / width / dst are HOST arrays of n entries;

@@ -385,14 +385,16 @@ def test_trainer_ddp_step_equals_the_manual_sequence():
 
 # ----------------------------------------------------------------------------- opt-in bf16x6 arithmetic of the training path
 
+@pytest.mark.parametrize("fname", ["hd_dw2_x6"])
 @pytest.mark.parametrize("H,rows", [(256, 4096), (256, 32 * 173), (128, 2048), (128, 32)])
-def test_dw2_x6_matches_a_float64_product(H, rows):
-    """hd_dw2_x6 (csrc/k_dw2.hpp): dW2 = G2^T P on a three-way bf16 split of both operands, six MFMAs per product - as close to
-    a float64 product as an fp32 GEMM of the same operands (the split drops terms below 2^-26 of a product), slab counts that
-    do and do not divide the rows, deterministic."""
+def test_dw2_matches_a_float64_product(H, rows, fname):
+    """csrc/k_dw2.hpp: dW2 = G2^T P with one workgroup per slab of edge rows owning the whole H x H result, on a three-way bf16
+    split of both operands, six MFMAs per product - closer to a float64 product than torch's fp32 GEMM of the same operands (the
+    split drops terms below 2^-26 of a product); slab counts that do and do not divide the rows; deterministic."""
     import ctypes as C
     from hierdiff_amd import _lib
     lib = _lib.load()
+    fn = getattr(lib, fname)
     g = torch.Generator().manual_seed(H + rows)
     G2 = (torch.randn(rows, H, generator=g) * torch.logspace(-3, 1, H)[None, :]).to(DEV)       # columns of very different scale
     P = torch.randn(rows, H, generator=g).to(DEV)
@@ -401,20 +403,20 @@ def test_dw2_x6_matches_a_float64_product(H, rows):
     for slabs in (256, 7, 1):
         dW2 = torch.full((H, H), float("nan"), device=DEV)
         ws = torch.empty(slabs * H * H, device=DEV)
-        _lib.check(lib.hd_dw2_x6(0, rows, H, G2.data_ptr(), P.data_ptr(), dW2.data_ptr(), H, ws.data_ptr(), ws.numel(),
-                                 torch.cuda.current_stream().cuda_stream), "hd_dw2_x6")
+        _lib.check(fn(0, rows, H, G2.data_ptr(), P.data_ptr(), dW2.data_ptr(), H, ws.data_ptr(), ws.numel(),
+                                 torch.cuda.current_stream().cuda_stream), fname)
         err = float((dW2.double() - ref).norm() / ref.norm())
         f32 = float(((G2.t() @ P).double() - ref).norm() / ref.norm())
-        print(f"dW2 x6 H={H} rows={rows} slabs<={slabs}: rel-L2 vs float64 {err:.2e} (torch fp32 matmul {f32:.2e})")
+        print(f"{fname} H={H} rows={rows} slabs<={slabs}: rel-L2 vs float64 {err:.2e} (torch fp32 matmul {f32:.2e})")
         assert err < 2e-6
         outs.append(dW2)
     again = torch.empty_like(outs[0])
     ws = torch.empty(256 * H * H, device=DEV)
-    _lib.check(lib.hd_dw2_x6(0, rows, H, G2.data_ptr(), P.data_ptr(), again.data_ptr(), H, ws.data_ptr(), ws.numel(),
-                             torch.cuda.current_stream().cuda_stream), "hd_dw2_x6")
+    _lib.check(fn(0, rows, H, G2.data_ptr(), P.data_ptr(), again.data_ptr(), H, ws.data_ptr(), ws.numel(),
+                             torch.cuda.current_stream().cuda_stream), fname)
     assert torch.equal(again, outs[0])                                   # no atomics: bit-reproducible
-    assert lib.hd_dw2_x6(0, 48, H, G2.data_ptr(), P.data_ptr(), again.data_ptr(), H, ws.data_ptr(), ws.numel(), None) != 0   # rows % 32
-    assert lib.hd_dw2_x6(0, rows, 64, G2.data_ptr(), P.data_ptr(), again.data_ptr(), 64, ws.data_ptr(), ws.numel(), None) != 0
+    assert fn(0, 48, H, G2.data_ptr(), P.data_ptr(), again.data_ptr(), H, ws.data_ptr(), ws.numel(), None) != 0   # rows % 32
+    assert fn(0, rows, 64, G2.data_ptr(), P.data_ptr(), again.data_ptr(), 64, ws.data_ptr(), ws.numel(), None) != 0
 
 
 @pytest.mark.parametrize("H", [256, 128])
