@@ -41,7 +41,9 @@ SIGNATURES = {
     "hd_weight_count": (C.c_longlong, [_VP]),
     "hd_set_weights": (C.c_int, [_VP, _FP, C.c_longlong, C.c_int, _VP]),
     "hd_topology_create": (C.c_int, [_VP, _U8P, _U8P, C.c_int, C.c_int, C.POINTER(_VP)]),
+    "hd_topology_create_s": (C.c_int, [_VP, _U8P, _U8P, C.c_int, C.c_int, _VP, C.POINTER(_VP)]),
     "hd_topology_destroy": (C.c_int, [_VP]),
+    "hd_arena_pool_trim": (C.c_int, []),
     "hd_topology_layout": (C.c_int, [_U8P, _U8P, C.c_int, C.c_int, C.POINTER(C.c_longlong), _VP, _VP, _VP, _VP, _VP, _VP]),
     "hd_topology_info": (C.c_int, [_VP, C.POINTER(C.c_longlong)]),
     "hd_egnn_forward": (C.c_int, [_VP, _VP, _FP, _FP, C.c_int, _FP, C.c_int, _FP, _VP]),
@@ -54,6 +56,7 @@ SIGNATURES = {
     "hd_sample_loop": (C.c_int, [_VP, _VP, _FP, _FP, C.c_int, C.c_int, C.c_int, _FP, _FP, C.c_int,
                                  C.c_uint64, C.c_uint64, C.c_int, _VP]),
     "hd_topology_nodes": (C.c_int, [_VP, _VP]),
+    "hd_topology_nodes_device": (C.c_int, [_VP, _VP, _VP]),
     "hd_edge_layer_forward": (C.c_int, [_VP, _VP, C.c_int] + [_FP] * 9 + [_VP]),
     "hd_edge_layer_forward_p": (C.c_int, [_VP, _VP, C.c_int, C.c_int] + [_FP] * 9 + [_VP]),
     "hd_dw2_x6": (C.c_int, [C.c_int, C.c_int, C.c_int, _FP, _FP, _FP, C.c_int, _FP, C.c_longlong, _VP]),
@@ -76,7 +79,7 @@ SIGNATURES = {
     "hd_debug_edge_trace": (C.c_int, [_VP, C.c_void_p, C.c_int]),
 }
 
-ABI_VERSION = 7          # HD_ABI_VERSION of include/hierdiff_hip.h
+ABI_VERSION = 8          # HD_ABI_VERSION of include/hierdiff_hip.h
 _lib: Optional[C.CDLL] = None
 
 

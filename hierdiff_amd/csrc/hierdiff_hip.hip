@@ -9,6 +9,7 @@
 #include <cstring>
 #include <cstdlib>
 #include <string>
+#include <mutex>
 #include <vector>
 
 // ----------------------------------------------------------------------------- errors
@@ -136,6 +137,15 @@ struct hd_topology {
     float *zbuf, *ctxbuf;
     hipGraphExec_t gexec;
     GraphKey gkey;
+    // lifetime: the tables arrive in stream order of `stream0` (hd_topology_create_s); `ready` marks their arrival for
+    // any other stream a caller launches on.  A topology used on one stream only hands its arena back to the pool
+    // (arena_release) with an event instead of a device-wide synchronisation.
+    size_t arena_bytes;
+    char* staging;                             // pinned host twin of the table region (source of the async upload)
+    size_t staging_bytes;
+    hipStream_t stream0, last_stream;
+    hipEvent_t ready;
+    bool multi_stream;
 };
 
 // ----------------------------------------------------------------------------- small helpers
@@ -561,15 +571,111 @@ extern "C" int hd_set_weights(hd_handle* h, const float* blob, long long n, int 
 
 // ----------------------------------------------------------------------------- topology
 
+// Arena pool.  A training loop meets new masks every step, so topologies come and go at step rate: their device
+// arena (tables + workspace, ~60 MB at B = 256) and its pinned staging twin are recycled through a small grow-only free
+// list instead of hipMalloc / hipFree (which synchronise the device).  A slot carries the event recorded behind the last
+// work of its previous owner; the next owner waits for it on the host before overwriting the staging buffer (in a
+// steady loop that work finished steps ago).
+struct ArenaSlot {
+    int device;
+    char* dev; size_t dev_bytes;
+    char* pinned; size_t pinned_bytes;
+    hipEvent_t done;                           // nullptr: nothing pending
+};
+static std::mutex g_pool_mu;
+static std::vector<ArenaSlot> g_pool;
+static constexpr size_t kPoolSlots = 12;
+
+static void slot_free(ArenaSlot& sl) {
+    if (sl.done) { (void)hipEventSynchronize(sl.done); (void)hipEventDestroy(sl.done); }
+    if (sl.dev) (void)hipFree(sl.dev);
+    if (sl.pinned) (void)hipHostFree(sl.pinned);
+    sl = ArenaSlot{};
+}
+
+// smallest pooled slot of this device that holds both sizes, or a new allocation (10 % head room: the next batch's masks
+// differ a little); HD_OK with sl filled, the slot's pending event already waited for
+static int arena_acquire(int device, size_t dev_bytes, size_t pinned_bytes, ArenaSlot& sl) {
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        int best = -1;
+        for (int i = 0; i < (int)g_pool.size(); ++i)
+            if (g_pool[i].device == device && g_pool[i].dev_bytes >= dev_bytes && g_pool[i].pinned_bytes >= pinned_bytes &&
+                (best < 0 || g_pool[i].dev_bytes < g_pool[best].dev_bytes)) best = i;
+        if (best >= 0) {
+            sl = g_pool[best];
+            g_pool.erase(g_pool.begin() + best);
+        } else {
+            sl = ArenaSlot{};
+        }
+    }
+    if (sl.dev) {
+        if (sl.done) { HIP_TRY(hipEventSynchronize(sl.done)); (void)hipEventDestroy(sl.done); sl.done = nullptr; }
+        return HD_OK;
+    }
+    sl.device = device;
+    sl.dev_bytes = (dev_bytes + dev_bytes / 10 + 4095) & ~size_t(4095);
+    sl.pinned_bytes = (pinned_bytes + pinned_bytes / 10 + 4095) & ~size_t(4095);
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&sl.dev), sl.dev_bytes);
+    if (e != hipSuccess) {                     // make room: drop the pool and try once more
+        (void)hipGetLastError();
+        std::vector<ArenaSlot> drop;
+        { std::lock_guard<std::mutex> lk(g_pool_mu); drop.swap(g_pool); }
+        for (auto& d : drop) slot_free(d);
+        e = hipMalloc(reinterpret_cast<void**>(&sl.dev), sl.dev_bytes);
+    }
+    if (e != hipSuccess) { sl.dev = nullptr; return fail(HD_E_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e)); }
+    e = hipHostMalloc(reinterpret_cast<void**>(&sl.pinned), sl.pinned_bytes, hipHostMallocDefault);
+    if (e != hipSuccess) { (void)hipFree(sl.dev); sl = ArenaSlot{}; return fail(HD_E_NOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e)); }
+    return HD_OK;
+}
+
+static void arena_release(ArenaSlot sl) {
+    ArenaSlot evict{};
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        g_pool.push_back(sl);
+        if (g_pool.size() > kPoolSlots) { evict = g_pool.front(); g_pool.erase(g_pool.begin()); }
+    }
+    if (evict.dev) slot_free(evict);
+}
+
+extern "C" int hd_arena_pool_trim(void) {
+    std::vector<ArenaSlot> drop;
+    { std::lock_guard<std::mutex> lk(g_pool_mu); drop.swap(g_pool); }
+    for (auto& d : drop) slot_free(d);
+    return HD_OK;
+}
+
 extern "C" int hd_topology_destroy(hd_topology* t) {
     if (!t) return HD_OK;
     (void)hipSetDevice(t->device);
-    (void)hipDeviceSynchronize();
+    ArenaSlot sl{t->device, t->arena, t->arena_bytes, t->staging, t->staging_bytes, nullptr};
+    // a captured graph, or launches on several streams: wait for the device (the rare case - a sampling topology lives as
+    // long as its model); otherwise an event behind the topology's last work guards the arena's next owner
+    bool pooled = t->arena && !t->gexec && !t->multi_stream;
+    if (pooled && hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) == hipSuccess) {
+        if (hipEventRecord(sl.done, t->last_stream) != hipSuccess) { (void)hipEventDestroy(sl.done); sl.done = nullptr; pooled = false; }
+    } else {
+        pooled = false;
+    }
+    if (!pooled) (void)hipDeviceSynchronize();
     if (t->gexec) hipGraphExecDestroy(t->gexec);
-    hipFree(t->arena);                                  // tables and workspace live in one allocation
+    if (t->ready) (void)hipEventDestroy(t->ready);
+    if (t->arena) arena_release(sl);                    // tables and workspace live in one allocation
     delete t->node_of_host;
     delete t;
     return HD_OK;
+}
+
+// every entry point that launches on a topology passes its stream through here: a stream other than the one the tables
+// were uploaded on first waits for their arrival
+static inline void topo_use(hd_topology* t, hipStream_t s) {
+    if (s != t->last_stream) {
+        if (t->ready) (void)hipStreamWaitEvent(s, t->ready, 0);
+        t->multi_stream = true;
+        t->last_stream = s;
+    }
 }
 
 // Edge tiles.  The unmasked edges of molecule b, sorted by receiving node, are cut into pieces at MOLECULE-relative
@@ -719,9 +825,10 @@ extern "C" int hd_topology_layout(const uint8_t* node_mask, const uint8_t* edge_
     return HD_OK;
 }
 
-extern "C" int hd_topology_create(hd_handle* h, const uint8_t* node_mask, const uint8_t* edge_mask, int B, int N,
-                                  hd_topology** out) {
+extern "C" int hd_topology_create_s(hd_handle* h, const uint8_t* node_mask, const uint8_t* edge_mask, int B, int N,
+                                    void* stream, hd_topology** out) {
     if (!h || !node_mask || !out) return fail(HD_E_INVALID, "hd_topology_create: null argument");
+    hipStream_t s0 = (hipStream_t)stream;
     *out = nullptr;
     TileLayout L;
     HD_TRY(build_layout(node_mask, edge_mask, B, N, L));
@@ -767,12 +874,18 @@ extern "C" int hd_topology_create(hd_handle* h, const uint8_t* node_mask, const 
     const size_t f_eps = carve(BN * h->D), f_z = carve(BN * h->D), f_ctx = carve(BN * (size_t)std::max(1, h->cfg.context_node_nf));
     const size_t f_w2 = carve((size_t)H * H * 3 / 2), f_w2t = carve((size_t)H * H * 3 / 2);      // fp32 images or the 1.5 x bf16x6 ones
     auto build = [&]() -> int {
-        hipError_t e = hipMalloc(reinterpret_cast<void**>(&t->arena), table_bytes + ws_floats * sizeof(float));
-        if (e != hipSuccess) { t->arena = nullptr; return fail(HD_E_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e)); }
+        ArenaSlot sl;
+        HD_TRY(arena_acquire(h->device, table_bytes + ws_floats * sizeof(float), table_bytes, sl));
+        t->arena = sl.dev; t->arena_bytes = sl.dev_bytes; t->staging = sl.pinned; t->staging_bytes = sl.pinned_bytes;
+        t->stream0 = t->last_stream = s0;
         char* base = t->arena;
-        HIP_TRY(hipMemcpy(base, blob.data(), blob.size(), hipMemcpyHostToDevice));
+        // no host wait from here on: tables pinned staging -> device and the workspace fill in stream order of s0
+        std::memcpy(t->staging, blob.data(), blob.size());
+        HIP_TRY(hipMemcpyAsync(base, t->staging, blob.size(), hipMemcpyHostToDevice, s0));
         // zero-filled workspace: pad rows stay zero for the lifetime of the topology (kernels never write them)
-        HIP_TRY(hipMemset(base + table_bytes, 0, ws_floats * sizeof(float)));
+        HIP_TRY(hipMemsetAsync(base + table_bytes, 0, ws_floats * sizeof(float), s0));
+        HIP_TRY(hipEventCreateWithFlags(&t->ready, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(t->ready, s0));
         auto I = [&](size_t off) { return reinterpret_cast<int*>(base + off); };
         t->node_of = I(o_node_of); t->slot_of = I(o_slot_of); t->ei = I(o_ei); t->ej = I(o_ej); t->seg_part = I(o_seg_part);
         t->tile_nseg = I(o_tile_nseg); t->pstart = I(o_pstart); t->nvalid = I(o_nvalid);
@@ -784,12 +897,37 @@ extern "C" int hd_topology_create(hd_handle* h, const uint8_t* node_mask, const 
         t->xcur = ws + f_xcur; t->part = ws + f_part; t->xpart = ws + f_xpart; t->eps = ws + f_eps; t->zbuf = ws + f_z;
         t->ctxbuf = ws + f_ctx; t->w2img = ws + f_w2; t->w2timg = ws + f_w2t;
         t->node_of_host = new std::vector<int>(node_of);
-        HIP_TRY(hipStreamSynchronize(nullptr));        // the memset ran on the NULL stream; callers launch on any stream
         return HD_OK;
     };
     const int r = build();
     if (r != HD_OK) { const std::string keep = g_err; hd_topology_destroy(t); g_err = keep; return r; }
     *out = t;
+    return HD_OK;
+}
+
+// the tables are on the device when this returns (any stream may launch on the topology)
+extern "C" int hd_topology_create(hd_handle* h, const uint8_t* node_mask, const uint8_t* edge_mask, int B, int N,
+                                  hd_topology** out) {
+    HD_TRY(hd_topology_create_s(h, node_mask, edge_mask, B, N, nullptr, out));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    hipEvent_t ev = (*out)->ready;              // arrived: no stream has anything to wait for
+    (*out)->ready = nullptr;
+    if (ev) (void)hipEventDestroy(ev);
+    return HD_OK;
+}
+
+__global__ void k_widen_index(const int* src, long long* dst, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
+// hd_topology_nodes for a device consumer: the compact node order as int64 flat indices b*N + n, written in stream order
+extern "C" int hd_topology_nodes_device(hd_topology* t, long long* index, void* stream) {
+    if (!t || !index) return fail(HD_E_INVALID, "hd_topology_nodes_device: null argument");
+    HIP_TRY(hipSetDevice(t->device));
+    topo_use(t, (hipStream_t)stream);
+    if (t->M > 0) hipLaunchKernelGGL(k_widen_index, dim3((t->M + 255) / 256), dim3(256), 0, (hipStream_t)stream, t->node_of, index, t->M);
+    HIP_TRY(hipGetLastError());
     return HD_OK;
 }
 
@@ -1287,6 +1425,7 @@ extern "C" int hd_egnn_forward(hd_handle* h, hd_topology* topo, const float* xh,
     if (h->cfg.context_node_nf > 0 && !context) return fail(HD_E_INVALID, "hd_egnn_forward: context required");
     if (mol_shape > topo->N) mol_shape = topo->N;
     HIP_TRY(hipSetDevice(h->device));
+    topo_use(topo, (hipStream_t)stream);
     return forward_impl(h, topo, xh, t, t_numel, context, mol_shape, out, (hipStream_t)stream);
 }
 
@@ -1367,6 +1506,7 @@ extern "C" int hd_edge_layer_forward_p(hd_handle* h, hd_topology* t, int coord, 
     HD_TRY(check_train(h, t, "hd_edge_layer_forward"));
     if (precision != 0 && precision != 2) return fail(HD_E_INVALID, "hd_edge_layer_forward_p: precision must be 0 (fp32) or 2 (bf16x6)");
     const bool x6 = precision == 2 && h->H >= 128;          // narrower widths run the exact-fp32 kernels, as in sampling
+    topo_use(t, (hipStream_t)stream);
     if (!AB || !x || !x0 || !wrd || !W2 || !b2 || !wa || !out) return fail(HD_E_INVALID, "hd_edge_layer_forward: null tensor");
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
@@ -1408,6 +1548,7 @@ extern "C" int hd_edge_layer_backward_p(hd_handle* h, hd_topology* t, int coord,
     HD_TRY(check_train(h, t, "hd_edge_layer_backward"));
     if (precision != 0 && precision != 2) return fail(HD_E_INVALID, "hd_edge_layer_backward_p: precision must be 0 (fp32) or 2 (bf16x6)");
     const bool x6 = precision == 2 && h->H >= 128;
+    topo_use(t, (hipStream_t)stream);
     if (!AB || !x || !x0 || !wrd || !W2 || !b2 || !wa || !gout || !G2 || !P || !G1 || !escal || !colpart || !bapart ||
         !b2part || !wrdpart || !dAB || !dx || !dx0)
         return fail(HD_E_INVALID, "hd_edge_layer_backward: null tensor");
@@ -1936,6 +2077,7 @@ extern "C" int hd_posterior_step(hd_handle* h, hd_topology* topo, const float* z
     const int mol = (mol_shape < 0 || mol_shape > topo->N) ? topo->N : mol_shape;
     if (zs == zt && mol != topo->N) return fail(HD_E_INVALID, "hd_posterior_step: in-place needs mol_shape == N");
     HIP_TRY(hipSetDevice(h->device));
+    topo_use(topo, (hipStream_t)stream);
     return step_impl(h, topo, zt, eps, coef, coef_rows, make_noise(raw_x, raw_h, noise_rows, 0, 0, 0, 0), mol, zs, mol,
                      nullptr, nullptr, 0, (hipStream_t)stream);
 }
@@ -1950,6 +2092,7 @@ extern "C" int hd_final_decode(hd_handle* h, hd_topology* topo, const float* z0,
     if (raw_x && noise_rows != 1 && noise_rows != topo->B) return fail(HD_E_INVALID, "hd_final_decode: noise_rows must be 1 or B");
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
+    topo_use(topo, s);
     ProfScope ps(h, s, 2);
     DecodeArgs a;
     a.z0 = z0; a.eps = eps; a.nm = topo->nm_bytes; a.x = x; a.hfeat = hfeat;
@@ -1968,6 +2111,7 @@ extern "C" int hd_noise(hd_handle* h, hd_topology* topo, const float* raw_x, con
     if (raw_x && noise_rows != 1 && noise_rows != topo->B) return fail(HD_E_INVALID, "hd_noise: noise_rows must be 1 or B");
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
+    topo_use(topo, s);
     ProfScope ps(h, s, 2);
     NoiseArgs a;
     a.nm = topo->nm_bytes; a.z = z; a.noise = make_noise(raw_x, raw_h, noise_rows, seed, sample_id_base, draw, share_rows);
@@ -2007,6 +2151,7 @@ extern "C" int hd_sample_loop(hd_handle* h, hd_topology* topo, float* z, const f
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
     const int nsteps = s_hi - s_lo;
+    topo_use(topo, s);
     if (nsteps == 0) return HD_OK;
     const int T = h->T;
     const uint32_t draw0 = (uint32_t)(T - (s_hi - 1));       // draw index of the first step (draw 0 = z_T)

@@ -396,6 +396,30 @@ class DiffusionQM9(_Base):
         neg_log_pxh = self.nll(x, h, node_mask, edge_mask, context=context, mol_shape=mol_shape, **replay)
         return {"loss": neg_log_pxh.mean(0)}
 
+    def stage_batch(self, batch, device=None):
+        """A collated HOST batch (the dict a DataLoader yields) -> the device batch `forward` / `training_step` take, without
+        a host wait: tensors travel through pinned copies in stream order, and the masks' topology is laid out from the
+        host copies on the way (`EGNN_dynamics_QM9.stage_masks`) - so a loop that stages batch k+1 after launching step k
+        overlaps the layout with the GPU's work.  This is the place of Lightning's transfer_batch_to_device in the reference's
+        trainer.  Pocket batches (their masks are composed on the device in `forward`) and tensors already on the device
+        are moved as they are."""
+        from .dynamics import _to_device_async
+        dev = self.dynamics._device() if device is None else torch.device(device)
+        out = {k: (_to_device_async(v, dev) if torch.is_tensor(v) else v) for k, v in batch.items()
+               if k not in ("atom_mask", "edge_mask")}
+        nm, em = batch.get("atom_mask"), batch.get("edge_mask")
+        if (not self.pocket and torch.is_tensor(nm) and nm.device.type == "cpu"
+                and (em is None or (torch.is_tensor(em) and em.device.type == "cpu"))):
+            nm_d, em_d = self.dynamics.stage_masks(nm, em, dev)
+            out["atom_mask"] = nm_d
+            if "edge_mask" in batch:
+                out["edge_mask"] = em_d
+        else:
+            for k in ("atom_mask", "edge_mask"):
+                if k in batch:
+                    out[k] = _to_device_async(batch[k], dev) if torch.is_tensor(batch[k]) else batch[k]
+        return out
+
     def training_step(self, batch, batch_idx=0):
         """diffusion_qm9.py:774-777: differentiable mean loss of the batch (call .backward() on it, then - multi-GPU -
         hierdiff_amd.sharding.allreduce_gradients, the DDP step of conf/trainer/default.yaml:2-3)."""

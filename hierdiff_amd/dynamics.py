@@ -103,12 +103,16 @@ class Topology:
     """Index tables + activation workspace for one (node_mask, edge_mask) pair (hd_topology)."""
 
     def __init__(self, owner: "EGNN_dynamics_QM9", node_mask: torch.Tensor, edge_mask: Optional[torch.Tensor],
-                 B: int, N: int, host_masks: Optional[Tuple[np.ndarray, Optional[np.ndarray]]] = None):
+                 B: int, N: int, host_masks: Optional[Tuple[np.ndarray, Optional[np.ndarray]]] = None,
+                 device: Optional[torch.device] = None):
         lib = _lib.load()
         nm, em = host_masks if host_masks is not None else masks_to_host(node_mask, edge_mask, B, N)
         self._h = C.c_void_p()
-        _lib.check(lib.hd_topology_create(owner._handle(), nm.ctypes.data, None if em is None else em.ctypes.data, B, N,
-                                          C.byref(self._h)), "hd_topology_create")
+        # tables upload in stream order of the current stream, no host wait (hd_topology_create_s)
+        dev = owner._device() if device is None else device
+        with torch.cuda.device(dev):
+            _lib.check(lib.hd_topology_create_s(owner._handle(), nm.ctypes.data, None if em is None else em.ctypes.data, B, N,
+                                                _stream(dev), C.byref(self._h)), "hd_topology_create_s")
         self.B, self.N = B, N
         self._finalizer = weakref.finalize(self, lib.hd_topology_destroy, self._h)
 
@@ -129,6 +133,47 @@ def masks_to_host(node_mask: torch.Tensor, edge_mask: Optional[torch.Tensor], B:
         return nm.cpu().numpy().astype(np.uint8), None
     both = torch.cat([nm.view(torch.uint8), edge_mask.reshape(B * N * N).to(torch.bool).view(torch.uint8)]).cpu().numpy()
     return np.ascontiguousarray(both[:B * N]), np.ascontiguousarray(both[B * N:])
+
+
+_PIN_RING: Dict[Tuple, list] = {}
+_PIN_DEPTH = 4
+
+
+def _to_device_async(t: torch.Tensor, device: torch.device) -> torch.Tensor:
+    """Host tensor -> device in stream order WITHOUT a host wait: through a pinned staging buffer this module keeps (a ring of
+    _PIN_DEPTH buffers per shape / dtype, each guarded by the event behind its last copy).  What it avoids, all measured in a
+    staged training loop at B = 256 (scratch/fresh_masks_trace.py, scratch/busy_gpu_experiments.py): a pageable source makes torch
+    wait for the stream (the host cannot run ahead); `Tensor.pin_memory()` allocates, and with the host ahead of the GPU its cached
+    blocks are still in flight, so it falls through to hipHostMalloc, which waits for the device (60 ms stalls); and
+    `pinned.copy_(t)` fans tensors of 32 K elements and more out over torch's intra-op thread pool - on a 128-core host those
+    spinning workers starve the runtime's completion-signal thread: 50 - 90 ms stalls of every other training step when a 230 KB
+    mask was staged that way.  Hence one plain memcpy into the pinned slot."""
+    if t.device.type != "cpu":
+        return t.to(device)
+    dev = torch.device(device)
+    key = (tuple(t.shape), t.dtype, str(dev))
+    ring = _PIN_RING.get(key)
+    if ring is None:
+        if len(_PIN_RING) >= 64:                                    # shapes of a loop repeat; do not grow without bound
+            _PIN_RING.pop(next(iter(_PIN_RING)))
+        ring = _PIN_RING[key] = [0, []]
+    pos, slots = ring
+    if len(slots) < _PIN_DEPTH:
+        slots.append([torch.empty(t.shape, dtype=t.dtype, pin_memory=True), None])
+        slot = slots[-1]
+    else:
+        slot = slots[pos % _PIN_DEPTH]
+        ring[0] = pos + 1
+        if slot[1] is not None:
+            slot[1].synchronize()                                   # copy issued _PIN_DEPTH stagings ago: long done
+    src = t.contiguous()
+    C.memmove(slot[0].data_ptr(), src.data_ptr(), src.numel() * src.element_size())
+    with torch.cuda.device(dev):
+        out = slot[0].to(dev, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+    slot[1] = ev
+    return out
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -394,20 +439,53 @@ class EGNN_dynamics_QM9(nn.Module):
         if hit is not None:
             return hit[0]
         nm, em = masks_to_host(node_mask, edge_mask, B, N)
+        topo = self._topology_by_content(nm, em, B, N)
+        self._remember(key, topo, node_mask, edge_mask)
+        return topo
+
+    def _topology_by_content(self, nm: np.ndarray, em: Optional[np.ndarray], B: int, N: int) -> Topology:
         dig = hashlib.blake2b(nm.tobytes() + (b"" if em is None else em.tobytes()), digest_size=16).digest()
         ckey = (dig, em is None, B, N)
         topo = self._topo_by_content.get(ckey)
         if topo is None:
             if len(self._topo_by_content) >= 8:
                 self._topo_by_content.pop(next(iter(self._topo_by_content)))
-            topo = Topology(self, node_mask, edge_mask, B, N, host_masks=(nm, em))
+            topo = Topology(self, None, None, B, N, host_masks=(nm, em))
             self._topo_by_content[ckey] = topo
         else:
             self._topo_by_content[ckey] = self._topo_by_content.pop(ckey)      # most recently used last
+        return topo
+
+    def _remember(self, key, topo, node_mask, edge_mask) -> None:
         if len(self._topo_cache) >= 8:
             self._topo_cache.pop(next(iter(self._topo_cache)))
         self._topo_cache[key] = (topo, node_mask, edge_mask)     # holding the tensors pins their addresses
-        return topo
+
+    def stage_masks(self, node_mask: torch.Tensor, edge_mask: Optional[torch.Tensor], device: Optional[torch.device] = None):
+        """Host masks in, device masks + their topology out, WITHOUT a host wait: what a training loop does with the
+        masks a DataLoader hands it (the reference's batches are collated on the host and moved by Lightning's
+        transfer_batch_to_device).  The index tables are laid out from the host tensors (no device-to-host copy, which would
+        stall the loop behind everything the GPU still has queued), uploaded in stream order from pinned staging into a pooled
+        arena (hd_topology_create_s), and the device copies of the masks are registered as this topology's identity -
+        `_forward(t, xh, node_mask, edge_mask, ...)` on them (or on views of them) finds it without touching the data.
+        Returns (node_mask_dev, edge_mask_dev)."""
+        if node_mask.device.type != "cpu" or (edge_mask is not None and edge_mask.device.type != "cpu"):
+            raise HierDiffHipError("stage_masks takes the HOST masks of a collated batch")
+        dev = self._device() if device is None else torch.device(device)
+        B = node_mask.shape[0]
+        N = node_mask.numel() // B
+        as_bytes = lambda m, n: np.ascontiguousarray(m.numpy().reshape(n) != 0).view(np.uint8)     # numpy: single-threaded
+        nm = as_bytes(node_mask, B * N)
+        em = None if edge_mask is None else as_bytes(edge_mask, B * N * N)
+        if self.mode == 'gnn_dynamics':
+            return node_mask.to(dev, non_blocking=True), None if edge_mask is None else edge_mask.to(dev, non_blocking=True)
+        self._handle()
+        topo = self._topology_by_content(nm, em, B, N)
+        nm_d = _to_device_async(node_mask, dev)
+        em_d = None if edge_mask is None else _to_device_async(edge_mask, dev)
+        sig = lambda m: None if m is None else (m.data_ptr(), m._version, m.numel(), m.dtype, str(m.device))
+        self._remember((sig(nm_d), sig(em_d), B, N), topo, nm_d, em_d)
+        return nm_d, em_d
 
     # ------------------------------------------------------------------ forward
     def _forward(self, t, xh, node_mask, edge_mask, context, mol_shape=None):

@@ -64,7 +64,7 @@ class GammaNetwork(torch.nn.Module):
             # GPU (the training-mode loss of a learned schedule): gamma_tilde is row-wise, so the normalisation points 0 and 1
             # ride along as two extra rows of ONE evaluation instead of two more evaluations on a [B, 1] column of equal
             # values (noise_model.py:186-200) - a third of the ~40 small launches per call, and of their backward
-            ends = torch.tensor([[0.0], [1.0]], dtype=t.dtype, device=t.device)
+            ends = torch.arange(2, dtype=t.dtype, device=t.device).view(2, 1)      # [[0], [1]] without a host-to-device copy
             g = self.gamma_tilde(torch.cat([t, ends], dim=0))
             gt, g0, g1 = g[:-2], g[-2:-1], g[-1:]
         else:

@@ -35,9 +35,8 @@ def _world() -> int:
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
-def ddp_step(model, batch: Dict[str, torch.Tensor], optimizer: torch.optim.Optimizer, clip_val: Optional[float] = 2.0) -> Dict[str, float]:
-    """One optimisation step on this rank's batch; returns {"loss", "grad_norm"} (the norm BEFORE clipping, like Lightning's
-    track_grad_norm: 2).  Every rank must call it the same number of times (the all-reduce is collective)."""
+def _launch_step(model, batch: Dict[str, torch.Tensor], optimizer: torch.optim.Optimizer, clip_val: Optional[float]):
+    """Everything of one optimisation step that is queued on the GPU; returns the (loss, grad norm) device scalars."""
     model.train()
     optimizer.zero_grad(set_to_none=True)
     loss = model.training_step(batch, 0)
@@ -50,18 +49,40 @@ def ddp_step(model, batch: Dict[str, torch.Tensor], optimizer: torch.optim.Optim
     else:
         norm = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(p.grad) for p in params]))
     optimizer.step()
-    return {"loss": float(loss.detach()), "grad_norm": float(norm)}
+    return loss.detach(), norm
+
+
+def ddp_step(model, batch: Dict[str, torch.Tensor], optimizer: torch.optim.Optimizer, clip_val: Optional[float] = 2.0) -> Dict[str, float]:
+    """One optimisation step on this rank's batch; returns {"loss", "grad_norm"} (the norm BEFORE clipping, like Lightning's
+    track_grad_norm: 2).  Every rank must call it the same number of times (the all-reduce is collective)."""
+    loss, norm = _launch_step(model, batch, optimizer, clip_val)
+    return {"loss": float(loss), "grad_norm": float(norm)}
 
 
 def fit_epoch(model, batches: Iterable[Dict[str, torch.Tensor]], optimizer, scheduler=None, clip_val: Optional[float] = 2.0,
               device: Optional[torch.device] = None):
     """`ddp_step` over an iterable of reference-style batch dicts (keys positions, atom_mask, edge_mask, node_feature ...), the
-    scheduler stepped once at the end (StepLR counts epochs).  Returns the list of per-step dicts."""
+    scheduler stepped once at the end (StepLR counts epochs).  Returns the list of per-step dicts.
+
+    With `device` the batches are HOST batches (a DataLoader's) and the loop is pipelined one batch deep: after step k is
+    queued, batch k+1 is staged (`model.stage_batch`: pinned copies in stream order and the masks' topology laid out from the
+    host copies) BEFORE the host waits for step k's loss - new masks every step cost no GPU idle time."""
     log = []
-    for batch in batches:
-        if device is not None:
-            batch = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
-        log.append(ddp_step(model, batch, optimizer, clip_val))
+    if device is None:
+        for batch in batches:
+            log.append(ddp_step(model, batch, optimizer, clip_val))
+    else:
+        stage = getattr(model, "stage_batch", None)
+        if stage is None:
+            stage = lambda b, d: {k: (v.to(d) if torch.is_tensor(v) else v) for k, v in b.items()}
+        it = iter(batches)
+        nxt = next(it, None)
+        cur = None if nxt is None else stage(nxt, device)
+        while cur is not None:
+            loss, norm = _launch_step(model, cur, optimizer, clip_val)
+            nxt = next(it, None)
+            cur = None if nxt is None else stage(nxt, device)
+            log.append({"loss": float(loss), "grad_norm": float(norm)})
     if scheduler is not None:
         scheduler.step()
     return log

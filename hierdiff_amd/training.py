@@ -44,9 +44,11 @@ class _TrainTables:
         n_wg = (info["tiles"] + 3) // 4
         self.tiles = max(1, 4 * n_wg)
         self.rows = 32 * self.tiles
-        node_of = np.zeros(max(1, self.M), dtype=np.int32)
-        _lib.check(lib.hd_topology_nodes(topo.ptr, node_of.ctypes.data), "hd_topology_nodes")
-        self.index = torch.from_numpy(node_of[:self.M].astype(np.int64)).to(device)      # flat index b*N + n
+        # flat index b*N + n of the compact node order, written on the device from the topology's own table (a host array
+        # would reach the device through a pageable copy = a stream synchronisation per new topology)
+        self.index = torch.empty(self.M, dtype=torch.int64, device=device)
+        with torch.cuda.device(device):
+            _lib.check(lib.hd_topology_nodes_device(topo.ptr, self.index.data_ptr(), _stream(device)), "hd_topology_nodes_device")
         self.H = H
         self.device = device
 

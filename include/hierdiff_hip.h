@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define HD_ABI_VERSION 7
+#define HD_ABI_VERSION 8
 
 #define HD_OK 0
 #define HD_E_INVALID (-1)      /* bad argument / unsupported configuration */
@@ -111,7 +111,18 @@ int hd_set_weights(hd_handle* h, const float* blob, long long n, int on_device, 
  * reproduces the single-GPU result exactly). */
 int hd_topology_create(hd_handle* h, const uint8_t* node_mask, const uint8_t* edge_mask, int B, int N,
                        hd_topology** out);
+/* The same, without a host wait: the tables travel pinned staging -> device in stream order of `stream` (the workspace
+ * fill behind them), so the call returns as soon as the host-side layout is done and a training loop that meets new masks
+ * every step keeps the GPU busy while the next batch's topology is laid out.  Launches on the topology from another stream
+ * wait for the tables' arrival by themselves.  Device arena and staging buffer come from a grow-only pool that
+ * hd_topology_destroy refills (no hipMalloc / hipFree / device-wide synchronisation per topology in steady state). */
+int hd_topology_create_s(hd_handle* h, const uint8_t* node_mask, const uint8_t* edge_mask, int B, int N, void* stream,
+                         hd_topology** out);
+/* Returns the topology's memory to the pool behind an event on the stream it was last used on (a topology that captured
+ * a sampling graph or ran on several streams waits for the device instead). */
 int hd_topology_destroy(hd_topology* t);
+/* Frees every pooled arena (after their pending work). */
+int hd_arena_pool_trim(void);
 /* Host-only view of the edge-tile tables hd_topology_create builds for the same masks (no device needed): edges are
  * packed in 32-row tiles per molecule - cuts at molecule-relative multiples of 32, remainders of neighbouring
  * molecules share a tile at 4-row-aligned offsets - so the rows summed into one partial sum ("part") of a node
@@ -189,6 +200,8 @@ int hd_sample_loop(hd_handle* h, hd_topology* topo, float* z, const float* conte
  * distance columns of the first Linear, W2 [H][H], b2 [H], wa [H], ba [1] (NULL: no attention bias).  The node-level Linears around an edge layer are plain GEMMs:
  * hierdiff_amd/training.py runs them on hd_gemm_f32 below (forward, dX and split-K dW; no BLAS-library kernel in a step). */
 int hd_topology_nodes(const hd_topology* t, int* node_of /* host, `active nodes` ints: flat index b*N + n */);
+/* The same order for a device consumer: `active nodes` int64 flat indices written to DEVICE memory in stream order. */
+int hd_topology_nodes_device(hd_topology* t, long long* index, void* stream);
 int hd_edge_layer_forward(hd_handle* h, hd_topology* topo, int coord, const float* AB, const float* x,
                           const float* x0, const float* wrd, const float* W2, const float* b2, const float* wa,
                           const float* ba, float* out, void* stream);

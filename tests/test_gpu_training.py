@@ -421,8 +421,9 @@ def test_dw2_matches_a_float64_product(H, rows, fname):
 
 @pytest.mark.parametrize("H", [256, 128])
 def test_training_precision_bf16x6_gradients(H):
-    """`dynamics.training_precision = "bf16x6"`: the forward's per-edge contraction (hd_edge_layer_forward_p, precision 2) and
-    dW2 (hd_dw2_x6) in the fp32-accurate bf16 split, everything else exact fp32.  Every parameter gradient and the input gradient
+    """`dynamics.training_precision = "bf16x6"`: the edge layer's H x H contractions - forward (hd_edge_layer_forward_p, precision 2),
+    both backward stages (hd_edge_layer_backward_p, precision 2) and dW2 (hd_dw2_x6) - in the fp32-accurate bf16 split, everything
+    else exact fp32.  Every parameter gradient and the input gradient
     meet the SAME bar against the oracle's autograd as the exact-fp32 step (1e-4) and agree with the exact-fp32 step itself to
     1e-5 - mixed precision without a loss of accuracy (the reference's own mixed mode is apex O2, conf/trainer/default.yaml:4-5)."""
     from hierdiff_amd.weights import synthetic_state_dict
@@ -457,3 +458,130 @@ def test_training_precision_bf16x6_gradients(H):
     assert between < 1e-5
     with pytest.raises(ValueError):
         dyn.training_precision = "bf16x3"
+
+
+# ----------------------------------------------------------------------------- new masks every step: staged batches, pooled arenas
+def _host_batch(seed, B=6, N=9, sizes=None):
+    g = torch.Generator().manual_seed(seed)
+    sizes = torch.randint(3, N + 1, (B,), generator=g) if sizes is None else torch.as_tensor(sizes)
+    nm = (torch.arange(N)[None, :] < sizes[:, None])[..., None]
+    em = (nm.float() @ nm.float().transpose(1, 2)).bool() & ~torch.eye(N, dtype=torch.bool)[None]
+    x = torch.randn(B, N, 3, generator=g) * nm
+    x = x - (x.sum(1, keepdim=True) / nm.sum(1, keepdim=True)) * nm
+    h = torch.cat([torch.randint(0, 5, (B, N, 5), generator=g).float(), torch.randn(B, N, 3, generator=g)], 2) * nm
+    return {"positions": x, "atom_mask": nm, "edge_mask": em, "node_feature": h}
+
+
+def _small_model(H=64, L=2, seed=31):
+    from hierdiff_amd import DiffusionQM9, default_config
+    from hierdiff_amd.weights import synthetic_state_dict
+    sd = synthetic_state_dict(9, 0, H, L, 2, True, seed, 0.5)
+    m = DiffusionQM9(default_config(hidden_nf=H, n_layers=L))
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+    return m.to(DEV).train()
+
+
+def test_stage_batch_builds_the_topology_from_the_host_masks(monkeypatch):
+    """`DiffusionQM9.stage_batch(host batch)`: same loss and gradients, bit for bit, as moving the batch with `.to(device)` -
+    and the step never copies a mask back to the host (the device-to-host copy of the fallback would stall a training loop
+    behind everything the GPU has queued)."""
+    import hierdiff_amd.dynamics as dyn_mod
+    host = _host_batch(5)
+    a, b = _small_model(), _small_model()
+    torch.manual_seed(3)
+    la = a.training_step({k: v.to(DEV) for k, v in host.items()}, 0)
+    la.backward()
+    calls = []
+    real = dyn_mod.masks_to_host
+    monkeypatch.setattr(dyn_mod, "masks_to_host", lambda *args: (calls.append(1), real(*args))[1])
+    staged = b.stage_batch(host)
+    assert all(v.device.type == "cuda" for v in staged.values())
+    torch.manual_seed(3)
+    lb = b.training_step(staged, 0)
+    lb.backward()
+    assert not calls, "the staged masks' topology must be found by identity"
+    assert torch.equal(la.detach(), lb.detach())
+    for (ka, pa), (kb, pb) in zip(a.named_parameters(), b.named_parameters()):
+        assert (pa.grad is None) == (pb.grad is None) and (pa.grad is None or torch.equal(pa.grad, pb.grad)), ka
+    # validation on staged masks takes the same shortcut
+    b.eval()
+    with torch.no_grad():
+        torch.manual_seed(4)
+        v1 = b.validation_step(b.stage_batch(host))["loss"]
+        torch.manual_seed(4)
+        v2 = b.validation_step({k: v.to(DEV) for k, v in host.items()})["loss"]
+    assert torch.equal(v1, v2)
+    with pytest.raises(Exception):
+        b.dynamics.stage_masks(host["atom_mask"].to(DEV), host["edge_mask"].to(DEV))
+
+
+def test_recycled_arenas_give_the_same_bits():
+    """hd_topology_destroy hands a topology's arena to the pool, hd_topology_create_s takes the smallest that fits: a forward
+    on a topology living in a RECYCLED arena (previous owner larger, different masks - stale tables and activations behind the
+    new ones) equals the forward on a freshly allocated one bit for bit, on the launching stream and on a side stream."""
+    import gc
+    from hierdiff_amd import _lib
+    from hierdiff_amd.weights import synthetic_state_dict
+    H, L = 64, 2
+    sd_np = synthetic_state_dict(9, 0, H, L, 2, True, 77, 0.5)
+    dyn = build_dynamics(sd_np, H, L)
+    lib = _lib.load()
+
+    def run(n_list, seed, stream=None):
+        xh, nm, em = orc.random_inputs(n_list, 8, seed)
+        B = xh.shape[0]
+        t = torch.full((B, 1), 0.4)
+        with torch.no_grad():
+            if stream is None:
+                return dyn._forward(t.to(DEV), xh.to(DEV), nm.to(DEV), em.to(DEV), None, None).cpu()
+            args = (t.to(DEV), xh.to(DEV), nm.to(DEV), em.to(DEV))
+            torch.cuda.synchronize()
+            with torch.cuda.stream(stream):
+                out = dyn._forward(*args, None, None)
+            stream.synchronize()
+            return out.cpu()
+
+    def forget():
+        dyn._topo_cache.clear(); dyn._topo_by_content.clear(); gc.collect()
+
+    forget(); _lib.check(lib.hd_arena_pool_trim(), "trim")
+    small = [7, 9, 4, 9]
+    want = run(small, 11)                       # fresh arena
+    forget(); _lib.check(lib.hd_arena_pool_trim(), "trim")
+    run([30] * 12, 12)                          # a larger owner fills an arena with its tables and activations
+    forget()                                    # ... and hands it to the pool
+    got = run(small, 11)                        # recycled
+    assert torch.equal(want, got)
+    forget()
+    side = torch.cuda.Stream()
+    got_side = run(small, 11, side)             # recycled again, uploaded and used on a side stream
+    assert torch.equal(want, got_side)
+    # a topology created on one stream and used on another waits for its tables by itself
+    forget()
+    xh, nm, em = orc.random_inputs(small, 8, 11)
+    args = (torch.full((4, 1), 0.4).to(DEV), xh.to(DEV), nm.to(DEV), em.to(DEV))
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        with torch.cuda.stream(side):
+            dyn.topology(args[2], args[3], xh.shape[0], xh.shape[1])
+        out = dyn._forward(*args, None, None)
+    assert torch.equal(want, out.cpu())
+    forget(); _lib.check(lib.hd_arena_pool_trim(), "trim")
+
+
+def test_pipelined_fit_epoch_equals_step_by_step():
+    """trainer.fit_epoch(..., device=...) stages batch k+1 (pinned copies + topology from the host masks) while step k runs:
+    per-step losses, gradient norms and the final weights are bit-equal to ddp_step over `.to(device)` batches; 12 batches of
+    never-repeated masks go through the 8-entry topology caches and the arena pool."""
+    from hierdiff_amd.trainer import configure_optimizers, ddp_step, fit_epoch
+    batches = [_host_batch(100 + k) for k in range(12)]
+    a, b = _small_model(), _small_model()
+    opt_a, _ = configure_optimizers(a)
+    opt_b, _ = configure_optimizers(b)
+    torch.manual_seed(9)
+    log_a = fit_epoch(a, batches, opt_a, device=DEV)
+    torch.manual_seed(9)
+    log_b = [ddp_step(b, {k: v.to(DEV) for k, v in bt.items()}, opt_b) for bt in batches]
+    assert log_a == log_b and len(log_a) == 12 and all(np.isfinite(r["loss"]) for r in log_a)
+    for (ka, pa), (kb, pb) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert torch.equal(pa, pb), ka
