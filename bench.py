@@ -44,10 +44,10 @@ import torch  # noqa: E402
 
 # /opt/skills/guides/MI355X_MICROARCH.md, dense matrix peaks: v_mfma_f32_32x32x2_f32 157.3 TFLOP/s,
 # bf16 MFMA ~2.5 PFLOP/s; HBM3E 8 TB/s.  The bf16x3 path executes 3 bf16 MFMA flops per algorithmic flop.
-MFMA_PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0, "bf16x6": 2500.0}
-MFMAS_PER_PRODUCT = {"fp32": 1, "bf16x3": 3, "bf16x6": 6}
+MFMA_PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0, "bf16x6": 2500.0, "fp16x3": 2500.0}
+MFMAS_PER_PRODUCT = {"fp32": 1, "bf16x3": 3, "bf16x6": 6, "fp16x3": 3}
 HBM_PEAK_GBPS = 8000.0
-DTYPE = {"fp32": "f32", "bf16x3": "bf16x3", "bf16x6": "bf16x6"}
+DTYPE = {"fp32": "f32", "bf16x3": "bf16x3", "bf16x6": "bf16x6", "fp16x3": "fp16x3"}
 # PMC figures are NOT measured by this process (counter passes need rocprofv3 around the run): they are replayed from the
 # newest committed summary of scratch/round_profiles.sh + summarize_profiles.py, and only when that summary was collected
 # on the very library that is loaded now (sha256 of libhierdiff_hip.so) and on this workload's shape.
@@ -221,7 +221,7 @@ def timed_headline(model, precision, args, dev, rank, world, dist):
                 roofline["executed_mfma_tflops"] = round(m * achieved, 2)
                 roofline["executed_frac"] = round(m * achieved / peak, 4)
                 roofline["vs_fp32_mfma_peak"] = round(achieved / MFMA_PEAK_TFLOPS["fp32"], 4)
-                roofline["note"] = (f"contraction on {m} bf16 MFMAs per product ({precision}); achieved counts algorithmic "
+                roofline["note"] = (f"contraction on {m} {'fp16' if precision == 'fp16x3' else 'bf16'} MFMAs per product ({precision}); achieved counts algorithmic "
                                     "flops, executed_* the issued MFMA flops; vs_fp32_mfma_peak = achieved / 157.3")
         if cnt[1] > 0:
             # the node side (family 1: the fused k_node_f32 / k_node launches, or k_gemm_r16 below HD_FUSE_MIN_ROWS): algorithmic
@@ -278,7 +278,10 @@ def precision_gap(model, args, dev, mode="bf16x3") -> dict:
         worst = max(worst, float(torch.linalg.norm(outs[mode] - outs["fp32"]) / torch.linalg.norm(outs["fp32"])))
     bound = {"bf16x3": "<= 1.3e-5 rel-L2 per forward on every golden fixture (tests/, bar 1e-4)",
              "bf16x6": "<= 7e-7 rel-L2 per forward on every golden fixture, the exact-fp32 mode's own figure; distance to a "
-                       "float64 evaluation 3.6e-7 vs 3.8e-7 (exact fp32) and 3.0e-7 (float32 reference), tests/test_gpu_parity.py"}
+                       "float64 evaluation 3.6e-7 vs 3.8e-7 (exact fp32) and 3.0e-7 (float32 reference), tests/test_gpu_parity.py",
+             "fp16x3": "<= 8e-7 rel-L2 per forward on every golden fixture, the exact-fp32 mode's own figure; distance to a float64 "
+                       "evaluation 3.5e-7 vs 3.8e-7 (exact fp32), 3.2e-7 (bf16x6) and 3.0e-7 (float32 reference), "
+                       "tests/test_gpu_parity.py; domain: edge-model activations below 16376 (beyond: the forward's NaN guard)"}
     return {"max_rel_l2_vs_fp32_path": float(f"{worst:.3e}"), "bound_vs_reference": bound[mode]}
 
 
@@ -346,7 +349,7 @@ def other_configs(args, dev) -> dict:
     m9 = build_model(256, 9, 1000, dev, 0, 1)
     m6 = build_model(256, 6, 1000, dev, 0, 1)
     m5 = build_model(256, 6, 1000, dev, 0, 1, context_nf=1, cls=EnVariationalDiffusion)
-    for prec in ("fp32", "bf16x6", "bf16x3"):
+    for prec in ("fp32", "fp16x3", "bf16x6", "bf16x3"):
         for m in (m9s, m6s, m9, m6, m5):
             m.dynamics.precision = prec
         blk = {}
@@ -613,6 +616,8 @@ def self_launch(n_gpus: int, argv) -> int:
 NOTES = {"fp32": "exact fp32 MFMA (v_mfma_f32_32x32x2_f32), the reference's arithmetic",
          "bf16x6": "fp32-accurate: per-edge H x H contraction on a three-way bf16 split (24 significant bits), 6 bf16 MFMAs per "
                    "product, fp32 accumulate; node-level GEMMs exact fp32",
+         "fp16x3": "fp32-accurate: per-edge H x H contraction on a two-way fp16 split (22 significant bits, operands ranged by exact "
+                   "powers of two), 3 fp16 MFMAs per product, fp32 accumulate; node-level GEMMs on the three-way bf16 split",
          "bf16x3": "fp32 operands split into bf16 head + tail, 3 bf16 MFMAs per product, fp32 accumulate"}
 
 
@@ -626,7 +631,7 @@ def main() -> None:
     ap.add_argument("--layers", type=int, default=6)
     ap.add_argument("--hidden", type=int, default=256)
     ap.add_argument("--timesteps", type=int, default=1000)
-    ap.add_argument("--precision", choices=["all", "fp32", "bf16x6", "bf16x3"], default="all",
+    ap.add_argument("--precision", choices=["all", "fp32", "fp16x3", "bf16x6", "bf16x3"], default="all",
                     help="'all' (default): headline = exact fp32, plus the bf16x6 and bf16x3 sibling blocks; a single mode "
                          "times only that mode (profiling runs)")
     ap.add_argument("--graph", action="store_true", help="replay each diffusion step from a captured hipGraph")
@@ -666,7 +671,7 @@ def main() -> None:
 
     H, L, B, N, T = args.hidden, args.layers, args.batch, args.nodes, args.timesteps
     model = build_model(H, L, T, dev, rank, world, dist_on=dist is not None)
-    modes = ["fp32", "bf16x6", "bf16x3"] if args.precision == "all" else [args.precision]
+    modes = ["fp32", "fp16x3", "bf16x6", "bf16x3"] if args.precision == "all" else [args.precision]
     blocks = {p: timed_headline(model, p, args, dev, rank, world, dist) for p in modes}
 
     if rank != 0:
@@ -700,7 +705,7 @@ def main() -> None:
                                       "the timed region; none on the data path"}
     if "roofline" in hb:
         out["roofline"] = hb["roofline"]
-    for mode in ("bf16x6", "bf16x3"):
+    for mode in ("fp16x3", "bf16x6", "bf16x3"):
         if mode in blocks and head != mode:
             sib = dict(blocks[mode])
             sib["precision_note"] = "opt-in mode: " + NOTES[mode] + "; same K steps, same workload, same process as the headline"

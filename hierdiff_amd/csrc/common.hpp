@@ -81,6 +81,33 @@ HD_DEVINL void bf16_split2(float y0, float y1, uint32_t& hi, uint32_t& lo) {
     lo = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){l0, l1}, bf16x2_t));
 }
 
+// fp16 head / tail of a pair ("fp16x3", PREC 3): 11 + 11 significant bits, |y - h - l| <= 2^-22 |y| as long as the tail stays a
+// normal fp16 number (|y| >= 2^-2 after the operand scaling described in k_edge.hpp); below that the tail is a SUBNORMAL fp16
+// with absolute error 2^-25, which v_mfma_f32_32x32x16_f16 takes at face value on gfx950 (scratch/mb/f16_denorm.hip).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+HD_DEVINL void f16_split2(float y0, float y1, uint32_t& hi, uint32_t& lo) {
+    const f16x2_t hp = __builtin_convertvector((f32x2){y0, y1}, f16x2_t);      // round to nearest even
+    const float l0 = y0 - (float)hp[0];
+    const float l1 = y1 - (float)hp[1];
+    hi = __builtin_bit_cast(uint32_t, hp);
+    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){l0, l1}, f16x2_t));
+}
+// the two-way modes share every line but these two: PREC 1 = bf16 pieces, PREC 3 = fp16 pieces
+template <bool F16>
+HD_DEVINL void split2(float y0, float y1, uint32_t& hi, uint32_t& lo) {
+    if constexpr (F16) f16_split2(y0, y1, hi, lo);
+    else bf16_split2(y0, y1, hi, lo);
+}
+template <bool F16>
+HD_DEVINL f32x16 mma16(bf16x8 a, bf16x8 b, f32x16 c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// fp16 mode: static part of the per-edge bound on the first-layer activation, |A_i[k] + B_j[k]| (scaled domain); see k_edge.hpp
+#define HD_F16_CAB 512.0f
+#define HD_TWOWAY(p) ((p) == 1 || (p) == 3)
+
 // three-way split (head, middle, tail: 24 significant bits, |y - h - m - l| <= 2^-27 |y|) for the bf16x6 contraction
 HD_DEVINL void bf16_split3(float y0, float y1, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
     const uint32_t hp = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){y0, y1}, bf16x2_t));

@@ -50,6 +50,7 @@ struct LayerW {                 // float offsets into hd_handle::dw
     size_t ab_img, ab_bias, wrd, w2_img, b2, wa, w3_img, b3, w4_img, b4;
     size_t ab_gimg, w3_gimg, w4_gimg;      // fp32 mode: the same weights as k_gemm_r16 images (node chain below HD_FUSE_MIN_ROWS)
     float ba;
+    float w2s, wrmax, wdmax;               // fp16x3: power-of-two scale of the W2 image (else 1); max |w_r|, max |w_d| as packed
 };
 
 struct ProfRec { int fam; hipEvent_t a, b; };
@@ -58,8 +59,13 @@ struct hd_handle {
     hd_config cfg;
     int device;
     int H, fin, F, D, NS;       // NS: 32-column sub-tiles per k_gemm workgroup tile
-    bool x6;                    // bf16x6: the edge kernels contract on six bf16 MFMAs per product (H >= 128; below that
-                                // the mode runs the exact-fp32 kernels), everything else is the fp32 path
+    // arithmetic of the two kernel families, derived from cfg.precision and the width (hd_create):
+    //   edge_mode 0 fp32 | 1 bf16x3 | 2 bf16x6 | 3 fp16x3      node_mode 0 fp32 (k_node_f32 / k_gemm_r16) | 1 bf16 two-piece | 2 bf16 three-piece
+    //   precision 0: 0 / 0;  1: 1 / 1;  2: 2 / 2 (H >= 128, else 0 / 0);  3: 3 / 2 (H >= 128, else 3 / 0)
+    // `scaled`: the edge model runs in the domain scaled by -log2(e) (two-way modes, silu_scaled in common.hpp)
+    int edge_mode, node_mode;
+    bool scaled;
+    bool x6;                    // edge_mode == 2
     long long n_weights;
     bool weights_set;
     float* dw;                  // packed weights
@@ -208,7 +214,7 @@ extern "C" int hd_create(const hd_config* cfg, int device, hd_handle** out) {
     const int F = cfg->in_node_nf - (cfg->condition_time ? 1 : 0);
     if (F < 1) return fail(HD_E_INVALID, "hd_create: in_node_nf must leave at least one feature column");
     if (cfg->context_node_nf < 0) return fail(HD_E_INVALID, "hd_create: context_node_nf < 0");
-    if (cfg->precision < 0 || cfg->precision > 2) return fail(HD_E_INVALID, "hd_create: precision must be 0 (fp32), 1 (bf16x3) or 2 (bf16x6)");
+    if (cfg->precision < 0 || cfg->precision > 3) return fail(HD_E_INVALID, "hd_create: precision must be 0 (fp32), 1 (bf16x3), 2 (bf16x6) or 3 (fp16x3)");
     if (!cfg->aggregation_mean && !(cfg->normalization_factor != 0.0f)) return fail(HD_E_INVALID, "hd_create: normalization_factor == 0");
     if (hd_device_count() <= device || device < 0)
         return fail(HD_E_HIP, "hd_create: no such HIP device (is a GPU visible?)");
@@ -220,7 +226,17 @@ extern "C" int hd_create(const hd_config* cfg, int device, hd_handle** out) {
     h->fin = cfg->in_node_nf + cfg->context_node_nf;
     h->F = F;
     h->D = 3 + F;
-    h->x6 = cfg->precision == 2 && cfg->hidden_nf >= 128;
+    {
+        const bool wide = cfg->hidden_nf >= 128;
+        switch (cfg->precision) {
+            case 1: h->edge_mode = 1; h->node_mode = 1; break;
+            case 2: h->edge_mode = wide ? 2 : 0; h->node_mode = wide ? 2 : 0; break;
+            case 3: h->edge_mode = 3; h->node_mode = wide ? 2 : 0; break;
+            default: h->edge_mode = 0; h->node_mode = 0; break;
+        }
+        h->scaled = h->edge_mode == 1 || h->edge_mode == 3;
+        h->x6 = h->edge_mode == 2;
+    }
     h->NS = (cfg->hidden_nf == 32) ? 1 : 2;
     h->n_weights = weight_count(*cfg);
     h->weights_set = false;
@@ -432,6 +448,34 @@ static void pack_edge_w2_bf(std::vector<float>& dstf, size_t off, int H, const f
                     }
 }
 
+// fp16x3 edge kernel: pack_edge_w2_bf's layout with fp16 pieces of W2 x 2^k, 2^k the power of two that puts the largest
+// |element| into [2^14, 2^15) (so heads stay finite and the tails of all but negligible elements normal).  Returns 2^k.
+static float pack_edge_w2_f16(std::vector<float>& dstf, size_t off, int H, const float* W2) {
+    float wmax = 0.0f;
+    for (size_t i = 0; i < (size_t)H * H; ++i) { const float v = std::fabs(W2[i]); if (v > wmax && std::isfinite(v)) wmax = v; }
+    int ex = 0;
+    if (wmax > 0.0f) (void)std::frexp(wmax, &ex);           // wmax = m 2^ex, m in [0.5, 1)
+    const int k = std::max(-100, std::min(100, 15 - ex));   // wmax 2^k in [2^14, 2^15)
+    const float sw = std::ldexp(1.0f, wmax > 0.0f ? k : 0);
+    _Float16* dst = reinterpret_cast<_Float16*>(dstf.data() + off);
+    const int NCT = H / 32;
+    for (int c = 0; c < H / 32; ++c)
+        for (int st = 0; st < 2; ++st)
+            for (int ct = 0; ct < NCT; ++ct)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int i = 0; i < 8; ++i) {
+                        const int kk = 32 * c + 16 * (lane >> 5) + 8 * st + i;
+                        const int col = 32 * ct + (lane & 31);
+                        const float v = W2[(size_t)col * H + kk] * sw;
+                        const _Float16 hi = (_Float16)v;
+                        const _Float16 lo = (_Float16)(v - (float)hi);
+                        const size_t blk = (size_t)c * 32 * H * 2;
+                        dst[blk + (((size_t)(0 * 2 + st) * NCT + ct) * 64 + lane) * 8 + i] = hi;
+                        dst[blk + (((size_t)(1 * 2 + st) * NCT + ct) * 64 + lane) * 8 + i] = lo;
+                    }
+    return sw;
+}
+
 extern "C" int hd_set_weights(hd_handle* h, const float* blob, long long n, int on_device, void* stream) {
     if (!h || !blob) return fail(HD_E_INVALID, "hd_set_weights: null argument");
     if (n != h->n_weights)
@@ -448,11 +492,11 @@ extern "C" int hd_set_weights(hd_handle* h, const float* blob, long long n, int 
     const hd_config& c = h->cfg;
     const int H = h->H, fin = h->fin;
     const int L = c.n_layers, S = c.inv_sublayers;
-    const bool bf = c.precision == 1;
+    const bool bf = h->scaled;                                // two-way edge modes: scaled domain
     const size_t w2_floats = h->x6 ? (size_t)H * H * 3 / 2 : (size_t)H * H;
-    const size_t gx = h->x6 ? 3 : 2;                          // node weight images: x gx / 2 (bf16x6: three bf16 pieces per weight)
-    const int NPc = h->x6 ? 3 : 2;
-    const bool nodef32 = !bf && !h->x6;                       // fp32 mode (and bf16x6 below width 128): k_node_f32
+    const size_t gx = h->node_mode == 2 ? 3 : 2;              // node weight images: x gx / 2 (three bf16 pieces per weight)
+    const int NPc = h->node_mode == 2 ? 3 : 2;
+    const bool nodef32 = h->node_mode == 0;                   // k_node_f32 / k_gemm_r16
     // layout of the packed buffer
     size_t off = 0;
     auto take = [&](size_t cnt) { size_t o = off; off += (cnt + 3) & ~size_t(3); return o; };
@@ -509,6 +553,20 @@ extern "C" int hd_set_weights(hd_handle* h, const float* blob, long long n, int 
             pk[w.wrd + k] = sc(W1[(size_t)k * ld + 2 * H]);
             pk[w.wrd + H + k] = sc(W1[(size_t)k * ld + 2 * H + 1]);
         }
+        w.wrmax = w.wdmax = 0.0f;
+        for (int k = 0; k < H; ++k) {
+            w.wrmax = std::max(w.wrmax, std::fabs(pk[w.wrd + k]));
+            w.wdmax = std::max(w.wdmax, std::fabs(pk[w.wrd + H + k]));
+        }
+    };
+    // second edge Linear in the image of the handle's edge mode; returns the scale S its accumulators carry (1 but for fp16x3)
+    auto pack_w2 = [&](LayerW& w, const float* W2) -> float {
+        switch (h->edge_mode) {
+            case 1: pack_edge_w2_bf(pk, w.w2_img, H, W2); return 1.0f;
+            case 2: pack_edge_w2_x6(pk, w.w2_img, H, W2); return 1.0f;
+            case 3: return pack_edge_w2_f16(pk, w.w2_img, H, W2);
+            default: pack_edge_w2(pk, w.w2_img, H, W2); return 1.0f;
+        }
     };
     for (int i = 0; i < L; ++i) {
         for (int j = 0; j < S; ++j) {
@@ -521,9 +579,7 @@ extern "C" int hd_set_weights(hd_handle* h, const float* blob, long long n, int 
             // node_mlp.0: columns k >= H multiply the neighbour sums, which arrive scaled by c
             auto w3 = [&](int col, int k) { const float v = W3[(size_t)col * 2 * H + k]; return k >= H ? sc_inv(v) : v; };
             auto w4 = [&](int col, int k) { return W4[(size_t)col * H + k]; };
-            if (bf) pack_edge_w2_bf(pk, w.w2_img, H, W2);
-            else if (h->x6) pack_edge_w2_x6(pk, w.w2_img, H, W2);
-            else pack_edge_w2(pk, w.w2_img, H, W2);
+            w.w2s = pack_w2(w, W2);
             if (nodef32) {
                 pack_node_b_f32(pk, w.w3_img, 2 * H, H, w3);
                 pack_node_b_f32(pk, w.w4_img, H, H, w4);
@@ -549,9 +605,7 @@ extern "C" int hd_set_weights(hd_handle* h, const float* blob, long long n, int 
         const float* W6 = next((size_t)H * H);           const float* b6 = next(H);
         const float* w7 = next(H);
         pack_first(w, W5, b5);
-        if (bf) pack_edge_w2_bf(pk, w.w2_img, H, W6);
-        else if (h->x6) pack_edge_w2_x6(pk, w.w2_img, H, W6);
-        else pack_edge_w2(pk, w.w2_img, H, W6);
+        w.w2s = pack_w2(w, W6);
         for (int k = 0; k < H; ++k) { pk[w.b2 + k] = sc(b6[k]); pk[w.wa + k] = sc_inv(w7[k]); }
         w.ba = 0.0f;
     }
@@ -1080,7 +1134,7 @@ static int prepare_node_h() { return prepare_node_hw<H, (H / 32 < 8 ? H / 32 : 8
 
 static void node_update(hd_handle* h, bool upd, int nab, const NodeArgs& a, hipStream_t s) {
     ProfScope ps(h, s, 1);
-    const int mode = h->x6 ? 2 : (h->cfg.precision == 1 ? 1 : 0);
+    const int mode = h->node_mode;
     switch (h->H) {
         case 32: launch_node_h<32>(upd, nab, mode, a, s); break;
         case 64: launch_node_h<64>(upd, nab, mode, a, s); break;
@@ -1155,8 +1209,9 @@ extern "C" int hd_debug_edge_trace(hd_handle*, long long*, int) { return 0; }   
 template <int H>
 static int launch_edge_h(hd_handle* h, bool coord, const EdgeArgs& a, hipStream_t s, int mode_override = -1) {
     const int lds = edge_lds_bytes<H>();
-    const int prec = mode_override >= 0 ? mode_override : h->cfg.precision;
-    const bool x6 = mode_override >= 0 ? (mode_override == 2 && H >= 128) : h->x6;
+    // kernel family of this launch: 0 fp32, 1 bf16x3, 2 bf16x6, 3 fp16x3
+    const int prec = mode_override >= 0 ? ((mode_override == 2 && H < 128) ? 0 : mode_override) : h->edge_mode;
+    const bool x6 = prec == 2;
     const dim3 grid(a.n_wg), block(256);
 #ifdef HD_DEBUG_KERNELS
     if constexpr (H == 256) {
@@ -1166,7 +1221,7 @@ static int launch_edge_h(hd_handle* h, bool coord, const EdgeArgs& a, hipStream_
     if constexpr (H >= 128) {
         // at most 512 tiles: one tile per workgroup, columns split over its four wavefronts (k_edge_split.hpp; bit-identical
         // to k_edge in every precision mode, a quarter of the serial MFMA chain per wavefront)
-        const int mode = x6 ? 2 : (prec == 1 ? 1 : 0);
+        const int mode = prec;
         // measured break-even (profiles/r02_split_sweep.log): between 490 and 654 tiles in the bf16 modes, between 654 and 870
         // in fp32 (the longer MFMA chain has more to gain from the split)
         if (a.n_tiles > 0 && a.n_tiles <= (mode == 0 ? h->split_max_tiles + h->split_max_tiles / 3 : h->split_max_tiles)) {
@@ -1177,6 +1232,9 @@ static int launch_edge_h(hd_handle* h, bool coord, const EdgeArgs& a, hipStream_
             } else if (mode == 1) {
                 if (coord) hipLaunchKernelGGL((k_edge_split<H, true, 1>), sgrid, block, 0, s, a);
                 else hipLaunchKernelGGL((k_edge_split<H, false, 1>), sgrid, block, 0, s, a);
+            } else if (mode == 3) {
+                if (coord) hipLaunchKernelGGL((k_edge_split<H, true, 3>), sgrid, block, 0, s, a);
+                else hipLaunchKernelGGL((k_edge_split<H, false, 3>), sgrid, block, 0, s, a);
             } else {
                 if (coord) hipLaunchKernelGGL((k_edge_split<H, true, 2>), sgrid, block, 0, s, a);
                 else hipLaunchKernelGGL((k_edge_split<H, false, 2>), sgrid, block, 0, s, a);
@@ -1187,7 +1245,7 @@ static int launch_edge_h(hd_handle* h, bool coord, const EdgeArgs& a, hipStream_
     if constexpr (H >= 128) {
         // between one whole-tile workgroup per CU and HD_MIX_MAX_TILES: R * n_cu whole-tile workgroups (every CU the same
         // number) + the remaining tiles as column-split workgroups that back-fill (k_edge_mixed; bit-identical per tile)
-        const int mode = x6 ? 2 : (prec == 1 ? 1 : 0);
+        const int mode = prec;
         const int per_round = 4 * h->n_cu;
         // Measured (profiles/r03_mix_sweep*.log, ms per forward, plain -> mixed): fp32 B = 40 1.89 -> 1.45, 64 1.93 -> 1.88,
         // 96 2.66 -> 2.60, 128 3.29 -> 3.17, 160 4.15 -> 3.89, 192 4.79 -> 4.40, 256 5.41 -> 5.51; the bf16 modes gain only
@@ -1209,6 +1267,9 @@ static int launch_edge_h(hd_handle* h, bool coord, const EdgeArgs& a, hipStream_
             } else if (mode == 1) {
                 if (coord) hipLaunchKernelGGL((k_edge_mixed<H, true, 1>), mgrid, block, ldsm, s, m);
                 else hipLaunchKernelGGL((k_edge_mixed<H, false, 1>), mgrid, block, ldsm, s, m);
+            } else if (mode == 3) {
+                if (coord) hipLaunchKernelGGL((k_edge_mixed<H, true, 3>), mgrid, block, ldsm, s, m);
+                else hipLaunchKernelGGL((k_edge_mixed<H, false, 3>), mgrid, block, ldsm, s, m);
             } else {
                 if (coord) hipLaunchKernelGGL((k_edge_mixed<H, true, 2>), mgrid, block, ldsm, s, m);
                 else hipLaunchKernelGGL((k_edge_mixed<H, false, 2>), mgrid, block, ldsm, s, m);
@@ -1224,7 +1285,10 @@ static int launch_edge_h(hd_handle* h, bool coord, const EdgeArgs& a, hipStream_
             return HD_OK;
         }
     }
-    if (prec != 1) {
+    if (prec == 3) {
+        if (coord) hipLaunchKernelGGL((k_edge<H, true, 3>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((k_edge<H, false, 3>), grid, block, lds, s, a);
+    } else if (prec != 1) {
         if (coord) hipLaunchKernelGGL((k_edge<H, true, 0>), grid, block, lds, s, a);
         else hipLaunchKernelGGL((k_edge<H, false, 0>), grid, block, lds, s, a);
     } else {
@@ -1243,6 +1307,8 @@ static int prepare_edge_h() {
     HIP_TRY(hipFuncSetAttribute((const void*)k_edge<H, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIP_TRY(hipFuncSetAttribute((const void*)k_edge<H, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIP_TRY(hipFuncSetAttribute((const void*)k_edge<H, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_edge<H, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_edge<H, false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     if constexpr (H >= 128) {
         HIP_TRY(hipFuncSetAttribute((const void*)k_edge<H, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, edge_lds_bytes<H>(true)));
         HIP_TRY(hipFuncSetAttribute((const void*)k_edge<H, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, edge_lds_bytes<H>(true)));
@@ -1251,6 +1317,8 @@ static int prepare_edge_h() {
         HIP_TRY(hipFuncSetAttribute((const void*)k_edge_mixed<H, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, m0));
         HIP_TRY(hipFuncSetAttribute((const void*)k_edge_mixed<H, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, m0));
         HIP_TRY(hipFuncSetAttribute((const void*)k_edge_mixed<H, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, m0));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_edge_mixed<H, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, m0));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_edge_mixed<H, false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, m0));
         HIP_TRY(hipFuncSetAttribute((const void*)k_edge_mixed<H, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, m2));
         HIP_TRY(hipFuncSetAttribute((const void*)k_edge_mixed<H, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, m2));
     }
@@ -1315,7 +1383,7 @@ static int forward_impl(hd_handle* h, hd_topology* t, const float* xh, const flo
         // (60 of them at B = 64), the k_agg + 3 x k_gemm chain spreads the same work over 64 x 64 tiles.  Both paths are
         // bit-identical (same MFMA order per output element, bias added after the contraction), so a sample's bits do
         // not depend on which one its batch size selects (test_fp32_node_paths_agree_bitwise).
-        const bool fused = c.precision == 1 || h->x6 || M >= h->fuse_min_rows;
+        const bool fused = h->node_mode != 0 || M >= h->fuse_min_rows;
         auto r16_args = [&]() {
             R16Args g;
             std::memset(&g, 0, sizeof(g));
@@ -1346,6 +1414,7 @@ static int forward_impl(hd_handle* h, hd_topology* t, const float* xh, const flo
                 EdgeArgs e;
                 std::memset(&e, 0, sizeof(e));
                 e.AB = ab_cur; e.wrd = W + w.wrd; e.W2img = W + w.w2_img; e.b2 = W + w.b2; e.wa = W + w.wa;
+                e.w2s_inv = 1.0f / w.w2s; e.wrmax = w.wrmax; e.wdmax = w.wdmax;
                 e.ei = t->ei; e.ej = t->ej; e.eseg = t->eseg; e.seg_part = t->seg_part; e.tile_nseg = t->tile_nseg;
                 e.xcur = t->xcur; e.x0 = t->x0; e.part = coord ? t->xpart : t->part; e.ba = w.ba;
                 e.norm_constant = c.norm_constant; e.coords_range = range; e.attention = c.attention;
@@ -1520,6 +1589,7 @@ extern "C" int hd_edge_layer_forward_p(hd_handle* h, hd_topology* t, int coord, 
     EdgeArgs e;
     std::memset(&e, 0, sizeof(e));
     e.AB = AB; e.wrd = wrd; e.W2img = t->w2img; e.b2 = b2; e.wa = wa;
+    e.w2s_inv = 1.0f; e.wrmax = e.wdmax = 0.0f;
     e.ei = t->ei; e.ej = t->ej; e.eseg = t->eseg; e.seg_part = t->seg_part; e.tile_nseg = t->tile_nseg;
     e.xcur = x; e.x0 = x0; e.part = coord ? t->xpart : t->part; e.ba = 0.0f; e.ba_ptr = ba;
     e.norm_constant = c.norm_constant; e.coords_range = c.coords_range / (float)c.n_layers; e.attention = c.attention;

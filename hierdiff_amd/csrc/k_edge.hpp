@@ -47,6 +47,8 @@ struct EdgeArgs {
     int attention, use_tanh;
     int n_tiles, n_wg;      // n_wg = number of 128-edge workgroup-tiles
     long long* trace;       // ABL & 16: per wave {start, loop start, loop end, end} cycle stamps
+    float w2s_inv;          // PREC 3: 1 / (power-of-two scale of the W2 image)
+    float wrmax, wdmax;     // PREC 3: max |w_r|, max |w_d| of this layer (bound on the distance terms of the first layer)
 };
 
 
@@ -60,6 +62,19 @@ struct EdgeArgs {
 // matrix cores proper only take 16-bit inputs - the fp32 MFMA runs on the SIMD's packed-fp32 datapath and nothing
 // overlaps with it - so this is the fp32-accurate form that leaves the VALU free for the SiLUs.
 // Everything else of the mode is the fp32 one (unscaled domain, compensated SiLU, fp32 node GEMMs); H >= 128.
+// PREC 3: "fp16x3" - PREC 1's structure line for line (two-way split, three MFMAs, scaled domain) on fp16 pieces
+// (v_mfma_f32_32x32x16_f16): 11 + 11 significant bits per operand instead of 8 + 8, so what the three kept terms drop is
+// <= 2^-21 of a product - at the rounding of the fp32 accumulation, like bf16x6 (measured with the real instruction,
+// scratch/mb/f16_denorm.hip: 1.9e-7 rel-L2 against fp64 vs 2.4e-7 for bf16x6, 4.1e-6 for bf16x3), at PREC 1's cost.  fp16 has
+// 5 exponent bits, so both operands are brought into range by exact powers of two.  The W2 image is stored x 2^k with its
+// largest element in [2^14, 2^15) (per matrix, by the packer).  The activations of an EDGE ROW are scaled by s = 2^(13 - E),
+// E = floor(log2(bound)), bound = HD_F16_CAB + radial max|w_r| + d0 max|w_d| >= |pre-activation| >= |SiLU| - the distance terms
+// are what makes first-layer activations large (coordinates far apart), and they are known per edge before the contraction
+// starts; s rides in the SiLU's reciprocal (`1 + e` becomes fma(e, 1/s, 1/s)).  A row of the accumulators therefore holds
+// s 2^k x its pre-activation; the epilogue undoes it in the fused multiply-add that also adds the bias (one instruction more
+// than PREC 1).  Tails below the normal range are subnormal fp16 numbers, which the matrix core keeps.  What is left of fp16's
+// range limit: the NODE terms of the first layer, |A_i[k] + B_j[k]| (scaled domain), must stay below ~4 x HD_F16_CAB = 2047 -
+// beyond that a head overflows to inf and trips the NaN guard of the forward (hd_nan_events), loudly.
 
 // Four LDS fragment reads / a counted wait that releases them (see k_edge).  The reads are inline asm so
 // they stay where they are written (hipcc otherwise sinks every LDS read next to its MFMA to save registers,
@@ -253,6 +268,14 @@ HD_DEVINL void edge_tile_body(const EdgeArgs& a, float* smem, float* wrd_s, cons
     const float ex = yi[0] - yj[0], ey = yi[1] - yj[1], ez = yi[2] - yj[2];
     const float d0 = ex * ex + ey * ey + ez * ez;
     const uint32_t segb_t = segb;
+    // fp16x3: this row's activation scale (see the header comment); 1 / (s 2^k) parked for the epilogue, which needs it by row slot
+    float f16_inv = 1.0f;
+    if constexpr (PREC == 3) {
+        const float bound = __builtin_fmaf(radial, a.wrmax, __builtin_fmaf(d0, a.wdmax, HD_F16_CAB));
+        const uint32_t eb = (__builtin_bit_cast(uint32_t, bound) >> 23) & 0xffu;      // bound in [2^(eb-127), 2^(eb-126))
+        f16_inv = __builtin_bit_cast(float, (eb - 13u) << 23);                        // 2^-(13 - E), E = eb - 127: bound x s < 2^14
+        if (hh == 0) my_scr[n] = f16_inv * a.w2s_inv;
+    }
     const int pid_l = tile_ok ? a.seg_part[tile * 32 + n] : 0;   // part id of segment n; requested here, used in the epilogue
     const int nseg = tile_ok ? a.tile_nseg[tile] : 0;
     if (hh == 0) reinterpret_cast<uint8_t*>(seg_s)[n] = (uint8_t)segb_t;
@@ -298,13 +321,13 @@ HD_DEVINL void edge_tile_body(const EdgeArgs& a, float* smem, float* wrd_s, cons
 #pragma unroll
         for (int j = 0; j < 4; ++j) e[j] = __builtin_amdgcn_exp2f(pre[j]);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) e[j] = 1.0f + e[j];
+        for (int j = 0; j < 4; ++j) e[j] = PREC == 3 ? __builtin_fmaf(e[j], f16_inv, f16_inv) : 1.0f + e[j];
 #pragma unroll
         for (int j = 0; j < 4; ++j) e[j] = __builtin_amdgcn_rcpf(e[j]);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) pre[j] *= e[j];
-        bf16_split2(pre[0], pre[1], hi[0], lo[0]);
-        bf16_split2(pre[2], pre[3], hi[1], lo[1]);
+        for (int j = 0; j < 4; ++j) pre[j] *= e[j];             // PREC 3: row scale x the activation
+        split2<PREC == 3>(pre[0], pre[1], hi[0], lo[0]);
+        split2<PREC == 3>(pre[2], pre[3], hi[1], lo[1]);
     };
     auto make_P_bf = [&](int c, u32x4 (&ph)[2], u32x4 (&pl)[2]) {
 #pragma unroll
@@ -350,7 +373,7 @@ HD_DEVINL void edge_tile_body(const EdgeArgs& a, float* smem, float* wrd_s, cons
     else asm volatile("s_waitcnt vmcnt(0)" : "+v"(pa[0]), "+v"(pa[1]), "+v"(pb[0]), "+v"(pb[1]));
     __syncthreads();               // chunk 0 landed in every wave's share (w_r / w_d staged on the first pass)
     if constexpr (PREC == 0) make_P(0, Pc);
-    else if constexpr (PREC == 1) make_P_bf(0, phc, plc);
+    else if constexpr (HD_TWOWAY(PREC)) make_P_bf(0, phc, plc);
     else {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -368,7 +391,7 @@ HD_DEVINL void edge_tile_body(const EdgeArgs& a, float* smem, float* wrd_s, cons
     f32x16 acc[NCT];
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {
-        const float b2v = wrd_s[2 * H + 32 * ct + n];
+        const float b2v = PREC == 3 ? 0.0f : wrd_s[2 * H + 32 * ct + n];      // fp16x3: the bias joins in the epilogue's un-scaling fma
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[ct][r] = b2v;
     }
@@ -442,7 +465,7 @@ HD_DEVINL void edge_tile_body(const EdgeArgs& a, float* smem, float* wrd_s, cons
                     else vm_load2o<16 * q>(pa[q], pb[q], Arow_n2, Brow_n2);
                 }
             });
-        } else if constexpr (PREC == 1) {
+        } else if constexpr (HD_TWOWAY(PREC)) {
             // chunk image: [hi|lo][2 k-steps][NCT][64 lanes][8 bf16]; lane (h, n), element i of step s is
             // W2[32ct + n][32c + 16h + 8s + i] - the same k order as P[8s + i].  Units u = (k-step, ct) of
             // three MFMAs (head*head, tail*head, head*tail) on one accumulator, two units per group.
@@ -500,12 +523,12 @@ HD_DEVINL void edge_tile_body(const EdgeArgs& a, float* smem, float* wrd_s, cons
                 constexpr int s0 = u0 / NCT, c0 = u0 % NCT, s1 = u1 / NCT, c1 = u1 % NCT;
                 const bf16x8 A_h0 = __builtin_bit_cast(bf16x8, phc[s0]), A_l0 = __builtin_bit_cast(bf16x8, plc[s0]);
                 const bf16x8 A_h1 = __builtin_bit_cast(bf16x8, phc[s1]), A_l1 = __builtin_bit_cast(bf16x8, plc[s1]);
-                acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_h0, cur[0], acc[c0], 0, 0, 0);
-                acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_h1, cur[2], acc[c1], 0, 0, 0);
-                acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_l0, cur[0], acc[c0], 0, 0, 0);
-                acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_l1, cur[2], acc[c1], 0, 0, 0);
-                acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_h0, cur[1], acc[c0], 0, 0, 0);
-                acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_h1, cur[3], acc[c1], 0, 0, 0);
+                acc[c0] = mma16<PREC == 3>(A_h0, cur[0], acc[c0]);
+                acc[c1] = mma16<PREC == 3>(A_h1, cur[2], acc[c1]);
+                acc[c0] = mma16<PREC == 3>(A_l0, cur[0], acc[c0]);
+                acc[c1] = mma16<PREC == 3>(A_l1, cur[2], acc[c1]);
+                acc[c0] = mma16<PREC == 3>(A_h0, cur[1], acc[c0]);
+                acc[c1] = mma16<PREC == 3>(A_h1, cur[3], acc[c1]);
 #pragma unroll
                 for (int k = 0; k < 6; ++k) {            // interleave: 1 MFMA, then up to 4 VALU
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -609,10 +632,15 @@ HD_DEVINL void edge_tile_body(const EdgeArgs& a, float* smem, float* wrd_s, cons
     float dot[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) dot[r] = 0.f;
+    f32x4 rsc[4];                          // fp16x3: 1 / (row scale x W2 scale) of the 16 rows this lane holds
+    if constexpr (PREC == 3) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rsc[q] = *reinterpret_cast<const f32x4*>(my_scr + 8 * q + 4 * hh);
+    }
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {
         const float wav = wrd_s[3 * H + 32 * ct + n];
-        if constexpr (PREC != 1) {
+        if constexpr (!HD_TWOWAY(PREC)) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float mv = PREC == 2 ? HD_X6_SILU(acc[ct][r]) : HD_F32_SILU(acc[ct][r]);
@@ -624,6 +652,12 @@ HD_DEVINL void edge_tile_body(const EdgeArgs& a, float* smem, float* wrd_s, cons
             // runs each value's exp -> add -> rcp -> mul chain back to back through one or two registers and
             // the epilogue sits out the transcendental latency ~500 times.
             float e[16];
+            if constexpr (PREC == 3) {
+                const float b2v = wrd_s[2 * H + 32 * ct + n];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[ct][r] = __builtin_fmaf(acc[ct][r], rsc[r >> 2][r & 3], b2v);
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) e[r] = __builtin_amdgcn_exp2f(acc[ct][r]);
             __builtin_amdgcn_sched_barrier(0);
@@ -686,7 +720,7 @@ HD_DEVINL void edge_tile_body(const EdgeArgs& a, float* smem, float* wrd_s, cons
         float att_mine = 1.0f;
         if (a.attention) {
             const float ba = a.ba_ptr ? *a.ba_ptr : a.ba;
-            if constexpr (PREC != 1) att_mine = sigmoid_f(rowdot + ba);
+            if constexpr (!HD_TWOWAY(PREC)) att_mine = sigmoid_f(rowdot + ba);
             else att_mine = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(rowdot + ba));   // scaled domain
         }
         float w[16];

@@ -26,7 +26,7 @@
 // place it in the dynamic LDS the whole-tile form uses for its W2 double buffer
 template <int H, int PREC>
 constexpr int edge_split_lds_bytes() {
-    return (H / (PREC == 2 ? 16 : 32)) * (PREC == 2 ? 3 : 4) * 64 * 16 + (16 * 64 + 64 + 8 + 32 + 96 + 4) * 4;
+    return (H / (PREC == 2 ? 16 : 32)) * (PREC == 2 ? 3 : 4) * 64 * 16 + (16 * 64 + 64 + 8 + 32 + 96 + 4 + 32) * 4;
 }
 
 // DEEP: the standalone launch (at most ~680 workgroups on 256 CUs: registers are free) keeps more K chunks of W2 fragments in
@@ -44,6 +44,7 @@ HD_DEVINL void edge_split_body(const EdgeArgs& a, char* lds, float* wrd_s, const
     float* cs_phi = reinterpret_cast<float*>(seg_s + 8);             // [32] coordinate head scratch (wavefront 3)
     float* cs_tr = cs_phi + 32;                                      // [96]
     int* nan_p = reinterpret_cast<int*>(cs_tr + 96);
+    float* rs_s = reinterpret_cast<float*>(nan_p + 4);               // [32] fp16x3: 1 / (row scale x W2 scale)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -66,6 +67,13 @@ HD_DEVINL void edge_split_body(const EdgeArgs& a, char* lds, float* wrd_s, const
     const float d0 = ex * ex + ey * ey + ez * ez;
     const int pid_l = a.seg_part[tile * 32 + n];
     const int nseg = a.tile_nseg[tile];
+    float f16_inv = 1.0f;                                            // fp16x3: this row's activation scale, as in k_edge
+    if constexpr (PREC == 3) {
+        const float bound = __builtin_fmaf(radial, a.wrmax, __builtin_fmaf(d0, a.wdmax, HD_F16_CAB));
+        const uint32_t eb = (__builtin_bit_cast(uint32_t, bound) >> 23) & 0xffu;
+        f16_inv = __builtin_bit_cast(float, (eb - 13u) << 23);
+        if (wave == 3 && hh == 0) rs_s[n] = f16_inv * a.w2s_inv;
+    }
     if (wave == 3 && hh == 0) {
         reinterpret_cast<uint8_t*>(seg_s)[n] = (uint8_t)segb;
         if constexpr (COORD) {
@@ -101,7 +109,7 @@ HD_DEVINL void edge_split_body(const EdgeArgs& a, char* lds, float* wrd_s, const
                     pre = __builtin_fmaf(d0, wd4[j], pre);
                     o.P[4 * u + j] = HD_F32_SILU(pre);
                 }
-            } else if constexpr (PREC == 1) {                        // k_edge's make_quad (scaled domain) + make_P_bf
+            } else if constexpr (HD_TWOWAY(PREC)) {                  // k_edge's make_quad (scaled domain) + make_P_bf
                 float pre[4], ev[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) pre[j] = w.a[u][j] + w.b[u][j];
@@ -112,14 +120,14 @@ HD_DEVINL void edge_split_body(const EdgeArgs& a, char* lds, float* wrd_s, const
 #pragma unroll
                 for (int j = 0; j < 4; ++j) ev[j] = __builtin_amdgcn_exp2f(pre[j]);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) ev[j] = 1.0f + ev[j];
+                for (int j = 0; j < 4; ++j) ev[j] = PREC == 3 ? __builtin_fmaf(ev[j], f16_inv, f16_inv) : 1.0f + ev[j];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) ev[j] = __builtin_amdgcn_rcpf(ev[j]);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) pre[j] *= ev[j];
                 uint32_t hi[2], lo[2];
-                bf16_split2(pre[0], pre[1], hi[0], lo[0]);
-                bf16_split2(pre[2], pre[3], hi[1], lo[1]);
+                split2<PREC == 3>(pre[0], pre[1], hi[0], lo[0]);
+                split2<PREC == 3>(pre[2], pre[3], hi[1], lo[1]);
                 o.ph[u >> 1][2 * (u & 1)] = hi[0]; o.ph[u >> 1][2 * (u & 1) + 1] = hi[1];
                 o.pl[u >> 1][2 * (u & 1)] = lo[0]; o.pl[u >> 1][2 * (u & 1) + 1] = lo[1];
             } else {                                                 // k_edge's make_quad_x6
@@ -153,13 +161,13 @@ HD_DEVINL void edge_split_body(const EdgeArgs& a, char* lds, float* wrd_s, const
             const int x = i / NCW, k = i % NCW;
             unsigned off;
             if constexpr (PREC == 0) off = frag_off_f32(x * NCT + ct0 + k);                       // x = q
-            else if constexpr (PREC == 1) off = (unsigned)(((((x >> 1) * 2 + (x & 1)) * NCT + ct0 + k) * 64) * 16);   // x = 2 hl + s
+            else if constexpr (HD_TWOWAY(PREC)) off = (unsigned)(((((x >> 1) * 2 + (x & 1)) * NCT + ct0 + k) * 64) * 16);   // x = 2 hl + s
             else off = (unsigned)((x * NCT + ct0 + k) * 64 * 16);                                 // x = part
             f[i] = *reinterpret_cast<const u32x4*>(base + off);
         }
     };
-    constexpr int RING0 = PREC == 0 ? 3 : (PREC == 1 ? 4 : 6);       // chunks of fragments in flight ahead of the MFMAs
-    constexpr int RING = DEEP ? (PREC == 0 ? 6 : (PREC == 1 ? 6 : 8)) : RING0;
+    constexpr int RING0 = PREC == 0 ? 3 : (HD_TWOWAY(PREC) ? 4 : 6);       // chunks of fragments in flight ahead of the MFMAs
+    constexpr int RING = DEEP ? (PREC == 0 ? 6 : (HD_TWOWAY(PREC) ? 6 : 8)) : RING0;
     u32x4 fr[RING][NF];
     static_for<0, (RING - 1 < NCH ? RING - 1 : NCH)>([&](auto Cc) { load_frags(decltype(Cc)::value, fr[decltype(Cc)::value]); });
     // The operand tile (32 edge rows x H) is the same for the four wavefronts: each builds a quarter of the K chunks
@@ -180,7 +188,7 @@ HD_DEVINL void edge_split_body(const EdgeArgs& a, char* lds, float* wrd_s, const
             if constexpr (PREC == 0) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) dst[q * 64] = __builtin_bit_cast(u32x4, f32x4{o.P[4 * q], o.P[4 * q + 1], o.P[4 * q + 2], o.P[4 * q + 3]});
-            } else if constexpr (PREC == 1) {
+            } else if constexpr (HD_TWOWAY(PREC)) {
                 dst[0] = o.ph[0]; dst[64] = o.ph[1]; dst[128] = o.pl[0]; dst[192] = o.pl[1];
             } else {
                 dst[0] = o.xh; dst[64] = o.xm; dst[128] = o.xl;
@@ -197,7 +205,7 @@ HD_DEVINL void edge_split_body(const EdgeArgs& a, char* lds, float* wrd_s, const
     f32x16 acc[NCW];
 #pragma unroll
     for (int k = 0; k < NCW; ++k) {
-        const float b2v = wrd_s[2 * H + 32 * (ct0 + k) + n];
+        const float b2v = PREC == 3 ? 0.0f : wrd_s[2 * H + 32 * (ct0 + k) + n];
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[k][r] = b2v;
     }
@@ -215,16 +223,16 @@ HD_DEVINL void edge_split_body(const EdgeArgs& a, char* lds, float* wrd_s, const
 #pragma unroll
                     for (int k = 0; k < NCW; ++k)
                         acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(f32x4, ov[q])[j], __builtin_bit_cast(f32x4, f[q * NCW + k])[j], acc[k], 0, 0, 0);
-        } else if constexpr (PREC == 1) {
+        } else if constexpr (HD_TWOWAY(PREC)) {
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
                 const bf16x8 A_h = __builtin_bit_cast(bf16x8, ov[st]), A_l = __builtin_bit_cast(bf16x8, ov[2 + st]);
 #pragma unroll
                 for (int k = 0; k < NCW; ++k) {
                     const bf16x8 Wh = __builtin_bit_cast(bf16x8, f[(0 + st) * NCW + k]), Wl = __builtin_bit_cast(bf16x8, f[(2 + st) * NCW + k]);
-                    acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_h, Wh, acc[k], 0, 0, 0);
-                    acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_l, Wh, acc[k], 0, 0, 0);
-                    acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_h, Wl, acc[k], 0, 0, 0);
+                    acc[k] = mma16<PREC == 3>(A_h, Wh, acc[k]);
+                    acc[k] = mma16<PREC == 3>(A_l, Wh, acc[k]);
+                    acc[k] = mma16<PREC == 3>(A_h, Wl, acc[k]);
                 }
             }
         } else {
@@ -244,6 +252,17 @@ HD_DEVINL void edge_split_body(const EdgeArgs& a, char* lds, float* wrd_s, const
     });
 
     // ---- epilogue.  acc[k][r] = row rho(r) = (r&3) + 8*(r>>2) + 4*hh, column 32*(ct0+k) + n.
+    if constexpr (PREC == 3) {                                       // un-scale + bias, the same fma as k_edge
+        f32x4 rsc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rsc[q] = *reinterpret_cast<const f32x4*>(rs_s + 8 * q + 4 * hh);
+#pragma unroll
+        for (int k = 0; k < NCW; ++k) {
+            const float b2v = wrd_s[2 * H + 32 * (ct0 + k) + n];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[k][r] = __builtin_fmaf(acc[k][r], rsc[r >> 2][r & 3], b2v);
+        }
+    }
 #pragma unroll
     for (int k = 0; k < NCW; ++k)
 #pragma unroll
@@ -311,7 +330,7 @@ HD_DEVINL void edge_split_body(const EdgeArgs& a, char* lds, float* wrd_s, const
             float att_mine = 1.0f;
             if (a.attention) {
                 const float ba = a.ba_ptr ? *a.ba_ptr : a.ba;
-                if constexpr (PREC != 1) att_mine = sigmoid_f(rowdot + ba);
+                if constexpr (!HD_TWOWAY(PREC)) att_mine = sigmoid_f(rowdot + ba);
                 else att_mine = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(rowdot + ba));   // scaled domain
             }
             att_s[lane] = att_mine;

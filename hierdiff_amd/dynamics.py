@@ -23,7 +23,7 @@ from . import _lib
 from ._lib import HdConfig, HierDiffHipError
 
 
-PRECISIONS = {"fp32": 0, "bf16x3": 1, "bf16x6": 2}
+PRECISIONS = {"fp32": 0, "bf16x3": 1, "bf16x6": 2, "fp16x3": 3}
 # Arithmetic of the H x H contractions.  The drop-in default is "fp32": exact fp32 matrix instructions
 # (v_mfma_f32_32x32x2_f32), the arithmetic the reference computes in (en_dynamics.py has no notion of reduced
 # precision; per-forward error vs the reference ~5e-7 rel-L2).  "bf16x3" is opt-in (`model.precision = "bf16x3"`

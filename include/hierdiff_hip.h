@@ -79,7 +79,13 @@ typedef struct hd_config {
                                     2 = "bf16x6" (opt-in): the per-edge H x H contraction on a three-way bf16 split,
                                         6 bf16 MFMAs per product, fp32 accumulation - truncation <= 2^-26 per product,
                                         below the rounding of the fp32 accumulation itself; everything else as in
-                                        mode 0 (hidden_nf < 128 runs mode 0's kernels) */
+                                        mode 0 (hidden_nf < 128 runs mode 0's kernels),
+                                    3 = "fp16x3" (opt-in): the per-edge contraction on a two-way FP16 split (11 + 11 significant
+                                        bits per operand), 3 fp16 MFMAs per product, fp32 accumulation - truncation <= 2^-21 per
+                                        product, at the rounding of the fp32 accumulation (measured 1.9e-7 rel-L2 on a 256-term
+                                        contraction, bf16x6 2.4e-7, bf16x3 4.1e-6) at mode 1's cost.  Operands are ranged by
+                                        exact powers of two (W2 per matrix, activations x 4): an edge-model activation beyond
+                                        16376 overflows and trips the forward's NaN guard.  Node GEMMs as in mode 2 */
     int32_t aggregation_mean;    /* 0: aggregation_method 'sum' - neighbour sums / normalization_factor (egnn_new.py:280-282);
                                     1: 'mean' (:283-288) - sums / number of edge-list entries of the receiving node.  The
                                        reference's edge list holds all N x N pairs of a molecule, masked or not

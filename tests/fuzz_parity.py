@@ -11,7 +11,7 @@ rng = np.random.Generator(np.random.PCG64(int(sys.argv[2]) if len(sys.argv) > 2 
 def rel(a, b):
     a, b = a.double(), b.double()
     return float((a - b).norm() / max(float(b.norm()), 1e-30))
-worst = {"fp32": 0.0, "bf16x6": 0.0, "bf16x3": 0.0}
+worst = {"fp32": 0.0, "bf16x6": 0.0, "fp16x3": 0.0, "bf16x3": 0.0}
 outside = []          # bf16x3 above 1e-4 outside the production-like option set: reported, not gated
 fails = 0
 t0 = time.time()
@@ -59,7 +59,7 @@ for case in range(cases):
     # its error grows with depth when nothing damps it (1.03e-4 in one case of 3,600), which is the mode's stated domain of
     # validity, not a tolerance to be moved.
     prod_like = nf >= 10.0 or L * (S + 1) <= 9
-    for prec in ("fp32", "bf16x6", "bf16x3"):
+    for prec in ("fp32", "bf16x6", "fp16x3", "bf16x3"):
         dyn.precision = prec
         with torch.no_grad():
             out = dyn._forward(t.to(DEV), xh.to(DEV), nm.to(DEV), em.to(DEV), None if ctx is None else ctx.to(DEV), mol).cpu()
@@ -113,7 +113,7 @@ for case in range(chains):
     m = m.to(DEV); m.schedule_gammas = grid
     line = f"chain {case:3d} H={H:3d} L={L} T={T} C={C_} gain={gain} fix_noise={int(fix)} pocket={0 if pocket is None else pocket[0].shape[1]} n={n_list}"
     pk = None if pocket is None else tuple(v.to(DEV) for v in pocket)
-    for prec in ("fp32", "bf16x6", "bf16x3"):
+    for prec in ("fp32", "bf16x6", "fp16x3", "bf16x3"):
         m.dynamics.precision = prec
         x, h = m.sample_from_masks(nm.to(DEV), em.to(DEV), None if ctx is None else ctx.to(DEV), fix_noise=fix, raw_noises=raws, pocket=pk)
         nmf = nm.float()
@@ -138,7 +138,7 @@ for case in range(splits):
     H = int(rng.choice([32, 64, 128])); L = int(rng.integers(1, 3)); T = int(rng.integers(2, 6))
     B = int(rng.integers(2, 13)); nmax = int(rng.choice([5, 12, 30]))
     n_list = [int(rng.integers(1, nmax + 1)) for _ in range(B)]
-    prec = str(rng.choice(["fp32", "bf16x6", "bf16x3"]))
+    prec = str(rng.choice(["fp32", "bf16x6", "fp16x3", "bf16x3"]))
     sd_np = synthetic_state_dict(9, 0, H, L, 2, True, 8000 + case, 0.02)
     m = DiffusionQM9(default_config(hidden_nf=H, n_layers=L, timesteps=T))
     m.load_state_dict({k: torch.from_numpy(np.asarray(v).copy()) for k, v in sd_np.items()})
@@ -178,7 +178,7 @@ for case in range(gnns):
                             aggregation_method=agg)
     dyn.load_numpy_state_dict(sd_np); dyn = dyn.to(DEV).eval()
     line = f"gnn {case:3d} H={H:3d} L={L} att={int(att)} agg={agg:4s} nf={nf:5.1f} n={n_list} N={xh.shape[1]}"
-    for prec in ("fp32", "bf16x6", "bf16x3"):
+    for prec in ("fp32", "bf16x6", "fp16x3", "bf16x3"):
         dyn.precision = prec
         with torch.no_grad():
             out = dyn._forward(t.to(DEV), xh.to(DEV), nm.to(DEV), em.to(DEV), None).cpu()

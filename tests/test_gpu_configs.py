@@ -421,7 +421,7 @@ def test_switching_precision_keeps_the_schedule():
     model = build_diffusion(sd_np, 128, 1, T=6, precision="fp32")
     nm, _ = orc.canonical_masks([4, 3])
     x0, _ = model.sample_from_masks(nm.to(DEV), None, None)
-    for p in ("bf16x3", "bf16x6", "fp32", "bf16x6", "bf16x3"):
+    for p in ("bf16x3", "bf16x6", "fp16x3", "fp32", "bf16x6", "fp16x3", "bf16x3"):
         model.dynamics.precision = p
         x1, _ = model.sample_from_masks(nm.to(DEV), None, None)
         assert torch.isfinite(x1).all()

@@ -4,7 +4,9 @@ the reference and against the CPU oracle on seeded inputs.
 Tolerance: rel-L2 over the whole [B,N,3+F] output < 1e-4 and
 max-abs < 1e-4*max(1, max|ref|); masked rows bit-exact 0.  A correct fp32 kernel lands near 1e-6.
 """
+import ctypes as C
 import os
+
 import numpy as np
 import pytest
 import torch
@@ -45,7 +47,7 @@ FORWARD_FIXTURES = ["f1_cfg1_h256_l3", "f1b_cfg1_h256_l3_gain1", "f7_h32_l2", "f
                     "f6_b16_n30_h256_l9", "f6b_n48_h256_l6"]
 
 
-PRECISIONS = ["fp32", "bf16x3", "bf16x6"]     # exact-fp32 matrix path / 3-term and 6-term bf16 splits; all must meet the same bar
+PRECISIONS = ["fp32", "bf16x3", "bf16x6", "fp16x3"]     # exact-fp32 matrix path / 3- and 6-term bf16 splits / 3-term fp16 split; one bar
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
@@ -235,8 +237,57 @@ def test_bf16x6_is_fp32_accurate():
     err["float32 reference"] = rel_l2(ref32, ref64)
     print("distance to the float64 oracle:", {k: f"{v:.2e}" for k, v in err.items()})
     assert err["bf16x6"] < 1.5 * max(err["fp32"], err["float32 reference"]), err
-    assert err["bf16x6"] < 2e-6 and err["fp32"] < 2e-6
-    assert err["bf16x3"] > 3 * err["bf16x6"], err          # the modes are really different arithmetic
+    assert err["fp16x3"] < 1.5 * max(err["fp32"], err["float32 reference"]), err      # the 3-term FP16 split: same claim
+    assert err["bf16x6"] < 2e-6 and err["fp32"] < 2e-6 and err["fp16x3"] < 2e-6
+    assert err["bf16x3"] > 3 * err["bf16x6"] and err["bf16x3"] > 3 * err["fp16x3"], err   # the modes are really different arithmetic
+
+
+@pytest.mark.parametrize("w2_gain,first_gain", [(2.0 ** -9 * 0.7, 1.0), (2.0 ** 7 * 1.3, 1.0), (1.0, 2.0 ** -8), (1.0, 40.0)])
+def test_fp16x3_operand_ranging(w2_gain, first_gain):
+    """fp16 has five exponent bits; the mode brings its operands into range by exact powers of two - the W2 image per matrix,
+    the activations per edge row from a bound on the pre-activation (k_edge.hpp).  Second-layer weights 700 x smaller / 170 x
+    larger than usual, first-layer terms 256 x smaller / 40 x larger: the distance to the float64 oracle stays that of the
+    exact-fp32 mode (a fixed scaling would lose 2 - 3 digits at either end: scratch/mb/f16_denorm.hip)."""
+    sd_np, sd, cfg, xh, nm, em = _oracle_case([30, 30, 17, 9], 256, 2, seed=505)
+    for k in list(sd_np):
+        if k.endswith("edge_mlp.2.weight") or k.endswith("coord_mlp.2.weight"):
+            sd_np[k] = (sd_np[k] * w2_gain).astype(np.float32)
+        if k.endswith("edge_mlp.0.weight") or k.endswith("edge_mlp.0.bias") or k.endswith("coord_mlp.0.weight") or k.endswith("coord_mlp.0.bias"):
+            sd_np[k] = (sd_np[k] * first_gain).astype(np.float32)
+    t = torch.full((4, 1), 0.4)
+    with torch.no_grad(), orc.float64():
+        ref64 = orc.dynamics_forward(orc.as_torch_sd(sd_np), cfg, t, xh, nm, em, None, None, prefix="dynamics.egnn.").numpy()
+    err = {}
+    for precision in ("fp32", "fp16x3"):
+        dyn = build_dynamics(sd_np, 256, 2)
+        dyn.precision = precision
+        out = dyn._forward(t.to(DEV), xh.to(DEV), nm.to(DEV), em.to(DEV), None, None).cpu().numpy()
+        assert np.isfinite(out).all()
+        err[precision] = rel_l2(out, ref64)
+    print(f"W2 x {w2_gain:.3g}, first layer x {first_gain:.3g}: distance to the float64 oracle", {k: f"{v:.2e}" for k, v in err.items()})
+    assert err["fp16x3"] < max(2.0 * err["fp32"], 1e-6), err
+
+
+def test_fp16x3_range_limit_is_loud():
+    """What is left of fp16's range: the NODE terms of the first edge Linear (|A_i + B_j| beyond ~2000 in the scaled domain).  Past it
+    a head overflows, the forward's NaN guard zeroes the batch like the reference does for a NaN (en_dynamics.py:109-111) and
+    hd_nan_events counts it; the exact-fp32 mode computes the same input."""
+    sd_np, sd, cfg, xh, nm, em = _oracle_case([9, 12], 128, 1, seed=606)
+    for k in list(sd_np):
+        if k.endswith("edge_mlp.0.bias"):
+            sd_np[k] = (sd_np[k] + 6000.0).astype(np.float32)
+    t = torch.full((2, 1), 0.4)
+    from hierdiff_amd import _lib
+    outs = {}
+    for precision in ("fp32", "fp16x3"):
+        dyn = build_dynamics(sd_np, 128, 1)
+        dyn.precision = precision
+        outs[precision] = dyn._forward(t.to(DEV), xh.to(DEV), nm.to(DEV), em.to(DEV), None, None).cpu()
+        cnt = C.c_longlong()
+        _lib.check(_lib.load().hd_nan_events(dyn._handle(), torch.cuda.current_stream().cuda_stream, C.byref(cnt)))
+        outs[precision + " events"] = cnt.value
+    assert outs["fp32 events"] == 0 and torch.isfinite(outs["fp32"]).all() and float(outs["fp32"].abs().max()) > 0
+    assert outs["fp16x3 events"] >= 1 and float(outs["fp16x3"].abs().max()) == 0.0
 
 
 def test_general_edge_mask_and_options_vs_oracle():
