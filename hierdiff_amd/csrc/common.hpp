@@ -105,7 +105,7 @@ HD_DEVINL f32x16 mma16(bf16x8 a, bf16x8 b, f32x16 c) {
     else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 // fp16 mode: static part of the per-edge bound on the first-layer activation, |A_i[k] + B_j[k]| (scaled domain); see k_edge.hpp
-#define HD_F16_CAB 512.0f
+#define HD_F16_CAB 8192.0f
 #define HD_TWOWAY(p) ((p) == 1 || (p) == 3)
 
 // three-way split (head, middle, tail: 24 significant bits, |y - h - m - l| <= 2^-27 |y|) for the bf16x6 contraction

@@ -72,9 +72,11 @@ struct EdgeArgs {
 // are what makes first-layer activations large (coordinates far apart), and they are known per edge before the contraction
 // starts; s rides in the SiLU's reciprocal (`1 + e` becomes fma(e, 1/s, 1/s)).  A row of the accumulators therefore holds
 // s 2^k x its pre-activation; the epilogue undoes it in the fused multiply-add that also adds the bias (one instruction more
-// than PREC 1).  Tails below the normal range are subnormal fp16 numbers, which the matrix core keeps.  What is left of fp16's
-// range limit: the NODE terms of the first layer, |A_i[k] + B_j[k]| (scaled domain), must stay below ~4 x HD_F16_CAB = 2047 -
-// beyond that a head overflows to inf and trips the NaN guard of the forward (hd_nan_events), loudly.
+// than PREC 1).  Tails below the normal range are subnormal fp16 numbers, which the matrix core keeps.  With HD_F16_CAB = 2^13 a
+// row without large distance terms gets s = 1: activations of order 1 keep 22 significant bits, a network whose activations are
+// all below ~1e-2 would see 1e-6 instead of 3e-7 (scratch/mb/f16_denorm.hip).  What is left of fp16's range limit: the NODE
+// terms of the first layer, |A_i[k] + B_j[k]| (scaled domain), must stay below ~4 x HD_F16_CAB = 32768 - beyond that a head
+// overflows to inf and the forward's NaN guard answers as the reference does for a NaN (vel zeroed, hd_nan_events counts it).
 
 // Four LDS fragment reads / a counted wait that releases them (see k_edge).  The reads are inline asm so
 // they stay where they are written (hipcc otherwise sinks every LDS read next to its MFMA to save registers,
