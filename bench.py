@@ -281,7 +281,7 @@ def precision_gap(model, args, dev, mode="bf16x3") -> dict:
                        "float64 evaluation 3.6e-7 vs 3.8e-7 (exact fp32) and 3.0e-7 (float32 reference), tests/test_gpu_parity.py",
              "fp16x3": "<= 8e-7 rel-L2 per forward on every golden fixture, the exact-fp32 mode's own figure; distance to a float64 "
                        "evaluation 3.5e-7 vs 3.8e-7 (exact fp32), 3.2e-7 (bf16x6) and 3.0e-7 (float32 reference), "
-                       "tests/test_gpu_parity.py; domain: edge-model activations below 16376 (beyond: the forward's NaN guard)"}
+                       "tests/test_gpu_parity.py; operands ranged per matrix / per edge row by exact powers of two: no range assumption"}
     return {"max_rel_l2_vs_fp32_path": float(f"{worst:.3e}"), "bound_vs_reference": bound[mode]}
 
 

@@ -104,8 +104,8 @@ HD_DEVINL f32x16 mma16(bf16x8 a, bf16x8 b, f32x16 c) {
     if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
-// fp16 mode: static part of the per-edge bound on the first-layer activation, |A_i[k] + B_j[k]| (scaled domain); see k_edge.hpp
-#define HD_F16_CAB 8192.0f
+// fp16 mode: floor of the per-edge bound on the first-layer activation (keeps the scale's exponent arithmetic in range)
+#define HD_F16_FLOOR 9.5367431640625e-07f      // 2^-20
 #define HD_TWOWAY(p) ((p) == 1 || (p) == 3)
 
 // three-way split (head, middle, tail: 24 significant bits, |y - h - m - l| <= 2^-27 |y|) for the bf16x6 contraction

@@ -138,6 +138,7 @@ struct hd_topology {
     float* nmask;
     // workspace
     float *hbuf, *AB, *AB2, *Tb, *agg, *x0, *xcur, *part, *xpart, *eps;
+    float* abmax;                              // fp16x3: [M_pad][2] row maxima of the AB buffer the next edge kernel reads
     // hd_sample_loop with use_graph: the captured step works on library-owned copies of z / context so that the
     // instantiated graph survives across calls (the caller's tensors move); one graph per topology
     float *zbuf, *ctxbuf;
@@ -925,6 +926,7 @@ extern "C" int hd_topology_create_s(hd_handle* h, const uint8_t* node_mask, cons
     const size_t f_Tb = carve((size_t)M_pad * H), f_agg = carve((size_t)M_pad * H);       // fp32 node chain of small batches; training
     const size_t f_x0 = carve((size_t)M_pad * 4), f_xcur = carve((size_t)M_pad * 4);
     const size_t f_part = carve((size_t)std::max(1, n_parts) * H), f_xpart = carve((size_t)std::max(1, n_parts) * 4);
+    const size_t f_abmax = carve((size_t)M_pad * 2);
     const size_t f_eps = carve(BN * h->D), f_z = carve(BN * h->D), f_ctx = carve(BN * (size_t)std::max(1, h->cfg.context_node_nf));
     const size_t f_w2 = carve((size_t)H * H * 3 / 2), f_w2t = carve((size_t)H * H * 3 / 2);      // fp32 images or the 1.5 x bf16x6 ones
     auto build = [&]() -> int {
@@ -949,6 +951,7 @@ extern "C" int hd_topology_create_s(hd_handle* h, const uint8_t* node_mask, cons
         float* ws = reinterpret_cast<float*>(base + table_bytes);
         t->hbuf = ws + f_h; t->AB = ws + f_AB; t->AB2 = ws + f_AB2; t->Tb = ws + f_Tb; t->agg = ws + f_agg; t->x0 = ws + f_x0;
         t->xcur = ws + f_xcur; t->part = ws + f_part; t->xpart = ws + f_xpart; t->eps = ws + f_eps; t->zbuf = ws + f_z;
+        t->abmax = ws + f_abmax;
         t->ctxbuf = ws + f_ctx; t->w2img = ws + f_w2; t->w2timg = ws + f_w2t;
         t->node_of_host = new std::vector<int>(node_of);
         return HD_OK;
@@ -1414,7 +1417,12 @@ static int forward_impl(hd_handle* h, hd_topology* t, const float* xh, const flo
                 EdgeArgs e;
                 std::memset(&e, 0, sizeof(e));
                 e.AB = ab_cur; e.wrd = W + w.wrd; e.W2img = W + w.w2_img; e.b2 = W + w.b2; e.wa = W + w.wa;
-                e.w2s_inv = 1.0f / w.w2s; e.wrmax = w.wrmax; e.wdmax = w.wdmax;
+                e.w2s_inv = 1.0f / w.w2s; e.wrmax = w.wrmax; e.wdmax = w.wdmax; e.abmax = t->abmax;
+                if (h->edge_mode == 3) {               // fp16x3: the per-node part of the activation bound (k_edge.hpp)
+                    ProfScope ps(h, s, 2);
+                    AbMaxArgs am{ab_cur, t->abmax, M, H};
+                    hipLaunchKernelGGL(k_ab_rowmax, dim3((M + 3) / 4), dim3(256), 0, s, am);
+                }
                 e.ei = t->ei; e.ej = t->ej; e.eseg = t->eseg; e.seg_part = t->seg_part; e.tile_nseg = t->tile_nseg;
                 e.xcur = t->xcur; e.x0 = t->x0; e.part = coord ? t->xpart : t->part; e.ba = w.ba;
                 e.norm_constant = c.norm_constant; e.coords_range = range; e.attention = c.attention;

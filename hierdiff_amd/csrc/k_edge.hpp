@@ -49,8 +49,27 @@ struct EdgeArgs {
     long long* trace;       // ABL & 16: per wave {start, loop start, loop end, end} cycle stamps
     float w2s_inv;          // PREC 3: 1 / (power-of-two scale of the W2 image)
     float wrmax, wdmax;     // PREC 3: max |w_r|, max |w_d| of this layer (bound on the distance terms of the first layer)
+    const float* abmax;     // PREC 3: [M_pad][2] max_k |A_i[k]|, max_k |B_i[k]| of the AB rows (k_ab_rowmax)
 };
 
+
+// fp16x3: max_k |A_i[k]| and max_k |B_i[k]| of every AB row (the node-level halves of the first edge Linear) - the per-node part of
+// the bound that ranges an edge row's activations.  One wavefront per row: 2H floats, two maxima.
+struct AbMaxArgs { const float* AB; float* out; int M, H; };
+__global__ void __launch_bounds__(256) k_ab_rowmax(AbMaxArgs a) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= a.M) return;
+    const float* r = a.AB + (size_t)row * 2 * a.H;
+    float ma = 0.f, mb = 0.f;
+    for (int k = 4 * lane; k < a.H; k += 256) {
+        const f32x4 va = *reinterpret_cast<const f32x4*>(r + k), vb = *reinterpret_cast<const f32x4*>(r + a.H + k);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { ma = fmaxf(ma, fabsf(va[j])); mb = fmaxf(mb, fabsf(vb[j])); }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { ma = fmaxf(ma, __shfl_xor(ma, o)); mb = fmaxf(mb, __shfl_xor(mb, o)); }
+    if (lane == 0) { a.out[2 * (size_t)row] = ma; a.out[2 * (size_t)row + 1] = mb; }
+}
 
 // PREC 0: exact fp32 (v_mfma_f32_32x32x2_f32).  PREC 1: "bf16x3" - both operands are split into a bf16
 // head and a bf16 tail (a = ah + al, |a - ah - al| <= 2^-18 |a|) and the product is formed as
@@ -67,16 +86,14 @@ struct EdgeArgs {
 // <= 2^-21 of a product - at the rounding of the fp32 accumulation, like bf16x6 (measured with the real instruction,
 // scratch/mb/f16_denorm.hip: 1.9e-7 rel-L2 against fp64 vs 2.4e-7 for bf16x6, 4.1e-6 for bf16x3), at PREC 1's cost.  fp16 has
 // 5 exponent bits, so both operands are brought into range by exact powers of two.  The W2 image is stored x 2^k with its
-// largest element in [2^14, 2^15) (per matrix, by the packer).  The activations of an EDGE ROW are scaled by s = 2^(13 - E),
-// E = floor(log2(bound)), bound = HD_F16_CAB + radial max|w_r| + d0 max|w_d| >= |pre-activation| >= |SiLU| - the distance terms
-// are what makes first-layer activations large (coordinates far apart), and they are known per edge before the contraction
-// starts; s rides in the SiLU's reciprocal (`1 + e` becomes fma(e, 1/s, 1/s)).  A row of the accumulators therefore holds
-// s 2^k x its pre-activation; the epilogue undoes it in the fused multiply-add that also adds the bias (one instruction more
-// than PREC 1).  Tails below the normal range are subnormal fp16 numbers, which the matrix core keeps.  With HD_F16_CAB = 2^13 a
-// row without large distance terms gets s = 1: activations of order 1 keep 22 significant bits, a network whose activations are
-// all below ~1e-2 would see 1e-6 instead of 3e-7 (scratch/mb/f16_denorm.hip).  What is left of fp16's range limit: the NODE
-// terms of the first layer, |A_i[k] + B_j[k]| (scaled domain), must stay below ~4 x HD_F16_CAB = 32768 - beyond that a head
-// overflows to inf and the forward's NaN guard answers as the reference does for a NaN (vel zeroed, hd_nan_events counts it).
+// largest element in [2^14, 2^15) (per matrix, by the packer).  The activations of an EDGE ROW (i, j) are scaled by
+// s = 2^(13 - E), E = floor(log2(bound)), with bound = max_k|A_i[k]| + max_k|B_j[k]| + radial max|w_r| + d0 max|w_d| >=
+// |pre-activation| >= |SiLU|: every term is known per edge before the contraction starts (the two row maxima come from
+// k_ab_rowmax, one small launch per edge layer over the AB rows), so s x activation < 2^14 ALWAYS - the mode has no range
+// assumption left, and rows of small activations are scaled up as much as rows of large ones are scaled down.  s rides in the
+// SiLU's reciprocal (`1 + e` becomes fma(e, 1/s, 1/s)); a row of the accumulators holds s 2^k x its pre-activation, and the
+// epilogue undoes it in the fused multiply-add that also adds the bias (one instruction more than PREC 1).  Tails below the
+// normal range are subnormal fp16 numbers, which the matrix core keeps.
 
 // Four LDS fragment reads / a counted wait that releases them (see k_edge).  The reads are inline asm so
 // they stay where they are written (hipcc otherwise sinks every LDS read next to its MFMA to save registers,
@@ -273,7 +290,8 @@ HD_DEVINL void edge_tile_body(const EdgeArgs& a, float* smem, float* wrd_s, cons
     // fp16x3: this row's activation scale (see the header comment); 1 / (s 2^k) parked for the epilogue, which needs it by row slot
     float f16_inv = 1.0f;
     if constexpr (PREC == 3) {
-        const float bound = __builtin_fmaf(radial, a.wrmax, __builtin_fmaf(d0, a.wdmax, HD_F16_CAB));
+        const float nodes = a.abmax[2 * (size_t)ni] + a.abmax[2 * (size_t)nj + 1] + HD_F16_FLOOR;
+        const float bound = __builtin_fmaf(radial, a.wrmax, __builtin_fmaf(d0, a.wdmax, nodes));
         const uint32_t eb = (__builtin_bit_cast(uint32_t, bound) >> 23) & 0xffu;      // bound in [2^(eb-127), 2^(eb-126))
         f16_inv = __builtin_bit_cast(float, (eb - 13u) << 23);                        // 2^-(13 - E), E = eb - 127: bound x s < 2^14
         if (hh == 0) my_scr[n] = f16_inv * a.w2s_inv;

@@ -69,7 +69,8 @@ HD_DEVINL void edge_split_body(const EdgeArgs& a, char* lds, float* wrd_s, const
     const int nseg = a.tile_nseg[tile];
     float f16_inv = 1.0f;                                            // fp16x3: this row's activation scale, as in k_edge
     if constexpr (PREC == 3) {
-        const float bound = __builtin_fmaf(radial, a.wrmax, __builtin_fmaf(d0, a.wdmax, HD_F16_CAB));
+        const float nodes = a.abmax[2 * (size_t)ni] + a.abmax[2 * (size_t)nj + 1] + HD_F16_FLOOR;
+        const float bound = __builtin_fmaf(radial, a.wrmax, __builtin_fmaf(d0, a.wdmax, nodes));
         const uint32_t eb = (__builtin_bit_cast(uint32_t, bound) >> 23) & 0xffu;
         f16_inv = __builtin_bit_cast(float, (eb - 13u) << 23);
         if (wave == 3 && hh == 0) rs_s[n] = f16_inv * a.w2s_inv;

@@ -84,8 +84,9 @@ typedef struct hd_config {
                                         bits per operand), 3 fp16 MFMAs per product, fp32 accumulation - truncation <= 2^-21 per
                                         product, at the rounding of the fp32 accumulation (measured 1.9e-7 rel-L2 on a 256-term
                                         contraction, bf16x6 2.4e-7, bf16x3 4.1e-6) at mode 1's cost.  Operands are ranged by
-                                        exact powers of two (W2 per matrix, activations x 4): an edge-model activation beyond
-                                        16376 overflows and trips the forward's NaN guard.  Node GEMMs as in mode 2 */
+                                        exact powers of two - W2 per matrix, the activations per edge row from a bound on the
+                                        pre-activation known before the contraction starts - so FP16's exponent range imposes
+                                        no assumption on the network.  Node GEMMs as in mode 2 */
     int32_t aggregation_mean;    /* 0: aggregation_method 'sum' - neighbour sums / normalization_factor (egnn_new.py:280-282);
                                     1: 'mean' (:283-288) - sums / number of edge-list entries of the receiving node.  The
                                        reference's edge list holds all N x N pairs of a molecule, masked or not

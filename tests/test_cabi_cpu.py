@@ -258,7 +258,7 @@ def test_no_register_spills_in_production_kernels():
     assert build.audit(res) == []
     prod = {k: v for k, v in res.items() if build._production(k)}
     edge = [v for k, v in prod.items() if k.startswith("_Z6k_edgeILi256")]
-    assert len(edge) == 6 and all(v["Occupancy"] >= 2 and v["ScratchSize"] == 0 for v in edge)
+    assert len(edge) == 8 and all(v["Occupancy"] >= 2 and v["ScratchSize"] == 0 for v in edge)
     node = [v for k, v in prod.items() if k.startswith("_Z6k_nodeILi256")]
     assert len(node) == 6 and all(v["ScratchSize"] == 0 for v in node)          # 3 variants x {bf16x3, bf16x6}
 

@@ -245,9 +245,9 @@ def test_bf16x6_is_fp32_accurate():
 @pytest.mark.parametrize("w2_gain,first_gain", [(2.0 ** -9 * 0.7, 1.0), (2.0 ** 7 * 1.3, 1.0), (1.0, 2.0 ** -8), (1.0, 40.0)])
 def test_fp16x3_operand_ranging(w2_gain, first_gain):
     """fp16 has five exponent bits; the mode brings its operands into range by exact powers of two - the W2 image per matrix,
-    the activations per edge row from a bound on the pre-activation (k_edge.hpp).  Second-layer weights 700 x smaller / 170 x
-    larger than usual, first-layer terms 256 x smaller / 40 x larger: the distance to the float64 oracle stays that of the
-    exact-fp32 mode (a fixed scaling would lose 2 - 3 digits at either end: scratch/mb/f16_denorm.hip)."""
+    the activations per edge row from a bound on the pre-activation (k_ab_rowmax, k_edge.hpp).  Second-layer weights 700 x
+    smaller / 170 x larger than usual, first-layer terms 256 x smaller / 40 x larger: the distance to the float64 oracle stays
+    that of the exact-fp32 mode (a fixed scaling would lose 2 - 3 digits at either end: scratch/mb/f16_denorm.hip)."""
     sd_np, sd, cfg, xh, nm, em = _oracle_case([30, 30, 17, 9], 256, 2, seed=505)
     for k in list(sd_np):
         if k.endswith("edge_mlp.2.weight") or k.endswith("coord_mlp.2.weight"):
@@ -265,31 +265,33 @@ def test_fp16x3_operand_ranging(w2_gain, first_gain):
         assert np.isfinite(out).all()
         err[precision] = rel_l2(out, ref64)
     print(f"W2 x {w2_gain:.3g}, first layer x {first_gain:.3g}: distance to the float64 oracle", {k: f"{v:.2e}" for k, v in err.items()})
-    # first-layer terms 256 x smaller = activations of order 1e-3 everywhere: the one case the per-row ranging does not cover
-    # (its static floor HD_F16_CAB keeps the scale at 1), still an order of magnitude inside bf16x3's error
-    assert err["fp16x3"] < (5e-6 if first_gain < 0.1 else max(2.0 * err["fp32"], 1e-6)), err
+    assert err["fp16x3"] < max(2.0 * err["fp32"], 1e-6), err
 
 
-def test_fp16x3_range_limit_is_loud():
-    """What is left of fp16's range: the NODE terms of the first edge Linear (|A_i + B_j| beyond ~32768 in the scaled domain).  Past
-    it a head overflows, the forward's NaN guard zeroes vel like the reference does for a NaN (en_dynamics.py:109-111) and
-    hd_nan_events counts it; the exact-fp32 mode computes the same input."""
+def test_fp16x3_has_no_range_limit():
+    """FP16 overflows at 65504; the mode's activations are ranged per edge row by max|A_i| + max|B_j| + the distance terms
+    (k_ab_rowmax + k_edge.hpp), so first-layer terms far beyond that - a bias of 60000, coordinates 1000 apart - are computed
+    like in exact fp32: no inf, no NaN event, same distance to the float64 oracle."""
+    from hierdiff_amd import _lib
     sd_np, sd, cfg, xh, nm, em = _oracle_case([9, 12], 128, 1, seed=606)
     for k in list(sd_np):
         if k.endswith("edge_mlp.0.bias"):
             sd_np[k] = (sd_np[k] + 60000.0).astype(np.float32)
+    xh = torch.cat([xh[..., :3] * 300.0, xh[..., 3:]], dim=-1)
     t = torch.full((2, 1), 0.4)
-    from hierdiff_amd import _lib
-    outs = {}
+    with torch.no_grad(), orc.float64():
+        ref64 = orc.dynamics_forward(orc.as_torch_sd(sd_np), cfg, t, xh, nm, em, None, None, prefix="dynamics.egnn.").numpy()
+    err = {}
     for precision in ("fp32", "fp16x3"):
         dyn = build_dynamics(sd_np, 128, 1)
         dyn.precision = precision
-        outs[precision] = dyn._forward(t.to(DEV), xh.to(DEV), nm.to(DEV), em.to(DEV), None, None).cpu()
+        out = dyn._forward(t.to(DEV), xh.to(DEV), nm.to(DEV), em.to(DEV), None, None).cpu()
         cnt = C.c_longlong()
         _lib.check(_lib.load().hd_nan_events(dyn._handle(), torch.cuda.current_stream().cuda_stream, C.byref(cnt)))
-        outs[precision + " events"] = cnt.value
-    assert outs["fp32 events"] == 0 and torch.isfinite(outs["fp32"]).all() and float(outs["fp32"].abs().max()) > 0
-    assert outs["fp16x3 events"] >= 1 and float(outs["fp16x3"][..., :3].abs().max()) == 0.0
+        assert cnt.value == 0 and torch.isfinite(out).all() and float(out.abs().max()) > 0
+        err[precision] = rel_l2(out.numpy(), ref64)
+    print("bias 60000, coordinates x 300: distance to the float64 oracle", {k: f"{v:.2e}" for k, v in err.items()})
+    assert err["fp16x3"] < max(2.0 * err["fp32"], 1e-6), err
 
 
 def test_general_edge_mask_and_options_vs_oracle():
