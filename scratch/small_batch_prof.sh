@@ -3,7 +3,7 @@
 # plus a kernel trace of one training step; writes gpurun_out/small_batch_prof.log
 mkdir -p gpurun_out
 {
-for prec in fp32 bf16x6 bf16x3; do
+for prec in fp32 fp16x3 bf16x6 bf16x3; do
   for B in 64 16 2; do
     echo "==== $prec B=$B"
     bash scratch/prof.sh $prec $B
