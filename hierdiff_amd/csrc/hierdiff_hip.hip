@@ -138,7 +138,7 @@ struct hd_topology {
     float* nmask;
     // workspace
     float *hbuf, *AB, *AB2, *Tb, *agg, *x0, *xcur, *part, *xpart, *eps;
-    float* abmax;                              // fp16x3: [M_pad][2] row maxima of the AB buffer the next edge kernel reads
+    float *abmax, *abmax2;                     // fp16x3: [M_pad][2] row maxima of the AB / AB2 buffers
     // hd_sample_loop with use_graph: the captured step works on library-owned copies of z / context so that the
     // instantiated graph survives across calls (the caller's tensors move); one graph per topology
     float *zbuf, *ctxbuf;
@@ -926,7 +926,7 @@ extern "C" int hd_topology_create_s(hd_handle* h, const uint8_t* node_mask, cons
     const size_t f_Tb = carve((size_t)M_pad * H), f_agg = carve((size_t)M_pad * H);       // fp32 node chain of small batches; training
     const size_t f_x0 = carve((size_t)M_pad * 4), f_xcur = carve((size_t)M_pad * 4);
     const size_t f_part = carve((size_t)std::max(1, n_parts) * H), f_xpart = carve((size_t)std::max(1, n_parts) * 4);
-    const size_t f_abmax = carve((size_t)M_pad * 2);
+    const size_t f_abmax = carve((size_t)M_pad * 2), f_abmax2 = carve((size_t)M_pad * 2);
     const size_t f_eps = carve(BN * h->D), f_z = carve(BN * h->D), f_ctx = carve(BN * (size_t)std::max(1, h->cfg.context_node_nf));
     const size_t f_w2 = carve((size_t)H * H * 3 / 2), f_w2t = carve((size_t)H * H * 3 / 2);      // fp32 images or the 1.5 x bf16x6 ones
     auto build = [&]() -> int {
@@ -951,7 +951,7 @@ extern "C" int hd_topology_create_s(hd_handle* h, const uint8_t* node_mask, cons
         float* ws = reinterpret_cast<float*>(base + table_bytes);
         t->hbuf = ws + f_h; t->AB = ws + f_AB; t->AB2 = ws + f_AB2; t->Tb = ws + f_Tb; t->agg = ws + f_agg; t->x0 = ws + f_x0;
         t->xcur = ws + f_xcur; t->part = ws + f_part; t->xpart = ws + f_xpart; t->eps = ws + f_eps; t->zbuf = ws + f_z;
-        t->abmax = ws + f_abmax;
+        t->abmax = ws + f_abmax; t->abmax2 = ws + f_abmax2;
         t->ctxbuf = ws + f_ctx; t->w2img = ws + f_w2; t->w2timg = ws + f_w2t;
         t->node_of_host = new std::vector<int>(node_of);
         return HD_OK;
@@ -1381,6 +1381,8 @@ static int forward_impl(hd_handle* h, hd_topology* t, const float* xh, const flo
         };
         auto set_ab = [&](NodeArgs& a, int q, const LayerW& nw, float* dst) {
             a.ABimg[q] = W + nw.ab_img; a.ABbias[q] = W + nw.ab_bias; a.ABout[q] = dst;
+            // fp16x3 at width 256: the fused node kernel leaves the row maxima of what it writes (narrower widths: k_ab_rowmax)
+            a.ABmax[q] = (h->edge_mode == 3 && h->node_mode != 0 && H == 256) ? (dst == t->AB ? t->abmax : t->abmax2) : nullptr;
         };
         // fp32 mode, few rows: the fused kernel's serial chain per 32-row workgroup (~50 us) is not hidden by other workgroups
         // (60 of them at B = 64), the k_agg + 3 x k_gemm chain spreads the same work over 64 x 64 tiles.  Both paths are
@@ -1417,8 +1419,10 @@ static int forward_impl(hd_handle* h, hd_topology* t, const float* xh, const flo
                 EdgeArgs e;
                 std::memset(&e, 0, sizeof(e));
                 e.AB = ab_cur; e.wrd = W + w.wrd; e.W2img = W + w.w2_img; e.b2 = W + w.b2; e.wa = W + w.wa;
-                e.w2s_inv = 1.0f / w.w2s; e.wrmax = w.wrmax; e.wdmax = w.wdmax; e.abmax = t->abmax;
-                if (h->edge_mode == 3) {               // fp16x3: the per-node part of the activation bound (k_edge.hpp)
+                e.w2s_inv = 1.0f / w.w2s; e.wrmax = w.wrmax; e.wdmax = w.wdmax;
+                const bool fused_max = h->edge_mode == 3 && h->node_mode != 0 && H == 256;
+                e.abmax = (fused_max && ab_cur == t->AB2) ? t->abmax2 : t->abmax;
+                if (h->edge_mode == 3 && !fused_max) {  // fp16x3: the per-node part of the activation bound (k_edge.hpp)
                     ProfScope ps(h, s, 2);
                     AbMaxArgs am{ab_cur, t->abmax, M, H};
                     hipLaunchKernelGGL(k_ab_rowmax, dim3((M + 3) / 4), dim3(256), 0, s, am);

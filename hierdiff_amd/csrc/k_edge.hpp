@@ -88,8 +88,8 @@ __global__ void __launch_bounds__(256) k_ab_rowmax(AbMaxArgs a) {
 // 5 exponent bits, so both operands are brought into range by exact powers of two.  The W2 image is stored x 2^k with its
 // largest element in [2^14, 2^15) (per matrix, by the packer).  The activations of an EDGE ROW (i, j) are scaled by
 // s = 2^(13 - E), E = floor(log2(bound)), with bound = max_k|A_i[k]| + max_k|B_j[k]| + radial max|w_r| + d0 max|w_d| >=
-// |pre-activation| >= |SiLU|: every term is known per edge before the contraction starts (the two row maxima come from
-// k_ab_rowmax, one small launch per edge layer over the AB rows), so s x activation < 2^14 ALWAYS - the mode has no range
+// |pre-activation| >= |SiLU|: every term is known per edge before the contraction starts (the two row maxima are written by the
+// node kernel next to the AB rows, k_node.hpp phase 3, or by k_ab_rowmax), so s x activation < 2^14 ALWAYS - the mode has no range
 // assumption left, and rows of small activations are scaled up as much as rows of large ones are scaled down.  s rides in the
 // SiLU's reciprocal (`1 + e` becomes fma(e, 1/s, 1/s)); a row of the accumulators holds s 2^k x its pre-activation, and the
 // epilogue undoes it in the fused multiply-add that also adds the bias (one instruction more than PREC 1).  Tails below the

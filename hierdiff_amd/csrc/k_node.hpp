@@ -260,6 +260,7 @@ struct NodeArgs {
     const float* ABimg[2];  // K = H, N = 2H
     const float* ABbias[2]; // [2H]
     float* ABout[2];        // [M_pad][2H]
+    float* ABmax[2];        // optional [M_pad][2]: max_k |A_i[k]|, max_k |B_i[k]| of the AB rows written (fp16x3 edge kernels)
     float norm;
     int M;
 };
@@ -546,9 +547,18 @@ __global__ __launch_bounds__(64 * NW, 1) void k_node(NodeArgs a) {
 #pragma unroll
             for (int u = 0; u < NP; ++u) {
                 const int idx = tid + u * NT, r = idx / Q, c4 = idx % Q;
-                if (row0 + r < a.M)
-                    *reinterpret_cast<f32x4*>(a.ABout[q] + (size_t)(row0 + r) * 2 * H + half * H + 4 * c4) =
-                        *reinterpret_cast<const f32x4*>(stage1 + r * LDS1 + 4 * c4);
+                const f32x4 v = *reinterpret_cast<const f32x4*>(stage1 + r * LDS1 + 4 * c4);
+                if (row0 + r < a.M) *reinterpret_cast<f32x4*>(a.ABout[q] + (size_t)(row0 + r) * 2 * H + half * H + 4 * c4) = v;
+                if constexpr (Q == 64) {
+                    // a wavefront stores one complete row of the half per pass: its maximum |value| is a wave reduction away
+                    // (the per-node part of the fp16x3 edge kernels' activation bound, k_edge.hpp)
+                    if (a.ABmax[q]) {
+                        float m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+                        if (lane == 0 && row0 + r < a.M) a.ABmax[q][2 * (size_t)(row0 + r) + half] = m;
+                    }
+                }
             }
         }
     }
