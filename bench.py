@@ -12,11 +12,12 @@ point sets, counter-based Gaussian noise) and deterministic random-init weights:
 checkpoint and there is no network.
 
 The JSON line's headline (`value`, `dtype`, `roofline`) is the EXACT-fp32 path (v_mfma_f32_32x32x2_f32), the
-arithmetic the reference computes in.  The two opt-in modes are timed in the same invocation over the same K steps and
-reported as sibling blocks with their own rooflines and their measured deviation from the fp32 path: `"bf16x6"`
-(per-edge contraction on a three-way bf16 split, 6 bf16 MFMAs per product - fp32-ACCURATE: as far from a float64
-evaluation as the exact-fp32 path and the float32 reference themselves, tests/test_gpu_parity.py) and `"bf16x3"`
-(two-way split, 3 MFMAs, ~1e-5 rel-L2).  At N=1 the line also carries
+arithmetic the reference computes in.  The three opt-in modes are timed in the same invocation over the same K steps and
+reported as sibling blocks with their own rooflines and their measured deviation from the fp32 path: `"fp16x3"`
+(per-edge contraction on a two-way FP16 split of operands ranged by exact powers of two, 3 fp16 MFMAs per product) and
+`"bf16x6"` (three-way bf16 split, 6 bf16 MFMAs) - both fp32-ACCURATE: as far from a float64 evaluation as the exact-fp32
+path and the float32 reference themselves, tests/test_gpu_parity.py - and `"bf16x3"` (two-way bf16 split, 3 MFMAs,
+~1e-5 rel-L2).  At N=1 the line also carries
 `cpu_baseline` (the oracle timed on this host) and `configs` (BASELINE.json configs 2, 3, 5 and the reference's
 default B=2 job, timed on short chains).
 
