@@ -51,6 +51,8 @@ struct LayerW {                 // float offsets into hd_handle::dw
     size_t ab_gimg, w3_gimg, w4_gimg;      // fp32 mode: the same weights as k_gemm_r16 images (node chain below HD_FUSE_MIN_ROWS)
     float ba;
     float w2s, wrmax, wdmax;               // fp16x3: power-of-two scale of the W2 image (else 1); max |w_r|, max |w_d| as packed
+    float w3s, w4s, abs_;                  // FP16 node kernel: power-of-two scales of the W3 / W4 / AB images (else 1)
+    float w3l1, w4l1, b3max, b4max;        // ... and the constants of its a-priori row bounds (k_node.hpp)
 };
 
 struct ProfRec { int fam; hipEvent_t a, b; };
@@ -60,8 +62,8 @@ struct hd_handle {
     int device;
     int H, fin, F, D, NS;       // NS: 32-column sub-tiles per k_gemm workgroup tile
     // arithmetic of the two kernel families, derived from cfg.precision and the width (hd_create):
-    //   edge_mode 0 fp32 | 1 bf16x3 | 2 bf16x6 | 3 fp16x3      node_mode 0 fp32 (k_node_f32 / k_gemm_r16) | 1 bf16 two-piece | 2 bf16 three-piece
-    //   precision 0: 0 / 0;  1: 1 / 1;  2: 2 / 2 (H >= 128, else 0 / 0);  3: 3 / 2 (H >= 128, else 3 / 0)
+    //   edge_mode 0 fp32 | 1 bf16x3 | 2 bf16x6 | 3 fp16x3      node_mode 0 fp32 (k_node_f32 / k_gemm_r16) | 1 bf16 two-piece | 2 bf16 three-piece | 3 fp16 two-piece
+    //   precision 0: 0 / 0;  1: 1 / 1;  2: 2 / 2 (H >= 128, else 0 / 0);  3: 3 / 3 (H = 256), 3 / 2 (H = 128), else 3 / 0
     // `scaled`: the edge model runs in the domain scaled by -log2(e) (two-way modes, silu_scaled in common.hpp)
     int edge_mode, node_mode;
     bool scaled;
@@ -232,7 +234,7 @@ extern "C" int hd_create(const hd_config* cfg, int device, hd_handle** out) {
         switch (cfg->precision) {
             case 1: h->edge_mode = 1; h->node_mode = 1; break;
             case 2: h->edge_mode = wide ? 2 : 0; h->node_mode = wide ? 2 : 0; break;
-            case 3: h->edge_mode = 3; h->node_mode = wide ? 2 : 0; break;
+            case 3: h->edge_mode = 3; h->node_mode = cfg->hidden_nf == 256 ? 3 : (wide ? 2 : 0); break;
             default: h->edge_mode = 0; h->node_mode = 0; break;
         }
         h->scaled = h->edge_mode == 1 || h->edge_mode == 3;
@@ -397,6 +399,35 @@ static void pack_node_b(std::vector<float>& dstf, size_t off, int K, int Nc, Fn 
                 }
 }
 
+// FP16 node kernel: pack_node_b's two-piece layout with FP16 pieces of W x 2^k (largest |element| in [2^14, 2^15)).  Returns 2^k;
+// *l1 = max over output columns of sum_k |W[col][k]| (the constant of the kernel's row bounds).
+template <typename Fn>
+static float pack_node_b_f16(std::vector<float>& dstf, size_t off, int K, int Nc, Fn W, float* l1) {
+    float wmax = 0.0f, l1max = 0.0f;
+    for (int col = 0; col < Nc; ++col) {
+        double sum = 0.0;
+        for (int k = 0; k < K; ++k) { const float v = std::fabs(W(col, k)); sum += v; if (v > wmax && std::isfinite(v)) wmax = v; }
+        l1max = std::max(l1max, (float)(sum * 1.000001));
+    }
+    if (l1) *l1 = l1max;
+    int ex = 0;
+    if (wmax > 0.0f) (void)std::frexp(wmax, &ex);
+    const float sw = std::ldexp(1.0f, wmax > 0.0f ? std::max(-100, std::min(100, 15 - ex)) : 0);
+    _Float16* dst = reinterpret_cast<_Float16*>(dstf.data() + off);
+    const int nct = Nc / 32;
+    for (int st = 0; st < K / 16; ++st)
+        for (int ct = 0; ct < nct; ++ct)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int i = 0; i < 8; ++i) {
+                    const float v = W(32 * ct + (lane & 31), 16 * st + 8 * (lane >> 5) + i) * sw;
+                    const size_t base = ((size_t)(st * nct + ct) * 2) * 512;
+                    const _Float16 hi = (_Float16)v;
+                    dst[base + (size_t)lane * 8 + i] = hi;
+                    dst[base + 512 + (size_t)lane * 8 + i] = (_Float16)(v - (float)hi);
+                }
+    return sw;
+}
+
 // bf16x6 edge kernel: per 16-wide K chunk [head|middle|tail][H/32 ct][64 lanes][8], k = 16c + 8*(lane>>5) + i
 // (1.5x the bytes of the fp32 image: three bf16 pieces per weight).
 static void pack_edge_w2_x6(std::vector<float>& dstf, size_t off, int H, const float* W2) {
@@ -546,7 +577,9 @@ extern "C" int hd_set_weights(hd_handle* h, const float* blob, long long n, int 
         auto wab = [&](int col, int k) {
             return sc((col < H) ? W1[(size_t)col * ld + k] : W1[(size_t)(col - H) * ld + H + k]);
         };
+        w.abs_ = 1.0f;
         if (nodef32) { pack_node_b_f32(pk, w.ab_img, H, 2 * H, wab); pack_gemm_b16(pk, w.ab_gimg, H, 2 * H, wab); }
+        else if (h->node_mode == 3) w.abs_ = pack_node_b_f16(pk, w.ab_img, H, 2 * H, wab, nullptr);
         else pack_node_b(pk, w.ab_img, H, 2 * H, wab, NPc);
         for (int k = 0; k < H; ++k) {
             pk[w.ab_bias + k] = sc(b1[k]);
@@ -586,6 +619,11 @@ extern "C" int hd_set_weights(hd_handle* h, const float* blob, long long n, int 
                 pack_node_b_f32(pk, w.w4_img, H, H, w4);
                 pack_gemm_b16(pk, w.w3_gimg, 2 * H, H, w3);
                 pack_gemm_b16(pk, w.w4_gimg, H, H, w4);
+            } else if (h->node_mode == 3) {
+                w.w3s = pack_node_b_f16(pk, w.w3_img, 2 * H, H, w3, &w.w3l1);
+                w.w4s = pack_node_b_f16(pk, w.w4_img, H, H, w4, &w.w4l1);
+                w.b3max = w.b4max = 0.0f;
+                for (int k = 0; k < H; ++k) { w.b3max = std::max(w.b3max, std::fabs(b3[k])); w.b4max = std::max(w.b4max, std::fabs(b4[k])); }
             } else {
                 pack_node_b(pk, w.w3_img, 2 * H, H, w3, NPc);
                 pack_node_b(pk, w.w4_img, H, H, w4, NPc);
@@ -1105,6 +1143,14 @@ static void launch_node_hw(bool upd, int nab, int mode, const NodeArgs& a, hipSt
         }
     }
     const int lds = node_lds_bytes<H>(upd);
+    if constexpr (H == 256) {
+        if (mode == 3) {                                   // two-piece FP16 (fp16x3 mode)
+            if (!upd) hipLaunchKernelGGL((k_node<H, NW, false, 1, 2, true>), grid, block, lds, s, a);
+            else if (nab == 1) hipLaunchKernelGGL((k_node<H, NW, true, 1, 2, true>), grid, block, lds, s, a);
+            else hipLaunchKernelGGL((k_node<H, NW, true, 2, 2, true>), grid, block, lds, s, a);
+            return;
+        }
+    }
     if (!upd) hipLaunchKernelGGL((k_node<H, NW, false, 1>), grid, block, lds, s, a);
     else if (nab == 1) hipLaunchKernelGGL((k_node<H, NW, true, 1>), grid, block, lds, s, a);
     else hipLaunchKernelGGL((k_node<H, NW, true, 2>), grid, block, lds, s, a);
@@ -1118,6 +1164,11 @@ static int prepare_node_hw() {
     HIP_TRY(hipFuncSetAttribute((const void*)k_node_f32<H, NW, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, node_f32_lds_bytes<H>(false)));
     HIP_TRY(hipFuncSetAttribute((const void*)k_node_f32<H, NW, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, node_f32_lds_bytes<H>(true)));
     HIP_TRY(hipFuncSetAttribute((const void*)k_node_f32<H, NW, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, node_f32_lds_bytes<H>(true)));
+    if constexpr (H == 256) {
+        HIP_TRY(hipFuncSetAttribute((const void*)k_node<H, NW, false, 1, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, node_lds_bytes<H>(false)));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_node<H, NW, true, 1, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, node_lds_bytes<H>(true)));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_node<H, NW, true, 2, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, node_lds_bytes<H>(true)));
+    }
     if constexpr (H >= 128) {
         HIP_TRY(hipFuncSetAttribute((const void*)k_node<H, NW, false, 1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, node_lds_bytes<H>(false, 3)));
         HIP_TRY(hipFuncSetAttribute((const void*)k_node<H, NW, true, 1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, node_lds_bytes<H>(true, 3)));
@@ -1381,6 +1432,7 @@ static int forward_impl(hd_handle* h, hd_topology* t, const float* xh, const flo
         };
         auto set_ab = [&](NodeArgs& a, int q, const LayerW& nw, float* dst) {
             a.ABimg[q] = W + nw.ab_img; a.ABbias[q] = W + nw.ab_bias; a.ABout[q] = dst;
+            a.abinv[q] = h->node_mode == 3 ? 1.0f / nw.abs_ : 1.0f;
             // fp16x3 at width 256: the fused node kernel leaves the row maxima of what it writes (narrower widths: k_ab_rowmax)
             a.ABmax[q] = (h->edge_mode == 3 && h->node_mode != 0 && H == 256) ? (dst == t->AB ? t->abmax : t->abmax2) : nullptr;
         };
@@ -1447,6 +1499,9 @@ static int forward_impl(hd_handle* h, hd_topology* t, const float* xh, const flo
                     if (fused) {
                         NodeArgs a = node_args();
                         a.W3img = W + w.w3_img; a.b3 = W + w.b3; a.W4img = W + w.w4_img; a.b4 = W + w.b4;
+                        if (h->node_mode == 3) {
+                            a.w3inv = 1.0f / w.w3s; a.w4inv = 1.0f / w.w4s; a.w3l1 = w.w3l1; a.w4l1 = w.w4l1; a.b3max = w.b3max; a.b4max = w.b4max;
+                        }
                         for (int q = 0; q < nab; ++q) set_ab(a, q, *nxt[q], dst[q]);
                         node_update(h, true, nab, a, s);
                     } else {

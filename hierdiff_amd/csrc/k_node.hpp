@@ -261,6 +261,9 @@ struct NodeArgs {
     const float* ABbias[2]; // [2H]
     float* ABout[2];        // [M_pad][2H]
     float* ABmax[2];        // optional [M_pad][2]: max_k |A_i[k]|, max_k |B_i[k]| of the AB rows written (fp16x3 edge kernels)
+    // F16 variant (two-piece FP16 operands, k_node<..., 2, true>): 1 / (power-of-two scale) of the three weight images, and the
+    // constants of the a-priori row bounds: max_c sum_k |W[c][k]| of W3 / W4 and max |b3| / |b4|
+    float w3inv, w4inv, abinv[2], w3l1, w4l1, b3max, b4max;
     float norm;
     int M;
 };
@@ -270,7 +273,7 @@ struct NodeArgs {
 // the barrier / epilogue that precedes the contraction, weights do not depend on data) and `run` consumes
 // it.  sched_barrier(0) at every k-step keeps hipcc from sinking the loads next to their MFMAs (it otherwise
 // shrinks the ring to 2-3 loads in flight to save registers and exposes the L2 latency every k-step).
-template <int KS, int CTn, int CTW, int PF, int NCT, int NP = 2>
+template <int KS, int CTn, int CTW, int PF, int NCT, int NP = 2, bool F16 = false>
 struct NodeMma {
     typedef u32x4 Ring[PF][CTn][NP];
     template <int s, int slot>
@@ -311,7 +314,10 @@ struct NodeMma {
                 for (int p = 0; p < NP; ++p) b[c][p] = __builtin_bit_cast(bf16x8_t, br[slot][c][p]);
             auto term = [&](int pa, int pb) {
 #pragma unroll
-                for (int c = 0; c < CTn; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa], b[c][pb], acc[c], 0, 0, 0);
+                for (int c = 0; c < CTn; ++c) {
+                    if constexpr (F16) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[pa]), __builtin_bit_cast(f16x8, b[c][pb]), acc[c], 0, 0, 0);
+                    else acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa], b[c][pb], acc[c], 0, 0, 0);
+                }
             };
             if constexpr (NP == 2) { term(0, 0); term(1, 0); term(0, 1); }
             else { term(0, 2); term(2, 0); term(1, 1); term(0, 1); term(1, 0); term(0, 0); }
@@ -334,8 +340,33 @@ HD_DEVINL void bf16_split_store(__bf16* d, int plane, float v) {
     }
 }
 
-template <int H, int NW, bool UPD, int NAB, int NPC = 2>
+// the same with FP16 pieces (two planes; the value arrives scaled into range, see k_node<..., F16>)
+HD_DEVINL void f16_split_store(__bf16* d, int plane, float v) {
+    _Float16* p = reinterpret_cast<_Float16*>(d);
+    const _Float16 hi = (_Float16)v;
+    p[0] = hi;
+    p[plane] = (_Float16)(v - (float)hi);
+}
+// power-of-two scale s with bound * s in [2^13, 2^14) and its inverse (k_edge.hpp, fp16x3)
+HD_DEVINL void f16_row_scale(float bound, float& s, float& inv) {
+    const uint32_t eb = (__builtin_bit_cast(uint32_t, bound + HD_F16_FLOOR) >> 23) & 0xffu;
+    inv = __builtin_bit_cast(float, (eb - 13u) << 23);
+    s = __builtin_bit_cast(float, (267u - eb) << 23);
+}
+
+// F16 (NPC = 2 only): the fp16x3 arithmetic of the edge kernels for the three node GEMMs - two-way FP16 split, three fp16 MFMAs per
+// product, operands ranged by exact powers of two.  Weights: per matrix, by the packer.  Activations: per ROW, from bounds that are
+// known before the first contraction starts (so no reduction across wavefronts is needed between the phases):
+//     X = [h | agg]:  max_k |X_r[k]|                                   (16 threads hold a row in phase 0: four shuffles)
+//     T = SiLU(X W3^T + b3):  |T_r| <= max|X_r| max_c sum_k|W3[c][k]| + max|b3|
+//     h' = (h + T W4^T + b4) mask:  |h'_r| <= max|h_r| + bound(T_r) max_c sum_k|W4[c][k]| + max|b4|
+// The bounds are loose (an L1 norm against a random-sign sum: ~16 x for T, ~128 x for h'), which costs nothing: a scaled operand
+// keeps 22 significant bits down to 2^-2, i.e. over 15 binades below its bound, and smaller elements keep an absolute error of
+// 2^-25 / scale.  Each phase's accumulators hold (row scale x weight scale) x the result; the epilogue undoes it in the fma that
+// adds the bias.
+template <int H, int NW, bool UPD, int NAB, int NPC = 2, bool F16 = false>
 __global__ __launch_bounds__(64 * NW, 1) void k_node(NodeArgs a) {
+    static_assert(!F16 || NPC == 2, "the FP16 variant is a two-piece split");
     constexpr int NT = 64 * NW;
     constexpr int NCT = H / 32;            // column tiles of an H-wide output
     constexpr int CT = NCT / NW;           // ... per wavefront
@@ -370,9 +401,12 @@ __global__ __launch_bounds__(64 * NW, 1) void k_node(NodeArgs a) {
     }
     const int row0 = rt * 32;
 
-    typedef NodeMma<KX / 16, CT, CT, PF12, NCT, NPC> M1;        // X W3^T      (UPD only)
-    typedef NodeMma<H / 16, CT, CT, PF12, NCT, NPC> M2;         // T W4^T      (UPD only)
-    typedef NodeMma<H / 16, 2 * CT, CT, PF3, 2 * NCT, NPC> M3;  // h' [W1a|W1b]^T
+    typedef NodeMma<KX / 16, CT, CT, PF12, NCT, NPC, F16> M1;        // X W3^T      (UPD only)
+    typedef NodeMma<H / 16, CT, CT, PF12, NCT, NPC, F16> M2;         // T W4^T      (UPD only)
+    typedef NodeMma<H / 16, 2 * CT, CT, PF3, 2 * NCT, NPC, F16> M3;  // h' [W1a|W1b]^T
+    // F16: per row of the tile {scale of T, scale of h', 1 / scale of X, 1 / scale of T, 1 / scale of h'}
+    __shared__ __attribute__((aligned(16))) float rsc[5][32];
+    auto row4 = [&](int k, int q) { return *reinterpret_cast<const f32x4*>(&rsc[k][8 * q + 4 * hh]); };
     auto rows_of = [&](const __bf16* base, int ld, int plane, const __bf16* (&out)[NPC]) {
 #pragma unroll
         for (int p = 0; p < NPC; ++p) out[p] = base + p * plane + n * ld + 8 * hh;
@@ -406,7 +440,18 @@ __global__ __launch_bounds__(64 * NW, 1) void k_node(NodeArgs a) {
         static_assert(Q % TPR == 0, "row pieces must divide evenly");
         const int r = tid / TPR, cq = tid % TPR;
         const int row = row0 + r;
+        float sX = 1.0f;                                  // F16: this row's scale of X
         auto put = [&](int col, f32x4 v) {
+            if constexpr (F16) {
+                typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+                v = f32x4{v[0] * sX, v[1] * sX, v[2] * sX, v[3] * sX};
+                const f16x4_t hi = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                const f16x4_t lo = {(_Float16)(v[0] - (float)hi[0]), (_Float16)(v[1] - (float)hi[1]), (_Float16)(v[2] - (float)hi[2]),
+                                    (_Float16)(v[3] - (float)hi[3])};
+                *reinterpret_cast<f16x4_t*>(Xh + r * LDX + col) = hi;
+                *reinterpret_cast<f16x4_t*>(Xh + PX + r * LDX + col) = lo;
+                return;
+            }
 #pragma unroll
             for (int p = 0; p < NPC; ++p) {
                 const __bf16 h0 = (__bf16)v[0], h1 = (__bf16)v[1], h2 = (__bf16)v[2], h3 = (__bf16)v[3];
@@ -434,6 +479,31 @@ __global__ __launch_bounds__(64 * NW, 1) void k_node(NodeArgs a) {
                 g0[u] = *reinterpret_cast<const f32x4*>(s0 + 4 * (cq + u * TPR));
                 g1[u] = *reinterpret_cast<const f32x4*>(s1 + 4 * (cq + u * TPR));
             }
+            if constexpr (F16) {
+                f32x4 gv[NP];
+                float mh = 0.f, mg = 0.f;
+#pragma unroll
+                for (int u = 0; u < NP; ++u) {
+                    f32x4 v = z4;
+                    if (has0) v += g0[u];
+                    if (has1) v += g1[u];
+                    for (int p = p0 + 2; p < p1; ++p) v += *reinterpret_cast<const f32x4*>(a.part + (size_t)p * H + 4 * (cq + u * TPR));
+                    gv[u] = v / a.norm;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { mh = fmaxf(mh, fabsf(hv[u][j])); mg = fmaxf(mg, fabsf(gv[u][j])); }
+                }
+#pragma unroll
+                for (int o = TPR / 2; o > 0; o >>= 1) { mh = fmaxf(mh, __shfl_xor(mh, o)); mg = fmaxf(mg, __shfl_xor(mg, o)); }
+                const float mx = fmaxf(mh, mg);
+                const float tb = __builtin_fmaf(mx, a.w3l1, a.b3max), hb = mh + __builtin_fmaf(tb, a.w4l1, a.b4max);
+                float iX, sT, iT, sH, iH;
+                f16_row_scale(mx, sX, iX); f16_row_scale(tb, sT, iT); f16_row_scale(hb, sH, iH);
+                if (cq == 0) { rsc[0][r] = sT; rsc[1][r] = sH; rsc[2][r] = iX * a.w3inv; rsc[3][r] = iT * a.w4inv; rsc[4][r] = iH; }
+#pragma unroll
+                for (int u = 0; u < NP; ++u) put(4 * (cq + u * TPR), hv[u]);
+#pragma unroll
+                for (int u = 0; u < NP; ++u) put(H + 4 * (cq + u * TPR), gv[u]);
+            } else {
 #pragma unroll
             for (int u = 0; u < NP; ++u) put(4 * (cq + u * TPR), hv[u]);
 #pragma unroll
@@ -444,7 +514,20 @@ __global__ __launch_bounds__(64 * NW, 1) void k_node(NodeArgs a) {
                 for (int p = p0 + 2; p < p1; ++p) v += *reinterpret_cast<const f32x4*>(a.part + (size_t)p * H + 4 * (cq + u * TPR));
                 put(H + 4 * (cq + u * TPR), v / a.norm);
             }
+            }
         } else {
+            if constexpr (F16) {                                     // AB only: X = h, the operand of phase 3
+                float mh = 0.f;
+#pragma unroll
+                for (int u = 0; u < NP; ++u)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) mh = fmaxf(mh, fabsf(hv[u][j]));
+#pragma unroll
+                for (int o = TPR / 2; o > 0; o >>= 1) mh = fmaxf(mh, __shfl_xor(mh, o));
+                float iX;
+                f16_row_scale(mh, sX, iX);
+                if (cq == 0) rsc[4][r] = iX;
+            }
 #pragma unroll
             for (int u = 0; u < NP; ++u) put(4 * (cq + u * TPR), hv[u]);
         }
@@ -456,7 +539,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_node(NodeArgs a) {
             f32x16 acc[CT];
 #pragma unroll
             for (int c = 0; c < CT; ++c) {
-                const float b = b3v[c];
+                const float b = F16 ? 0.f : b3v[c];                  // F16: the bias joins in the un-scaling fma
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[c][r] = b;
             }
@@ -465,6 +548,19 @@ __global__ __launch_bounds__(64 * NW, 1) void k_node(NodeArgs a) {
             const __bf16* xr[NPC];
             rows_of(Xh, LDX, PX, xr);
             M1::run(acc, br1, xr, W3l, ct0, 0);
+            if constexpr (F16) {
+                f32x4 un[4], sc[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { un[q] = row4(2, q); sc[q] = row4(0, q); }
+#pragma unroll
+                for (int c = 0; c < CT; ++c)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int R = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                        const float t = silu_f(__builtin_fmaf(acc[c][r], un[r >> 2][r & 3], b3v[c]));
+                        f16_split_store(Th + R * LDH + 32 * (ct0 + c) + n, PH, t * sc[r >> 2][r & 3]);
+                    }
+            } else {
 #pragma unroll
             for (int c = 0; c < CT; ++c)
 #pragma unroll
@@ -473,6 +569,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_node(NodeArgs a) {
                     // bf16x3: plain SiLU (the contraction error is ~1e-6 anyway); bf16x6: the fp32 mode's compensated one
                     bf16_split_store<NPC>(Th + R * LDH + 32 * (ct0 + c) + n, PH, NPC == 3 ? silu_f(acc[c][r]) : silu_fast(acc[c][r]));
                 }
+            }
         }
         __syncthreads();
         // ---- phase 2: h' = (h + T W4^T + b4) * mask
@@ -483,7 +580,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_node(NodeArgs a) {
             for (int r = 0; r < 16; ++r) mk[r] = a.nmask[row0 + (r & 3) + 8 * (r >> 2) + 4 * hh];
 #pragma unroll
             for (int c = 0; c < CT; ++c) {
-                const float b = b4v[c];
+                const float b = F16 ? 0.f : b4v[c];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     acc[c][r] = b;
@@ -499,9 +596,15 @@ __global__ __launch_bounds__(64 * NW, 1) void k_node(NodeArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int R = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    if constexpr (F16) {
+                        const float v = (hres[c][r] + __builtin_fmaf(acc[c][r], row4(3, r >> 2)[r & 3], b4v[c])) * mk[r];
+                        f16_split_store(Nh + R * LDH + 32 * (ct0 + c) + n, PH, v * row4(1, r >> 2)[r & 3]);
+                        stage0[R * H + 32 * (ct0 + c) + n] = v;
+                    } else {
                     const float v = (hres[c][r] + acc[c][r]) * mk[r];
                     bf16_split_store<NPC>(Nh + R * LDH + 32 * (ct0 + c) + n, PH, v);
                     stage0[R * H + 32 * (ct0 + c) + n] = v;
+                    }
                 }
         }
         __syncthreads();
@@ -522,7 +625,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_node(NodeArgs a) {
         f32x16 acc[2 * CT];
 #pragma unroll
         for (int c = 0; c < 2 * CT; ++c) {
-            const float b = abv[q][c];
+            const float b = F16 ? 0.f : abv[q][c];
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[c][r] = b;
         }
@@ -534,6 +637,16 @@ __global__ __launch_bounds__(64 * NW, 1) void k_node(NodeArgs a) {
         const __bf16* nr[NPC];
         rows_of(Nh, LDH, PH, nr);                            // (!UPD: h' is X itself, LDX == LDH)
         M3::run(acc, br3, nr, ABl, ct0, NCT);
+        if constexpr (F16) {
+            f32x4 un[4];
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) un[qq] = row4(4, qq);
+            const float wi = a.abinv[q];
+#pragma unroll
+            for (int c = 0; c < 2 * CT; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[c][r] = __builtin_fmaf(acc[c][r], un[r >> 2][r & 3] * wi, abv[q][c]);
+        }
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             if (half || q) __syncthreads();                 // previous staging tile fully stored

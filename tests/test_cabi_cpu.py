@@ -260,7 +260,7 @@ def test_no_register_spills_in_production_kernels():
     edge = [v for k, v in prod.items() if k.startswith("_Z6k_edgeILi256")]
     assert len(edge) == 8 and all(v["Occupancy"] >= 2 and v["ScratchSize"] == 0 for v in edge)
     node = [v for k, v in prod.items() if k.startswith("_Z6k_nodeILi256")]
-    assert len(node) == 6 and all(v["ScratchSize"] == 0 for v in node)          # 3 variants x {bf16x3, bf16x6}
+    assert len(node) == 9 and all(v["ScratchSize"] == 0 for v in node)          # 3 variants x {bf16 two-piece, bf16 three-piece, fp16 two-piece}
 
 
 def test_nodes_distribution_draws_equal_reference():
