@@ -268,6 +268,32 @@ def test_fp16x3_operand_ranging(w2_gain, first_gain):
     assert err["fp16x3"] < max(2.0 * err["fp32"], 1e-6), err
 
 
+@pytest.mark.parametrize("node_gain,emb_gain", [(2.0 ** -8, 1.0), (60.0, 1.0), (1.0, 2.0 ** -10), (1.0, 3000.0)])
+def test_fp16x3_node_operand_ranging(node_gain, emb_gain):
+    """The node update of the mode (k_node<..., F16>, width 256) ranges its three activation operands per row from a-priori bounds
+    (row maximum of [h | agg], L1 norms of W3 / W4) and its weights per matrix: node-MLP weights 256 x smaller / 60 x larger,
+    node features 1000 x smaller / 3000 x larger (|h| up to ~1e5, beyond FP16's 65504) stay at the exact-fp32 mode's distance
+    to the float64 oracle."""
+    sd_np, sd, cfg, xh, nm, em = _oracle_case([30, 30, 17, 9], 256, 2, seed=707)
+    for k in list(sd_np):
+        if ".node_mlp." in k:
+            sd_np[k] = (sd_np[k] * node_gain).astype(np.float32)
+        if k.endswith("egnn.embedding.weight") or k.endswith("egnn.embedding.bias"):
+            sd_np[k] = (sd_np[k] * emb_gain).astype(np.float32)
+    t = torch.full((4, 1), 0.4)
+    with torch.no_grad(), orc.float64():
+        ref64 = orc.dynamics_forward(orc.as_torch_sd(sd_np), cfg, t, xh, nm, em, None, None, prefix="dynamics.egnn.").numpy()
+    err = {}
+    for precision in ("fp32", "fp16x3"):
+        dyn = build_dynamics(sd_np, 256, 2)
+        dyn.precision = precision
+        out = dyn._forward(t.to(DEV), xh.to(DEV), nm.to(DEV), em.to(DEV), None, None).cpu().numpy()
+        assert np.isfinite(out).all()
+        err[precision] = rel_l2(out, ref64)
+    print(f"node MLP x {node_gain:.3g}, embedding x {emb_gain:.3g}: distance to the float64 oracle", {k: f"{v:.2e}" for k, v in err.items()})
+    assert err["fp16x3"] < max(2.0 * err["fp32"], 1e-6), err
+
+
 def test_fp16x3_has_no_range_limit():
     """FP16 overflows at 65504; the mode's activations are ranged per edge row by max|A_i| + max|B_j| + the distance terms
     (k_ab_rowmax + k_edge.hpp), so first-layer terms far beyond that - a bias of 60000, coordinates 1000 apart - are computed
