@@ -28,7 +28,10 @@ PRECISIONS = {"fp32": 0, "bf16x3": 1, "bf16x6": 2, "fp16x3": 3}
 # (v_mfma_f32_32x32x2_f32), the arithmetic the reference computes in (en_dynamics.py has no notion of reduced
 # precision; per-forward error vs the reference ~5e-7 rel-L2).  "bf16x3" is opt-in (`model.precision = "bf16x3"`
 # or HIERDIFF_PRECISION=bf16x3): fp32 operands split into bf16 head + tail, three bf16 matrix instructions with fp32
-# accumulation, ~1e-5 rel-L2 per forward (bar 1e-4) and ~2.7x faster end to end.
+# accumulation, ~1e-5 rel-L2 per forward (bar 1e-4) and ~2.6x faster end to end.  "fp16x3" and "bf16x6"
+# are the fp32-ACCURATE opt-ins (two-way FP16 split with operands ranged by exact powers of two, three MFMAs per product /
+# three-way bf16 split, six MFMAs): as far from a float64 evaluation as exact fp32, 2.4x / 1.7x faster; "fp16x3" is the one to use
+# for sampling.
 DEFAULT_PRECISION = "fp32"
 
 # ----------------------------------------------------------------------------- parameter holders
@@ -345,7 +348,9 @@ class EGNN_dynamics_QM9(nn.Module):
         """"fp32": exact fp32 matrix instructions.  "bf16x3": fp32 operands split into bf16 head+tail, three
         bf16 matrix instructions with fp32 accumulation (error ~1e-6 per contraction, ~5x the throughput).  "bf16x6": the
         per-edge contraction on a three-way bf16 split, six bf16 matrix instructions per product - truncation below the
-        rounding of the fp32 accumulation, everything else as in "fp32"."""
+        rounding of the fp32 accumulation, everything else as in "fp32".  "fp16x3": edge and node contractions on a two-way FP16
+        split (three fp16 matrix instructions per product), every operand ranged by an exact power of two per matrix / per row -
+        as accurate as "fp32" and "bf16x6", at "bf16x3"'s cost; the recommended sampling mode."""
         if name not in PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(PRECISIONS)}")
         if self.mode == 'gnn_dynamics':
