@@ -62,3 +62,31 @@ def test_fp16x3_ranging_cannot_overflow():
     for wmax in (1e-12, 3e-3, 0.06, 1.0, 17.0, 9e8):
         W = np.array([[wmax, -wmax / 3]], dtype=np.float32)
         assert 2.0 ** 14 <= float(np.abs(W).max() * _weight_scale(W)) < 2.0 ** 15
+
+
+def test_node_update_row_bounds_hold_and_are_usable():
+    """k_node<..., F16> ranges T and h' per row from bounds known before the first contraction (k_node.hpp):
+    |T_r| <= max|X_r| max_c sum_k|W3[c][k]| + max|b3|,  |h'_r| <= max|h_r| + bound(T_r) max_c sum_k|W4[c][k]| + max|b4|.
+    They must hold for every element (no FP16 overflow possible) and must not be so loose that typical elements fall out of the
+    22-bit range of a scaled operand (15 binades below the bound)."""
+    rng = np.random.Generator(np.random.PCG64(9))
+    H, R = 256, 200
+    for gain_h, gain_w in ((1.0, 1.0), (300.0, 1.0), (1e-3, 1.0), (1.0, 40.0), (1.0, 1e-2)):
+        h = rng.standard_normal((R, H)).astype(np.float32) * np.float32(gain_h) * (2.0 ** rng.integers(-4, 5, (R, 1))).astype(np.float32)
+        agg = rng.standard_normal((R, H)).astype(np.float32) * np.float32(gain_h)
+        X = np.concatenate([h, agg], 1)
+        W3 = ((rng.random((H, 2 * H)) * 2 - 1) / 22).astype(np.float32) * np.float32(gain_w)
+        W4 = ((rng.random((H, H)) * 2 - 1) / 16).astype(np.float32) * np.float32(gain_w)
+        b3 = rng.standard_normal(H).astype(np.float32) * 0.1
+        b4 = rng.standard_normal(H).astype(np.float32) * 0.1
+        pre = X.astype(np.float64) @ W3.astype(np.float64).T + b3
+        T = pre / (1 + np.exp(-np.clip(pre, -700, 700)))
+        hn = h + T @ W4.astype(np.float64).T + b4
+        mx, mh = np.abs(X).max(1), np.abs(h).max(1)
+        tb = mx * np.abs(W3).sum(1).max() + np.abs(b3).max()
+        hb = mh + tb * np.abs(W4).sum(1).max() + np.abs(b4).max()
+        assert (np.abs(T).max(1) <= tb * (1 + 1e-6)).all() and (np.abs(hn).max(1) <= hb * (1 + 1e-6)).all()
+        # looseness: the row's own largest element sits fewer than 12 binades below its bound, i.e. at least 3 binades inside
+        # the range where an element keeps both FP16 pieces normal
+        assert (np.log2(tb / np.maximum(np.abs(T).max(1), 1e-300)) < 12).all()
+        assert (np.log2(hb / np.maximum(np.abs(hn).max(1), 1e-300)) < 12).all()
