@@ -63,7 +63,7 @@ struct hd_handle {
     int H, fin, F, D, NS;       // NS: 32-column sub-tiles per k_gemm workgroup tile
     // arithmetic of the two kernel families, derived from cfg.precision and the width (hd_create):
     //   edge_mode 0 fp32 | 1 bf16x3 | 2 bf16x6 | 3 fp16x3      node_mode 0 fp32 (k_node_f32 / k_gemm_r16) | 1 bf16 two-piece | 2 bf16 three-piece | 3 fp16 two-piece
-    //   precision 0: 0 / 0;  1: 1 / 1;  2: 2 / 2 (H >= 128, else 0 / 0);  3: 3 / 3 (H = 256), 3 / 2 (H = 128), else 3 / 0
+    //   precision 0: 0 / 0;  1: 1 / 1;  2: 2 / 2 (H >= 128, else 0 / 0);  3: 3 / 3 (H >= 128), else 3 / 0
     // `scaled`: the edge model runs in the domain scaled by -log2(e) (two-way modes, silu_scaled in common.hpp)
     int edge_mode, node_mode;
     bool scaled;
@@ -234,7 +234,7 @@ extern "C" int hd_create(const hd_config* cfg, int device, hd_handle** out) {
         switch (cfg->precision) {
             case 1: h->edge_mode = 1; h->node_mode = 1; break;
             case 2: h->edge_mode = wide ? 2 : 0; h->node_mode = wide ? 2 : 0; break;
-            case 3: h->edge_mode = 3; h->node_mode = cfg->hidden_nf == 256 ? 3 : (wide ? 2 : 0); break;
+            case 3: h->edge_mode = 3; h->node_mode = wide ? 3 : 0; break;
             default: h->edge_mode = 0; h->node_mode = 0; break;
         }
         h->scaled = h->edge_mode == 1 || h->edge_mode == 3;
@@ -1143,7 +1143,7 @@ static void launch_node_hw(bool upd, int nab, int mode, const NodeArgs& a, hipSt
         }
     }
     const int lds = node_lds_bytes<H>(upd);
-    if constexpr (H == 256) {
+    if constexpr (H >= 128) {
         if (mode == 3) {                                   // two-piece FP16 (fp16x3 mode)
             if (!upd) hipLaunchKernelGGL((k_node<H, NW, false, 1, 2, true>), grid, block, lds, s, a);
             else if (nab == 1) hipLaunchKernelGGL((k_node<H, NW, true, 1, 2, true>), grid, block, lds, s, a);
@@ -1164,7 +1164,7 @@ static int prepare_node_hw() {
     HIP_TRY(hipFuncSetAttribute((const void*)k_node_f32<H, NW, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, node_f32_lds_bytes<H>(false)));
     HIP_TRY(hipFuncSetAttribute((const void*)k_node_f32<H, NW, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, node_f32_lds_bytes<H>(true)));
     HIP_TRY(hipFuncSetAttribute((const void*)k_node_f32<H, NW, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, node_f32_lds_bytes<H>(true)));
-    if constexpr (H == 256) {
+    if constexpr (H >= 128) {
         HIP_TRY(hipFuncSetAttribute((const void*)k_node<H, NW, false, 1, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, node_lds_bytes<H>(false)));
         HIP_TRY(hipFuncSetAttribute((const void*)k_node<H, NW, true, 1, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, node_lds_bytes<H>(true)));
         HIP_TRY(hipFuncSetAttribute((const void*)k_node<H, NW, true, 2, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, node_lds_bytes<H>(true)));
@@ -1433,8 +1433,8 @@ static int forward_impl(hd_handle* h, hd_topology* t, const float* xh, const flo
         auto set_ab = [&](NodeArgs& a, int q, const LayerW& nw, float* dst) {
             a.ABimg[q] = W + nw.ab_img; a.ABbias[q] = W + nw.ab_bias; a.ABout[q] = dst;
             a.abinv[q] = h->node_mode == 3 ? 1.0f / nw.abs_ : 1.0f;
-            // fp16x3 at width 256: the fused node kernel leaves the row maxima of what it writes (narrower widths: k_ab_rowmax)
-            a.ABmax[q] = (h->edge_mode == 3 && h->node_mode != 0 && H == 256) ? (dst == t->AB ? t->abmax : t->abmax2) : nullptr;
+            // fp16x3 at widths >= 128: the fused node kernel leaves the row maxima of what it writes (narrower widths: k_ab_rowmax)
+            a.ABmax[q] = (h->edge_mode == 3 && h->node_mode != 0) ? (dst == t->AB ? t->abmax : t->abmax2) : nullptr;
         };
         // fp32 mode, few rows: the fused kernel's serial chain per 32-row workgroup (~50 us) is not hidden by other workgroups
         // (60 of them at B = 64), the k_agg + 3 x k_gemm chain spreads the same work over 64 x 64 tiles.  Both paths are
@@ -1472,7 +1472,7 @@ static int forward_impl(hd_handle* h, hd_topology* t, const float* xh, const flo
                 std::memset(&e, 0, sizeof(e));
                 e.AB = ab_cur; e.wrd = W + w.wrd; e.W2img = W + w.w2_img; e.b2 = W + w.b2; e.wa = W + w.wa;
                 e.w2s_inv = 1.0f / w.w2s; e.wrmax = w.wrmax; e.wdmax = w.wdmax;
-                const bool fused_max = h->edge_mode == 3 && h->node_mode != 0 && H == 256;
+                const bool fused_max = h->edge_mode == 3 && h->node_mode != 0;
                 e.abmax = (fused_max && ab_cur == t->AB2) ? t->abmax2 : t->abmax;
                 if (h->edge_mode == 3 && !fused_max) {  // fp16x3: the per-node part of the activation bound (k_edge.hpp)
                     ProfScope ps(h, s, 2);

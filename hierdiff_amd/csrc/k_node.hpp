@@ -662,14 +662,15 @@ __global__ __launch_bounds__(64 * NW, 1) void k_node(NodeArgs a) {
                 const int idx = tid + u * NT, r = idx / Q, c4 = idx % Q;
                 const f32x4 v = *reinterpret_cast<const f32x4*>(stage1 + r * LDS1 + 4 * c4);
                 if (row0 + r < a.M) *reinterpret_cast<f32x4*>(a.ABout[q] + (size_t)(row0 + r) * 2 * H + half * H + 4 * c4) = v;
-                if constexpr (Q == 64) {
-                    // a wavefront stores one complete row of the half per pass: its maximum |value| is a wave reduction away
-                    // (the per-node part of the fp16x3 edge kernels' activation bound, k_edge.hpp)
+                if constexpr (Q == 64 || Q == 32) {
+                    // Q consecutive lanes store one complete row of the half per pass (a wavefront at width 256, half of one at
+                    // 128): its maximum |value| is a lane reduction away (the per-node part of the fp16x3 edge kernels'
+                    // activation bound, k_edge.hpp)
                     if (a.ABmax[q]) {
                         float m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
 #pragma unroll
-                        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-                        if (lane == 0 && row0 + r < a.M) a.ABmax[q][2 * (size_t)(row0 + r) + half] = m;
+                        for (int o = Q / 2; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+                        if ((lane & (Q - 1)) == 0 && row0 + r < a.M) a.ABmax[q][2 * (size_t)(row0 + r) + half] = m;
                     }
                 }
             }

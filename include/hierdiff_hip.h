@@ -86,7 +86,8 @@ typedef struct hd_config {
                                         contraction, bf16x6 2.4e-7, bf16x3 4.1e-6) at mode 1's cost.  Operands are ranged by
                                         exact powers of two - W2 per matrix, the activations per edge row from a bound on the
                                         pre-activation known before the contraction starts - so FP16's exponent range imposes
-                                        no assumption on the network.  Node GEMMs as in mode 2 */
+                                        no assumption on the network.  The node GEMMs run the same arithmetic (hidden_nf >= 128;
+                                        narrower: mode 0's node kernels) */
     int32_t aggregation_mean;    /* 0: aggregation_method 'sum' - neighbour sums / normalization_factor (egnn_new.py:280-282);
                                     1: 'mean' (:283-288) - sums / number of edge-list entries of the receiving node.  The
                                        reference's edge list holds all N x N pairs of a molecule, masked or not
