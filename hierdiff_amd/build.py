@@ -60,7 +60,7 @@ def _parse_resource_remarks(text: str) -> dict:
 def _production(name: str) -> bool:
     """Everything except the ablated / traced edge-kernel instantiations of a --debug-kernels build."""
     import re
-    m = re.match(r"_Z6k_edgeILi\d+ELb[01]ELi[012]ELi(\d+)EE", name)
+    m = re.match(r"_Z6k_edgeILi\d+ELb[01]ELi[0123]ELi(\d+)EE", name)
     if m:
         return m.group(1) == "0"
     return True

@@ -1251,6 +1251,8 @@ static bool launch_edge_ablated(hd_handle* h, const EdgeArgs& a, hipStream_t s) 
         case 20: run(std::integral_constant<int, 20>{}); return true;
         case 24: run(std::integral_constant<int, 24>{}); return true;
         case 30: run(std::integral_constant<int, 30>{}); return true;
+        case 32: run(std::integral_constant<int, 32>{}); return true;
+        case 64: run(std::integral_constant<int, 64>{}); return true;
         default: return false;
     }
 }
@@ -1269,7 +1271,7 @@ static int launch_edge_h(hd_handle* h, bool coord, const EdgeArgs& a, hipStream_
     const dim3 grid(a.n_wg), block(256);
 #ifdef HD_DEBUG_KERNELS
     if constexpr (H == 256) {
-        if (h->ablate && !coord && (x6 ? launch_edge_ablated<2>(h, a, s) : prec == 1 ? launch_edge_ablated<1>(h, a, s) : launch_edge_ablated<0>(h, a, s))) return HD_OK;
+        if (h->ablate && !coord && (x6 ? launch_edge_ablated<2>(h, a, s) : prec == 1 ? launch_edge_ablated<1>(h, a, s) : prec == 3 ? launch_edge_ablated<3>(h, a, s) : launch_edge_ablated<0>(h, a, s))) return HD_OK;
     }
 #endif
     if constexpr (H >= 128) {

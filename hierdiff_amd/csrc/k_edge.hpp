@@ -199,7 +199,8 @@ constexpr unsigned frag_off_x6(int p, int ct) { return (unsigned)((p * NCT + ct)
 
 // ABL: ablation switches for bottleneck hunting (never set in production launches; env HD_ABLATE, H=256 bf16x3 GCL):
 //   1 = skip the epilogue, 2 = skip operand generation (SiLU etc.), 4 = no per-chunk barrier / W2 streaming,
-//   8 = no AB row gathers, 16 = record per-wave cycle stamps + HW placement (hd_debug_edge_trace, scratch/edge_trace.py)
+//   8 = no AB row gathers, 16 = record per-wave cycle stamps + HW placement (hd_debug_edge_trace, scratch/edge_trace.py),
+//   32 = barrier kept, W2 stream dropped; 64 = W2 stream kept, barrier dropped (round 5: which half of "4" costs what)
 //
 // One workgroup = one 128-edge workgroup-tile (4 wavefronts x 32 edges), two workgroups per CU.  Forms that were built and
 // measured slower: a persistent one that walks several tiles per workgroup (spilled); the pipelined one-wave-per-SIMD form of
@@ -407,21 +408,31 @@ HD_DEVINL void edge_tile_body(const EdgeArgs& a, float* smem, float* wrd_s, cons
 #pragma unroll
     for (int u = 0; u < NQ; ++u) rows_issue(u, NCH > 1 ? 1 : 0);
 
-    // accumulators start at the second layer's bias (saves the H/32 * 16 bias adds of the epilogue)
+    // accumulators start at the second layer's bias (saves the H/32 * 16 bias adds of the epilogue).  fp16x3: the bias joins
+    // in the epilogue's un-scaling fma, so the accumulators start at zero - and are not initialised at all: the first chunk
+    // is peeled off the loop and the first MFMA on each accumulator takes the inline constant 0 as its C operand (128
+    // v_mov per tile less; the same bits as adding to a zeroed register).
+    #ifdef HD_NO_PEEL
+    constexpr bool PEEL = false;
+#else
+    constexpr bool PEEL = PREC == 3 && !(ABL & 2);
+#endif
     f32x16 acc[NCT];
+    if constexpr (!PEEL) {
 #pragma unroll
-    for (int ct = 0; ct < NCT; ++ct) {
-        const float b2v = PREC == 3 ? 0.0f : wrd_s[2 * H + 32 * ct + n];      // fp16x3: the bias joins in the epilogue's un-scaling fma
+        for (int ct = 0; ct < NCT; ++ct) {
+            const float b2v = PREC == 3 ? 0.0f : wrd_s[2 * H + 32 * ct + n];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[ct][r] = b2v;
+            for (int r = 0; r < 16; ++r) acc[ct][r] = b2v;
+        }
     }
     if constexpr (ABL & 16) ts1 = __builtin_readcyclecounter();
     // (Unrolling this loop by two with swapped operand sets, to drop the 16 register copies per chunk, was
     // measured twice: 9-17 spilled registers, 125 vs 109 us and later 110-116 vs 103-106 us; fp32 285 vs 278.)
-#pragma unroll 1
-    for (int c = 0; c < NCH; ++c, ++gc) {
+    auto chunk = [&](auto First, const int c) {
+        constexpr bool FIRST = decltype(First)::value;
         const int buf = (ABL & 4) ? 0 : (gc & 1);
-        if constexpr (!(ABL & 4)) {
+        if constexpr (!(ABL & 4) && !(ABL & 64)) {
             // chunk c landed in LDS and every wave is done with the other buffer.  The only VMEM operations younger
             // than chunk c's stream are the 8 row gathers of the previous iteration.
             if constexpr (PREC == 2) { if (c > 0) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory"); }
@@ -454,7 +465,7 @@ HD_DEVINL void edge_tile_body(const EdgeArgs& a, float* smem, float* wrd_s, cons
                           frag_off_f32(q * NCT + c0 + (HC > 2 ? 2 : 0)), frag_off_f32(q * NCT + c0 + (HC > 3 ? 3 : 0))>(f, wb_lds);
             };
             read_unit(std::integral_constant<int, 0>{}, f0);
-            if constexpr (!(ABL & 4)) issue_chunk(c + 1 < NCH ? c + 1 : 0, buf ^ 1);
+            if constexpr (!(ABL & 4) && !(ABL & 32)) issue_chunk(c + 1 < NCH ? c + 1 : 0, buf ^ 1);
             // Operands of chunk c+1 are produced IN PLACE: once the MFMAs of k-quad q have been issued their four operand
             // registers are dead, so quad q of the next chunk is built there (from rows requested one iteration ago) and
             // the rows of chunk c+2 go into the freed row registers.  Outstanding VMEM at that point, oldest first:
@@ -503,7 +514,7 @@ HD_DEVINL void edge_tile_body(const EdgeArgs& a, float* smem, float* wrd_s, cons
             lds_read4<bf16x8, frag_off_bf<NCT>(0, 0), frag_off_bf<NCT>(0, 1), frag_off_bf<NCT>(1, 0), frag_off_bf<NCT>(1, 1)>(f0, wb_lds);
             // the stream for the next chunk goes out behind the first fragment reads: its eight LDS-DMA issues cover
             // the LDS latency the first MFMA group would otherwise wait out
-            if constexpr (!(ABL & 4)) issue_chunk(c + 1 < NCH ? c + 1 : 0, buf ^ 1);
+            if constexpr (!(ABL & 4) && !(ABL & 32)) issue_chunk(c + 1 < NCH ? c + 1 : 0, buf ^ 1);
             static_for<0, NG>([&](auto Gc) {
                 constexpr int g = decltype(Gc)::value;
                 bf16x8(&cur)[4] = (g & 1) ? f1 : f0;
@@ -543,8 +554,10 @@ HD_DEVINL void edge_tile_body(const EdgeArgs& a, float* smem, float* wrd_s, cons
                 constexpr int s0 = u0 / NCT, c0 = u0 % NCT, s1 = u1 / NCT, c1 = u1 % NCT;
                 const bf16x8 A_h0 = __builtin_bit_cast(bf16x8, phc[s0]), A_l0 = __builtin_bit_cast(bf16x8, plc[s0]);
                 const bf16x8 A_h1 = __builtin_bit_cast(bf16x8, phc[s1]), A_l1 = __builtin_bit_cast(bf16x8, plc[s1]);
-                acc[c0] = mma16<PREC == 3>(A_h0, cur[0], acc[c0]);
-                acc[c1] = mma16<PREC == 3>(A_h1, cur[2], acc[c1]);
+                if constexpr (FIRST && s0 == 0) acc[c0] = mma16<PREC == 3>(A_h0, cur[0], f32x16{});
+                else acc[c0] = mma16<PREC == 3>(A_h0, cur[0], acc[c0]);
+                if constexpr (FIRST && s1 == 0) acc[c1] = mma16<PREC == 3>(A_h1, cur[2], f32x16{});
+                else acc[c1] = mma16<PREC == 3>(A_h1, cur[2], acc[c1]);
                 acc[c0] = mma16<PREC == 3>(A_l0, cur[0], acc[c0]);
                 acc[c1] = mma16<PREC == 3>(A_l1, cur[2], acc[c1]);
                 acc[c0] = mma16<PREC == 3>(A_h0, cur[1], acc[c0]);
@@ -579,7 +592,7 @@ HD_DEVINL void edge_tile_body(const EdgeArgs& a, float* smem, float* wrd_s, cons
             };
             req_A(std::integral_constant<int, 0>{}, fA[0]);
             req_B(std::integral_constant<int, 0>{}, fB[0]);
-            if constexpr (!(ABL & 4)) issue_chunk(c + 1 < NCH ? c + 1 : 0, buf ^ 1);
+            if constexpr (!(ABL & 4) && !(ABL & 32)) issue_chunk(c + 1 < NCH ? c + 1 : 0, buf ^ 1);
             const bf16x8 A_h = __builtin_bit_cast(bf16x8, xh), A_m = __builtin_bit_cast(bf16x8, xm), A_l = __builtin_bit_cast(bf16x8, xl);
             static_for<0, NCT / 2>([&](auto Gc) {
                 constexpr int g = decltype(Gc)::value, c0 = 2 * g, c1 = 2 * g + 1, NP = NCT / 2;
@@ -627,7 +640,10 @@ HD_DEVINL void edge_tile_body(const EdgeArgs& a, float* smem, float* wrd_s, cons
             });
             xh = nh; xm = nm; xl = nl;
         }
-    }
+    };
+    if constexpr (PEEL) { chunk(std::true_type{}, 0); ++gc; }
+#pragma unroll 1
+    for (int c = PEEL ? 1 : 0; c < NCH; ++c, ++gc) chunk(std::false_type{}, c);
 
     {                                      // drain the (unused) last gathers before their registers are reused
         if constexpr (NQ == 4) asm volatile("s_waitcnt vmcnt(0)" : "+v"(pa[0]), "+v"(pa[1]), "+v"(pa[2]), "+v"(pa[3]),

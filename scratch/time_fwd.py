@@ -13,6 +13,7 @@ dyn = build_dynamics(sd_np, 256, 6); dyn.precision = prec
 topo = dyn.topology(nm, None, B, 30); dyn.sync_weights()
 for _ in range(3): o = dyn.forward_with_topology(topo, t, xh, None, None)
 torch.cuda.synchronize(); t0 = time.perf_counter()
-for _ in range(20): o = dyn.forward_with_topology(topo, t, xh, None, None)
-torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 20
+R = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+for _ in range(R): o = dyn.forward_with_topology(topo, t, xh, None, None)
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / R
 print(prec, "B", B, "stagger", os.environ.get("HD_STAGGER"), f"{dt*1e3:.3f} ms/forward")

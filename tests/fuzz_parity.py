@@ -12,6 +12,8 @@ def rel(a, b):
     a, b = a.double(), b.double()
     return float((a - b).norm() / max(float(b.norm()), 1e-30))
 worst = {"fp32": 0.0, "bf16x6": 0.0, "fp16x3": 0.0, "bf16x3": 0.0}
+chain_outside = []    # (chain case, mode, gain, rel-L2) above the 1e-3 trajectory bar in the one un-gated combination
+wc_gated = 0.0
 outside = []          # bf16x3 above 1e-4 outside the production-like option set: reported, not gated
 fails = 0
 t0 = time.time()
@@ -126,10 +128,17 @@ for case in range(chains):
         bad = (gated and r > 1e-3) or not torch.isfinite(x).all()
         if not gated and r > 1e-3:
             outside.append((1000 + case, r))
+            chain_outside.append((case, prec, gain, r))
+        if gated:
+            wc_gated = max(wc_gated, r)
         wc = max(wc, r); fails += int(bad)
-        line += f"  {prec} {r:.1e}{' FAIL' if bad else ''}"
+        line += f"  {prec} {r:.1e}{' FAIL' if bad else (' (un-gated)' if not gated and r > 1e-3 else '')}"
     print(line, flush=True)
-print(f"{chains} chains in {time.time() - t1:.0f} s, failures so far {fails}, worst rel-L2 {wc:.2e}")
+print(f"{chains} chains in {time.time() - t1:.0f} s, failures so far {fails}, worst GATED rel-L2 {wc_gated:.2e} (bar 1e-3), worst over "
+      f"everything incl. the un-gated combination {wc:.2e}")
+print("un-gated exceedances of the 1e-3 trajectory bar (bf16x3 with coordinate-head gain 1.0 only: an untrained net with a saturated "
+      "tanh amplifies the mode's ~1e-5 per-forward error over a chain; every single forward stays under the 1e-4 forward bar): "
+      f"{[(f'chain {c}', p_, f'gain {g}', float(f'{r:.2e}')) for c, p_, g, r in chain_outside]}")
 
 # ---- phase 3: a sample's bits depend on its global id, its size and the weights only - not on how the batch is cut or padded
 splits = max(1, cases // 8)

@@ -478,7 +478,7 @@ def test_world2_processes_reproduce_single_process_bits(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "fp16x3"])
 def test_two_stream_sampler_reproduces_single_stream_bits(precision):
     """hierdiff_amd.TwoStreamSampler (opt-in: two half batches on two HIP streams, twin handle) returns the bits of the
     plain sampler: ragged sizes, an odd batch, a context model, repeated calls (cached cuts / topologies / graphs) and a
@@ -592,7 +592,7 @@ def test_bench_self_launches_its_ranks(tmp_path):
 
 # ----------------------------------------------------------------------------- (l) the reference's shipped job: many small batches
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "fp16x3"])
 def test_merged_sample_batches_equal_the_loop(precision):
     """`sample_batches(batch_size=2, num_batches=16)` is the reference's shipped job (conf/sample/default.yaml:1-2,
     diffusion_qm9.py:397-436: 16 calls of sample(2)).  Here the 32 molecules run as one device batch (`merge_batches`);

@@ -345,26 +345,58 @@ def test_general_edge_mask_and_options_vs_oracle():
     assert_parity(out.numpy(), ref.numpy(), "general edge mask")
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x6"])
-def test_pocket_sized_graph_vs_oracle(precision):
+@pytest.mark.parametrize("precision,H", [("fp32", 64), ("bf16x6", 64), ("fp16x3", 64), ("fp16x3", 128), ("bf16x3", 64)])
+def test_pocket_sized_graph_vs_oracle(precision, H):
     """Pocket-conditioned jobs put the ligand fragments AND the pocket residues into one graph (diffusion_qm9.py:362-371):
     N in the hundreds, a node's edges span 7 tiles, ligand rows fixed through mol_shape.  N = 200 / 137, dense edges plus
-    a block the mask removes, against the oracle."""
-    sd_np, sd, cfg, xh, nm, em = _oracle_case([200, 137], 64, 2, seed=808, n_max=200)
+    a block the mask removes, against the oracle.  fp16x3 at both of its node paths (width 64: fp32 node kernels + k_ab_rowmax;
+    width 128: the FP16 node kernel with its fused row maxima) - the squared distances of a 200-node graph are where the
+    per-row ranging of the edge activations has the most to do."""
+    sd_np, sd, cfg, xh, nm, em = _oracle_case([200, 137], H, 2, seed=808, n_max=200)
     em = em.clone()
     em[1, :30, 100:137] = False                     # ligand fragments do not see the far half of this pocket
     em[1, 100:137, :30] = False
     t = torch.tensor([[0.2], [0.7]])
     with torch.no_grad():
         ref = orc.dynamics_forward(sd, cfg, t, xh, nm, em, None, 30, prefix="dynamics.egnn.")
-    dyn = build_dynamics(sd_np, 64, 2)
+    dyn = build_dynamics(sd_np, H, 2)
     dyn.precision = precision
     out = dyn._forward(t.to(DEV), xh.to(DEV), nm.to(DEV), em.to(DEV), None, 30).cpu()
-    assert_parity(out.numpy(), ref.numpy(), f"pocket-sized graph {precision}")
+    assert_parity(out.numpy(), ref.numpy(), f"pocket-sized graph {precision} H={H}")
     assert np.all(out.numpy()[~nm.numpy()[..., 0]] == 0.0)
     # nodes >= mol_shape are fixed: their velocity is that of a rigid translation only (the centre-of-gravity removal)
     v = out[0, 30:200, :3]
     assert float((v - v[0:1]).abs().max()) < 1e-6
+
+
+@pytest.mark.parametrize("H", [32, 64, 128])
+def test_fp16x3_node_path_by_width(H):
+    """Which node kernels the fp16x3 mode runs, stated as behaviour: below width 128 the FP16 node kernel does not exist
+    and the mode runs the exact-fp32 node kernels (k_node_f32 / k_gemm_r16; the edge kernels are FP16 at every width), from
+    128 up it runs k_node<..., F16>.  With the second edge Linear, its bias and the coordinate head zeroed every message
+    and every coordinate update is exactly 0 in every arithmetic (SiLU(0) = 0), so the output features are a function of
+    the NODE path alone: bit-equal to the fp32 mode's at widths 32 and 64, fp32-accurate but not bit-equal at 128."""
+    from hierdiff_amd.weights import synthetic_state_dict
+    L = 2
+    sd_np = synthetic_state_dict(9, 0, H, L, 2, True, 717, 1.0)
+    for k in list(sd_np):
+        if ".edge_mlp.2." in k or ".coord_mlp.4." in k or ".coord_mlp.2." in k:
+            sd_np[k] = np.zeros_like(sd_np[k])
+    xh, nm, em = orc.random_inputs([30, 17, 1, 24, 9, 30], 8, 71, 30)
+    t = torch.linspace(0.1, 0.9, 6).view(6, 1)
+    out = {}
+    for precision in ("fp32", "fp16x3"):
+        dyn = build_dynamics(sd_np, H, L)
+        dyn.precision = precision
+        out[precision] = dyn._forward(t.to(DEV), xh.to(DEV), nm.to(DEV), em.to(DEV), None, None).cpu()
+        assert torch.isfinite(out[precision]).all()
+        assert float(out[precision][..., :3].abs().max()) == 0.0           # no coordinate update at all
+    same = torch.equal(out["fp32"], out["fp16x3"])
+    if H < 128:
+        assert same, f"H={H}: fp16x3 is expected to run the fp32 node kernels (max diff {(out['fp32'] - out['fp16x3']).abs().max():.3e})"
+    else:
+        assert not same, "H=128: fp16x3 is expected to run the FP16 node kernel"
+        assert rel_l2(out["fp16x3"].numpy(), out["fp32"].numpy()) < 2e-6
 
 
 @pytest.mark.parametrize("H,L,B", [(64, 2, 210), (256, 1, 170), (32, 2, 170)])

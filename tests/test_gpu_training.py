@@ -185,7 +185,7 @@ def test_training_step_with_learned_schedule_and_optimizer():
     assert torch.isfinite(loss) and loss.requires_grad
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "fp16x3"])
 def test_eval_mode_nll_does_not_depend_on_grad_mode(precision):
     """an evaluation call made WITHOUT torch.no_grad() (this test runs with autograd recording) takes the
     inference kernels of the configured precision - it neither raises in the bf16 modes nor switches the schedule from the
