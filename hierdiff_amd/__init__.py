@@ -14,8 +14,9 @@ The compute lives in lib/libhierdiff_hip.so (include/hierdiff_hip.h); build it w
 from .concurrent import TwoStreamSampler  # noqa: F401
 from .diffusion import AttrDict, DiffusionQM9, EnVariationalDiffusion, default_config  # noqa: F401
 from .distributions import DistributionNodes  # noqa: F401
-from .dynamics import EGNN_dynamics_QM9, Topology  # noqa: F401
+from .dynamics import EGNN_dynamics_QM9, Topology, release_cached_memory  # noqa: F401
 from .noise_model import GammaNetwork, PredefinedNoiseSchedule  # noqa: F401
 
 __all__ = ["EGNN_dynamics_QM9", "DiffusionQM9", "EnVariationalDiffusion", "GammaNetwork",
-           "PredefinedNoiseSchedule", "DistributionNodes", "Topology", "AttrDict", "default_config", "TwoStreamSampler"]
+           "PredefinedNoiseSchedule", "DistributionNodes", "Topology", "AttrDict", "default_config", "TwoStreamSampler",
+           "release_cached_memory"]

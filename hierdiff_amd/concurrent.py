@@ -4,7 +4,7 @@ Why.  At B = 32 .. 128 the node kernels of the bf16 modes occupy a fraction of t
 the edge kernels fill it; the molecules of a batch are independent and the edge tiles are cut per molecule, so a batch
 can be cut in two and the halves run side by side - the node kernels of one beside the edge kernels of the other - with
 BIT-IDENTICAL results (a sample's bits depend on its global id, mask and weights only).  Measured on one MI355X at B = 64,
-N = 30, H = 256, L = 6 (scratch/concurrent_shards.py, profiles/r02_concurrent_shards.log): bf16x3 72.4 -> 82.1
+N = 30, H = 256, L = 6 (scratch/concurrent_shards.py, profiles/history/r02_concurrent_shards.log): bf16x3 72.4 -> 82.1
 molecules/s, bf16x6 49.5 -> 57.2; exact fp32 does NOT gain (32.2 -> 31.0: its node GEMMs compete with the edge kernel for
 the same fp32 MFMA pipe), more than two streams serialise, and at B = 256 the chip is full either way (+-2 %).  Hence
 opt-in, and meant for the bf16 modes at medium batch sizes.

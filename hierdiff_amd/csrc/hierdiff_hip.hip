@@ -39,6 +39,9 @@ static int fail(int code, const std::string& msg) {
 // fp32 mode: batches with fewer active rows than this run the node side as three k_gemm_r16 launches instead of the fused
 // k_node_f32 (profiles/r03_r16_sweep.log: B = 128 3.22 vs 3.31 ms per forward, B = 160 equal, B = 192 4.46 vs 4.29)
 #define HD_FUSE_MIN_ROWS 4800
+// fp16x3 mode: batches with fewer active rows than this run the node update as the three launches of k_node_split.hpp (32 x 32
+// output tiles, four K quarters per workgroup) instead of the fused k_node<..., F16> (one workgroup per 32 rows); bit-identical
+#define HD_NODE_SPLIT_MAX_ROWS 2048
 // topologies with at most this many edge tiles (a third more in fp32) run k_edge_split (one tile per workgroup, columns
 // over its four wavefronts) instead of k_edge (one tile per wavefront); bit-identical, see k_edge_split.hpp
 #define HD_SPLIT_MAX_TILES 512
@@ -95,6 +98,7 @@ struct hd_handle {
     unsigned long long weights_gen, sched_gen;   // bumped when the packed weights / schedule tables are re-allocated
     int split_max_tiles;        // HD_SPLIT_MAX_TILES (a measurement build may override it from the environment)
     int fuse_min_rows;          // HD_FUSE_MIN_ROWS
+    int node_split_max_rows;    // HD_NODE_SPLIT_MAX_ROWS
     int mix_max_tiles;          // HD_MIX_MAX_TILES
     int mix_rounds;             // measurement build: force the number of whole-tile rounds of k_edge_mixed (-1 = rule)
     int n_cu;                   // compute units of the device
@@ -141,6 +145,7 @@ struct hd_topology {
     // workspace
     float *hbuf, *AB, *AB2, *Tb, *agg, *x0, *xcur, *part, *xpart, *eps;
     float *abmax, *abmax2;                     // fp16x3: [M_pad][2] row maxima of the AB / AB2 buffers
+    float *rowinfo;                            // fp16x3, split node chain: [M_pad][2] {max |h_r|, max |[h | agg]_r|} (k_node_split.hpp)
     // hd_sample_loop with use_graph: the captured step works on library-owned copies of z / context so that the
     // instantiated graph survives across calls (the caller's tensors move); one graph per topology
     float *zbuf, *ctxbuf;
@@ -261,6 +266,7 @@ extern "C" int hd_create(const hd_config* cfg, int device, hd_handle** out) {
     h->split_max_tiles = HD_SPLIT_MAX_TILES;
     h->mix_max_tiles = HD_MIX_MAX_TILES;
     h->fuse_min_rows = HD_FUSE_MIN_ROWS;
+    h->node_split_max_rows = HD_NODE_SPLIT_MAX_ROWS;
     h->mix_rounds = -1;
     {
         hipDeviceProp_t prop;
@@ -272,6 +278,7 @@ extern "C" int hd_create(const hd_config* cfg, int device, hd_handle** out) {
     { const char* e = getenv("HD_SPLIT_MAX_TILES"); if (e) h->split_max_tiles = atoi(e); }
     { const char* e = getenv("HD_MIX_MAX_TILES"); if (e) h->mix_max_tiles = atoi(e); }
     { const char* e = getenv("HD_FUSE_MIN_ROWS"); if (e) h->fuse_min_rows = atoi(e); }
+    { const char* e = getenv("HD_NODE_SPLIT_MAX_ROWS"); if (e) h->node_split_max_rows = atoi(e); }
     { const char* e = getenv("HD_MIX_ROUNDS"); if (e) h->mix_rounds = atoi(e); }
 #endif
     auto create_rest = [&]() -> int {        // every failure below leaves through hd_destroy (frees what exists)
@@ -723,14 +730,23 @@ static int arena_acquire(int device, size_t dev_bytes, size_t pinned_bytes, Aren
     return HD_OK;
 }
 
+// The pool is bounded by slots AND by bytes (kPoolBytes of device memory, which torch's caching allocator cannot see or
+// reclaim - ADVICE round 4): the oldest slots go first; a slot larger than the whole budget is never kept.
+static const size_t kPoolBytes = size_t(1) << 30;
 static void arena_release(ArenaSlot sl) {
-    ArenaSlot evict{};
+    std::vector<ArenaSlot> evict;
     {
         std::lock_guard<std::mutex> lk(g_pool_mu);
         g_pool.push_back(sl);
-        if (g_pool.size() > kPoolSlots) { evict = g_pool.front(); g_pool.erase(g_pool.begin()); }
+        size_t total = 0;
+        for (const auto& p : g_pool) total += p.dev_bytes;
+        while (!g_pool.empty() && (g_pool.size() > kPoolSlots || total > kPoolBytes)) {
+            total -= g_pool.front().dev_bytes;
+            evict.push_back(g_pool.front());
+            g_pool.erase(g_pool.begin());
+        }
     }
-    if (evict.dev) slot_free(evict);
+    for (auto& e : evict) slot_free(e);
 }
 
 extern "C" int hd_arena_pool_trim(void) {
@@ -964,7 +980,7 @@ extern "C" int hd_topology_create_s(hd_handle* h, const uint8_t* node_mask, cons
     const size_t f_Tb = carve((size_t)M_pad * H), f_agg = carve((size_t)M_pad * H);       // fp32 node chain of small batches; training
     const size_t f_x0 = carve((size_t)M_pad * 4), f_xcur = carve((size_t)M_pad * 4);
     const size_t f_part = carve((size_t)std::max(1, n_parts) * H), f_xpart = carve((size_t)std::max(1, n_parts) * 4);
-    const size_t f_abmax = carve((size_t)M_pad * 2), f_abmax2 = carve((size_t)M_pad * 2);
+    const size_t f_abmax = carve((size_t)M_pad * 2), f_abmax2 = carve((size_t)M_pad * 2), f_rowinfo = carve((size_t)M_pad * 2);
     const size_t f_eps = carve(BN * h->D), f_z = carve(BN * h->D), f_ctx = carve(BN * (size_t)std::max(1, h->cfg.context_node_nf));
     const size_t f_w2 = carve((size_t)H * H * 3 / 2), f_w2t = carve((size_t)H * H * 3 / 2);      // fp32 images or the 1.5 x bf16x6 ones
     auto build = [&]() -> int {
@@ -989,7 +1005,7 @@ extern "C" int hd_topology_create_s(hd_handle* h, const uint8_t* node_mask, cons
         float* ws = reinterpret_cast<float*>(base + table_bytes);
         t->hbuf = ws + f_h; t->AB = ws + f_AB; t->AB2 = ws + f_AB2; t->Tb = ws + f_Tb; t->agg = ws + f_agg; t->x0 = ws + f_x0;
         t->xcur = ws + f_xcur; t->part = ws + f_part; t->xpart = ws + f_xpart; t->eps = ws + f_eps; t->zbuf = ws + f_z;
-        t->abmax = ws + f_abmax; t->abmax2 = ws + f_abmax2;
+        t->abmax = ws + f_abmax; t->abmax2 = ws + f_abmax2; t->rowinfo = ws + f_rowinfo;
         t->ctxbuf = ws + f_ctx; t->w2img = ws + f_w2; t->w2timg = ws + f_w2t;
         t->node_of_host = new std::vector<int>(node_of);
         return HD_OK;
@@ -1197,6 +1213,36 @@ static void node_update(hd_handle* h, bool upd, int nab, const NodeArgs& a, hipS
     }
 }
 
+// fp16x3, few rows: the node update as three launches of 32 x 32 output tiles (k_node_split.hpp), bit-identical to the fused kernel
+template <int H, int PH, int CTW>
+static void launch_node_split_hc(const NodeSplitArgs& a, hipStream_t s) {
+    const int nrt = (a.M + 31) / 32;
+    const int per = (PH == 3 ? 2 * H / 32 * a.n_img : H / 32) / CTW;
+    const int lds = node_split_lds_bytes<H, PH, CTW>();
+    hipLaunchKernelGGL((k_node_split<H, PH, CTW>), dim3(8 * ((nrt + 7) / 8) * per), dim3(256), lds, s, a);
+}
+// one 32-column tile per workgroup: two (half the workgroups, half the redundant operand loads; same bits) were measured slower
+// at every size from 24 to 64 molecules (profiles/r05_node_split_sweep.log: 0.85 / 0.86 / 0.94 / 0.96 of the fused kernel's forward
+// time with one tile, 0.90 / 0.91 / 0.95 / 0.97 with two)
+template <int H, int PH>
+static void launch_node_split_h(const NodeSplitArgs& a, hipStream_t s) { launch_node_split_hc<H, PH, 1>(a, s); }
+template <int PH>
+static void launch_node_split(hd_handle* h, const NodeSplitArgs& a, hipStream_t s) {
+    ProfScope ps(h, s, 1);
+    if (h->H == 128) launch_node_split_h<128, PH>(a, s); else launch_node_split_h<256, PH>(a, s);
+}
+template <int H, int PH, int CTW>
+static int prepare_node_split_one() {
+    const int lds = node_split_lds_bytes<H, PH, CTW>();
+    HIP_TRY(hipFuncSetAttribute((const void*)k_node_split<H, PH, CTW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    return HD_OK;
+}
+template <int H>
+static int prepare_node_split_h() {
+    HD_TRY((prepare_node_split_one<H, 1, 1>())); HD_TRY((prepare_node_split_one<H, 2, 1>())); HD_TRY((prepare_node_split_one<H, 3, 1>()));
+    return HD_OK;
+}
+
 template <int H>
 static int edge_lds_bytes(bool x6 = false) {       // dynamic part: W2 double buffer + wave scratch (w_r/w_d/b2/wa are static)
     return (2 * (x6 ? 24 : 32) * H + 2 * H + 4 * 136) * 4;
@@ -1278,7 +1324,7 @@ static int launch_edge_h(hd_handle* h, bool coord, const EdgeArgs& a, hipStream_
         // at most 512 tiles: one tile per workgroup, columns split over its four wavefronts (k_edge_split.hpp; bit-identical
         // to k_edge in every precision mode, a quarter of the serial MFMA chain per wavefront)
         const int mode = prec;
-        // measured break-even (profiles/r02_split_sweep.log): between 490 and 654 tiles in the bf16 modes, between 654 and 870
+        // measured break-even (profiles/history/r02_split_sweep.log): between 490 and 654 tiles in the bf16 modes, between 654 and 870
         // in fp32 (the longer MFMA chain has more to gain from the split)
         if (a.n_tiles > 0 && a.n_tiles <= (mode == 0 ? h->split_max_tiles + h->split_max_tiles / 3 : h->split_max_tiles)) {
             const dim3 sgrid(a.n_tiles);
@@ -1385,8 +1431,8 @@ static int prepare_kernels(hd_handle* h) {
     switch (h->H) {
         case 32: HD_TRY(prepare_node_h<32>()); HD_TRY(prepare_edge_bwd_h<32>()); return prepare_edge_h<32>();
         case 64: HD_TRY(prepare_node_h<64>()); HD_TRY(prepare_edge_bwd_h<64>()); return prepare_edge_h<64>();
-        case 128: HD_TRY(prepare_node_h<128>()); HD_TRY(prepare_edge_bwd_h<128>()); return prepare_edge_h<128>();
-        default: HD_TRY(prepare_node_h<256>()); HD_TRY(prepare_edge_bwd_h<256>()); return prepare_edge_h<256>();
+        case 128: HD_TRY(prepare_node_h<128>()); HD_TRY(prepare_node_split_h<128>()); HD_TRY(prepare_edge_bwd_h<128>()); return prepare_edge_h<128>();
+        default: HD_TRY(prepare_node_h<256>()); HD_TRY(prepare_node_split_h<256>()); HD_TRY(prepare_edge_bwd_h<256>()); return prepare_edge_h<256>();
     }
 }
 
@@ -1415,6 +1461,8 @@ static int forward_impl(hd_handle* h, hd_topology* t, const float* xh, const flo
             a.xh = xh; a.t = tt; a.ctx = context; a.node_of = t->node_of; a.nmask = t->nmask;
             a.embT = W + h->embT; a.emb_b = W + h->emb_b; a.h = t->hbuf; a.x0 = t->x0; a.xcur = t->xcur;
             a.nanflag = h->d_nanflag;
+            // fp16x3, few rows: the AB-only launch of k_node_split accumulates the row maxima of AB with an atomic max
+            a.zero_max = (h->node_mode == 3 && M < h->node_split_max_rows && h->edge_mode == 3) ? t->abmax : nullptr;
             a.M = M; a.N = t->N; a.D = h->D; a.F = h->F; a.C = c.context_node_nf; a.H = H;
             a.t_stride = (t_numel == 1) ? 0 : 1; a.cond_time = c.condition_time;
             const long long total = (long long)M * (H / 4);
@@ -1455,10 +1503,29 @@ static int forward_impl(hd_handle* h, hd_topology* t, const float* xh, const flo
             for (int q = 0; q < nab; ++q) { g.Bimg[q] = W + nxt[q]->ab_gimg; g.bias[q] = W + nxt[q]->ab_bias; g.C[q] = dst[q]; }
             gemm_r16(h, EPI_BIAS, false, g, s);
         };
+        // fp16x3, few rows: the fused kernel's chain per 32-row workgroup (20 - 27 us, a weight stream through one CU) is not hidden
+        // when only a few workgroups exist; k_node_split spreads every phase's columns over workgroups (bit-identical)
+        const bool nsplit = h->node_mode == 3 && M < h->node_split_max_rows;
+        auto split_args = [&]() {
+            NodeSplitArgs a;
+            std::memset(&a, 0, sizeof(a));
+            a.h_in = t->hbuf; a.h_out = t->hbuf; a.part = t->part; a.pstart = t->pstart; a.nmask = t->nmask; a.norm = agg_norm(c, t);
+            a.T = t->Tb; a.rowinfo = t->rowinfo; a.M = M; a.n_img = 1;
+            return a;
+        };
+        auto split_ab = [&](NodeSplitArgs& a, int q, const LayerW& nw, float* dst) {
+            a.Wimg[q] = W + nw.ab_img; a.bias[q] = W + nw.ab_bias; a.winv[q] = 1.0f / nw.abs_; a.ABout[q] = dst;
+            a.ABmax[q] = h->edge_mode == 3 ? (dst == t->AB ? t->abmax : t->abmax2) : nullptr;
+        };
         {
             const LayerW* first[2] = {&h->gcl[0], nullptr};
             float* dst[2] = {t->AB, nullptr};
-            if (fused) {
+            if (nsplit) {
+                NodeSplitArgs a = split_args();
+                split_ab(a, 0, h->gcl[0], t->AB);
+                a.upd = 0;                   // (the row maxima start from the zeros k_node_init left)
+                launch_node_split<3>(h, a, s);
+            } else if (fused) {
                 NodeArgs a = node_args();
                 set_ab(a, 0, h->gcl[0], t->AB);
                 node_update(h, false, 1, a, s);
@@ -1498,7 +1565,18 @@ static int forward_impl(hd_handle* h, hd_topology* t, const float* xh, const flo
                         nxt[0] = &h->coord[i];
                         if (i + 1 < c.n_layers) { nxt[1] = &h->gcl[(size_t)(i + 1) * S]; nab = 2; }
                     }
-                    if (fused) {
+                    if (nsplit) {
+                        NodeSplitArgs a = split_args();
+                        a.w3l1 = w.w3l1; a.w4l1 = w.w4l1; a.b3max = w.b3max; a.b4max = w.b4max;
+                        NodeSplitArgs p1 = a, p2 = a, p3 = a;
+                        p1.Wimg[0] = W + w.w3_img; p1.bias[0] = W + w.b3; p1.winv[0] = 1.0f / w.w3s;
+                        launch_node_split<1>(h, p1, s);
+                        p2.Wimg[0] = W + w.w4_img; p2.bias[0] = W + w.b4; p2.winv[0] = 1.0f / w.w4s;
+                        p3.n_img = nab; p3.upd = 1;
+                        for (int q = 0; q < nab; ++q) { split_ab(p3, q, *nxt[q], dst[q]); p2.zero_max[q] = p3.ABmax[q]; }
+                        launch_node_split<2>(h, p2, s);
+                        launch_node_split<3>(h, p3, s);
+                    } else if (fused) {
                         NodeArgs a = node_args();
                         a.W3img = W + w.w3_img; a.b3 = W + w.b3; a.W4img = W + w.w4_img; a.b4 = W + w.b4;
                         if (h->node_mode == 3) {
@@ -2145,11 +2223,17 @@ static int dw2_impl(const char* who, int device, int rows, int H, const float* G
     slabs = (rows + kslab - 1) / kslab;
     Dw2Args a;
     a.G = G2; a.P = P; a.ws = ws; a.rows = rows; a.kslab = kslab;
-    static bool prepared = false;
-    if (!prepared) {
-        HIP_TRY(hipFuncSetAttribute((const void*)k_dw2_x6<256>, hipFuncAttributeMaxDynamicSharedMemorySize, dw2_lds_bytes<256>()));
-        HIP_TRY(hipFuncSetAttribute((const void*)k_dw2_x6<128>, hipFuncAttributeMaxDynamicSharedMemorySize, dw2_lds_bytes<128>()));
-        prepared = true;
+    {   // the dynamic-LDS limit is a per-DEVICE attribute: prepared once per device, under a lock (autograd's backward threads
+        // may call this concurrently)
+        static std::mutex mu;
+        static unsigned long long prepared_mask = 0;
+        std::lock_guard<std::mutex> lk(mu);
+        const unsigned long long bit = 1ull << (device & 63);
+        if (!(prepared_mask & bit)) {
+            HIP_TRY(hipFuncSetAttribute((const void*)k_dw2_x6<256>, hipFuncAttributeMaxDynamicSharedMemorySize, dw2_lds_bytes<256>()));
+            HIP_TRY(hipFuncSetAttribute((const void*)k_dw2_x6<128>, hipFuncAttributeMaxDynamicSharedMemorySize, dw2_lds_bytes<128>()));
+            prepared_mask |= bit;
+        }
     }
     if (H == 256) hipLaunchKernelGGL((k_dw2_x6<256>), dim3(slabs), dim3(512), dw2_lds_bytes<256>(), s, a);
     else hipLaunchKernelGGL((k_dw2_x6<128>), dim3(slabs), dim3(512), dw2_lds_bytes<128>(), s, a);

@@ -653,7 +653,7 @@ HD_DEVINL void edge_tile_body(const EdgeArgs& a, float* smem, float* wrd_s, cons
     if constexpr (ABL & 16) ts2 = __builtin_readcyclecounter();
     if (!tile_ok) return;                  // padding tile of the last workgroup: nothing to store
     // (Priority experiments - s_setprio raised for the VALU-only prologue / epilogue, for the MFMA loop, or both - were
-    // all null within +-0.5 % on both precisions: profiles/r02_ablate_fp32.log.)
+    // all null within +-0.5 % on both precisions: profiles/history/r02_ablate_fp32.log.)
     if constexpr (ABL & 1) {
         float sacc = 0.f;
 #pragma unroll

@@ -19,6 +19,7 @@ struct InitArgs {
     float* x0;              // [M_pad][4]
     float* xcur;            // [M_pad][4]
     int* nanflag;           // reset here (first kernel of a forward), raised by k_post1, consumed by k_post2
+    float* zero_max;        // optional [M_pad][2]: row maxima the split node chain (k_node_split.hpp) accumulates with an atomic max
     int M, N, D, F, C, H, t_stride, cond_time;
 };
 
@@ -48,6 +49,7 @@ __global__ void k_node_init(InitArgs a) {
         const f32x4 v = {row[0] * m, row[1] * m, row[2] * m, 0.0f};
         *reinterpret_cast<f32x4*>(a.x0 + (size_t)i * 4) = v;
         *reinterpret_cast<f32x4*>(a.xcur + (size_t)i * 4) = v;
+        if (a.zero_max) { a.zero_max[2 * (size_t)i] = 0.f; a.zero_max[2 * (size_t)i + 1] = 0.f; }
     }
 }
 
@@ -292,12 +294,28 @@ struct NodeMma {
     }
     // Ap[p]: this lane's row of piece p of the A tile (head, [middle,] tail).  Two pieces: a_h b_h + a_l b_h + a_h b_l (bf16x3);
     // three pieces: a_h b_l + a_l b_h + a_m b_m + a_h b_m + a_m b_h + a_h b_h, small terms first (bf16x6, k_edge.hpp).
+    // F16: the K range is summed in four QUARTERS with their own accumulators, result = ((q0 + q1) + q2) + q3 - the order of
+    // k_node_split.hpp, whose four wavefronts per output tile own one quarter each (the two paths are bit-identical).  `acc`
+    // arrives zeroed in that mode (the bias joins in the un-scaling fma) and serves as q0.
+    static constexpr int NQ = F16 ? 4 : 1;
     static HD_DEVINL void run(f32x16 (&acc)[CTn], Ring& br, const __bf16* const (&Ap)[NP], const u32x4* Bl, int ct0, int CTG) {
+        static_assert(KS % NQ == 0, "whole k-steps per quarter");
+        f32x16 accq[NQ > 1 ? NQ - 1 : 1][CTn];
+        if constexpr (NQ > 1) {
+#pragma unroll
+            for (int q = 0; q < NQ - 1; ++q)
+#pragma unroll
+                for (int c = 0; c < CTn; ++c)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) accq[q][c][r] = 0.f;
+        }
         bf16x8_t a[NP];
 #pragma unroll
         for (int p = 0; p < NP; ++p) a[p] = *reinterpret_cast<const bf16x8_t*>(Ap[p]);
         static_for<0, KS>([&](auto S) {
             constexpr int s = decltype(S)::value, slot = s % PF;
+            constexpr int qi = s / (KS / NQ);
+            f32x16(&dst)[CTn] = *(qi == 0 ? &acc : &accq[qi > 0 ? qi - 1 : 0]);
             __builtin_amdgcn_sched_barrier(0);
             bf16x8_t an[NP];
 #pragma unroll
@@ -315,8 +333,8 @@ struct NodeMma {
             auto term = [&](int pa, int pb) {
 #pragma unroll
                 for (int c = 0; c < CTn; ++c) {
-                    if constexpr (F16) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[pa]), __builtin_bit_cast(f16x8, b[c][pb]), acc[c], 0, 0, 0);
-                    else acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa], b[c][pb], acc[c], 0, 0, 0);
+                    if constexpr (F16) dst[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[pa]), __builtin_bit_cast(f16x8, b[c][pb]), dst[c], 0, 0, 0);
+                    else dst[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa], b[c][pb], dst[c], 0, 0, 0);
                 }
             };
             if constexpr (NP == 2) { term(0, 0); term(1, 0); term(0, 1); }
@@ -326,6 +344,12 @@ struct NodeMma {
             for (int p = 0; p < NP; ++p) a[p] = an[p];
         });
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (NQ > 1) {
+#pragma unroll
+            for (int c = 0; c < CTn; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[c][r] = ((acc[c][r] + accq[0][c][r]) + accq[1][c][r]) + accq[2][c][r];
+        }
     }
 };
 

@@ -17,6 +17,7 @@
 #pragma once
 #include "common.hpp"
 #include "k_node.hpp"
+#include "k_node_split.hpp"
 #include "k_gemm_r16.hpp"
 #include "k_edge.hpp"
 #include "k_edge_split.hpp"

@@ -138,6 +138,16 @@ def masks_to_host(node_mask: torch.Tensor, edge_mask: Optional[torch.Tensor], B:
     return np.ascontiguousarray(both[:B * N]), np.ascontiguousarray(both[B * N:])
 
 
+def release_cached_memory() -> None:
+    """Frees the device arenas (and their pinned twins) the library keeps for recycled topologies - memory torch's caching
+    allocator cannot see.  The counterpart of torch.cuda.empty_cache(): call it before a phase that needs the room; the pool
+    refills on demand.  (hd_arena_pool_trim; also called when a dynamics module releases its handle.)"""
+    try:
+        _lib.load().hd_arena_pool_trim()
+    except Exception:
+        pass
+
+
 _PIN_RING: Dict[Tuple, list] = {}
 _PIN_DEPTH = 4
 
@@ -154,15 +164,20 @@ def _to_device_async(t: torch.Tensor, device: torch.device) -> torch.Tensor:
     if t.device.type != "cpu":
         return t.to(device)
     dev = torch.device(device)
-    key = (tuple(t.shape), t.dtype, str(dev))
+    nbytes = t.numel() * t.element_size()
+    # rings are keyed by a rounded-up BYTE size, not by shape: a loader that pads every batch to its own n_max yields dozens of
+    # shapes per epoch, and a ring per shape would keep evicting and re-allocating pinned memory (hipHostMalloc waits for the
+    # device - the stall this function exists to avoid).  Powers of two from 4 KiB: at most ~20 rings per device.
+    cap = 4096
+    while cap < nbytes:
+        cap *= 2
+    key = (cap, str(dev))
     ring = _PIN_RING.get(key)
     if ring is None:
-        if len(_PIN_RING) >= 64:                                    # shapes of a loop repeat; do not grow without bound
-            _PIN_RING.pop(next(iter(_PIN_RING)))
         ring = _PIN_RING[key] = [0, []]
     pos, slots = ring
     if len(slots) < _PIN_DEPTH:
-        slots.append([torch.empty(t.shape, dtype=t.dtype, pin_memory=True), None])
+        slots.append([torch.empty(cap, dtype=torch.uint8, pin_memory=True), None])
         slot = slots[-1]
     else:
         slot = slots[pos % _PIN_DEPTH]
@@ -170,9 +185,11 @@ def _to_device_async(t: torch.Tensor, device: torch.device) -> torch.Tensor:
         if slot[1] is not None:
             slot[1].synchronize()                                   # copy issued _PIN_DEPTH stagings ago: long done
     src = t.contiguous()
-    C.memmove(slot[0].data_ptr(), src.data_ptr(), src.numel() * src.element_size())
+    if nbytes:
+        C.memmove(slot[0].data_ptr(), src.data_ptr(), nbytes)
+    staged = slot[0][:nbytes].view(t.dtype).view(t.shape)
     with torch.cuda.device(dev):
-        out = slot[0].to(dev, non_blocking=True)
+        out = staged.to(dev, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(dev))
     slot[1] = ev
@@ -323,9 +340,10 @@ class EGNN_dynamics_QM9(nn.Module):
     @property
     def training_precision(self) -> str:
         """"fp32" (default): every kernel of a training step is exact fp32.  "bf16x6" (opt-in): the forward's per-edge H x H
-        contraction and the dense reduction dW2 = G2^T P run on the matrix cores proper in the fp32-ACCURATE three-way bf16 split
-        of the sampler's bf16x6 mode (six MFMAs per product, fp32 accumulation; hidden_nf >= 128) while the two backward
-        stages, the node-level GEMMs and the loss stay exact fp32 - this implementation's counterpart of the reference's
+        contraction, BOTH backward stages' contractions (the recomputed W2 P and dP = G2 W2) and the dense reduction
+        dW2 = G2^T P run on the matrix cores proper in the fp32-ACCURATE three-way bf16 split of the sampler's bf16x6 mode (six
+        MFMAs per product, fp32 accumulation; hidden_nf >= 128) while everything around them - first-layer recomputation,
+        SiLU and its derivative, the node-level GEMMs and the loss - stays exact fp32: this implementation's counterpart of the reference's
         mixed-precision training (apex O2, conf/trainer/default.yaml:4-5), without its loss of accuracy: gradients agree with
         the exact-fp32 step to ~1e-6 (tests/test_gpu_training.py)."""
         return getattr(self, "_training_precision", "fp32")
@@ -402,6 +420,7 @@ class EGNN_dynamics_QM9(nn.Module):
         if self._hd is not None:
             self._finalizer()
             self._hd = None
+            release_cached_memory()      # the topologies' arenas went back to the library's pool: hand them to the driver
 
     def canonical_blob(self) -> torch.Tensor:
         """Parameters flattened in registration order (== hierdiff_amd.weights.flatten_dynamics)."""

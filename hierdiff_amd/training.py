@@ -47,8 +47,9 @@ class _TrainTables:
         # flat index b*N + n of the compact node order, written on the device from the topology's own table (a host array
         # would reach the device through a pageable copy = a stream synchronisation per new topology)
         self.index = torch.empty(self.M, dtype=torch.int64, device=device)
-        with torch.cuda.device(device):
-            _lib.check(lib.hd_topology_nodes_device(topo.ptr, self.index.data_ptr(), _stream(device)), "hd_topology_nodes_device")
+        if self.M > 0:                  # a batch without a single unmasked node: nothing to index (an empty tensor has no address)
+            with torch.cuda.device(device):
+                _lib.check(lib.hd_topology_nodes_device(topo.ptr, self.index.data_ptr(), _stream(device)), "hd_topology_nodes_device")
         self.H = H
         self.device = device
 

@@ -1,6 +1,6 @@
 // EXPERIMENT (round 2), NOT part of the library: kept for the record, with its measurements.
 //   Result: bit-identical to k_edge (46 GPU parity / shard-equality tests green), but SLOWER: 305.6 us (GCL) / 285.2 us (COORD)
-//   against k_edge's 265.6 us at B = 256, N = 30, H = 256.  Ablations (gpurun_out -> profiles/r02_f32p_experiment.log): without
+//   against k_edge's 265.6 us at B = 256, N = 30, H = 256.  Ablations (gpurun_out -> profiles/history/r02_f32p_experiment.log): without
 //   the riding VALU work 223.5 us (the MFMA floor at the power-limited clock), without barrier / stream 296.9 us, without
 //   the forced MFMA / VALU interleave 300.3 us.  I.e. the VALU work adds its FULL issue time to the MFMA time: inside one
 //   wavefront nothing overlaps with v_mfma_f32_32x32x2_f32.  scratch/mb/coissue32.hip confirms it in isolation (same log):

@@ -1,4 +1,4 @@
-// EXPERIMENT (round 2), NOT part of the library: kept for the record, with its measurements (profiles/r02_x6p_experiment.log).
+// EXPERIMENT (round 2), NOT part of the library: kept for the record, with its measurements (profiles/history/r02_x6p_experiment.log).
 //   Result: bit-identical to k_edge<256, *, 2> (GPU parity / shard-equality tests green) and NOT faster: 173 us (GCL) / 164 us
 //   (COORD) with two W2 buffers, 178 / 171 us with three, against 153-165 us for k_edge<256, *, 2>.  Ablations of the
 //   three-buffer version: without the riding VALU work 126 us; without the W2 stream (barrier kept) 145 us; without the barrier

@@ -1,6 +1,6 @@
 // EXPERIMENT (round 2, not in the library): the fp32 node update of small batches as ONE launch on 16-row tiles and 16 x 16
 // accumulators, meant to replace the k_agg + 3 x k_gemm chain (36-46 us per update) below 6,144 active rows.
-// Result (profiles/r02_r16_sweep.log, scratch/r16_sweep.sh at the commit that carried it): BIT-IDENTICAL to k_node_f32 and
+// Result (profiles/history/r02_r16_sweep.log, scratch/r16_sweep.sh at the commit that carried it): BIT-IDENTICAL to k_node_f32 and
 // to the chain (59 bitwise / parity tests green) and SLOWER at every size - forward B=2 0.83 -> 1.29 ms, B=64 1.96 -> 2.35,
 // B=192 4.92 -> 5.69 - i.e. ~75 us per update.  Why: a workgroup pulls 1.3-1.8 MB of fp32 weights through ONE CU's L2 port;
 // with three 32-wide K chunks in flight per wavefront (96 KB per CU) against a >= 2 us path (the 24 MB of weights do not

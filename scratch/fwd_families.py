@@ -18,8 +18,11 @@ lib = _lib.load()
 rng = np.random.Generator(np.random.PCG64(2022))
 keys = np.array([k for k in HIST if k <= 48]); p = np.array([HIST[k] for k in keys], float)
 n3 = [int(v) for v in rng.choice(keys, size=256, p=p / p.sum())]
+only = os.environ.get("FAM_CASES")
 cases = [("B256_N30", [30] * 256, None), ("B64_N30", [30] * 64, None), ("geom256_pad48", n3, None), ("cfg5_B64_mol24", [30] * 64, "blk"),
          ("B128_N30", [30] * 128, None), ("B16_N30", [30] * 16, None), ("B2_N30", [30] * 2, None)]
+if only:
+    cases = [(f"B{b}_N30", [30] * int(b), None) for b in only.split(",")]
 for name, sizes, em_kind in cases:
     B, N = len(sizes), max(max(sizes), 30 if em_kind else 0)
     N = 48 if name.startswith("geom") else N

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerates the rocprofv3 evidence of round 2 under gpurun_out/prof_r02 (copy into profiles/ afterwards):
 #   per precision: kernel stats of a 50-timestep bench; FETCH_SIZE / WRITE_SIZE / SQ counter passes of a 3-timestep bench
-#   (each --pmc set in its own run, with --kernel-trace only), then profiles/r02_counters.json via summarize_profiles.py.
+#   (each --pmc set in its own run, with --kernel-trace only), then profiles/history/r02_counters.json via summarize_profiles.py.
 # usage: scratch/round_profiles.sh [tag]     (tag defaults to r02)
 export TMPDIR=/tmp
 cd /root/repo

@@ -421,6 +421,32 @@ def test_fp32_node_paths_agree_bitwise(H, L, B):
     assert torch.equal(big[:8], small)
 
 
+@pytest.mark.parametrize("H,L,B", [(256, 2, 100), (128, 2, 100), (256, 1, 90)])
+def test_fp16x3_node_paths_agree_bitwise(H, L, B):
+    """fp16x3 runs the node update fused (k_node<..., F16>: one launch, one workgroup per 32 rows) from 2,048 active rows on and
+    as the three launches of k_node_split below (32 x 32 output tiles over many workgroups, the four K quarters of a contraction
+    on four wavefronts: a batch of 2 - 64 molecules does not fill 256 CUs with a serial 20 - 27 us chain per row tile).  Both sum
+    every contraction as ((q0 + q1) + q2) + q3 over the same K quarters, range their FP16 operands by the same row bounds and
+    leave the same row maxima for the edge kernels, so a molecule's bits do not depend on the size of the batch it is sampled
+    in: B molecules (>= 2,600 rows, fused) against their first 30, 8 and 2 alone
+    (k_node_split), ragged sizes."""
+    from hierdiff_amd.weights import synthetic_state_dict
+    N = 30
+    sd_np = synthetic_state_dict(9, 0, H, L, 2, True, 518, 1.0)
+    dyn = build_dynamics(sd_np, H, L)
+    dyn.precision = "fp16x3"
+    n_list = [30, 17, 1, 24, 30, 9, 30, 28] + [30] * (B - 8)
+    xh, nm, em = orc.random_inputs(n_list, 8, 34, N)
+    xh, nm, em = xh.to(DEV), nm.to(DEV), em.to(DEV)
+    t = torch.linspace(0.05, 0.95, B, device=DEV).view(-1, 1)
+    big = dyn._forward(t, xh, nm, em, None, None)
+    assert dyn.topology(nm, em, B, N).info()["nodes"] >= 2048
+    assert torch.isfinite(big).all()
+    for k in (30, 8, 2):
+        small = dyn._forward(t[:k], xh[:k], nm[:k].contiguous(), em[:k].contiguous(), None, None)
+        assert torch.equal(big[:k], small), f"k={k}: max diff {(big[:k] - small).abs().max().item():.3e}"
+
+
 @pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("H,C_,general", [(256, 0, False), (128, 1, True)])
 def test_small_batch_edge_kernel_is_bit_identical(H, C_, general, precision):

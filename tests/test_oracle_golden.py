@@ -255,7 +255,7 @@ def test_long_chain_schedule_deviation_end_to_end():
     the recorded grid reproduces the reference's x / h; (2) the product's default schedule table (GammaNetwork evaluated
     once in float64, hierdiff_amd/noise_model.py:evaluate_gamma) differs from the recorded fp32 grid by < 1e-3 and moves the
     END of the 1000-step trajectory by 3.6e-3 (x) / 2.7e-3 (h) rel-L2 - the stated bound is 1e-2, the same size as the
-    reference's own host-to-host spread (profiles/r02_gamma_spread_*.txt); (3) the opt-in `schedule_eval = "fp32"`
+    reference's own host-to-host spread (profiles/history/r02_gamma_spread_*.txt); (3) the opt-in `schedule_eval = "fp32"`
     evaluation (a [B,1] column per grid value, like diffusion_qm9.py:376-379) is inside 5e-4 of the recorded grid on any
     host and reproduces it bit for bit on the host that generated the fixture."""
     from hierdiff_amd.noise_model import GammaNetwork, evaluate_gamma, evaluate_gamma_fp32
