@@ -36,9 +36,10 @@ static int fail(int code, const std::string& msg) {
 
 // ----------------------------------------------------------------------------- objects
 
-// fp32 mode: batches with fewer active rows than this run the node side as three k_gemm_r16 launches instead of the fused
-// k_node_f32 (profiles/r03_r16_sweep.log: B = 128 3.22 vs 3.31 ms per forward, B = 160 equal, B = 192 4.46 vs 4.29)
-#define HD_FUSE_MIN_ROWS 4800
+// fp32 mode: batches with fewer active rows than this run the node side as three launches (widths >= 128: k_node_split_f32,
+// narrower: k_gemm_r16) instead of the fused k_node_f32 (round 5, profiles/r05_f32_fuse_threshold.log, ms per forward chain vs
+// fused: B = 128 3.10 vs 3.27, B = 160 3.73 vs 3.78, B = 192 4.28 vs 4.25, B = 224 4.88 vs 4.74)
+#define HD_FUSE_MIN_ROWS 5400
 // fp16x3 mode: batches with fewer active rows than this run the node update as the three launches of k_node_split.hpp (32 x 32
 // output tiles, four K quarters per workgroup) instead of the fused k_node<..., F16> (one workgroup per 32 rows); bit-identical
 #define HD_NODE_SPLIT_MAX_ROWS 2048
@@ -99,6 +100,7 @@ struct hd_handle {
     int split_max_tiles;        // HD_SPLIT_MAX_TILES (a measurement build may override it from the environment)
     int fuse_min_rows;          // HD_FUSE_MIN_ROWS
     int node_split_max_rows;    // HD_NODE_SPLIT_MAX_ROWS
+    int f32_split;              // 1: the fp32 small-row node chain of widths >= 128 is k_node_split_f32 (0, measurement build: k_gemm_r16)
     int mix_max_tiles;          // HD_MIX_MAX_TILES
     int mix_rounds;             // measurement build: force the number of whole-tile rounds of k_edge_mixed (-1 = rule)
     int n_cu;                   // compute units of the device
@@ -267,6 +269,7 @@ extern "C" int hd_create(const hd_config* cfg, int device, hd_handle** out) {
     h->mix_max_tiles = HD_MIX_MAX_TILES;
     h->fuse_min_rows = HD_FUSE_MIN_ROWS;
     h->node_split_max_rows = HD_NODE_SPLIT_MAX_ROWS;
+    h->f32_split = 1;
     h->mix_rounds = -1;
     {
         hipDeviceProp_t prop;
@@ -279,6 +282,7 @@ extern "C" int hd_create(const hd_config* cfg, int device, hd_handle** out) {
     { const char* e = getenv("HD_MIX_MAX_TILES"); if (e) h->mix_max_tiles = atoi(e); }
     { const char* e = getenv("HD_FUSE_MIN_ROWS"); if (e) h->fuse_min_rows = atoi(e); }
     { const char* e = getenv("HD_NODE_SPLIT_MAX_ROWS"); if (e) h->node_split_max_rows = atoi(e); }
+    { const char* e = getenv("HD_F32_SPLIT"); if (e) h->f32_split = atoi(e); }
     { const char* e = getenv("HD_MIX_ROUNDS"); if (e) h->mix_rounds = atoi(e); }
 #endif
     auto create_rest = [&]() -> int {        // every failure below leaves through hd_destroy (frees what exists)
@@ -1237,8 +1241,29 @@ static int prepare_node_split_one() {
     HIP_TRY(hipFuncSetAttribute((const void*)k_node_split<H, PH, CTW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     return HD_OK;
 }
+// exact fp32, widths >= 128, below HD_FUSE_MIN_ROWS rows: the same three launches on k_node_f32's arithmetic (k_node_split_f32)
+template <int H, int PH>
+static void launch_node_split_f32_h(const NodeSplitArgs& a, hipStream_t s) {
+    const int nrt = (a.M + 31) / 32;
+    const int per = (PH == 3 ? 2 * H / 32 * a.n_img : H / 32);
+    const int lds = node_split_f32_lds_bytes<H, PH>();
+    hipLaunchKernelGGL((k_node_split_f32<H, PH>), dim3(8 * ((nrt + 7) / 8) * per), dim3(256), lds, s, a);
+}
+template <int PH>
+static void launch_node_split_f32(hd_handle* h, const NodeSplitArgs& a, hipStream_t s) {
+    ProfScope ps(h, s, 1);
+    if (h->H == 128) launch_node_split_f32_h<128, PH>(a, s); else launch_node_split_f32_h<256, PH>(a, s);
+}
+template <int H, int PH>
+static int prepare_node_split_f32_one() {
+    const int lds = node_split_f32_lds_bytes<H, PH>();
+    HIP_TRY(hipFuncSetAttribute((const void*)k_node_split_f32<H, PH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    return HD_OK;
+}
+
 template <int H>
 static int prepare_node_split_h() {
+    HD_TRY((prepare_node_split_f32_one<H, 1>())); HD_TRY((prepare_node_split_f32_one<H, 2>())); HD_TRY((prepare_node_split_f32_one<H, 3>()));
     HD_TRY((prepare_node_split_one<H, 1, 1>())); HD_TRY((prepare_node_split_one<H, 2, 1>())); HD_TRY((prepare_node_split_one<H, 3, 1>()));
     return HD_OK;
 }
@@ -1506,6 +1531,8 @@ static int forward_impl(hd_handle* h, hd_topology* t, const float* xh, const flo
         // fp16x3, few rows: the fused kernel's chain per 32-row workgroup (20 - 27 us, a weight stream through one CU) is not hidden
         // when only a few workgroups exist; k_node_split spreads every phase's columns over workgroups (bit-identical)
         const bool nsplit = h->node_mode == 3 && M < h->node_split_max_rows;
+        // exact fp32, widths >= 128, below HD_FUSE_MIN_ROWS: k_node_split_f32 (bit-identical to k_node_f32) instead of k_gemm_r16
+        const bool fsplit = h->node_mode == 0 && M < h->fuse_min_rows && H >= 128 && h->f32_split;
         auto split_args = [&]() {
             NodeSplitArgs a;
             std::memset(&a, 0, sizeof(a));
@@ -1525,6 +1552,10 @@ static int forward_impl(hd_handle* h, hd_topology* t, const float* xh, const flo
                 split_ab(a, 0, h->gcl[0], t->AB);
                 a.upd = 0;                   // (the row maxima start from the zeros k_node_init left)
                 launch_node_split<3>(h, a, s);
+            } else if (fsplit) {
+                NodeSplitArgs a = split_args();
+                a.Wimg[0] = W + h->gcl[0].ab_img; a.bias[0] = W + h->gcl[0].ab_bias; a.ABout[0] = t->AB; a.upd = 0;
+                launch_node_split_f32<3>(h, a, s);
             } else if (fused) {
                 NodeArgs a = node_args();
                 set_ab(a, 0, h->gcl[0], t->AB);
@@ -1576,6 +1607,15 @@ static int forward_impl(hd_handle* h, hd_topology* t, const float* xh, const flo
                         for (int q = 0; q < nab; ++q) { split_ab(p3, q, *nxt[q], dst[q]); p2.zero_max[q] = p3.ABmax[q]; }
                         launch_node_split<2>(h, p2, s);
                         launch_node_split<3>(h, p3, s);
+                    } else if (fsplit) {
+                        NodeSplitArgs p1 = split_args(), p2 = split_args(), p3 = split_args();
+                        p1.Wimg[0] = W + w.w3_img; p1.bias[0] = W + w.b3;
+                        launch_node_split_f32<1>(h, p1, s);
+                        p2.Wimg[0] = W + w.w4_img; p2.bias[0] = W + w.b4;
+                        launch_node_split_f32<2>(h, p2, s);
+                        p3.n_img = nab; p3.upd = 1;
+                        for (int q = 0; q < nab; ++q) { p3.Wimg[q] = W + nxt[q]->ab_img; p3.bias[q] = W + nxt[q]->ab_bias; p3.ABout[q] = dst[q]; }
+                        launch_node_split_f32<3>(h, p3, s);
                     } else if (fused) {
                         NodeArgs a = node_args();
                         a.W3img = W + w.w3_img; a.b3 = W + w.b3; a.W4img = W + w.w4_img; a.b4 = W + w.b4;

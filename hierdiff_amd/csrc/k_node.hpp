@@ -722,7 +722,10 @@ __device__ long long hd_ntrace[512 * 8 * HD_NTRACE_STAMPS];
 //   * the 32-row activation tile lives in LDS as fp32, row stride K+4 floats (conflict-free ds_read_b128);
 //   * weights go L2 -> registers in fragment order, per 32-wide K chunk and column tile [4 q][64 lanes][4 j] floats with
 //     k = 32 s + 16 (lane>>5) + 4 q + j, col = 32 ct + (lane&31)   (pack_node_b_f32), a ring of PF chunks per wavefront.
-template <int KS, int CTn, int CTW, int PF, int NCT>
+// NQ = 4 (widths >= 128, round 5): the K range is summed in four QUARTERS with their own accumulators, result = ((q0 + q1) + q2) + q3 -
+// the order of k_node_split_f32 (k_node_split.hpp), whose four wavefronts per output tile own one quarter each.  `acc` arrives
+// zeroed and serves as q0.  NQ = 1: one chain (narrow widths, whose small-batch twin is k_gemm_r16).
+template <int KS, int CTn, int CTW, int PF, int NCT, int NQ = 1>
 struct NodeMmaF {
     typedef u32x4 Ring[PF][CTn][4];
     template <int s, int slot>
@@ -740,11 +743,23 @@ struct NodeMmaF {
         __builtin_amdgcn_sched_barrier(0);
     }
     static HD_DEVINL void run(f32x16 (&acc)[CTn], Ring& br, const float* Arow, const u32x4* Bl, int ct0, int CTG) {
+        static_assert(KS % NQ == 0, "whole K chunks per quarter");
+        f32x16 accq[NQ > 1 ? NQ - 1 : 1][CTn];
+        if constexpr (NQ > 1) {
+#pragma unroll
+            for (int q = 0; q < NQ - 1; ++q)
+#pragma unroll
+                for (int c = 0; c < CTn; ++c)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) accq[q][c][r] = 0.f;
+        }
         f32x4 a[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) a[q] = *reinterpret_cast<const f32x4*>(Arow + 4 * q);
         static_for<0, KS>([&](auto S) {
             constexpr int s = decltype(S)::value, slot = s % PF;
+            constexpr int qi = s / (KS / NQ);
+            f32x16(&dst)[CTn] = *(qi == 0 ? &acc : &accq[qi > 0 ? qi - 1 : 0]);
             __builtin_amdgcn_sched_barrier(0);
             f32x4 an[4];
 #pragma unroll
@@ -764,12 +779,18 @@ struct NodeMmaF {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int c = 0; c < CTn; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][j], b[c][q][j], acc[c], 0, 0, 0);
+                    for (int c = 0; c < CTn; ++c) dst[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][j], b[c][q][j], dst[c], 0, 0, 0);
             if constexpr (s + PF < KS) load<s + PF, slot>(br, Bl, ct0, CTG);
 #pragma unroll
             for (int q = 0; q < 4; ++q) a[q] = an[q];
         });
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (NQ > 1) {
+#pragma unroll
+            for (int c = 0; c < CTn; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[c][r] = ((acc[c][r] + accq[0][c][r]) + accq[1][c][r]) + accq[2][c][r];
+        }
     }
 };
 
@@ -804,9 +825,13 @@ __global__ __launch_bounds__(64 * NW, 1) void k_node_f32(NodeArgs a) {
     const int row0 = rt * 32;
     HD_NSTAMP(0);
 
-    typedef NodeMmaF<KX / 32, CT, CT, PF12, NCT> M1;            // X W3^T      (UPD only)
-    typedef NodeMmaF<H / 32, CT, CT, PF12, NCT> M2;             // T W4^T      (UPD only)
-    typedef NodeMmaF<H / 32, 2 * CT, CT, PF3, 2 * NCT> M3;      // h' [W1a|W1b]^T
+    // widths >= 128 sum every contraction in four K quarters (NodeMmaF, bit-identical to k_node_split_f32); their AB phase then
+    // runs one H-wide half at a time (four quarter accumulators per column tile: two halves at once would not fit the registers)
+    constexpr int NQ = H >= 128 ? 4 : 1;
+    constexpr bool HALVES = NQ > 1;
+    typedef NodeMmaF<KX / 32, CT, CT, PF12, NCT, NQ> M1;            // X W3^T      (UPD only)
+    typedef NodeMmaF<H / 32, CT, CT, PF12, NCT, NQ> M2;             // T W4^T      (UPD only)
+    typedef NodeMmaF<H / 32, (HALVES ? CT : 2 * CT), CT, (HALVES ? 2 * PF3 : PF3), 2 * NCT, NQ> M3;      // h' [W1a|W1b]^T (HALVES: one half per run)
     typename M1::Ring br1;
     typename M2::Ring br2;
     typename M3::Ring br3;
@@ -945,14 +970,21 @@ __global__ __launch_bounds__(64 * NW, 1) void k_node_f32(NodeArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
         const u32x4* ABl = reinterpret_cast<const u32x4*>(a.ABimg[q]) + lane;
-        if (q > 0 || !UPD) {
+        if ((q > 0 && !HALVES) || !UPD) {                            // (HALVES: image q's first chunks were requested behind image q-1's last half)
             M3::prefetch(br3, ABl, ct0, NCT);
             if (!UPD) __syncthreads();                               // h tile complete
         }
-        M3::run(acc, br3, Nn + n * LDH + 16 * hh, ABl, ct0, NCT);
+        if constexpr (!HALVES) M3::run(acc, br3, Nn + n * LDH + 16 * hh, ABl, ct0, NCT);
         HD_NSTAMP(7 + 2 * q);
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
+            if constexpr (HALVES) {
+                // this half's contraction (its first chunks were requested before the previous half was staged)
+                f32x16(&ah)[CT] = *reinterpret_cast<f32x16(*)[CT]>(&acc[half * CT]);
+                M3::run(ah, br3, Nn + n * LDH + 16 * hh, ABl, ct0 + half * NCT, 0);
+                if (half == 0) M3::prefetch(br3, ABl, ct0 + NCT, 0);
+                else if (q + 1 < NAB) M3::prefetch(br3, reinterpret_cast<const u32x4*>(a.ABimg[q + 1 < NAB ? q + 1 : q]) + lane, ct0, 0);
+            }
             if (half || q) __syncthreads();                 // previous staging tile fully stored
 #pragma unroll
             for (int c = 0; c < CT; ++c) {

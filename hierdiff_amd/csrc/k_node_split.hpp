@@ -246,3 +246,132 @@ constexpr int node_split_lds_bytes() {
     const int planes = 2 * 32 * ((PH == 1 ? 2 * H : H) + 8) * 2, red = 4 * CTW * 16 * 64 * 4;
     return planes > red ? planes : red;
 }
+
+
+// ----------------------------------------------------------------------------- the same chain in exact fp32 (widths >= 128)
+// k_node_f32's arithmetic, bit for bit (it sums its contractions in the same four K quarters, NodeMmaF NQ = 4), for batches below
+// HD_FUSE_MIN_ROWS active rows: 32 x 32 output tiles over many workgroups, a quarter of the K range per wavefront
+// (v_mfma_f32_32x32x2_f32: 64 dependent instructions for K = 512 instead of the 128 of k_gemm_r16's 16 x 16 x 4 chain and the
+// 256 of an unsplit 32 x 32 x 2 one), all of a wavefront's weight fragments (k_node_f32's images: [32-wide K chunk][column tile]
+// [4 q][64 lanes][4 j]) requested at entry.  Narrow widths keep k_gemm_r16 (their fused kernel sums in one chain).
+template <int H, int PH>
+__global__ __launch_bounds__(256, 2) void k_node_split_f32(NodeSplitArgs a) {
+    constexpr int K = PH == 1 ? 2 * H : H;
+    constexpr int NCTW = (PH == 3 ? 2 * H : H) / 32;
+    constexpr int KC = K / 32, KQ = KC / 4;             // 32-wide K chunks, chunks per wavefront
+    static_assert(KC % 4 == 0, "four K quarters");
+    constexpr int LD = K + 4;                           // fp32 row stride (conflict-free ds_read_b128, as in k_node_f32)
+    extern __shared__ __attribute__((aligned(16))) char smem_s[];
+    float* X = reinterpret_cast<float*>(smem_s);        // [32][LD]
+    float* red = reinterpret_cast<float*>(smem_s);      // [4 quarters][16][64], over the operand tile once every wavefront is done with it
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hh = lane >> 5, n = lane & 31;
+    int rt, ct, img = 0;
+    {
+        const int nrt = (a.M + 31) >> 5;
+        const int per = NCTW * (PH == 3 ? a.n_img : 1);
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int q = nrt >> 3, r = nrt & 7;
+        const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        const int len = q + (xcd < r ? 1 : 0);
+        if (idx >= len * per) return;
+        rt = start + idx / per;
+        const int rem = idx % per;
+        if constexpr (PH == 3) { img = rem / NCTW; ct = rem % NCTW; } else ct = rem;
+    }
+    const int row0 = rt * 32;
+
+    const u32x4* Wl = reinterpret_cast<const u32x4*>(a.Wimg[img]) + lane;
+    u32x4 bf[KQ][4];
+#pragma unroll
+    for (int s = 0; s < KQ; ++s)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bf[s][q] = Wl[((size_t)((wave * KQ + s) * NCTW + ct) * 4 + q) * 64];
+    const float bias_v = a.bias[img][32 * ct + n];
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- operand tile -> LDS (k_node_f32 phase 0 / its hand-overs, same expressions)
+    {
+        constexpr int Q = H / 4, TPR = 8, NP = Q / TPR;
+        const int r = tid / TPR, cq = tid % TPR;
+        const int row = row0 + r;
+        if constexpr (PH == 1) {
+            int p0 = 0, p1 = 0;
+            if (row < a.M) { p0 = a.pstart[row]; p1 = a.pstart[row + 1]; }
+            f32x4 hv[NP];
+#pragma unroll
+            for (int u = 0; u < NP; ++u) hv[u] = *reinterpret_cast<const f32x4*>(a.h_in + (size_t)row * H + 4 * (cq + u * TPR));
+            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+            const bool has0 = p0 < p1, has1 = p0 + 1 < p1;
+            const float* s0 = a.part + (size_t)(has0 ? p0 : 0) * H;
+            const float* s1 = a.part + (size_t)(has1 ? p0 + 1 : 0) * H;
+            f32x4 g0[NP], g1[NP];
+#pragma unroll
+            for (int u = 0; u < NP; ++u) {
+                g0[u] = *reinterpret_cast<const f32x4*>(s0 + 4 * (cq + u * TPR));
+                g1[u] = *reinterpret_cast<const f32x4*>(s1 + 4 * (cq + u * TPR));
+            }
+#pragma unroll
+            for (int u = 0; u < NP; ++u) *reinterpret_cast<f32x4*>(X + r * LD + 4 * (cq + u * TPR)) = hv[u];
+#pragma unroll
+            for (int u = 0; u < NP; ++u) {
+                f32x4 v = z4;                        // parts ascending, then / norm (k_node_f32, k_agg)
+                if (has0) v += g0[u];
+                if (has1) v += g1[u];
+                for (int p = p0 + 2; p < p1; ++p) v += *reinterpret_cast<const f32x4*>(a.part + (size_t)p * H + 4 * (cq + u * TPR));
+                *reinterpret_cast<f32x4*>(X + r * LD + H + 4 * (cq + u * TPR)) = v / a.norm;
+            }
+        } else {
+            const float* src = PH == 2 ? a.T : (a.upd ? a.h_out : a.h_in);
+#pragma unroll
+            for (int u = 0; u < NP; ++u)
+                *reinterpret_cast<f32x4*>(X + r * LD + 4 * (cq + u * TPR)) = *reinterpret_cast<const f32x4*>(src + (size_t)row * H + 4 * (cq + u * TPR));
+        }
+    }
+    __syncthreads();
+
+    // ---- this wavefront's K quarter on its own accumulator (from zero): chunks ascending, q, j - k_node_f32's order
+    {
+        const float* Arow = X + n * LD + 16 * hh + 32 * (wave * KQ);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KQ; ++s) {
+            f32x4 av[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) av[q] = *reinterpret_cast<const f32x4*>(Arow + 32 * s + 4 * q);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 b = __builtin_bit_cast(f32x4, bf[s][q]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][j], b[j], acc, 0, 0, 0);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = 4 * wave + j;
+        const int R = (r & 3) + 8 * (r >> 2) + 4 * hh;
+        const int row = row0 + R, col = 32 * ct + n;
+        const float v = ((red[(0 * 16 + r) * 64 + lane] + red[(1 * 16 + r) * 64 + lane]) + red[(2 * 16 + r) * 64 + lane]) + red[(3 * 16 + r) * 64 + lane];
+        if (row >= a.M) continue;
+        if constexpr (PH == 1) a.T[(size_t)row * H + col] = silu_f(v + bias_v);
+        else if constexpr (PH == 2) a.h_out[(size_t)row * H + col] = (a.h_in[(size_t)row * H + col] + (v + bias_v)) * a.nmask[row];
+        else a.ABout[img][(size_t)row * 2 * H + col] = v + bias_v;
+    }
+}
+
+template <int H, int PH>
+constexpr int node_split_f32_lds_bytes() {
+    const int tile = 32 * ((PH == 1 ? 2 * H : H) + 4) * 4, red = 4 * 16 * 64 * 4;
+    return tile > red ? tile : red;
+}

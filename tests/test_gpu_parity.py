@@ -399,14 +399,15 @@ def test_fp16x3_node_path_by_width(H):
         assert rel_l2(out["fp16x3"].numpy(), out["fp32"].numpy()) < 2e-6
 
 
-@pytest.mark.parametrize("H,L,B", [(64, 2, 210), (256, 1, 170), (32, 2, 170)])
+@pytest.mark.parametrize("H,L,B", [(64, 2, 210), (256, 1, 190), (32, 2, 190), (128, 2, 190)])
 def test_fp32_node_paths_agree_bitwise(H, L, B):
     """fp32 mode runs the node side fused (k_node_f32: one launch per update, 32-row workgroups on 32 x 32 x 2 MFMAs) from
-    4,800 active rows on and as three k_gemm_r16 launches below (16-row workgroups on 16 x 16 x 4 MFMAs, the neighbour-sum
-    reduction folded into the first: small batches do not fill 256 CUs with a serial 50 us chain per row tile).  The two are
-    bit-identical by construction (the same fmaf chain per output element, bias added after the contraction), so a
-    molecule's bits do not depend on the size of the batch it is sampled in: B molecules (>= 5,100 rows, fused) against
-    their first 8 alone (240 rows, k_gemm_r16), narrow and production widths."""
+    5,400 active rows on and as three launches below: widths >= 128 k_node_split_f32 (32 x 32 output tiles, the four K quarters
+    of a contraction on four wavefronts - k_node_f32 sums in the same quarters), narrower widths k_gemm_r16 (16-row workgroups on
+    16 x 16 x 4 MFMAs, one chain like their fused kernel).  Small batches do not fill 256 CUs with a serial 50 us chain per row
+    tile.  Each pair is bit-identical by construction (the same fmaf chains per output element, bias added after the
+    contraction), so a molecule's bits do not depend on the size of the batch it is sampled in: B molecules (>= 5,700 rows,
+    fused) against their first 8 alone (240 rows), narrow and production widths."""
     from hierdiff_amd.weights import synthetic_state_dict
     N = 30
     sd_np = synthetic_state_dict(9, 0, H, L, 2, True, 515, 1.0)
