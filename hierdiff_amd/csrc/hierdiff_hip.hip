@@ -1324,6 +1324,7 @@ static bool launch_edge_ablated(hd_handle* h, const EdgeArgs& a, hipStream_t s) 
         case 30: run(std::integral_constant<int, 30>{}); return true;
         case 32: run(std::integral_constant<int, 32>{}); return true;
         case 64: run(std::integral_constant<int, 64>{}); return true;
+        case 128: run(std::integral_constant<int, 128>{}); return true;
         default: return false;
     }
 }

@@ -200,7 +200,8 @@ constexpr unsigned frag_off_x6(int p, int ct) { return (unsigned)((p * NCT + ct)
 // ABL: ablation switches for bottleneck hunting (never set in production launches; env HD_ABLATE, H=256 bf16x3 GCL):
 //   1 = skip the epilogue, 2 = skip operand generation (SiLU etc.), 4 = no per-chunk barrier / W2 streaming,
 //   8 = no AB row gathers, 16 = record per-wave cycle stamps + HW placement (hd_debug_edge_trace, scratch/edge_trace.py),
-//   32 = barrier kept, W2 stream dropped; 64 = W2 stream kept, barrier dropped (round 5: which half of "4" costs what)
+//   32 = barrier kept, W2 stream dropped; 64 = W2 stream kept, barrier dropped (round 5: which half of "4" costs what);
+//   128 = a quarter of the stream pieces
 //
 // One workgroup = one 128-edge workgroup-tile (4 wavefronts x 32 edges), two workgroups per CU.  Forms that were built and
 // measured slower: a persistent one that walks several tiles per workgroup (spilled); the pipelined one-wave-per-SIMD form of
@@ -218,7 +219,9 @@ HD_DEVINL void edge_tile_body(const EdgeArgs& a, float* smem, float* wrd_s, cons
     constexpr int NCH = H / KC;          // K chunks
     constexpr int CHF = PREC == 2 ? 24 * H : 32 * H;   // floats per W2 chunk image
     static_assert(CHF % 1024 == 0, "a chunk image is streamed in 1 KiB pieces, four waves");
-    constexpr int GL_PER_WAVE = CHF / (4 * 256);   // 1 KiB pieces per wave per chunk
+    // (ABL bit 128, measurement only: a quarter of the stream - what keeping the W2 heads resident and sharing the tails between
+    // eight wavefronts would leave; results are garbage, the time is what the DMA volume is worth)
+    constexpr int GL_PER_WAVE = (ABL & 128) ? CHF / (4 * 256) / 4 : CHF / (4 * 256);   // 1 KiB pieces per wave per chunk
     float* wbuf = smem;                   // [2][CHF]
     // w_r / w_d live in their own LDS object (wrd_s: [w_r | w_d | b2 | wa], staged once per workgroup): hipcc makes every
     // compiler-visible LDS read that may alias the destination of an in-flight global_load_lds wait for vmcnt(0) - with
