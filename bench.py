@@ -256,8 +256,42 @@ def timed_headline(model, precision, args, dev, rank, world, dist):
              "elapsed_max_s": round(elapsed, 4), "rank_elapsed_s": [round(v, 4) for v in rank_elapsed],
              "launch": "hipGraph replay" if model.use_graph else "plain launches"}
     if roofline:
+        sus = sustained_mfma(precision, dev)
+        if sus:
+            # the chip's own rate for this mode's matrix instruction under its power budget, measured right here (hd_mfma_probe:
+            # register operands, random data, two wavefronts per SIMD): what `frac` (against the guide's dense peak at 2.4 GHz)
+            # cannot be, and what the kernel's matrix work is priced against in DESIGN.md section 12b
+            m = MFMAS_PER_PRODUCT[precision]
+            sus["executed_frac_of_sustained"] = round(m * roofline["achieved"] / sus["tflops"], 4)
+            sus["matrix_time_us_per_launch"] = round(m * roofline["flops_per_launch"] / (sus["tflops"] * 1e12) * 1e6, 1)
+            roofline["sustained"] = sus
         block["roofline"] = roofline
     return block
+
+
+def sustained_mfma(precision: str, dev) -> dict:
+    """TFLOP/s the chip sustains when every SIMD streams the mode's MFMA opcode from registers (include/hierdiff_hip.h:
+    hd_mfma_probe); {} if the probe is unavailable.  ~30 ms, outside every timed region."""
+    from hierdiff_amd import _lib
+    try:
+        lib = _lib.load()
+        kind = {"fp32": 0, "fp16x3": 1, "bf16x3": 2, "bf16x6": 2}[precision]
+        g = torch.Generator().manual_seed(11)
+        data = (torch.rand(1024, generator=g) * 2 - 1).to(dev)
+        n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+        scratch = torch.empty(2 * 256 * n_cu, device=dev, dtype=torch.float32)
+        ns = C.c_double()
+        iters = 3000 if kind == 0 else 12000
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        _lib.check(lib.hd_mfma_probe(idx, kind, data.data_ptr(), scratch.data_ptr(), iters, C.byref(ns),
+                                     torch.cuda.current_stream(dev).cuda_stream), "hd_mfma_probe")
+        flop_per_mfma = 2.0 * 32 * 32 * (2 if kind == 0 else 16)
+        tf = flop_per_mfma / (ns.value * 1e-9) * 4 * n_cu / 1e12
+        return {"instruction": ["v_mfma_f32_32x32x2_f32", "v_mfma_f32_32x32x16_f16", "v_mfma_f32_32x32x16_bf16"][kind],
+                "ns_per_mfma_per_simd": round(ns.value, 2), "tflops": round(tf, 1),
+                "what": "register-operand MFMA loop on every SIMD, 2 wavefronts per SIMD, random operands, measured in this process"}
+    except Exception:               # a measurement aid must never fail the bench
+        return {}
 
 
 @torch.no_grad()

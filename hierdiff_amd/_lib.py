@@ -76,10 +76,11 @@ SIGNATURES = {
     "hd_philox_normal_host": (C.c_float, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]),
     "hd_profile_enable": (C.c_int, [_VP, C.c_int]),
     "hd_profile_read": (C.c_int, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
+    "hd_mfma_probe": (C.c_int, [C.c_int, C.c_int, _FP, _FP, C.c_int, C.POINTER(C.c_double), _VP]),
     "hd_debug_edge_trace": (C.c_int, [_VP, C.c_void_p, C.c_int]),
 }
 
-ABI_VERSION = 8          # HD_ABI_VERSION of include/hierdiff_hip.h
+ABI_VERSION = 9          # HD_ABI_VERSION of include/hierdiff_hip.h
 _lib: Optional[C.CDLL] = None
 
 

@@ -2497,6 +2497,40 @@ extern "C" int hd_sample_loop(hd_handle* h, hd_topology* topo, float* z, const f
     return HD_OK;
 }
 
+// ----------------------------------------------------------------------------- measurement aid: sustained MFMA rate
+extern "C" int hd_mfma_probe(int device, int kind, const float* in1024, float* scratch, int iters, double* ns_per_mfma_per_simd,
+                             void* stream) {
+    if (!in1024 || !scratch || !ns_per_mfma_per_simd) return fail(HD_E_INVALID, "hd_mfma_probe: null argument");
+    if (kind < 0 || kind > 2 || iters < 1) return fail(HD_E_INVALID, "hd_mfma_probe: kind must be 0 (fp32), 1 (fp16) or 2 (bf16), iters >= 1");
+    if (hd_device_count() <= device || device < 0) return fail(HD_E_HIP, "hd_mfma_probe: no such HIP device (is a GPU visible?)");
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t s = (hipStream_t)stream;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    const int n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    const dim3 grid(2 * n_cu), block(256);                 // two wavefronts per SIMD: the edge kernels' occupancy
+    auto launch = [&](int n) {
+        if (kind == 0) hipLaunchKernelGGL((k_mfma_probe<0>), grid, block, 0, s, in1024, scratch, n);
+        else if (kind == 1) hipLaunchKernelGGL((k_mfma_probe<1>), grid, block, 0, s, in1024, scratch, n);
+        else hipLaunchKernelGGL((k_mfma_probe<2>), grid, block, 0, s, in1024, scratch, n);
+    };
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    launch(iters);                                          // warm-up (clocks, code)
+    (void)hipEventRecord(e0, s);
+    launch(iters);
+    (void)hipEventRecord(e1, s);
+    const hipError_t se = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (se == hipSuccess) (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (se != hipSuccess) return fail(HD_E_HIP, std::string("hd_mfma_probe: ") + hipGetErrorString(se));
+    HIP_TRY(hipGetLastError());
+    *ns_per_mfma_per_simd = (double)ms * 1e6 / ((double)iters * 8 * 2);     // 8 MFMAs per iteration and wavefront, 2 wavefronts per SIMD
+    return HD_OK;
+}
+
 // ----------------------------------------------------------------------------- host RNG twin
 
 static inline void philox_round_h(uint32_t c[4], uint32_t k0, uint32_t k1) {

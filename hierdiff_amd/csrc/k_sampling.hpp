@@ -374,3 +374,41 @@ __global__ void k_advance(int* step, uint32_t* draw, float* t_cur, const float* 
     *draw = *draw + 1;
     *t_cur = tau[s + 1 >= 0 ? s + 1 : 0];
 }
+
+
+// ----------------------------------------------------------------------------- measurement aid: the matrix instruction's own rate
+// hd_mfma_probe (round 5): every SIMD of the chip streams one MFMA opcode from REGISTER operands on eight accumulators (no LDS, no
+// memory) - the rate the chip sustains for that instruction under its power budget, on the caller's data.  The edge kernels'
+// matrix time is priced against it: 19.7 ns per v_mfma_f32_32x32x16_f16 and SIMD at full occupancy, not the
+// 13.3 ns of 32 cycles at 2.4 GHz.  KIND 0: v_mfma_f32_32x32x2_f32, 1: v_mfma_f32_32x32x16_f16, 2: v_mfma_f32_32x32x16_bf16.
+template <int KIND>
+__global__ __launch_bounds__(256, 2) void k_mfma_probe(const float* in, float* out, int iters) {
+    const int lane = threadIdx.x & 63;
+    f32x16 acc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+    f16x8 ah, bh;
+    bf16x8 ab, bb;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        ah[i] = (_Float16)in[(lane * 8 + i) & 1023]; bh[i] = (_Float16)in[(lane * 8 + i + 512) & 1023];
+        ab[i] = (__bf16)in[(lane * 8 + i) & 1023]; bb[i] = (__bf16)in[(lane * 8 + i + 512) & 1023];
+    }
+    const float af = in[lane & 1023], bfv = in[(lane + 64) & 1023];
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            if constexpr (KIND == 0) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[c]) : "v"(af), "v"(bfv));
+            if constexpr (KIND == 1) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[c]) : "v"(ah), "v"(bh));
+            if constexpr (KIND == 2) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[c]) : "v"(ab), "v"(bb));
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[c][r];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}

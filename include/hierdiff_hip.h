@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define HD_ABI_VERSION 8
+#define HD_ABI_VERSION 9
 
 #define HD_OK 0
 #define HD_E_INVALID (-1)      /* bad argument / unsupported configuration */
@@ -318,6 +318,13 @@ float hd_philox_normal_host(uint64_t seed, uint64_t sample_id, uint32_t draw, ui
  * bracketed. */
 int hd_profile_enable(hd_handle* h, int on);
 int hd_profile_read(hd_handle* h, double* ms3, long long* launches3);
+
+/* Measurement aid (no reference counterpart; bench.py's `roofline.sustained`): the rate at which THIS chip, under its power budget,
+ * issues one matrix instruction when every SIMD streams it from register operands at the edge kernels' occupancy (two wavefronts per
+ * SIMD, eight accumulators, operands taken from `in1024` - pass random data, zeros clock higher).  kind 0: v_mfma_f32_32x32x2_f32,
+ * 1: v_mfma_f32_32x32x16_f16, 2: v_mfma_f32_32x32x16_bf16.  `scratch`: 2 * 256 * (number of CUs) device floats.  Runs the loop twice
+ * (warm-up, timed with HIP events on `stream`) and waits for it.  *ns_per_mfma_per_simd = elapsed / (MFMAs issued per SIMD). */
+int hd_mfma_probe(int device, int kind, const float* in1024, float* scratch, int iters, double* ns_per_mfma_per_simd, void* stream);
 
 /* Debug aid (no reference counterpart), live only in a measurement build of the library
  * (python -m hierdiff_amd.build --debug-kernels; the product build returns 0): per-wave cycle stamps of the
