@@ -1112,6 +1112,7 @@ static void launch_gemm(int epi, bool cat, const GemmArgs& g, hipStream_t s) {
     else if (cat) hipLaunchKernelGGL((k_gemm<WM, WN, CN, EPI_BIAS_SILU, true>), grid, block, 0, s, g);
     else if (epi == EPI_BIAS_SILU) hipLaunchKernelGGL((k_gemm<WM, WN, CN, EPI_BIAS_SILU, false>), grid, block, 0, s, g);
     else if (epi == EPI_BIAS) hipLaunchKernelGGL((k_gemm<WM, WN, CN, EPI_BIAS, false>), grid, block, 0, s, g);
+    else if (epi == EPI_EGCL_PRE) hipLaunchKernelGGL((k_gemm<WM, WN, CN, EPI_EGCL_PRE, false>), grid, block, 0, s, g);
     else hipLaunchKernelGGL((k_gemm<WM, WN, CN, EPI_RESID_MASK, false>), grid, block, 0, s, g);
 }
 
@@ -2100,20 +2101,32 @@ extern "C" int hd_egcl_forward(hd_egcl* g, hd_egcl_graph* t, const float* h, con
         a.Nc = Nc; a.nmask = nmask;
         return a;
     };
-    {   // node inputs
+    // Round 5, layers without context columns that update the coordinates (every layer of Edge_denoise): the caller's tensors are
+    // read and written in place of the packed copies - no k_egcl_node_in / k_egcl_node_out launch (the residual comes from `h`, the
+    // masked output goes straight to `h_out`, the coordinates leave with the sum over incoming edges) - and, for H-wide edge
+    // attributes, k_egcl_pre's expression is the epilogue of the edge-attribute GEMM.  Same expressions, same order: same bits.
+    const bool direct = ctx == 0 && c.coord_update && h_out != h && x_out != x;
+    const float* hsrc = direct ? h : t->hin;
+    const float* xsrc = direct ? x : t->x4;
+    const int xs = direct ? 3 : 4;
+    if (!direct) {   // node inputs
         EgclNodeInArgs a;
         a.h = h; a.x = x; a.hin = t->hin; a.hres = t->hres; a.x4 = t->x4; a.M = M; a.H = H; a.ctx = ctx;
         hipLaunchKernelGGL(k_egcl_node_in, blocks((long long)M * H), dim3(256), 0, s, a);
     }
-    egcl_gemm(g, EPI_BIAS, false, gemm_args(t->hin, H, H, H, nullptr, g->ab_img, g->ab_bias, t->AB, 2 * H, M, 2 * H, nullptr), s);
+    egcl_gemm(g, EPI_BIAS, false, gemm_args(hsrc, H, H, H, nullptr, g->ab_img, g->ab_bias, t->AB, 2 * H, M, 2 * H, nullptr), s);
     if (E > 0) {
-        if (wide) {
+        if (wide && direct) {
+            GemmArgs p = gemm_args(edge_attr, H, H, H, nullptr, g->w1e_img, g->zero_bias, t->P, H, E, H, nullptr);
+            p.erow = t->row; p.ecol = t->col; p.ABn = t->AB; p.xn = xsrc; p.xs = xs; p.geo = t->geo; p.geo_mode = c.geo; p.colv = W + g->w_r;
+            egcl_gemm(g, EPI_EGCL_PRE, false, p, s);
+        } else if (wide) {
             egcl_gemm(g, EPI_BIAS, false, gemm_args(edge_attr, H, H, H, nullptr, g->w1e_img, g->zero_bias, t->T1, H, E, H, nullptr), s);
         }
-        {
+        if (!(wide && direct)) {
             EgclPreArgs a;
             a.AB = t->AB; a.T1 = wide ? t->T1 : nullptr; a.ea = wide ? nullptr : edge_attr; a.w_e = W + g->w_e; a.w_r = W + g->w_r;
-            a.w_c = W + g->w_c; a.hin = t->hin; a.x = t->x4; a.row = t->row; a.col = t->col; a.P = t->P; a.geo = t->geo;
+            a.w_c = W + g->w_c; a.hin = hsrc; a.x = xsrc; a.xs = xs; a.row = t->row; a.col = t->col; a.P = t->P; a.geo = t->geo;
             a.E = E; a.H = H; a.De = De; a.ctx = ctx; a.geo_mode = c.geo;
             hipLaunchKernelGGL(k_egcl_pre, blocks((long long)E * (H / 4)), dim3(256), 0, s, a);
         }
@@ -2139,13 +2152,20 @@ extern "C" int hd_egcl_forward(hd_egcl* g, hd_egcl_graph* t, const float* h, con
         cs.ptr = t->cptr; cs.rows = t->crows; cs.M = M; cs.col0 = 0;
         cs.G = t->M1; cs.out = t->agg; cs.H = H; cs.ldo = H;
         cs.G2 = c.coord_update ? t->trans : nullptr; cs.out2 = t->xagg;      // the [E][4] translations in the same launch
+        if (direct) { cs.x_in = x; cs.x_out = x_out; cs.xmask = node_mask; }   // ... and k_egcl_node_out's coordinate line with them
         hipLaunchKernelGGL(k_csr_sum, blocks((long long)M * (H / 4 + (c.coord_update ? 1 : 0))), dim3(256), 0, s, cs);
     }
     // node model: h_new = (h + node_mlp([h | agg])) (* node_mask)
     const float* nm = node_mask ? node_mask : t->ones;
-    egcl_gemm(g, EPI_BIAS_SILU, true, gemm_args(t->hin, H, H, 2 * H, t->agg, g->wn1_img, g->bn1, t->Tn, H, M, H, nullptr), s);
-    if (!c.recurrent) HIP_TRY(hipMemsetAsync(t->hres, 0, (size_t)t->Mp * H * sizeof(float), s));
-    egcl_gemm(g, EPI_RESID_MASK, false, gemm_args(t->Tn, H, H, H, nullptr, g->wn2_img, g->bn2, t->hres, H, M, H, nm), s);
+    egcl_gemm(g, EPI_BIAS_SILU, true, gemm_args(hsrc, H, H, 2 * H, t->agg, g->wn1_img, g->bn1, t->Tn, H, M, H, nullptr), s);
+    if (direct) {
+        GemmArgs n2 = gemm_args(t->Tn, H, H, H, nullptr, g->wn2_img, g->bn2, h_out, H, M, H, nm);
+        n2.resid = h; n2.ldr = H; n2.resid_none = c.recurrent ? 0 : 1;
+        egcl_gemm(g, EPI_RESID_MASK, false, n2, s);
+    } else {
+        if (!c.recurrent) HIP_TRY(hipMemsetAsync(t->hres, 0, (size_t)t->Mp * H * sizeof(float), s));
+        egcl_gemm(g, EPI_RESID_MASK, false, gemm_args(t->Tn, H, H, H, nullptr, g->wn2_img, g->bn2, t->hres, H, M, H, nm), s);
+    }
     if (c.edge_update && E > 0) {
         // edge_mlp: E1 = SiLU([edge_feat | edge_attr] We1^T + radial w_er + be1);  edge_attr' = (E1 We2^T + be2) * edge_mask
         // (round 3: the radial column + SiLU and the final mask ride in the GEMM epilogues, and the second GEMM writes the caller's
@@ -2156,7 +2176,7 @@ extern "C" int hd_egcl_forward(hd_egcl* g, hd_egcl_graph* t, const float* h, con
         egcl_gemm(g, edge_mask ? EPI_BIAS_MASK : EPI_BIAS, false,
                   gemm_args(t->C1, H, H, H, nullptr, g->we2_img, g->be2, edge_attr_out, H, E, H, edge_mask), s);
     }
-    {
+    if (!direct) {
         EgclNodeOutArgs a;
         a.hnew = t->hres; a.hin = t->hin; a.x4 = t->x4; a.xagg = c.coord_update ? t->xagg : nullptr; a.nmask = node_mask;
         a.h_out = h_out; a.x_out = x_out; a.M = M; a.H = H; a.ctx = ctx;

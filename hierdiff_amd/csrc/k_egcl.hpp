@@ -26,6 +26,7 @@ struct EgclPreArgs {
     float* P;               // [E][H]
     float* geo;             // [E][4] = {cdiff_x, cdiff_y, cdiff_z, radial}
     int E, H, De, ctx, geo_mode;      // geo_mode: the message model's distance input is 1 / radial^2 (gcl.py:170-175)
+    int xs;                           // floats per coordinate row of `x` (4: the padded copy; 3: the caller's tensor, round 5)
 };
 
 __global__ void k_egcl_pre(EgclPreArgs a) {
@@ -34,8 +35,8 @@ __global__ void k_egcl_pre(EgclPreArgs a) {
     const int e = (int)(idx / q), c4 = (int)(idx - (long long)e * q);
     if (e >= a.E) return;
     const int r = a.row[e], c = a.col[e];
-    const f32x4 xr = *reinterpret_cast<const f32x4*>(a.x + (size_t)r * 4);
-    const f32x4 xc = *reinterpret_cast<const f32x4*>(a.x + (size_t)c * 4);
+    const float* xr = a.x + (size_t)r * a.xs;
+    const float* xc = a.x + (size_t)c * a.xs;
     const float dx = xr[0] - xc[0], dy = xr[1] - xc[1], dz = xr[2] - xc[2];
     const float radial = dx * dx + dy * dy + dz * dz;
     if (c4 == 0) {

@@ -61,7 +61,9 @@ __global__ void k_node_init(InitArgs a) {
 
 enum { EPI_BIAS = 0, EPI_BIAS_SILU = 1, EPI_RESID_MASK = 2,
        EPI_BIAS_MASK = 3,        // (acc + bias) * nmask[row]                                   (stage 2: new edge attributes * edge_mask)
-       EPI_RANK1_SILU = 4 };     // silu(rowv[row * rowv_stride] * colv[col] + (acc + bias))    (stage 2: the radial column of edge_mlp.0)
+       EPI_RANK1_SILU = 4,       // silu(rowv[row * rowv_stride] * colv[col] + (acc + bias))    (stage 2: the radial column of edge_mlp.0)
+       EPI_EGCL_PRE = 5 };       // silu(A[erow] + B[ecol] + radial w_r + (acc + bias)), radial / unit direction written on the way
+                                 // (stage 2, round 5: k_egcl_pre's expression in the epilogue of the edge-attribute GEMM)
 
 struct GemmArgs {
     const float* A;       // [M_pad][lda], columns k < K1
@@ -72,8 +74,16 @@ struct GemmArgs {
     float* C;             // [M_pad][ldc]
     int lda, ldc, K1, K, M, Nc;
     const float* rowv;    // EPI_RANK1_SILU: per-row scalar at rowv[row * rowv_stride] ...
-    const float* colv;    // ... times the per-column vector colv[Nc]
+    const float* colv;    // ... times the per-column vector colv[Nc]; EPI_EGCL_PRE: w_r
     int rowv_stride;
+    const float* resid;   // EPI_RESID_MASK: residual rows [M][ldr] (NULL: the destination itself, in place)
+    int ldr, resid_none;  // resid_none: no residual at all (stage 2, non-recurrent layer)
+    // EPI_EGCL_PRE (rows = edges): node tables and where the geometry of an edge goes
+    const int* erow; const int* ecol;     // [E] receiving / sending node of the edge
+    const float* ABn;     // [M][2 Nc]: cols < Nc: W1a h + b1; cols >= Nc: W1b h
+    const float* xn;      // [M][xs] coordinates
+    float* geo;           // [E][4] = {cdiff_x, cdiff_y, cdiff_z, radial}, written by the column tile 0 workgroups
+    int xs, geo_mode;
 };
 
 
@@ -216,7 +226,30 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm(GemmArgs g) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = silu_f(v[j]);
             }
-            if (EPI == EPI_RESID_MASK) v = (*dst + v) * g.nmask[row];
+            if (EPI == EPI_RESID_MASK) {
+                if (g.resid_none) v = v * g.nmask[row];                          // (0 + v) * mask: the same bits
+                else if (g.resid) v = (*reinterpret_cast<const f32x4*>(g.resid + (size_t)row * g.ldr + col) + v) * g.nmask[row];
+                else v = (*dst + v) * g.nmask[row];
+            }
+            if (EPI == EPI_EGCL_PRE) {              // k_egcl_pre's expressions, element by element, v = T1 row piece
+                const int er = g.erow[row], ec = g.ecol[row];
+                const float* xr = g.xn + (size_t)er * g.xs;
+                const float* xc = g.xn + (size_t)ec * g.xs;
+                const float dx = xr[0] - xc[0], dy = xr[1] - xc[1], dz = xr[2] - xc[2];
+                const float radial = dx * dx + dy * dy + dz * dz;
+                if (col == 0) {
+                    const float inv = 1.0f / (sqrtf(radial + 1e-8f) + 1.0f);
+                    *reinterpret_cast<f32x4*>(g.geo + (size_t)row * 4) = f32x4{dx * inv, dy * inv, dz * inv, radial};
+                }
+                f32x4 pre = *reinterpret_cast<const f32x4*>(g.ABn + (size_t)er * 2 * g.Nc + col) +
+                            *reinterpret_cast<const f32x4*>(g.ABn + (size_t)ec * 2 * g.Nc + g.Nc + col);
+                const f32x4 wr = *reinterpret_cast<const f32x4*>(g.colv + col);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pre[j] = __builtin_fmaf(g.geo_mode ? 1.0f / (radial * radial) : radial, wr[j], pre[j]);
+                pre += v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = silu_f(pre[j]);
+            }
             if (EPI == EPI_BIAS_MASK) v = v * g.nmask[row];
             if (EPI == EPI_RANK1_SILU) {            // k_egcl_ew<0>'s expression, element by element
                 const float rv = g.rowv[(size_t)row * g.rowv_stride];
