@@ -1862,7 +1862,7 @@ extern "C" int hd_edge_layer_backward_p(hd_handle* h, hd_topology* t, int coord,
     EdgeDxArgs d;
     d.escal = escal; d.ei = t->ei; d.ej = t->ej; d.rptr = t->rptr; d.rrows = t->rrows; d.sptr = t->sptr; d.srows = t->srows;
     d.xcur = x; d.x0 = x0; d.dx = dx; d.dx0 = dx0; d.norm_constant = c.norm_constant; d.M = M; d.coord = coord ? 1 : 0;
-    hipLaunchKernelGGL(k_edge_dx, dim3((M + 255) / 256), dim3(256), 0, s, d);
+    hipLaunchKernelGGL(k_edge_dx, dim3((M + 3) / 4), dim3(256), 0, s, d);          // one wavefront per node
     HIP_TRY(hipGetLastError());
     return HD_OK;
 }

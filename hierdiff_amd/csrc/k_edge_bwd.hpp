@@ -511,34 +511,54 @@ struct EdgeDxArgs {
     int M, coord;
 };
 
+// One WAVEFRONT per node (round 5; was one thread per node: 7,680 threads each walking 58 edges through a three-deep chain of
+// dependent loads - 67 us, 18 times per training step).  Lane l takes the node's l-th incident edge - its receiving edges first,
+// then its sending ones - in rounds of 64; the six partial sums are added across the lanes by a fixed butterfly and across the
+// rounds in order: deterministic, though not the sequential order of the old kernel (gradients agree to round-off).
 __global__ void k_edge_dx(EdgeDxArgs a) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (k >= a.M) return;
     const f32x4 xk = *reinterpret_cast<const f32x4*>(a.xcur + (size_t)k * 4);
     const f32x4 yk = *reinterpret_cast<const f32x4*>(a.x0 + (size_t)k * 4);
-    float gx = 0.f, gy = 0.f, gz = 0.f, hx = 0.f, hy = 0.f, hz = 0.f;
-    auto edge = [&](int row, int other, float sign) {
-        // diff = x_recv - x_send; this node is the receiver (sign +1) or the sender (sign -1)
-        const f32x4 xo = *reinterpret_cast<const f32x4*>(a.xcur + (size_t)other * 4);
-        const f32x4 yo = *reinterpret_cast<const f32x4*>(a.x0 + (size_t)other * 4);
-        const float* es = a.escal + (size_t)row * 8;
-        const float ddx = sign * (xk[0] - xo[0]), ddy = sign * (xk[1] - xo[1]), ddz = sign * (xk[2] - xo[2]);   // = diff
-        float cx = 2.0f * es[4] * ddx, cy = 2.0f * es[4] * ddy, cz = 2.0f * es[4] * ddz;                          // via radial
-        if (a.coord) {
-            const float rad = ddx * ddx + ddy * ddy + ddz * ddz;
-            const float sq = sqrtf(rad + 1e-8f), nrm = sq + a.norm_constant;
-            const float dot = es[0] * ddx + es[1] * ddy + es[2] * ddz;
-            const float k2 = dot / (nrm * nrm * sq);
-            cx += es[0] / nrm - k2 * ddx; cy += es[1] / nrm - k2 * ddy; cz += es[2] / nrm - k2 * ddz;
+    const int r0 = a.rptr[k], nr = a.rptr[k + 1] - r0, s0 = a.sptr[k], ns = a.sptr[k + 1] - s0;
+    float tx = 0.f, ty = 0.f, tz = 0.f, ux = 0.f, uy = 0.f, uz = 0.f;
+    for (int base = 0; base < nr + ns; base += 64) {
+        const int l = base + lane;
+        float gx = 0.f, gy = 0.f, gz = 0.f, hx = 0.f, hy = 0.f, hz = 0.f;
+        if (l < nr + ns) {
+            const bool recv = l < nr;
+            const int row = recv ? a.rrows[r0 + l] : a.srows[s0 + (l - nr)];
+            const int other = recv ? a.ej[row] : a.ei[row];
+            const float sign = recv ? 1.0f : -1.0f;
+            // diff = x_recv - x_send; this node is the receiver (sign +1) or the sender (sign -1)
+            const f32x4 xo = *reinterpret_cast<const f32x4*>(a.xcur + (size_t)other * 4);
+            const f32x4 yo = *reinterpret_cast<const f32x4*>(a.x0 + (size_t)other * 4);
+            const f32x4 e03 = *reinterpret_cast<const f32x4*>(a.escal + (size_t)row * 8);
+            const f32x4 e47 = *reinterpret_cast<const f32x4*>(a.escal + (size_t)row * 8 + 4);
+            const float ddx = sign * (xk[0] - xo[0]), ddy = sign * (xk[1] - xo[1]), ddz = sign * (xk[2] - xo[2]);   // = diff
+            float cx = 2.0f * e47[0] * ddx, cy = 2.0f * e47[0] * ddy, cz = 2.0f * e47[0] * ddz;                      // via radial
+            if (a.coord) {
+                const float rad = ddx * ddx + ddy * ddy + ddz * ddz;
+                const float sq = sqrtf(rad + 1e-8f), nrm = sq + a.norm_constant;
+                const float dot = e03[0] * ddx + e03[1] * ddy + e03[2] * ddz;
+                const float k2 = dot / (nrm * nrm * sq);
+                cx += e03[0] / nrm - k2 * ddx; cy += e03[1] / nrm - k2 * ddy; cz += e03[2] / nrm - k2 * ddz;
+            }
+            gx = sign * cx; gy = sign * cy; gz = sign * cz;
+            const float e0x = sign * (yk[0] - yo[0]), e0y = sign * (yk[1] - yo[1]), e0z = sign * (yk[2] - yo[2]);
+            hx = sign * 2.0f * e47[1] * e0x; hy = sign * 2.0f * e47[1] * e0y; hz = sign * 2.0f * e47[1] * e0z;
         }
-        gx += sign * cx; gy += sign * cy; gz += sign * cz;
-        const float e0x = sign * (yk[0] - yo[0]), e0y = sign * (yk[1] - yo[1]), e0z = sign * (yk[2] - yo[2]);
-        hx += sign * 2.0f * es[5] * e0x; hy += sign * 2.0f * es[5] * e0y; hz += sign * 2.0f * es[5] * e0z;
-    };
-    for (int p = a.rptr[k]; p < a.rptr[k + 1]; ++p) { const int row = a.rrows[p]; edge(row, a.ej[row], 1.0f); }
-    for (int p = a.sptr[k]; p < a.sptr[k + 1]; ++p) { const int row = a.srows[p]; edge(row, a.ei[row], -1.0f); }
-    *reinterpret_cast<f32x4*>(a.dx + (size_t)k * 4) = f32x4{gx, gy, gz, 0.f};
-    *reinterpret_cast<f32x4*>(a.dx0 + (size_t)k * 4) = f32x4{hx, hy, hz, 0.f};
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            gx += __shfl_xor(gx, o); gy += __shfl_xor(gy, o); gz += __shfl_xor(gz, o);
+            hx += __shfl_xor(hx, o); hy += __shfl_xor(hy, o); hz += __shfl_xor(hz, o);
+        }
+        tx += gx; ty += gy; tz += gz; ux += hx; uy += hy; uz += hz;
+    }
+    if (lane == 0) {
+        *reinterpret_cast<f32x4*>(a.dx + (size_t)k * 4) = f32x4{tx, ty, tz, 0.f};
+        *reinterpret_cast<f32x4*>(a.dx0 + (size_t)k * 4) = f32x4{ux, uy, uz, 0.f};
+    }
 }
 
 // W [H][H] (state_dict layout, row = output) -> chunk image of the forward fp32 edge kernel (pack_edge_w2), either of W
