@@ -52,7 +52,8 @@ DTYPE = {"fp32": "f32", "bf16x3": "bf16x3", "bf16x6": "bf16x6", "fp16x3": "fp16x
 # PMC figures are NOT measured by this process (counter passes need rocprofv3 around the run): they are replayed from the
 # newest committed summary of scratch/round_profiles.sh + summarize_profiles.py, and only when that summary was collected
 # on the very library that is loaded now (sha256 of libhierdiff_hip.so) and on this workload's shape.
-COUNTER_FILES = [os.path.join(REPO, "profiles", f) for f in ("r04_counters.json", "r03_counters.json", "r02_counters.json")]
+COUNTER_FILES = [os.path.join(REPO, "profiles", f) for f in ("r05_counters.json", "r04_counters.json", "r03_counters.json",
+                                                              os.path.join("history", "r02_counters.json"))]
 
 
 def lib_sha256() -> str:
