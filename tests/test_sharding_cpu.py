@@ -217,3 +217,29 @@ def test_bench_self_launch_command_line(monkeypatch):
         assert e.code == 0
     assert seen == {"n": 2, "argv": ["--gpus", "2", "--steps", "3"]}
     assert 1024 < bench.free_port() < 65536
+
+
+def test_bench_line_keeps_the_creditable_blocks_in_the_drivers_tail():
+    """The driver's record keeps the last ~8 KB of bench.py's JSON line: `driver_visible_order` must put the
+    exact-fp32 configs block, the fp16x3 blocks, the contract's keys, `roofline` and `cpu_baseline` there, lose nothing and stay
+    valid JSON with the same content."""
+    import json
+    import bench
+    blk = lambda n: {f"case{i}": {"molecules_per_s": 1.0 * i, "ms_per_forward": 2.0, "what": "x" * 40} for i in range(n)}
+    line = {"metric": "m", "value": 1.0, "unit": "molecules/s", "n_gpus": 1, "steps": 2, "warmup": 1, "ms_per_step": 5.0,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "w"}, "roofline": {"frac": 0.7, "pad": "r" * 600},
+            "fp16x3": {"value": 2.0, "pad": "p" * 1500}, "bf16x6": {"value": 1.5, "pad": "p" * 1800}, "bf16x3": {"value": 2.1, "pad": "p" * 1600},
+            "configs": {"note": "n", "f32": blk(10), "fp16x3": blk(10), "bf16x6": blk(10), "bf16x3": blk(10)},
+            "next_rows": {f"row{i}": {"ms_per_step": 1.0, "what": "y" * 300} for i in range(10)},
+            "cpu_baseline": {"value": 0.03, "sample": "s" * 400}}
+    out = bench.driver_visible_order(line)
+    assert out == line and list(out)[-3:] == ["config", "roofline", "cpu_baseline"]
+    assert list(out["configs"])[-2:] == ["fp16x3", "f32"]
+    text = json.dumps(out)
+    assert json.loads(text) == line
+    tail = text[-8000:]
+    i_f32 = tail.find('"f32": {"case0"')
+    assert i_f32 >= 0, "the fp32 configs block fell out of the tail"
+    assert '"fp16x3": {"value"' in tail and '"metric"' in tail and '"cpu_baseline"' in tail and '"roofline"' in tail
+    assert '"next_rows"' not in tail                      # the rows outside the hot path go first
