@@ -2137,11 +2137,7 @@ extern "C" int hd_egcl_forward(hd_egcl* g, hd_egcl_graph* t, const float* h, con
             a.X = t->M1; a.w = W + g->wa; a.bias = W + g->ba; a.emask = edge_mask; a.E = E; a.H = H; a.attention = c.attention;
             hipLaunchKernelGGL((k_egcl_row<0>), dim3((E + 3) / 4), dim3(256), 0, s, a);
         }
-        // Round 5: with the caller's tensors read directly and H <= 256 the coordinate head rides in the sum over incoming edges
-        const bool head_in_sum = direct && H <= 256;
-        if (c.coord_update && head_in_sum) {
-            egcl_gemm(g, EPI_BIAS_SILU, false, gemm_args(t->M1, H, H, H, nullptr, g->wc1_img, g->bc1, t->C1, H, E, H, nullptr), s);
-        } else if (c.coord_update) {
+        if (c.coord_update) {
             egcl_gemm(g, EPI_BIAS_SILU, false, gemm_args(t->M1, H, H, H, nullptr, g->wc1_img, g->bc1, t->C1, H, E, H, nullptr), s);
             EgclRowArgs a;
             std::memset(&a, 0, sizeof(a));
@@ -2150,14 +2146,7 @@ extern "C" int hd_egcl_forward(hd_egcl* g, hd_egcl_graph* t, const float* h, con
             hipLaunchKernelGGL((k_egcl_row<1>), dim3((E + 3) / 4), dim3(256), 0, s, a);
         }
     }
-    if (direct && H <= 256 && E > 0) {      // agg, the coordinate head, xagg and the new coordinates in one launch (k_egcl_agg)
-        EgclAggArgs a;
-        std::memset(&a, 0, sizeof(a));
-        a.M1 = t->M1; a.C1 = t->C1; a.w = W + g->wc2; a.emask = edge_mask; a.geo = t->geo; a.ptr = t->cptr; a.rows = t->crows;
-        a.agg = t->agg; a.xagg = t->xagg; a.x_in = x; a.x_out = x_out; a.xmask = node_mask; a.range = c.coords_range;
-        a.M = M; a.H = H; a.use_tanh = c.tanh;
-        hipLaunchKernelGGL(k_egcl_agg, dim3((M + 3) / 4), dim3(256), 0, s, a);
-    } else {   // sums over incoming edges (receiving index = col), ascending edge order
+    {   // sums over incoming edges (receiving index = col), ascending edge order
         CsrSumArgs cs;
         std::memset(&cs, 0, sizeof(cs));
         cs.ptr = t->cptr; cs.rows = t->crows; cs.M = M; cs.col0 = 0;

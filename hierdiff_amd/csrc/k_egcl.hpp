@@ -113,81 +113,6 @@ __global__ void k_egcl_row(EgclRowArgs a) {
     }
 }
 
-// Round 5: the coordinate head (k_egcl_row<1>) and the two sums over incoming edges (k_csr_sum) in ONE launch, one wavefront per
-// receiving node: for every incoming edge in ascending list order  agg += edge_feat[e],  phi = w . C1[e] (the same per-lane fmaf chain
-// and xor butterfly as k_egcl_row<1>),  trans = cdiff (tanh(phi) range | phi) edge_mask,  xsum += trans - the same expressions in the
-// same order, so the same bits - and the new coordinates leave with the sum (k_egcl_node_out's line).  H <= 256 (one float4 per lane).
-struct EgclAggArgs {
-    const float* M1;        // [E][H] edge features (gated, masked)
-    const float* C1;        // [E][H] hidden layer of the coordinate head
-    const float* w;         // [H] coord_mlp's last layer
-    const float* emask;     // [E] or NULL
-    const float* geo;       // [E][4]
-    const int* ptr;         // [M+1] CSR by receiving node
-    const int* rows;        // [E]
-    float* agg;             // [M][H]
-    float* xagg;            // [M][4]
-    const float* x_in;      // optional [M][3] ...
-    float* x_out;           // ... x_out = (x_in + xsum) * xmask
-    const float* xmask;     // [M] or NULL
-    float range;
-    int M, H, use_tanh;
-};
-
-__global__ void k_egcl_agg(EgclAggArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (i >= a.M) return;
-    const int k = lane * 4;
-    const bool on = k < a.H;
-    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-    const f32x4 wv = on ? *reinterpret_cast<const f32x4*>(a.w + k) : z4;
-    f32x4 v = z4, xs = z4;
-    auto one = [&](int e, f32x4 mrow, f32x4 crow, f32x4 g, float m) {
-        v += mrow;
-        float dot = 0.f;
-        if (on) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) dot = __builtin_fmaf(crow[j], wv[j], dot);
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
-        const float sc = (a.use_tanh ? tanhf(dot) * a.range : dot) * m;
-        xs += f32x4{g[0] * sc, g[1] * sc, g[2] * sc, 0.f};
-    };
-    const int p0 = a.ptr[i], p1 = a.ptr[i + 1];
-    int p = p0;
-    for (; p + 4 <= p1; p += 4) {                      // four edges' rows requested together, consumed in list order
-        int e[4]; f32x4 mr[4], cr[4], g[4]; float m[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) e[u] = a.rows[p + u];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            mr[u] = on ? *reinterpret_cast<const f32x4*>(a.M1 + (size_t)e[u] * a.H + k) : z4;
-            cr[u] = on ? *reinterpret_cast<const f32x4*>(a.C1 + (size_t)e[u] * a.H + k) : z4;
-            g[u] = *reinterpret_cast<const f32x4*>(a.geo + (size_t)e[u] * 4);
-            m[u] = a.emask ? a.emask[e[u]] : 1.0f;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) one(e[u], mr[u], cr[u], g[u], m[u]);
-    }
-    for (; p < p1; ++p) {
-        const int e = a.rows[p];
-        one(e, on ? *reinterpret_cast<const f32x4*>(a.M1 + (size_t)e * a.H + k) : z4,
-            on ? *reinterpret_cast<const f32x4*>(a.C1 + (size_t)e * a.H + k) : z4,
-            *reinterpret_cast<const f32x4*>(a.geo + (size_t)e * 4), a.emask ? a.emask[e] : 1.0f);
-    }
-    if (on) *reinterpret_cast<f32x4*>(a.agg + (size_t)i * a.H + k) = v;
-    if (lane == 0) {
-        *reinterpret_cast<f32x4*>(a.xagg + (size_t)i * 4) = xs;
-        if (a.x_out) {
-            const float m = a.xmask ? a.xmask[i] : 1.0f;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) a.x_out[(size_t)i * 3 + c] = (a.x_in[(size_t)i * 3 + c] + xs[c]) * m;
-        }
-    }
-}
-
 // edge_mlp first layer epilogue: E1 = SiLU(E1 + radial w_er)  (the radial column of edge_mlp.0, gcl.py:111-112); and the
 // final masking of the new edge attributes, EA *= edge_mask (:114-116, :192-193).  MODE 0 / 1.
 struct EgclEwArgs {
