@@ -5,7 +5,7 @@ from tests.test_gpu_parity import build_diffusion, DEV
 from hierdiff_amd.weights import synthetic_state_dict
 Bs = [int(v) for v in sys.argv[1:]] or [2]
 sd = synthetic_state_dict(9, 0, 256, 6, 2, True, 0, 1.0)
-for prec in ("fp32", "bf16x6", "bf16x3"):
+for prec in ("fp32", "fp16x3", "bf16x3"):
     m = build_diffusion(sd, 256, 6, T=1000, precision=prec)
     for B in Bs:
         nm = torch.ones(B, 30, 1, dtype=torch.bool, device=DEV)
