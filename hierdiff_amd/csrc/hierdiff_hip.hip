@@ -1888,6 +1888,9 @@ struct hd_egcl {
     // float offsets into dw
     size_t ab_img, ab_bias, w_r, w_e, w_c, w1e_img, zero_bias, w2_img, b2, wa, ba, wc1_img, bc1, wc2, we1_img, be1, w_er,
         we2_img, be2, wn1_img, bn1, wn2_img, bn2, ones;
+    // widths 128 / 256 (round 5): the three node-level contractions also as k_node_f32 fragment images, for k_node_split_f32
+    size_t ab_nimg, wn1_nimg, wn2_nimg;
+    bool node_split;
 };
 
 struct hd_egcl_graph {
@@ -1925,6 +1928,9 @@ extern "C" int hd_egcl_create(const hd_egcl_config* cfg, int device, hd_egcl** o
     g->cfg = *cfg; g->device = device; g->H = H; g->De = cfg->edges_in_d; g->ctx = cfg->context_nf;
     g->NS = (H == 32) ? 1 : 2;
     g->n_weights = egcl_weight_count(*cfg);
+    // k_node_split_f32 (the layer's node side at widths 128 / 256) needs more than 64 KB of dynamic LDS: raise the limit on this device
+    if (H == 128) { const int r = prepare_node_split_h<128>(); if (r != HD_OK) { delete g; return r; } }
+    if (H == 256) { const int r = prepare_node_split_h<256>(); if (r != HD_OK) { delete g; return r; } }
     *out = g;
     return HD_OK;
 }
@@ -1962,6 +1968,8 @@ extern "C" int hd_egcl_set_weights(hd_egcl* g, const float* blob, long long n, i
     g->wc1_img = take((size_t)H * H); g->bc1 = take(H); g->wc2 = take(H);
     g->we1_img = take((size_t)2 * H * H); g->be1 = take(H); g->w_er = take(H); g->we2_img = take((size_t)H * H); g->be2 = take(H);
     g->wn1_img = take((size_t)2 * H * H); g->bn1 = take(H); g->wn2_img = take((size_t)H * H); g->bn2 = take(H);
+    g->node_split = (H == 128 || H == 256);
+    if (g->node_split) { g->ab_nimg = take((size_t)H * 2 * H); g->wn1_nimg = take((size_t)2 * H * H); g->wn2_nimg = take((size_t)H * H); }
     std::vector<float> pk(off, 0.0f);
     const float* p = src;
     auto next = [&](size_t cnt) { const float* q = p; p += cnt; return q; };
@@ -1969,6 +1977,8 @@ extern "C" int hd_egcl_set_weights(hd_egcl* g, const float* blob, long long n, i
         const int ld = 2 * H + 1 + De + ctx;
         const float* W1 = next((size_t)H * ld); const float* b1 = next(H);
         pack_gemm_b(pk, g->ab_img, H, 2 * H, WN, [&](int col, int k) {
+            return (col < H) ? W1[(size_t)col * ld + k] : W1[(size_t)(col - H) * ld + H + k]; });
+        if (g->node_split) pack_node_b_f32(pk, g->ab_nimg, H, 2 * H, [&](int col, int k) {
             return (col < H) ? W1[(size_t)col * ld + k] : W1[(size_t)(col - H) * ld + H + k]; });
         for (int k = 0; k < H; ++k) {
             pk[g->ab_bias + k] = b1[k];
@@ -1994,9 +2004,11 @@ extern "C" int hd_egcl_set_weights(hd_egcl* g, const float* blob, long long n, i
     {   // node_mlp.0 [H][2H]: columns [h | agg] (gcl.py:123-126)
         const float* Wn1 = next((size_t)H * 2 * H); const float* bn1 = next(H);
         pack_gemm_b(pk, g->wn1_img, 2 * H, H, WN, [&](int col, int k) { return Wn1[(size_t)col * 2 * H + k]; });
+        if (g->node_split) pack_node_b_f32(pk, g->wn1_nimg, 2 * H, H, [&](int col, int k) { return Wn1[(size_t)col * 2 * H + k]; });
         std::copy(bn1, bn1 + H, pk.begin() + g->bn1);
         const float* Wn2 = next((size_t)H * H); const float* bn2 = next(H);
         pack_gemm_b(pk, g->wn2_img, H, H, WN, [&](int col, int k) { return Wn2[(size_t)col * H + k]; });
+        if (g->node_split) pack_node_b_f32(pk, g->wn2_nimg, H, H, [&](int col, int k) { return Wn2[(size_t)col * H + k]; });
         std::copy(bn2, bn2 + H, pk.begin() + g->bn2);
     }
     if (c.coord_update) {
@@ -2114,7 +2126,23 @@ extern "C" int hd_egcl_forward(hd_egcl* g, hd_egcl_graph* t, const float* h, con
         a.h = h; a.x = x; a.hin = t->hin; a.hres = t->hres; a.x4 = t->x4; a.M = M; a.H = H; a.ctx = ctx;
         hipLaunchKernelGGL(k_egcl_node_in, blocks((long long)M * H), dim3(256), 0, s, a);
     }
-    egcl_gemm(g, EPI_BIAS, false, gemm_args(hsrc, H, H, H, nullptr, g->ab_img, g->ab_bias, t->AB, 2 * H, M, 2 * H, nullptr), s);
+    // Round 5, widths 128 / 256: the three node-level contractions (288 rows for a beam of 24: 20 workgroups of k_gemm, each a chain of
+    // 8 - 16 K chunks behind barriers) run on k_node_split_f32 - 32 x 32 tiles, four K quarters per workgroup, weights requested at
+    // entry: 9.3 / 14.4 / 9.0 us -> see profiles/r05_stage2_layer_kstats_node_split.log
+    const bool nsplit = direct && g->node_split;
+    auto nsargs = [&]() {
+        NodeSplitArgs a;
+        std::memset(&a, 0, sizeof(a));
+        a.h_in = h; a.h_out = h_out; a.nmask = node_mask ? node_mask : t->ones; a.T = t->Tn; a.M = M; a.n_img = 1; a.norm = 1.0f;
+        return a;
+    };
+    if (nsplit) {
+        NodeSplitArgs a = nsargs();
+        a.Wimg[0] = W + g->ab_nimg; a.bias[0] = W + g->ab_bias; a.ABout[0] = t->AB; a.upd = 0;
+        if (H == 128) launch_node_split_f32_h<128, 3>(a, s); else launch_node_split_f32_h<256, 3>(a, s);
+    } else {
+        egcl_gemm(g, EPI_BIAS, false, gemm_args(hsrc, H, H, H, nullptr, g->ab_img, g->ab_bias, t->AB, 2 * H, M, 2 * H, nullptr), s);
+    }
     if (E > 0) {
         if (wide && direct) {
             GemmArgs p = gemm_args(edge_attr, H, H, H, nullptr, g->w1e_img, g->zero_bias, t->P, H, E, H, nullptr);
@@ -2157,6 +2185,13 @@ extern "C" int hd_egcl_forward(hd_egcl* g, hd_egcl_graph* t, const float* h, con
     }
     // node model: h_new = (h + node_mlp([h | agg])) (* node_mask)
     const float* nm = node_mask ? node_mask : t->ones;
+    if (nsplit) {
+        NodeSplitArgs p1 = nsargs(), p2 = nsargs();
+        p1.Wimg[0] = W + g->wn1_nimg; p1.bias[0] = W + g->bn1; p1.agg_dense = t->agg;
+        p2.Wimg[0] = W + g->wn2_nimg; p2.bias[0] = W + g->bn2; p2.resid_none = c.recurrent ? 0 : 1;
+        if (H == 128) { launch_node_split_f32_h<128, 1>(p1, s); launch_node_split_f32_h<128, 2>(p2, s); }
+        else { launch_node_split_f32_h<256, 1>(p1, s); launch_node_split_f32_h<256, 2>(p2, s); }
+    } else {
     egcl_gemm(g, EPI_BIAS_SILU, true, gemm_args(hsrc, H, H, 2 * H, t->agg, g->wn1_img, g->bn1, t->Tn, H, M, H, nullptr), s);
     if (direct) {
         GemmArgs n2 = gemm_args(t->Tn, H, H, H, nullptr, g->wn2_img, g->bn2, h_out, H, M, H, nm);
@@ -2165,6 +2200,7 @@ extern "C" int hd_egcl_forward(hd_egcl* g, hd_egcl_graph* t, const float* h, con
     } else {
         if (!c.recurrent) HIP_TRY(hipMemsetAsync(t->hres, 0, (size_t)t->Mp * H * sizeof(float), s));
         egcl_gemm(g, EPI_RESID_MASK, false, gemm_args(t->Tn, H, H, H, nullptr, g->wn2_img, g->bn2, t->hres, H, M, H, nm), s);
+    }
     }
     if (c.edge_update && E > 0) {
         // edge_mlp: E1 = SiLU([edge_feat | edge_attr] We1^T + radial w_er + be1);  edge_attr' = (E1 We2^T + be2) * edge_mask

@@ -36,6 +36,10 @@ struct NodeSplitArgs {
     float* ABmax[2];        // phase 3, optional: [M_pad][2] row maxima of the two halves (atomic max; zeroed by phase 2 / the caller)
     float* zero_max[2];     // phase 2: the ABmax tables phase 3 is going to fill (zeroed here, one row tile per ct == 0 workgroup)
     int M, n_img, upd;
+    // k_node_split_f32 as the node side of the stage-2 layer (hd_egcl_forward, round 5): phase 1's second operand half as a dense
+    // [M][H] array of finished sums instead of partial sums; phase 2 without a residual (non-recurrent layer)
+    const float* agg_dense;
+    int resid_none;
 };
 
 // PH 1 / 2 / 3 as above.  H = 128 or 256.  CTW = 32-column tiles per workgroup; the library launches CTW = 1 (CTW = 2 - half the
@@ -298,12 +302,21 @@ __global__ __launch_bounds__(256, 2) void k_node_split_f32(NodeSplitArgs a) {
         constexpr int Q = H / 4, TPR = 8, NP = Q / TPR;
         const int r = tid / TPR, cq = tid % TPR;
         const int row = row0 + r;
+        const int lrow = row < a.M ? row : a.M - 1;      // rows past the end are never stored: read a valid one (the stage-2 layer hands unpadded tensors)
         if constexpr (PH == 1) {
             int p0 = 0, p1 = 0;
-            if (row < a.M) { p0 = a.pstart[row]; p1 = a.pstart[row + 1]; }
+            if (row < a.M && !a.agg_dense) { p0 = a.pstart[row]; p1 = a.pstart[row + 1]; }
             f32x4 hv[NP];
 #pragma unroll
-            for (int u = 0; u < NP; ++u) hv[u] = *reinterpret_cast<const f32x4*>(a.h_in + (size_t)row * H + 4 * (cq + u * TPR));
+            for (int u = 0; u < NP; ++u) hv[u] = *reinterpret_cast<const f32x4*>(a.h_in + (size_t)lrow * H + 4 * (cq + u * TPR));
+            if (a.agg_dense) {
+#pragma unroll
+                for (int u = 0; u < NP; ++u) {
+                    *reinterpret_cast<f32x4*>(X + r * LD + 4 * (cq + u * TPR)) = hv[u];
+                    *reinterpret_cast<f32x4*>(X + r * LD + H + 4 * (cq + u * TPR)) =
+                        *reinterpret_cast<const f32x4*>(a.agg_dense + (size_t)lrow * H + 4 * (cq + u * TPR));
+                }
+            } else {
             const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
             const bool has0 = p0 < p1, has1 = p0 + 1 < p1;
             const float* s0 = a.part + (size_t)(has0 ? p0 : 0) * H;
@@ -324,11 +337,12 @@ __global__ __launch_bounds__(256, 2) void k_node_split_f32(NodeSplitArgs a) {
                 for (int p = p0 + 2; p < p1; ++p) v += *reinterpret_cast<const f32x4*>(a.part + (size_t)p * H + 4 * (cq + u * TPR));
                 *reinterpret_cast<f32x4*>(X + r * LD + H + 4 * (cq + u * TPR)) = v / a.norm;
             }
+            }
         } else {
             const float* src = PH == 2 ? a.T : (a.upd ? a.h_out : a.h_in);
 #pragma unroll
             for (int u = 0; u < NP; ++u)
-                *reinterpret_cast<f32x4*>(X + r * LD + 4 * (cq + u * TPR)) = *reinterpret_cast<const f32x4*>(src + (size_t)row * H + 4 * (cq + u * TPR));
+                *reinterpret_cast<f32x4*>(X + r * LD + 4 * (cq + u * TPR)) = *reinterpret_cast<const f32x4*>(src + (size_t)lrow * H + 4 * (cq + u * TPR));
         }
     }
     __syncthreads();
@@ -365,7 +379,10 @@ __global__ __launch_bounds__(256, 2) void k_node_split_f32(NodeSplitArgs a) {
         const float v = ((red[(0 * 16 + r) * 64 + lane] + red[(1 * 16 + r) * 64 + lane]) + red[(2 * 16 + r) * 64 + lane]) + red[(3 * 16 + r) * 64 + lane];
         if (row >= a.M) continue;
         if constexpr (PH == 1) a.T[(size_t)row * H + col] = silu_f(v + bias_v);
-        else if constexpr (PH == 2) a.h_out[(size_t)row * H + col] = (a.h_in[(size_t)row * H + col] + (v + bias_v)) * a.nmask[row];
+        else if constexpr (PH == 2) {
+            if (a.resid_none) a.h_out[(size_t)row * H + col] = (v + bias_v) * a.nmask[row];
+            else a.h_out[(size_t)row * H + col] = (a.h_in[(size_t)row * H + col] + (v + bias_v)) * a.nmask[row];
+        }
         else a.ABout[img][(size_t)row * 2 * H + col] = v + bias_v;
     }
 }
