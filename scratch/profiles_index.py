@@ -6,6 +6,7 @@ import os, re, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RULES = [
     (r"edge_kernel_traffic\.json", "HBM bytes of the edge kernel by counter, round 1", "DESIGN 4 (roofline table, traffic column)"),
+    (r"r05_bench_default_slow_box\.json", "default bench line mid-round on a box whose 16-bit MFMA clock was ~6 % lower (fp16 22.2 ns per MFMA)", "DESIGN 6 (box-to-box spread)"),
     (r"r\d+_bench_default.*\.json|r\d+_bench_\d+steps.*\.json|r\d+_bench_(fp32|bf16x3|first_path)\.json|r\d+_bench_3steps\.json",
      "complete JSON line of a `python bench.py` run on a gpurun box", "DESIGN 6 (bench numbers of that round); the `configs` / `next_rows` blocks the driver's tail truncates"),
     (r"r\d+_(fp32|bf16x3|bf16x6|fp16x3|first_path)_T\d+_kernel_stats.*\.csv", "rocprofv3 --kernel-trace --stats of a 50-timestep bench run in that arithmetic", "roofline.achieved / avg_launch_us of the bench line must agree with this average"),
@@ -26,9 +27,11 @@ RULES = [
     (r"r03_node_phase_trace\.log|r04_node_first_loads_reorder_ab\.log", "phase stamps of k_node_f32 / a reorder A-B (null)", "DESIGN 4 k_node_f32, 12a"),
     (r"r03_power_clock\.log", "rocm-smi clock / power during sustained forwards", "DESIGN 4 (power-limited clock)"),
     (r"r\d+_pmc_tgemm.*\.log|r\d+_pmc_train\.log", "counters of the training GEMM kernels", "DESIGN 10"),
+    (r"r05_train_kstats\.log", "kernel tables of the training step in both arithmetics after the k_edge_dx rewrite", "DESIGN 10 round 5"),
     (r"r\d+_train.*\.log|r02_loss_host_profile_before\.log|r02_topology_and_loss_host\.log|r03_topology_time\.log|r04_fresh_masks\.log", "training step: per-kernel / per-op times, host-side costs, fresh-mask staging", "DESIGN 10; r05: 10 'round 5'"),
     (r"r04_edge_res_.*", "register-resident persistent fp32 edge kernel k_edge_res (rejected), versions v1-v5 and the A/B", "DESIGN 12a, EXPERIMENTS D"),
     (r"r04_headline_trajectory_modes\.log", "final x / h of a complete T = 1000 run in every mode against the exact-fp32 run", "DESIGN 4 precision modes"),
+    (r"r05_stage2_layer_kstats_.*\.log", "stage-2 gcl_full layer, per-kernel averages: before / after the direct path / the rejected agg variant / with the node side on k_node_split_f32", "DESIGN 11 round 5 (0.115 -> 0.086 ms)"),
     (r"r04_stage2_profile\.log|r05_stage2.*", "stage-2 growth step and E_GCL layer, kernel stats", "DESIGN 11"),
     (r"r04_sustained_20steps\.log|r05_sustained.*", "20 timed bench steps per mode (sustained clocks)", "DESIGN 6"),
     (r"r02_concurrent_shards\.log", "two shards on one GPU through two streams", "DESIGN 7"),
@@ -41,6 +44,8 @@ RULES = [
     (r"r05_copybuffer_probe\.log", "kernel trace with 23 vs 63 forwards: every __amd_rocclr_copyBuffer precedes the first forward kernel", "VERDICT r4 weak 8: the copies are load_numpy_state_dict's, not the forward's"),
     (r"r05_families_.*\.log", "scratch/fwd_families.py: ms per forward and per-family launch averages by batch", "DESIGN 12b / 6"),
     (r"r05_node_split_sweep\.log", "fused k_node<F16> vs the three-launch k_node_split chain by batch size, two runs", "DESIGN 4 k_node_split (threshold 2,048 rows)"),
+    (r"r05_f32_node_split_sweep\.log", "exact fp32: headline A/B of k_node_f32 with K quarters, and k_gemm_r16 chain vs k_node_split_f32 chain by batch size (two interleaved repetitions)", "DESIGN 4 k_node_split (fp32 paragraph)"),
+    (r"r05_f32_fuse_threshold\.log", "exact fp32: fused k_node_f32 vs the three-launch chain at B = 128 .. 256", "HD_FUSE_MIN_ROWS = 5,400"),
     (r"r05_.*", "round-5 measurement", "DESIGN 0a"),
 ]
 def commit(path):
