@@ -40,6 +40,7 @@ RULES = [
     (r"r05_mb_mfma_stream\.log", "scratch/mb/mstream.hip: ns per fp16 MFMA per SIMD, register operands vs LDS fragments, 1-2 waves per SIMD, whole chip", "DESIGN 12b: the sustained fp16 MFMA rate is 19.7 ns (1.62 GHz under load), not 13.3"),
     (r"r05_mb_wave_specialisation.*\.log", "scratch/mb/ws.hip: matrix-only + vector-only wavefronts on one SIMD (v0: rows without L2 locality / request sunk by hipcc; final: fixed)", "DESIGN 12b: wave specialisation predicts at most -15 %"),
     (r"r05_ablate_fp16x3\.log", "fp16x3 edge kernel with parts ablated, incl. the stream / barrier split (bits 32 / 64)", "DESIGN 12b: the W2 LDS-DMA stream costs 16 %, the barrier 3 %"),
+    (r"r05_ab_pgen_spread\.log", "same-box A/B: first-layer operand generation spread over the whole chunk (null)", "EXPERIMENTS H"),
     (r"r05_ab_peel_first_chunk\.log", "same-box A/B of the peeled first chunk (zero C operand)", "DESIGN 12b (-1 %)"),
     (r"r05_copybuffer_probe\.log", "kernel trace with 23 vs 63 forwards: every __amd_rocclr_copyBuffer precedes the first forward kernel", "VERDICT r4 weak 8: the copies are load_numpy_state_dict's, not the forward's"),
     (r"r05_families_.*\.log", "scratch/fwd_families.py: ms per forward and per-family launch averages by batch", "DESIGN 12b / 6"),
