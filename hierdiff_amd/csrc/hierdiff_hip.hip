@@ -1333,6 +1333,18 @@ static bool launch_edge_ablated(hd_handle* h, const EdgeArgs& a, hipStream_t s) 
 extern "C" int hd_debug_edge_trace(hd_handle*, long long*, int) { return 0; }      // product build: nothing is traced
 #endif
 
+// Which kernel family runs a list of n_tiles edge tiles at width >= 128 in arithmetic `mode` (launch_edge_h below and
+// hd_edge_layer_save_rows ask the same question): the column-split kernel, the mix of whole and column-split tiles, or k_edge.
+static bool edge_runs_split(const hd_handle* h, int n_tiles, int mode) {
+    return n_tiles > 0 && n_tiles <= (mode == 0 ? h->split_max_tiles + h->split_max_tiles / 3 : h->split_max_tiles);
+}
+static bool edge_runs_mixed(const hd_handle* h, int n_tiles, int mode) {
+    const int per_round = 4 * h->n_cu;
+    const int left = n_tiles - (n_tiles / per_round) * per_round;
+    const bool pays = left > 0 && left * 10 <= (mode == 0 ? 29 : 10) * h->n_cu;
+    return n_tiles > per_round && n_tiles < h->mix_max_tiles && (pays || h->mix_rounds >= 0);
+}
+
 // `mode_override` >= 0 selects the arithmetic of THIS launch (0 fp32, 1 bf16x3, 2 bf16x6) instead of the handle's: the opt-in
 // bf16x6 forward of the training path (hd_edge_layer_forward_p) on a handle whose other kernels stay exact fp32
 template <int H>
@@ -1342,6 +1354,21 @@ static int launch_edge_h(hd_handle* h, bool coord, const EdgeArgs& a, hipStream_
     const int prec = mode_override >= 0 ? ((mode_override == 2 && H < 128) ? 0 : mode_override) : h->edge_mode;
     const bool x6 = prec == 2;
     const dim3 grid(a.n_wg), block(256);
+    if (a.pre2) {
+        // training forward that keeps pre2 for the backward pass (HD_EDGE_SAVE): always the whole-tile kernel, whose accumulator
+        // layout is the saved layout (the caller offers the buffer only where this kernel would run anyway: edge_layer_saves)
+        if constexpr (H >= 128) {
+            if (x6) {
+                const int lds6 = edge_lds_bytes<H>(true);
+                if (coord) hipLaunchKernelGGL((k_edge<H, true, 2, HD_EDGE_SAVE>), grid, block, lds6, s, a);
+                else hipLaunchKernelGGL((k_edge<H, false, 2, HD_EDGE_SAVE>), grid, block, lds6, s, a);
+                return HD_OK;
+            }
+        }
+        if (coord) hipLaunchKernelGGL((k_edge<H, true, 0, HD_EDGE_SAVE>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((k_edge<H, false, 0, HD_EDGE_SAVE>), grid, block, lds, s, a);
+        return HD_OK;
+    }
 #ifdef HD_DEBUG_KERNELS
     if constexpr (H == 256) {
         if (h->ablate && !coord && (x6 ? launch_edge_ablated<2>(h, a, s) : prec == 1 ? launch_edge_ablated<1>(h, a, s) : prec == 3 ? launch_edge_ablated<3>(h, a, s) : launch_edge_ablated<0>(h, a, s))) return HD_OK;
@@ -1353,7 +1380,7 @@ static int launch_edge_h(hd_handle* h, bool coord, const EdgeArgs& a, hipStream_
         const int mode = prec;
         // measured break-even (profiles/history/r02_split_sweep.log): between 490 and 654 tiles in the bf16 modes, between 654 and 870
         // in fp32 (the longer MFMA chain has more to gain from the split)
-        if (a.n_tiles > 0 && a.n_tiles <= (mode == 0 ? h->split_max_tiles + h->split_max_tiles / 3 : h->split_max_tiles)) {
+        if (edge_runs_split(h, a.n_tiles, mode)) {
             const dim3 sgrid(a.n_tiles);
             if (mode == 0) {
                 if (coord) hipLaunchKernelGGL((k_edge_split<H, true, 0>), sgrid, block, 0, s, a);
@@ -1382,9 +1409,7 @@ static int launch_edge_h(hd_handle* h, bool coord, const EdgeArgs& a, hipStream_
         // whole one in SIMD time, so the mix pays when it replaces a badly filled last round: at most 2.9 left-over tiles per
         // CU in fp32, 1.0 in the bf16 modes.
         int R = a.n_tiles / per_round;
-        const int left = a.n_tiles - R * per_round;
-        const bool pays = left > 0 && left * 10 <= (mode == 0 ? 29 : 10) * h->n_cu;
-        if (a.n_tiles > per_round && a.n_tiles < h->mix_max_tiles && (pays || h->mix_rounds >= 0)) {
+        if (edge_runs_mixed(h, a.n_tiles, mode)) {
             if (h->mix_rounds >= 0) R = std::min(R, h->mix_rounds);
             EdgeArgs m = a;
             m.n_wg = R * h->n_cu;
@@ -1438,7 +1463,11 @@ static int prepare_edge_h() {
     HIP_TRY(hipFuncSetAttribute((const void*)k_edge<H, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIP_TRY(hipFuncSetAttribute((const void*)k_edge<H, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIP_TRY(hipFuncSetAttribute((const void*)k_edge<H, false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_edge<H, true, 0, HD_EDGE_SAVE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_edge<H, false, 0, HD_EDGE_SAVE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     if constexpr (H >= 128) {
+        HIP_TRY(hipFuncSetAttribute((const void*)k_edge<H, true, 2, HD_EDGE_SAVE>, hipFuncAttributeMaxDynamicSharedMemorySize, edge_lds_bytes<H>(true)));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_edge<H, false, 2, HD_EDGE_SAVE>, hipFuncAttributeMaxDynamicSharedMemorySize, edge_lds_bytes<H>(true)));
         HIP_TRY(hipFuncSetAttribute((const void*)k_edge<H, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, edge_lds_bytes<H>(true)));
         HIP_TRY(hipFuncSetAttribute((const void*)k_edge<H, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, edge_lds_bytes<H>(true)));
         const int m0 = std::max(edge_lds_bytes<H>(false), edge_split_lds_bytes<H, 0>()), m2 = std::max(edge_lds_bytes<H>(true), edge_split_lds_bytes<H, 2>());
@@ -1725,6 +1754,12 @@ static int prepare_edge_bwd_h() {
 template <int H>
 static void launch_edge_bwd_h(bool coord, int stage, bool x6, const EdgeBwdArgs& a, int n_wg, hipStream_t s) {
     const dim3 grid(n_wg), block(256);
+    if (stage == 0 && a.pre2) {                     // pre2 kept by the forward pass: stage A loads it (one kernel for both arithmetics)
+        const int ldss = 4 * 288 * 4;
+        if (coord) hipLaunchKernelGGL((k_edge_bwd<H, true, 0, 0, true>), grid, block, ldss, s, a);
+        else hipLaunchKernelGGL((k_edge_bwd<H, false, 0, 0, true>), grid, block, ldss, s, a);
+        return;
+    }
     if constexpr (H >= 128) {
         if (x6) {
             const int lds6 = edge_bwd_lds_bytes<H>(true);
@@ -1758,9 +1793,19 @@ static int check_train(hd_handle* h, hd_topology* t, const char* who) {
     return HD_OK;
 }
 
-extern "C" int hd_edge_layer_forward_p(hd_handle* h, hd_topology* t, int coord, int precision, const float* AB, const float* x,
+// Rows of the pre2 buffer a training forward may keep for its backward pass (hd_edge_layer_forward_s), or 0 where keeping does
+// not pay: batches small enough for the column-split / mixed edge kernels keep their faster forward and recompute.
+extern "C" long long hd_edge_layer_save_rows(hd_handle* h, hd_topology* t, int precision) {
+    if (!h || !t || t->h != h || t->n_wg == 0 || t->M == 0) return 0;
+    if (h->H >= 128 && precision != 0 && precision != 2) return 0;
+    const int mode = (precision == 2 && h->H >= 128) ? 2 : 0;
+    if (h->H >= 128 && (edge_runs_split(h, t->n_tiles, mode) || edge_runs_mixed(h, t->n_tiles, mode))) return 0;
+    return (long long)t->n_wg * 4 * 32;
+}
+
+extern "C" int hd_edge_layer_forward_s(hd_handle* h, hd_topology* t, int coord, int precision, const float* AB, const float* x,
                                        const float* x0, const float* wrd, const float* W2, const float* b2,
-                                       const float* wa, const float* ba, float* out, void* stream) {
+                                       const float* wa, const float* ba, float* out, float* pre2, void* stream) {
     HD_TRY(check_train(h, t, "hd_edge_layer_forward"));
     if (precision != 0 && precision != 2) return fail(HD_E_INVALID, "hd_edge_layer_forward_p: precision must be 0 (fp32) or 2 (bf16x6)");
     const bool x6 = precision == 2 && h->H >= 128;          // narrower widths run the exact-fp32 kernels, as in sampling
@@ -1783,6 +1828,7 @@ extern "C" int hd_edge_layer_forward_p(hd_handle* h, hd_topology* t, int coord, 
     e.xcur = x; e.x0 = x0; e.part = coord ? t->xpart : t->part; e.ba = 0.0f; e.ba_ptr = ba;
     e.norm_constant = c.norm_constant; e.coords_range = c.coords_range / (float)c.n_layers; e.attention = c.attention;
     e.use_tanh = c.tanh; e.n_tiles = t->n_tiles; e.n_wg = t->n_wg;
+    e.pre2 = pre2;
     HD_TRY(edge(h, coord != 0, e, s, x6 ? 2 : 0));
     AggArgs ag;
     ag.part = coord ? t->xpart : t->part; ag.pstart = t->pstart; ag.agg = out; ag.norm = agg_norm(c, t);
@@ -1793,15 +1839,21 @@ extern "C" int hd_edge_layer_forward_p(hd_handle* h, hd_topology* t, int coord, 
     return HD_OK;
 }
 
+extern "C" int hd_edge_layer_forward_p(hd_handle* h, hd_topology* t, int coord, int precision, const float* AB, const float* x,
+                                       const float* x0, const float* wrd, const float* W2, const float* b2,
+                                       const float* wa, const float* ba, float* out, void* stream) {
+    return hd_edge_layer_forward_s(h, t, coord, precision, AB, x, x0, wrd, W2, b2, wa, ba, out, nullptr, stream);
+}
+
 extern "C" int hd_edge_layer_forward(hd_handle* h, hd_topology* t, int coord, const float* AB, const float* x,
                                      const float* x0, const float* wrd, const float* W2, const float* b2,
                                      const float* wa, const float* ba, float* out, void* stream) {
     return hd_edge_layer_forward_p(h, t, coord, 0, AB, x, x0, wrd, W2, b2, wa, ba, out, stream);
 }
 
-extern "C" int hd_edge_layer_backward_p(hd_handle* h, hd_topology* t, int coord, int precision, const float* AB, const float* x,
+extern "C" int hd_edge_layer_backward_s(hd_handle* h, hd_topology* t, int coord, int precision, const float* AB, const float* x,
                                       const float* x0, const float* wrd, const float* W2, const float* b2,
-                                      const float* wa, const float* ba, const float* gout, float* G2, float* P, float* G1,
+                                      const float* wa, const float* ba, const float* gout, const float* pre2, float* G2, float* P, float* G1,
                                       float* escal, float* colpart, float* bapart, float* b2part, float* wrdpart,
                                       float* dAB, float* dx, float* dx0, void* stream) {
     HD_TRY(check_train(h, t, "hd_edge_layer_backward"));
@@ -1833,11 +1885,12 @@ extern "C" int hd_edge_layer_backward_p(hd_handle* h, hd_topology* t, int coord,
     // every output row is written by the kernels below (all tiles of the padded table exist; the CSR sums and k_edge_dx
     // cover every active node), so nothing is cleared first; escal[:, 0:4] is only defined (and only read) in coordinate layers
     if (coord) HIP_TRY(hipMemsetAsync(bapart, 0, (size_t)tiles * sizeof(float), s));     // no attention bias in a coordinate layer
+    // (stage A streams the W2 image only when it has to recompute pre2)
     if (x6) {
-        hipLaunchKernelGGL((k_pack_w2_x6<false>), dim3((H * H / 2 + 255) / 256), dim3(256), 0, s, W2, reinterpret_cast<uint32_t*>(t->w2img), H);
+        if (!pre2) hipLaunchKernelGGL((k_pack_w2_x6<false>), dim3((H * H / 2 + 255) / 256), dim3(256), 0, s, W2, reinterpret_cast<uint32_t*>(t->w2img), H);
         hipLaunchKernelGGL((k_pack_w2_x6<true>), dim3((H * H / 2 + 255) / 256), dim3(256), 0, s, W2, reinterpret_cast<uint32_t*>(t->w2timg), H);
     } else {
-        hipLaunchKernelGGL((k_pack_w2<false>), dim3((H * H + 255) / 256), dim3(256), 0, s, W2, t->w2img, H);
+        if (!pre2) hipLaunchKernelGGL((k_pack_w2<false>), dim3((H * H + 255) / 256), dim3(256), 0, s, W2, t->w2img, H);
         hipLaunchKernelGGL((k_pack_w2<true>), dim3((H * H + 255) / 256), dim3(256), 0, s, W2, t->w2timg, H);
     }
     EdgeBwdArgs a;
@@ -1846,7 +1899,7 @@ extern "C" int hd_edge_layer_backward_p(hd_handle* h, hd_topology* t, int coord,
     a.ba_ptr = ba; a.norm_constant = c.norm_constant; a.coords_range = c.coords_range / (float)c.n_layers;
     a.inv_norm = 1.0f / agg_norm(c, t); a.attention = c.attention; a.use_tanh = c.tanh; a.n_tiles = t->n_tiles;
     a.gin = gout; a.G2 = G2; a.escal = escal; a.colpart = colpart; a.bapart = bapart; a.Pout = P; a.G1 = G1;
-    a.b2part = b2part; a.wrdpart = wrdpart;
+    a.b2part = b2part; a.wrdpart = wrdpart; a.pre2 = pre2;
     a.Wimg = t->w2img;
     launch_edge_bwd(h, coord != 0, 0, x6, a, t->n_wg, s);
     a.Wimg = t->w2timg;
@@ -1865,6 +1918,15 @@ extern "C" int hd_edge_layer_backward_p(hd_handle* h, hd_topology* t, int coord,
     hipLaunchKernelGGL(k_edge_dx, dim3((M + 3) / 4), dim3(256), 0, s, d);          // one wavefront per node
     HIP_TRY(hipGetLastError());
     return HD_OK;
+}
+
+extern "C" int hd_edge_layer_backward_p(hd_handle* h, hd_topology* t, int coord, int precision, const float* AB, const float* x,
+                                      const float* x0, const float* wrd, const float* W2, const float* b2,
+                                      const float* wa, const float* ba, const float* gout, float* G2, float* P, float* G1,
+                                      float* escal, float* colpart, float* bapart, float* b2part, float* wrdpart,
+                                      float* dAB, float* dx, float* dx0, void* stream) {
+    return hd_edge_layer_backward_s(h, t, coord, precision, AB, x, x0, wrd, W2, b2, wa, ba, gout, nullptr, G2, P, G1, escal, colpart,
+                                    bapart, b2part, wrdpart, dAB, dx, dx0, stream);
 }
 
 extern "C" int hd_edge_layer_backward(hd_handle* h, hd_topology* t, int coord, const float* AB, const float* x,

@@ -50,7 +50,14 @@ struct EdgeArgs {
     float w2s_inv;          // PREC 3: 1 / (power-of-two scale of the W2 image)
     float wrmax, wdmax;     // PREC 3: max |w_r|, max |w_d| of this layer (bound on the distance terms of the first layer)
     const float* abmax;     // PREC 3: [M_pad][2] max_k |A_i[k]|, max_k |B_i[k]| of the AB rows (k_ab_rowmax)
+    float* pre2;            // HD_EDGE_SAVE: [4 n_wg tiles][H/32][4][64 lanes][4] second-layer pre-activations, accumulator order
 };
+
+// Flag in the ABL template argument that is not an ablation: the training forward keeps the second-layer pre-activations of
+// every edge row (W2 P + b2, the accumulators as they leave the K loop) for the backward pass, which then needs no second
+// contraction to get them back (k_edge_bwd<., ., 0, ., true>).  Layout = the accumulator's: one 16-byte store per lane and
+// (column tile, row quad), 1 KiB per wavefront instruction; 32 H floats per tile like a row-major [32][H] block.
+constexpr int HD_EDGE_SAVE = 256;
 
 
 // fp16x3: max_k |A_i[k]| and max_k |B_i[k]| of every AB row (the node-level halves of the first edge Linear) - the per-node part of
@@ -654,6 +661,17 @@ HD_DEVINL void edge_tile_body(const EdgeArgs& a, float* smem, float* wrd_s, cons
         else asm volatile("s_waitcnt vmcnt(0)" : "+v"(pa[0]), "+v"(pa[1]), "+v"(pb[0]), "+v"(pb[1]));
     }
     if constexpr (ABL & 16) ts2 = __builtin_readcyclecounter();
+    if constexpr (ABL & HD_EDGE_SAVE) {
+        static_assert(!HD_TWOWAY(PREC), "the saved pre-activations are those of the unscaled modes");
+        // every tile of the padded table is written (a tile past n_tiles recomputes node 0's self edge: finite values the
+        // backward kernels multiply by zero)
+        float* dst = a.pre2 + (size_t)tile * (32 * H) + lane * 4;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<f32x4*>(dst + (ct * 4 + q) * 256) = f32x4{acc[ct][4 * q], acc[ct][4 * q + 1], acc[ct][4 * q + 2], acc[ct][4 * q + 3]};
+    }
     if (!tile_ok) return;                  // padding tile of the last workgroup: nothing to store
     // (Priority experiments - s_setprio raised for the VALU-only prologue / epilogue, for the MFMA loop, or both - were
     // all null within +-0.5 % on both precisions: profiles/history/r02_ablate_fp32.log.)

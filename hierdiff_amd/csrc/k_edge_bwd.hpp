@@ -36,6 +36,7 @@ struct EdgeBwdArgs {
     float norm_constant, coords_range, inv_norm;
     int attention, use_tanh, n_tiles;
     // stage A
+    const float* pre2;      // SAVED: [tiles][H/32][4][64][4] second-layer pre-activations kept by the forward kernel (HD_EDGE_SAVE)
     const float* gin;       // GCL: d(agg) [M_pad][H];  COORD: d(xagg) [M_pad][4]
     float* G2;              // [E_pad][H]
     float* escal;           // [E_pad][8]: {du_x, du_y, du_z, dphi, d(radial), d(d0), -, -}
@@ -57,13 +58,17 @@ HD_DEVINL float dsilu_from_sigmoid(float x, float s) { return s * __builtin_fmaf
 // rows split in registers, weight images [head | middle | tail] per 16-wide K chunk (k_pack_w2_x6), six MFMAs per product on two
 // alternating accumulators, fp32 accumulation; everything around the contraction (first-layer recomputation, SiLU and its
 // derivative, gate / head, the materialised G2 / P / G1 tiles, per-tile partial sums) is the fp32 code of PREC 0.
-template <int H, bool COORD, int STAGE, int PREC = 0>
+// SAVED (stage A only, round 5): the forward pass kept pre2 (k_edge with HD_EDGE_SAVE, 32 H floats per tile in accumulator order); the
+// accumulators are loaded instead of recomputed - no weight stream, no MFMA, 32 16-byte loads per lane up front - and the stage is
+// the HBM-bound element-wise kernel it is at heart (reads pre2 + the gathered gradient rows, writes G2: 2 x 4 H bytes per edge row).
+template <int H, bool COORD, int STAGE, int PREC = 0, bool SAVED = false>
 __global__ __launch_bounds__(256, 2) void k_edge_bwd(EdgeBwdArgs a) {
+    static_assert(!SAVED || STAGE == 0, "only stage A has something to load");
     constexpr int KC = PREC == 2 ? 16 : 32;                        // K chunk width
     constexpr int NCT = H / 32, NCH = H / KC, CHF = PREC == 2 ? 24 * H : 32 * H;   // CHF: floats per weight chunk image
     extern __shared__ __attribute__((aligned(16))) float smem_b[];
     float* wbuf0 = smem_b;                       // [2][CHF] two K chunks of the weight image (double buffer)
-    float* scr = smem_b + 2 * CHF;               // per wave: 32 phi + 96 unit dir + 32 ni + 32 nj + 32 radial + 32 d0 + 32 valid
+    float* scr = smem_b + (SAVED ? 0 : 2 * CHF); // per wave: 32 phi + 96 unit dir + 32 ni + 32 nj + 32 radial + 32 d0 + 32 valid
     __shared__ __attribute__((aligned(16))) float wrd_s[4 * H];    // [w_r | w_d | b2 | wa]
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -145,13 +150,25 @@ __global__ __launch_bounds__(256, 2) void k_edge_bwd(EdgeBwdArgs a) {
         for (int k = tid * 4; k < CHF; k += 256 * 4) glds16(src + k, dst + (k - lane * 4));
     };
 
+    f32x16 acc[NCT];
+    if constexpr (SAVED) {
+        const float* src = a.pre2 + (size_t)tile * (32 * H) + lane * 4;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(src + (ct * 4 + q) * 256);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[ct][4 * q + j] = v[j];
+            }
+        __syncthreads();                                         // wrd_s staged
+    } else {
     issue_chunk(0);
     __syncthreads();                                             // wrd_s staged
     float P[4 * NQ];
     Raw raw;
     load_raw(0, raw);
     finish_P(0, raw, P);
-    f32x16 acc[NCT];
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {
         const float b2v = (STAGE == 0) ? wrd_s[2 * H + 32 * ct + n] : 0.0f;
@@ -231,6 +248,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_bwd(EdgeBwdArgs a) {
         }
         if (c + 1 < NCH) finish_P(c + 1, raw, P);
         __builtin_amdgcn_sched_barrier(0);
+    }
     }
 
     // acc[ct][r] = row rho(r) = (r&3) + 8*(r>>2) + 4*hh, column 32*ct + n.

@@ -354,6 +354,12 @@ class EGNN_dynamics_QM9(nn.Module):
             raise ValueError('training_precision must be "fp32" or "bf16x6"')
         object.__setattr__(self, "_training_precision", name)
 
+    #: Training forward keeps the second-layer pre-activations W2 P + b2 of every edge row for its backward pass where the
+    #: whole-tile edge kernel runs (large batches; `hd_edge_layer_save_rows`), so stage A of the backward pass loads them instead
+    #: of recomputing them on the matrix cores: [edge rows, hidden_nf] fp32 per edge layer - 228 MB x 18 layers = 4.1 GB at
+    #: B = 256, N = 30, H = 256, a size chosen for this GPU's 288 GB.  False = recompute (rounds 2-4; same gradients to the bit).
+    keep_edge_activations = True
+
     # ------------------------------------------------------------------ precision of the matrix-core path
     @property
     def precision(self) -> str:

@@ -231,20 +231,29 @@ class _EdgeLayer(torch.autograd.Function):
         ba_c = None if ba is None else ba.detach().contiguous()
         out = torch.empty((max(1, tr.M), 4 if coord else tr.H), device=AB.device, dtype=torch.float32)
         x6 = getattr(dyn, "training_precision", "fp32") == "bf16x6"
-        _lib.check(lib.hd_edge_layer_forward_p(dyn._handle(), topo.ptr, int(coord), 2 if x6 else 0, AB.data_ptr(), x4.data_ptr(),
+        # keep W2 P + b2 of every edge row for the backward pass where the library says it pays (large batches) and a gradient
+        # will be asked for: [rows, H] fp32 per edge layer, 4.1 GB for the 18 layers of the headline shape at B = 256
+        pre2 = None
+        if getattr(dyn, "keep_edge_activations", True) and any(ctx.needs_input_grad):
+            rows = int(lib.hd_edge_layer_save_rows(dyn._handle(), topo.ptr, 2 if x6 else 0))
+            if rows > 0:
+                pre2 = torch.empty((rows, tr.H), device=AB.device, dtype=torch.float32)
+        _lib.check(lib.hd_edge_layer_forward_s(dyn._handle(), topo.ptr, int(coord), 2 if x6 else 0, AB.data_ptr(), x4.data_ptr(),
                                                x04.data_ptr(), wrd.data_ptr(), W2.data_ptr(), b2.data_ptr(), wa.data_ptr(),
-                                               None if ba_c is None else ba_c.data_ptr(), out.data_ptr(), _stream(AB.device)),
-                   "hd_edge_layer_forward_p")
-        ctx.save_for_backward(AB, x4, x04, wrd, W2, b2, wa, hd, Wst, *([] if ba_c is None else [ba_c]))
-        ctx.misc = (dyn, topo, tr, coord, ba_c is not None)
+                                               None if ba_c is None else ba_c.data_ptr(), out.data_ptr(),
+                                               None if pre2 is None else pre2.data_ptr(), _stream(AB.device)),
+                   "hd_edge_layer_forward_s")
+        ctx.save_for_backward(AB, x4, x04, wrd, W2, b2, wa, hd, Wst, *([] if ba_c is None else [ba_c]), *([] if pre2 is None else [pre2]))
+        ctx.misc = (dyn, topo, tr, coord, ba_c is not None, pre2 is not None)
         return out[:tr.M]
 
     @staticmethod
     def backward(ctx, gout):
-        dyn, topo, tr, coord, has_ba = ctx.misc
+        dyn, topo, tr, coord, has_ba, has_pre2 = ctx.misc
         saved = ctx.saved_tensors
         AB, x4, x04, wrd, W2, b2, wa, hd, Wst = saved[:9]
         ba = saved[9] if has_ba else None
+        pre2 = saved[-1] if has_pre2 else None
         lib = _lib.load()
         ws = tr.workspace()
         dev = AB.device
@@ -257,12 +266,13 @@ class _EdgeLayer(torch.autograd.Function):
         dx = torch.empty((M, 4), device=dev, dtype=torch.float32)
         dx0 = torch.empty((M, 4), device=dev, dtype=torch.float32)
         x6 = getattr(dyn, "training_precision", "fp32") == "bf16x6"
-        _lib.check(lib.hd_edge_layer_backward_p(
+        _lib.check(lib.hd_edge_layer_backward_s(
             dyn._handle(), topo.ptr, int(coord), 2 if x6 else 0, AB.data_ptr(), x4.data_ptr(), x04.data_ptr(), wrd.data_ptr(), W2.data_ptr(),
-            b2.data_ptr(), wa.data_ptr(), None if ba is None else ba.data_ptr(), g.data_ptr(), ws["G2"].data_ptr(),
+            b2.data_ptr(), wa.data_ptr(), None if ba is None else ba.data_ptr(), g.data_ptr(),
+            None if pre2 is None else pre2.data_ptr(), ws["G2"].data_ptr(),
             ws["P"].data_ptr(), ws["G1"].data_ptr(), ws["escal"].data_ptr(), ws["colpart"].data_ptr(), ws["bapart"].data_ptr(),
             ws["b2part"].data_ptr(), ws["wrdpart"].data_ptr(), dAB.data_ptr(), dx.data_ptr(), dx0.data_ptr(), _stream(dev)),
-            "hd_edge_layer_backward_p")
+            "hd_edge_layer_backward_s")
         # the one dense reduction over all edge rows: dL/dW2[c][k] = sum_e G2[e][c] P[e][k] (K = edge rows, split-K in slab order)
         if getattr(dyn, "training_precision", "fp32") == "bf16x6" and tr.H in (128, 256):
             # opt-in: the same reduction on a three-way bf16 split of both operands (hd_dw2_x6: fp32-accurate, every row read once)

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define HD_ABI_VERSION 9
+#define HD_ABI_VERSION 10
 
 #define HD_OK 0
 #define HD_E_INVALID (-1)      /* bad argument / unsupported configuration */
@@ -228,6 +228,22 @@ int hd_edge_layer_backward_p(hd_handle* h, hd_topology* topo, int coord, int pre
                              const float* x0, const float* wrd, const float* W2, const float* b2, const float* wa,
                              const float* ba, const float* gout, float* G2, float* P, float* G1, float* escal, float* colpart,
                              float* bapart, float* b2part, float* wrdpart, float* dAB, float* dx, float* dx0, void* stream);
+/* Round 5 (ABI 10): keep the second-layer pre-activations instead of recomputing them.  hd_edge_layer_save_rows = rows of a
+ * [rows][hidden_nf] fp32 buffer the forward of this topology can fill (0: the batch is small enough for the column-split / mixed
+ * edge kernels, which keep their faster forward - pass pre2 = NULL and the backward recomputes as before).  hd_edge_layer_forward_s
+ * with pre2 != NULL writes W2 P + b2 of every edge row into it (accumulator order per 32-row tile, opaque to the caller; 228 MB per
+ * layer at B = 256, N = 30, H = 256 - sized for this GPU's HBM, not for a 16 GB card); hd_edge_layer_backward_s with the same
+ * buffer runs stage A as an element-wise kernel over it (no weight stream, no matrix instruction).  pre2 = NULL in either call is
+ * exactly the _p function.  Same results to the bit as the recomputing path in the same arithmetic (tests/test_gpu_training.py). */
+long long hd_edge_layer_save_rows(hd_handle* h, hd_topology* topo, int precision);
+int hd_edge_layer_forward_s(hd_handle* h, hd_topology* topo, int coord, int precision, const float* AB, const float* x,
+                            const float* x0, const float* wrd, const float* W2, const float* b2, const float* wa,
+                            const float* ba, float* out, float* pre2, void* stream);
+int hd_edge_layer_backward_s(hd_handle* h, hd_topology* topo, int coord, int precision, const float* AB, const float* x,
+                             const float* x0, const float* wrd, const float* W2, const float* b2, const float* wa,
+                             const float* ba, const float* gout, const float* pre2, float* G2, float* P, float* G1, float* escal,
+                             float* colpart, float* bapart, float* b2part, float* wrdpart, float* dAB, float* dx, float* dx0,
+                             void* stream);
 /* Backward of hd_edge_layer_forward given gout = dL/d(out).  Per-edge activations are recomputed; the caller provides
  * workspaces G2, P, G1 [rows][H], escal [rows][8], colpart, b2part [tiles][H], wrdpart [tiles][2][H], bapart [tiles]
  * (rows / tiles from hd_topology_layout's counts, tiles rounded up to a multiple of 4).  Written: dAB [M][2H],

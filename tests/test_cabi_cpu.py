@@ -28,7 +28,7 @@ def test_header_symbols_all_exported(lib):
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.hd_version() == _lib.ABI_VERSION == 9
+    assert lib.hd_version() == _lib.ABI_VERSION == 10
 
 
 def test_no_gpu_fails_loudly(lib):

@@ -460,6 +460,54 @@ def test_training_precision_bf16x6_gradients(H):
         dyn.training_precision = "bf16x3"
 
 
+@pytest.mark.parametrize("H,B,mode", [(32, 5, "fp32"), (64, 7, "fp32"), (128, 32, "fp32"), (128, 32, "bf16x6"), (256, 32, "fp32"),
+                                      (256, 32, "bf16x6"), (256, 6, "fp32")])
+def test_kept_edge_activations_equal_the_recomputing_backward(H, B, mode, monkeypatch):
+    """Round 5: the training forward keeps W2 P + b2 of every edge row (hd_edge_layer_forward_s) where the whole-tile edge kernel
+    runs, and stage A of the backward pass loads it instead of recomputing it on the matrix cores (hd_edge_layer_backward_s).
+    `dynamics.keep_edge_activations = False` is the recomputing path of rounds 2-4: same output bits, gradients equal to the
+    bit in exact fp32 (the kept values ARE the recomputed ones: same arithmetic in the same order; in the bf16x6 mode the
+    recomputation orders its partial products differently - 3e-6 - and the kept values are the forward's own) - and the path under test is the
+    one that ran: 870 tiles at B = 32 take the whole-tile kernel at widths 128 / 256, every batch does below 128, and the
+    6-molecule batch at width 256 (column-split forward) keeps nothing."""
+    from hierdiff_amd import _lib
+    from hierdiff_amd.weights import synthetic_state_dict
+    L = 2
+    n_list = [30] * (B - 2) + [17, 9]
+    sd_np = synthetic_state_dict(9, 0, H, L, 2, True, 78, 0.5)
+    xh, nm, em = orc.random_inputs(n_list, 8, 73)
+    t = torch.linspace(0.1, 0.9, B).view(B, 1)
+    w = torch.randn(B, xh.shape[1], 11, generator=torch.Generator().manual_seed(7))
+    lib = _lib.load()
+    orig = lib.hd_edge_layer_forward_s
+    kept = []
+    monkeypatch.setattr(lib, "hd_edge_layer_forward_s", lambda *a: (kept.append(a[13] is not None), orig(*a))[1])
+    res = {}
+    for keep in (True, False):
+        kept.clear()
+        dyn = build_dynamics(sd_np, H, L)
+        dyn.precision = "fp32"
+        dyn.training_precision = mode
+        dyn.keep_edge_activations = keep
+        xg = xh.to(DEV).requires_grad_(True)
+        out = dyn._forward(t.to(DEV), xg, nm.to(DEV), em.to(DEV), None, None)
+        (out * w.to(DEV)).sum().backward()
+        expect = keep and not (H >= 128 and B < 32)
+        assert kept and all(k == expect for k in kept), (keep, kept)
+        res[keep] = (out.detach().clone(), xg.grad.clone(), {k: p.grad.detach().clone() for k, p in dyn.egnn.named_parameters()})
+    assert torch.equal(res[True][0], res[False][0])
+    worst = 0.0
+    for k, g in res[False][2].items():
+        d = float((res[True][2][k] - g).norm() / g.norm().clamp_min(1e-30))
+        worst = max(worst, d)
+    dx = float((res[True][1] - res[False][1]).norm() / res[False][1].norm())
+    print(f"H={H} B={B} {mode}: kept vs recomputed - worst parameter-gradient rel-L2 {worst:.2e}, d/dxh {dx:.2e}")
+    if mode == "fp32":
+        assert worst == 0.0 and dx == 0.0
+    else:       # bf16x6: stage A's own contraction sums its six partial products in another order than the forward kernel's
+        assert worst < 1e-5 and dx < 1e-5
+
+
 # ----------------------------------------------------------------------------- new masks every step: staged batches, pooled arenas
 def _host_batch(seed, B=6, N=9, sizes=None):
     g = torch.Generator().manual_seed(seed)
