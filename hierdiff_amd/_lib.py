@@ -64,7 +64,9 @@ SIGNATURES = {
     "hd_edge_layer_backward_p": (C.c_int, [_VP, _VP, C.c_int, C.c_int] + [_FP] * 20 + [_VP]),
     "hd_edge_layer_save_rows": (C.c_longlong, [_VP, _VP, C.c_int]),
     "hd_edge_layer_forward_s": (C.c_int, [_VP, _VP, C.c_int, C.c_int] + [_FP] * 10 + [_VP]),
-    "hd_edge_layer_backward_s": (C.c_int, [_VP, _VP, C.c_int, C.c_int] + [_FP] * 21 + [_VP]),
+    "hd_edge_layer_backward_s": (C.c_int, [_VP, _VP, C.c_int, C.c_int] + [_FP] * 22 + [_VP]),
+    "hd_edge_layer_f16ws_floats": (C.c_longlong, [_VP, _VP, C.POINTER(C.c_int)]),
+    "hd_dw2_f16": (C.c_int, [C.c_int, C.c_int, C.c_int, _FP, _FP, _FP, _FP, C.c_int, _FP, C.c_int, _FP, C.c_longlong, _VP]),
     "hd_egcl_create": (C.c_int, [C.POINTER(HdEgclConfig), C.c_int, C.POINTER(_VP)]),
     "hd_egcl_destroy": (C.c_int, [_VP]),
     "hd_egcl_weight_count": (C.c_longlong, [_VP]),

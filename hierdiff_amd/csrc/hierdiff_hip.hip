@@ -1354,6 +1354,19 @@ static int launch_edge_h(hd_handle* h, bool coord, const EdgeArgs& a, hipStream_
     const int prec = mode_override >= 0 ? ((mode_override == 2 && H < 128) ? 0 : mode_override) : h->edge_mode;
     const bool x6 = prec == 2;
     const dim3 grid(a.n_wg), block(256);
+    if constexpr (H >= 128) {
+        if (a.dscal) {
+            // training forward in fp16x3 arithmetic: the whole-tile kernel on the unscaled parameters (HD_EDGE_UNSCALED), keeping pre2 or not
+            if (a.pre2) {
+                if (coord) hipLaunchKernelGGL((k_edge<H, true, 3, HD_EDGE_SAVE | HD_EDGE_UNSCALED>), grid, block, lds, s, a);
+                else hipLaunchKernelGGL((k_edge<H, false, 3, HD_EDGE_SAVE | HD_EDGE_UNSCALED>), grid, block, lds, s, a);
+            } else {
+                if (coord) hipLaunchKernelGGL((k_edge<H, true, 3, HD_EDGE_UNSCALED>), grid, block, lds, s, a);
+                else hipLaunchKernelGGL((k_edge<H, false, 3, HD_EDGE_UNSCALED>), grid, block, lds, s, a);
+            }
+            return HD_OK;
+        }
+    }
     if (a.pre2) {
         // training forward that keeps pre2 for the backward pass (HD_EDGE_SAVE): always the whole-tile kernel, whose accumulator
         // layout is the saved layout (the caller offers the buffer only where this kernel would run anyway: edge_layer_saves)
@@ -1466,6 +1479,10 @@ static int prepare_edge_h() {
     HIP_TRY(hipFuncSetAttribute((const void*)k_edge<H, true, 0, HD_EDGE_SAVE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIP_TRY(hipFuncSetAttribute((const void*)k_edge<H, false, 0, HD_EDGE_SAVE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     if constexpr (H >= 128) {
+        HIP_TRY(hipFuncSetAttribute((const void*)k_edge<H, true, 3, HD_EDGE_SAVE | HD_EDGE_UNSCALED>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_edge<H, false, 3, HD_EDGE_SAVE | HD_EDGE_UNSCALED>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_edge<H, true, 3, HD_EDGE_UNSCALED>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_edge<H, false, 3, HD_EDGE_UNSCALED>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_edge<H, true, 2, HD_EDGE_SAVE>, hipFuncAttributeMaxDynamicSharedMemorySize, edge_lds_bytes<H>(true)));
         HIP_TRY(hipFuncSetAttribute((const void*)k_edge<H, false, 2, HD_EDGE_SAVE>, hipFuncAttributeMaxDynamicSharedMemorySize, edge_lds_bytes<H>(true)));
         HIP_TRY(hipFuncSetAttribute((const void*)k_edge<H, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, edge_lds_bytes<H>(true)));
@@ -1747,13 +1764,16 @@ static int prepare_edge_bwd_h() {
         HIP_TRY(hipFuncSetAttribute((const void*)k_edge_bwd<H, false, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds6));
         HIP_TRY(hipFuncSetAttribute((const void*)k_edge_bwd<H, true, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds6));
         HIP_TRY(hipFuncSetAttribute((const void*)k_edge_bwd<H, true, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds6));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_edge_bwd<H, false, 1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_edge_bwd<H, true, 1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     }
     return HD_OK;
 }
 
 template <int H>
-static void launch_edge_bwd_h(bool coord, int stage, bool x6, const EdgeBwdArgs& a, int n_wg, hipStream_t s) {
+static void launch_edge_bwd_h(bool coord, int stage, int prec, const EdgeBwdArgs& a, int n_wg, hipStream_t s) {
     const dim3 grid(n_wg), block(256);
+    const bool x6 = prec == 2;
     if (stage == 0 && a.pre2) {                     // pre2 kept by the forward pass: stage A loads it (one kernel for both arithmetics)
         const int ldss = 4 * 288 * 4;
         if (coord) hipLaunchKernelGGL((k_edge_bwd<H, true, 0, 0, true>), grid, block, ldss, s, a);
@@ -1761,6 +1781,12 @@ static void launch_edge_bwd_h(bool coord, int stage, bool x6, const EdgeBwdArgs&
         return;
     }
     if constexpr (H >= 128) {
+        if (prec == 3 && stage == 1) {              // fp16x3 contraction of stage B (16-wide chunks of 16 H floats)
+            const int lds = (2 * 16 * H + 4 * 288) * 4;
+            if (coord) hipLaunchKernelGGL((k_edge_bwd<H, true, 1, 3>), grid, block, lds, s, a);
+            else hipLaunchKernelGGL((k_edge_bwd<H, false, 1, 3>), grid, block, lds, s, a);
+            return;
+        }
         if (x6) {
             const int lds6 = edge_bwd_lds_bytes<H>(true);
             if (!coord && stage == 0) hipLaunchKernelGGL((k_edge_bwd<H, false, 0, 2>), grid, block, lds6, s, a);
@@ -1777,12 +1803,12 @@ static void launch_edge_bwd_h(bool coord, int stage, bool x6, const EdgeBwdArgs&
     else hipLaunchKernelGGL((k_edge_bwd<H, true, 1>), grid, block, lds, s, a);
 }
 
-static void launch_edge_bwd(hd_handle* h, bool coord, int stage, bool x6, const EdgeBwdArgs& a, int n_wg, hipStream_t s) {
+static void launch_edge_bwd(hd_handle* h, bool coord, int stage, int prec, const EdgeBwdArgs& a, int n_wg, hipStream_t s) {
     switch (h->H) {
-        case 32: launch_edge_bwd_h<32>(coord, stage, false, a, n_wg, s); break;
-        case 64: launch_edge_bwd_h<64>(coord, stage, false, a, n_wg, s); break;
-        case 128: launch_edge_bwd_h<128>(coord, stage, x6, a, n_wg, s); break;
-        default: launch_edge_bwd_h<256>(coord, stage, x6, a, n_wg, s); break;
+        case 32: launch_edge_bwd_h<32>(coord, stage, 0, a, n_wg, s); break;
+        case 64: launch_edge_bwd_h<64>(coord, stage, 0, a, n_wg, s); break;
+        case 128: launch_edge_bwd_h<128>(coord, stage, prec, a, n_wg, s); break;
+        default: launch_edge_bwd_h<256>(coord, stage, prec, a, n_wg, s); break;
     }
 }
 
@@ -1793,22 +1819,32 @@ static int check_train(hd_handle* h, hd_topology* t, const char* who) {
     return HD_OK;
 }
 
+// Floats of the workspace the fp16x3 backward wants (hd_edge_layer_backward_s, precision 3): image scalars, per-workgroup maxima of
+// |G2| and |P| (read by hd_dw2_f16 at offsets 4 and 4 + n), per-row maxima of G2.  *n_wg = n, the number of per-workgroup maxima.
+extern "C" long long hd_edge_layer_f16ws_floats(hd_handle* h, hd_topology* t, int* n_wg) {
+    if (!h || !t || t->h != h) return 0;
+    if (n_wg) *n_wg = t->n_wg;
+    return 4 + 2 * (long long)t->n_wg + (long long)t->n_wg * 4 * 32;
+}
+
 // Rows of the pre2 buffer a training forward may keep for its backward pass (hd_edge_layer_forward_s), or 0 where keeping does
 // not pay: batches small enough for the column-split / mixed edge kernels keep their faster forward and recompute.
 extern "C" long long hd_edge_layer_save_rows(hd_handle* h, hd_topology* t, int precision) {
     if (!h || !t || t->h != h || t->n_wg == 0 || t->M == 0) return 0;
-    if (h->H >= 128 && precision != 0 && precision != 2) return 0;
-    const int mode = (precision == 2 && h->H >= 128) ? 2 : 0;
+    if (precision != 0 && precision != 2 && precision != 3) return 0;
+    const int mode = h->H >= 128 ? precision : 0;
     if (h->H >= 128 && (edge_runs_split(h, t->n_tiles, mode) || edge_runs_mixed(h, t->n_tiles, mode))) return 0;
-    return (long long)t->n_wg * 4 * 32;
+    return (long long)t->n_wg * 4 * 32 + 32;        // one tile more than the table has: the fp16x3 forward parks its image scalars there
 }
 
 extern "C" int hd_edge_layer_forward_s(hd_handle* h, hd_topology* t, int coord, int precision, const float* AB, const float* x,
                                        const float* x0, const float* wrd, const float* W2, const float* b2,
                                        const float* wa, const float* ba, float* out, float* pre2, void* stream) {
     HD_TRY(check_train(h, t, "hd_edge_layer_forward"));
-    if (precision != 0 && precision != 2) return fail(HD_E_INVALID, "hd_edge_layer_forward_p: precision must be 0 (fp32) or 2 (bf16x6)");
+    if (precision != 0 && precision != 2 && precision != 3)
+        return fail(HD_E_INVALID, "hd_edge_layer_forward: precision must be 0 (fp32), 2 (bf16x6) or 3 (fp16x3)");
     const bool x6 = precision == 2 && h->H >= 128;          // narrower widths run the exact-fp32 kernels, as in sampling
+    const bool f16 = precision == 3 && h->H >= 128;
     topo_use(t, (hipStream_t)stream);
     if (!AB || !x || !x0 || !wrd || !W2 || !b2 || !wa || !out) return fail(HD_E_INVALID, "hd_edge_layer_forward: null tensor");
     HIP_TRY(hipSetDevice(h->device));
@@ -1818,10 +1854,20 @@ extern "C" int hd_edge_layer_forward_s(hd_handle* h, hd_topology* t, int coord, 
     const int ow = coord ? 4 : H;
     HIP_TRY(hipMemsetAsync(out, 0, (size_t)std::max(1, M) * ow * sizeof(float), s));
     if (t->n_wg == 0 || M == 0) return HD_OK;
-    if (x6) hipLaunchKernelGGL((k_pack_w2_x6<false>), dim3((H * H / 2 + 255) / 256), dim3(256), 0, s, W2, reinterpret_cast<uint32_t*>(t->w2img), H);
-    else hipLaunchKernelGGL((k_pack_w2<false>), dim3((H * H + 255) / 256), dim3(256), 0, s, W2, t->w2img, H);
     EdgeArgs e;
     std::memset(&e, 0, sizeof(e));
+    if (f16) {
+        // fp16 image of the parameter and its scalars (behind the image: the buffer holds 1.5 H^2 floats), row maxima of the AB rows
+        // (with a kept pre2 the scalars live in the buffer's extra tile, where the backward call finds them again)
+        float* scal = pre2 ? pre2 + (size_t)t->n_wg * 128 * H : t->w2img + (size_t)H * H;
+        hipLaunchKernelGGL(k_f16_prep, dim3(1), dim3(1024), 0, s, W2, wrd, scal, H);
+        hipLaunchKernelGGL((k_pack_w2_f16<false>), dim3((H * H / 8 + 255) / 256), dim3(256), 0, s, W2, (const float*)scal,
+                           reinterpret_cast<f16x8*>(t->w2img), H);
+        AbMaxArgs am{AB, t->abmax, M, H};
+        hipLaunchKernelGGL(k_ab_rowmax, dim3((M + 3) / 4), dim3(256), 0, s, am);
+        e.dscal = scal; e.abmax = t->abmax;
+    } else if (x6) hipLaunchKernelGGL((k_pack_w2_x6<false>), dim3((H * H / 2 + 255) / 256), dim3(256), 0, s, W2, reinterpret_cast<uint32_t*>(t->w2img), H);
+    else hipLaunchKernelGGL((k_pack_w2<false>), dim3((H * H + 255) / 256), dim3(256), 0, s, W2, t->w2img, H);
     e.AB = AB; e.wrd = wrd; e.W2img = t->w2img; e.b2 = b2; e.wa = wa;
     e.w2s_inv = 1.0f; e.wrmax = e.wdmax = 0.0f;
     e.ei = t->ei; e.ej = t->ej; e.eseg = t->eseg; e.seg_part = t->seg_part; e.tile_nseg = t->tile_nseg;
@@ -1829,7 +1875,7 @@ extern "C" int hd_edge_layer_forward_s(hd_handle* h, hd_topology* t, int coord, 
     e.norm_constant = c.norm_constant; e.coords_range = c.coords_range / (float)c.n_layers; e.attention = c.attention;
     e.use_tanh = c.tanh; e.n_tiles = t->n_tiles; e.n_wg = t->n_wg;
     e.pre2 = pre2;
-    HD_TRY(edge(h, coord != 0, e, s, x6 ? 2 : 0));
+    HD_TRY(edge(h, coord != 0, e, s, f16 ? 3 : x6 ? 2 : 0));
     AggArgs ag;
     ag.part = coord ? t->xpart : t->part; ag.pstart = t->pstart; ag.agg = out; ag.norm = agg_norm(c, t);
     ag.M = M; ag.H = ow;
@@ -1842,6 +1888,7 @@ extern "C" int hd_edge_layer_forward_s(hd_handle* h, hd_topology* t, int coord, 
 extern "C" int hd_edge_layer_forward_p(hd_handle* h, hd_topology* t, int coord, int precision, const float* AB, const float* x,
                                        const float* x0, const float* wrd, const float* W2, const float* b2,
                                        const float* wa, const float* ba, float* out, void* stream) {
+    if (precision == 3) return fail(HD_E_INVALID, "hd_edge_layer_forward_p: precision must be 0 (fp32) or 2 (bf16x6)");
     return hd_edge_layer_forward_s(h, t, coord, precision, AB, x, x0, wrd, W2, b2, wa, ba, out, nullptr, stream);
 }
 
@@ -1853,12 +1900,17 @@ extern "C" int hd_edge_layer_forward(hd_handle* h, hd_topology* t, int coord, co
 
 extern "C" int hd_edge_layer_backward_s(hd_handle* h, hd_topology* t, int coord, int precision, const float* AB, const float* x,
                                       const float* x0, const float* wrd, const float* W2, const float* b2,
-                                      const float* wa, const float* ba, const float* gout, const float* pre2, float* G2, float* P, float* G1,
+                                      const float* wa, const float* ba, const float* gout, const float* pre2, float* f16ws,
+                                      float* G2, float* P, float* G1,
                                       float* escal, float* colpart, float* bapart, float* b2part, float* wrdpart,
                                       float* dAB, float* dx, float* dx0, void* stream) {
     HD_TRY(check_train(h, t, "hd_edge_layer_backward"));
-    if (precision != 0 && precision != 2) return fail(HD_E_INVALID, "hd_edge_layer_backward_p: precision must be 0 (fp32) or 2 (bf16x6)");
+    if (precision != 0 && precision != 2 && precision != 3)
+        return fail(HD_E_INVALID, "hd_edge_layer_backward: precision must be 0 (fp32), 2 (bf16x6) or 3 (fp16x3)");
+    if (precision == 3 && (!pre2 || !f16ws))
+        return fail(HD_E_INVALID, "hd_edge_layer_backward_s: precision 3 (fp16x3) needs the kept pre2 and the f16ws workspace");
     const bool x6 = precision == 2 && h->H >= 128;
+    const bool f16 = precision == 3 && h->H >= 128;
     topo_use(t, (hipStream_t)stream);
     if (!AB || !x || !x0 || !wrd || !W2 || !b2 || !wa || !gout || !G2 || !P || !G1 || !escal || !colpart || !bapart ||
         !b2part || !wrdpart || !dAB || !dx || !dx0)
@@ -1886,7 +1938,11 @@ extern "C" int hd_edge_layer_backward_s(hd_handle* h, hd_topology* t, int coord,
     // cover every active node), so nothing is cleared first; escal[:, 0:4] is only defined (and only read) in coordinate layers
     if (coord) HIP_TRY(hipMemsetAsync(bapart, 0, (size_t)tiles * sizeof(float), s));     // no attention bias in a coordinate layer
     // (stage A streams the W2 image only when it has to recompute pre2)
-    if (x6) {
+    const float* f16scal = f16 ? pre2 + (size_t)t->n_wg * 128 * H : nullptr;     // {2^k, 2^-k, ..} of W2, left by the precision-3 forward
+    if (f16) {
+        hipLaunchKernelGGL((k_pack_w2_f16c<true>), dim3((H * H / 8 + 255) / 256), dim3(256), 0, s, W2, f16scal,
+                           reinterpret_cast<f16x8*>(t->w2timg), H);
+    } else if (x6) {
         if (!pre2) hipLaunchKernelGGL((k_pack_w2_x6<false>), dim3((H * H / 2 + 255) / 256), dim3(256), 0, s, W2, reinterpret_cast<uint32_t*>(t->w2img), H);
         hipLaunchKernelGGL((k_pack_w2_x6<true>), dim3((H * H / 2 + 255) / 256), dim3(256), 0, s, W2, reinterpret_cast<uint32_t*>(t->w2timg), H);
     } else {
@@ -1900,10 +1956,14 @@ extern "C" int hd_edge_layer_backward_s(hd_handle* h, hd_topology* t, int coord,
     a.inv_norm = 1.0f / agg_norm(c, t); a.attention = c.attention; a.use_tanh = c.tanh; a.n_tiles = t->n_tiles;
     a.gin = gout; a.G2 = G2; a.escal = escal; a.colpart = colpart; a.bapart = bapart; a.Pout = P; a.G1 = G1;
     a.b2part = b2part; a.wrdpart = wrdpart; a.pre2 = pre2;
+    if (f16) {      // f16ws: {2^k, 2^-k, -, -} | per-workgroup maxima of |G2|, |P| | row maxima of G2  (hd_edge_layer_f16ws_floats)
+        a.w2scal = f16scal; a.g2wgmax = f16ws + 4; a.pwgmax = f16ws + 4 + t->n_wg; a.g2max = f16ws + 4 + 2 * (size_t)t->n_wg;
+    }
+    const int prec = f16 ? 3 : x6 ? 2 : 0;
     a.Wimg = t->w2img;
-    launch_edge_bwd(h, coord != 0, 0, x6, a, t->n_wg, s);
+    launch_edge_bwd(h, coord != 0, 0, prec, a, t->n_wg, s);
     a.Wimg = t->w2timg;
-    launch_edge_bwd(h, coord != 0, 1, x6, a, t->n_wg, s);
+    launch_edge_bwd(h, coord != 0, 1, prec, a, t->n_wg, s);
     CsrSumArgs cs;
     std::memset(&cs, 0, sizeof(cs));
     cs.G = G1; cs.out = dAB; cs.M = M; cs.H = H; cs.ldo = 2 * H;
@@ -1925,7 +1985,8 @@ extern "C" int hd_edge_layer_backward_p(hd_handle* h, hd_topology* t, int coord,
                                       const float* wa, const float* ba, const float* gout, float* G2, float* P, float* G1,
                                       float* escal, float* colpart, float* bapart, float* b2part, float* wrdpart,
                                       float* dAB, float* dx, float* dx0, void* stream) {
-    return hd_edge_layer_backward_s(h, t, coord, precision, AB, x, x0, wrd, W2, b2, wa, ba, gout, nullptr, G2, P, G1, escal, colpart,
+    if (precision == 3) return fail(HD_E_INVALID, "hd_edge_layer_backward_p: precision must be 0 (fp32) or 2 (bf16x6)");
+    return hd_edge_layer_backward_s(h, t, coord, precision, AB, x, x0, wrd, W2, b2, wa, ba, gout, nullptr, nullptr, G2, P, G1, escal, colpart,
                                     bapart, b2part, wrdpart, dAB, dx, dx0, stream);
 }
 
@@ -2404,6 +2465,41 @@ static int dw2_impl(const char* who, int device, int rows, int H, const float* G
 extern "C" int hd_dw2_x6(int device, int rows, int H, const float* G2, const float* P, float* dW2, int ldc, float* ws,
                          long long ws_floats, void* stream) {
     return dw2_impl("hd_dw2_x6", device, rows, H, G2, P, dW2, ldc, ws, ws_floats, stream);
+}
+
+// dW2 = G2^T P in fp16x3 arithmetic (k_dw2_f16): gmax / pmax = the n per-workgroup maxima the fp16x3 backward left in its workspace
+extern "C" int hd_dw2_f16(int device, int rows, int H, const float* G2, const float* P, const float* gmax, const float* pmax, int n,
+                          float* dW2, int ldc, float* ws, long long ws_floats, void* stream) {
+    const char* who = "hd_dw2_f16";
+    if (!G2 || !P || !dW2 || !ws || !gmax || !pmax || n < 1) return fail(HD_E_INVALID, std::string(who) + ": null tensor / no maxima");
+    if (H != 128 && H != 256) return fail(HD_E_INVALID, std::string(who) + ": H must be 128 or 256 (narrower layers use hd_gemm_f32)");
+    if (rows <= 0 || rows % 32 != 0 || ldc < H) return fail(HD_E_INVALID, std::string(who) + ": rows must be a positive multiple of 32 (whole edge tiles), ldc >= H");
+    if (hd_device_count() <= device || device < 0) return fail(HD_E_HIP, std::string(who) + ": no such HIP device (is a GPU visible?)");
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t s = (hipStream_t)stream;
+    int slabs = (int)std::min<long long>(256, ws_floats / ((long long)H * H));
+    slabs = std::max(1, std::min(slabs, rows / 128));
+    if ((long long)slabs * H * H > ws_floats) return fail(HD_E_INVALID, std::string(who) + ": workspace smaller than one H x H slab");
+    const int kslab = ((rows / 32 + slabs - 1) / slabs) * 32;
+    slabs = (rows + kslab - 1) / kslab;
+    Dw2F16Args a;
+    a.G = G2; a.P = P; a.ws = ws; a.gmax = gmax; a.pmax = pmax; a.rows = rows; a.kslab = kslab; a.nmax = n;
+    {
+        static std::mutex mu;
+        static unsigned long long prepared_mask = 0;
+        std::lock_guard<std::mutex> lk(mu);
+        const unsigned long long bit = 1ull << (device & 63);
+        if (!(prepared_mask & bit)) {
+            HIP_TRY(hipFuncSetAttribute((const void*)k_dw2_f16<256>, hipFuncAttributeMaxDynamicSharedMemorySize, dw2_f16_lds_bytes<256>()));
+            HIP_TRY(hipFuncSetAttribute((const void*)k_dw2_f16<128>, hipFuncAttributeMaxDynamicSharedMemorySize, dw2_f16_lds_bytes<128>()));
+            prepared_mask |= bit;
+        }
+    }
+    if (H == 256) hipLaunchKernelGGL((k_dw2_f16<256>), dim3(slabs), dim3(512), dw2_f16_lds_bytes<256>(), s, a);
+    else hipLaunchKernelGGL((k_dw2_f16<128>), dim3(slabs), dim3(512), dw2_f16_lds_bytes<128>(), s, a);
+    hipLaunchKernelGGL(k_dw2_reduce, dim3((H * H + 255) / 256), dim3(256), 0, s, ws, dW2, H * H, H, ldc, slabs);
+    HIP_TRY(hipGetLastError());
+    return HD_OK;
 }
 
 extern "C" int hd_colsum_f32(int device, int rows, int n, const float* const* src, const int* width, float* const* dst,

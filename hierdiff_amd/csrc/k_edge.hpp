@@ -50,6 +50,7 @@ struct EdgeArgs {
     float w2s_inv;          // PREC 3: 1 / (power-of-two scale of the W2 image)
     float wrmax, wdmax;     // PREC 3: max |w_r|, max |w_d| of this layer (bound on the distance terms of the first layer)
     const float* abmax;     // PREC 3: [M_pad][2] max_k |A_i[k]|, max_k |B_i[k]| of the AB rows (k_ab_rowmax)
+    const float* dscal;     // HD_EDGE_UNSCALED: device scalars {2^k, 2^-k, max |w_r|, max |w_d|} (k_f16_prep) instead of w2s_inv, wrmax, wdmax
     float* pre2;            // HD_EDGE_SAVE: [4 n_wg tiles][H/32][4][64 lanes][4] second-layer pre-activations, accumulator order
 };
 
@@ -58,6 +59,12 @@ struct EdgeArgs {
 // contraction to get them back (k_edge_bwd<., ., 0, ., true>).  Layout = the accumulator's: one 16-byte store per lane and
 // (column tile, row quad), 1 KiB per wavefront instruction; 32 H floats per tile like a row-major [32][H] block.
 constexpr int HD_EDGE_SAVE = 256;
+// Second such flag (PREC 3 only): the fp16x3 kernel on UNSCALED inputs.  The sampler's two-way modes run the edge model in a domain
+// scaled by c = -log2(e) (the factor sits in the packed weights, so exp(-x) is a bare v_exp_f32); the training forward works on the
+// parameters themselves - AB rows from a plain GEMM, w_r / w_d / b2 / wa as they are - and pays the multiplication by c in front of
+// every exponential instead (one VALU instruction per activation).  The image scalars come from device memory (EdgeArgs.dscal).
+constexpr int HD_EDGE_UNSCALED = 512;
+constexpr float HD_NEG_LOG2E = -1.4426950408889634f;
 
 
 // fp16x3: max_k |A_i[k]| and max_k |B_i[k]| of every AB row (the node-level halves of the first edge Linear) - the per-node part of
@@ -302,10 +309,11 @@ HD_DEVINL void edge_tile_body(const EdgeArgs& a, float* smem, float* wrd_s, cons
     float f16_inv = 1.0f;
     if constexpr (PREC == 3) {
         const float nodes = a.abmax[2 * (size_t)ni] + a.abmax[2 * (size_t)nj + 1] + HD_F16_FLOOR;
-        const float bound = __builtin_fmaf(radial, a.wrmax, __builtin_fmaf(d0, a.wdmax, nodes));
+        const float wrmax = (ABL & HD_EDGE_UNSCALED) ? a.dscal[2] : a.wrmax, wdmax = (ABL & HD_EDGE_UNSCALED) ? a.dscal[3] : a.wdmax;
+        const float bound = __builtin_fmaf(radial, wrmax, __builtin_fmaf(d0, wdmax, nodes));
         const uint32_t eb = (__builtin_bit_cast(uint32_t, bound) >> 23) & 0xffu;      // bound in [2^(eb-127), 2^(eb-126))
         f16_inv = __builtin_bit_cast(float, (eb - 13u) << 23);                        // 2^-(13 - E), E = eb - 127: bound x s < 2^14
-        if (hh == 0) my_scr[n] = f16_inv * a.w2s_inv;
+        if (hh == 0) my_scr[n] = f16_inv * ((ABL & HD_EDGE_UNSCALED) ? a.dscal[1] : a.w2s_inv);
     }
     const int pid_l = tile_ok ? a.seg_part[tile * 32 + n] : 0;   // part id of segment n; requested here, used in the epilogue
     const int nseg = tile_ok ? a.tile_nseg[tile] : 0;
@@ -350,7 +358,7 @@ HD_DEVINL void edge_tile_body(const EdgeArgs& a, float* smem, float* wrd_s, cons
             return;
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) e[j] = __builtin_amdgcn_exp2f(pre[j]);
+        for (int j = 0; j < 4; ++j) e[j] = __builtin_amdgcn_exp2f((ABL & HD_EDGE_UNSCALED) ? pre[j] * HD_NEG_LOG2E : pre[j]);
 #pragma unroll
         for (int j = 0; j < 4; ++j) e[j] = PREC == 3 ? __builtin_fmaf(e[j], f16_inv, f16_inv) : 1.0f + e[j];
 #pragma unroll
@@ -662,7 +670,19 @@ HD_DEVINL void edge_tile_body(const EdgeArgs& a, float* smem, float* wrd_s, cons
     }
     if constexpr (ABL & 16) ts2 = __builtin_readcyclecounter();
     if constexpr (ABL & HD_EDGE_SAVE) {
-        static_assert(!HD_TWOWAY(PREC), "the saved pre-activations are those of the unscaled modes");
+        static_assert(!HD_TWOWAY(PREC) || (PREC == 3 && (ABL & HD_EDGE_UNSCALED)), "the saved pre-activations are those of the unscaled modes");
+        if constexpr (PREC == 3) {         // the un-scaling fma of the epilogue (row scale x image scale out, bias in), done here for all tiles
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                const float b2v = wrd_s[2 * H + 32 * ct + n];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 rs = *reinterpret_cast<const f32x4*>(my_scr + 8 * q + 4 * hh);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[ct][4 * q + j] = __builtin_fmaf(acc[ct][4 * q + j], rs[j], b2v);
+                }
+            }
+        }
         // every tile of the padded table is written (a tile past n_tiles recomputes node 0's self edge: finite values the
         // backward kernels multiply by zero)
         float* dst = a.pre2 + (size_t)tile * (32 * H) + lane * 4;
@@ -709,14 +729,14 @@ HD_DEVINL void edge_tile_body(const EdgeArgs& a, float* smem, float* wrd_s, cons
             // runs each value's exp -> add -> rcp -> mul chain back to back through one or two registers and
             // the epilogue sits out the transcendental latency ~500 times.
             float e[16];
-            if constexpr (PREC == 3) {
+            if constexpr (PREC == 3 && !(ABL & HD_EDGE_SAVE)) {
                 const float b2v = wrd_s[2 * H + 32 * ct + n];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[ct][r] = __builtin_fmaf(acc[ct][r], rsc[r >> 2][r & 3], b2v);
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) e[r] = __builtin_amdgcn_exp2f(acc[ct][r]);
+            for (int r = 0; r < 16; ++r) e[r] = __builtin_amdgcn_exp2f((ABL & HD_EDGE_UNSCALED) ? acc[ct][r] * HD_NEG_LOG2E : acc[ct][r]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int r = 0; r < 16; ++r) e[r] = 1.0f + e[r];
@@ -778,7 +798,7 @@ HD_DEVINL void edge_tile_body(const EdgeArgs& a, float* smem, float* wrd_s, cons
         if (a.attention) {
             const float ba = a.ba_ptr ? *a.ba_ptr : a.ba;
             if constexpr (!HD_TWOWAY(PREC)) att_mine = sigmoid_f(rowdot + ba);
-            else att_mine = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(rowdot + ba));   // scaled domain
+            else att_mine = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f((ABL & HD_EDGE_UNSCALED) ? (rowdot + ba) * HD_NEG_LOG2E : rowdot + ba));   // scaled domain
         }
         float w[16];
         int sg[16];

@@ -47,6 +47,11 @@ struct EdgeBwdArgs {
     float* Pout;            // [E_pad][H]
     float* G1;              // [E_pad][H]
     float* wrdpart;         // [tiles][2][H] per-tile sum_r radial_r G1[r][:], sum_r d0_r G1[r][:]   (d(w_r), d(w_d))
+    // fp16x3 contractions (training_precision "fp16x3"; only with SAVED stage A)
+    float* g2max;           // [E_pad] max_c |G2[e][c]| - written by stage A (SAVED), ranges the rows of stage B's operand
+    float* g2wgmax;         // [workgroups] the same maximum per workgroup of stage A  (global range of G2 for k_dw2_f16)
+    float* pwgmax;          // [workgroups] max |P| per workgroup of stage B (PREC 3)   (global range of P for k_dw2_f16)
+    const float* w2scal;    // stage B PREC 3: device scalars of the fp16 weight image {2^k, 2^-k, ...} (k_f16_prep)
 };
 
 // sigmoid and the SiLU derivative from it: silu'(x) = s (1 + x (1 - s))
@@ -61,11 +66,16 @@ HD_DEVINL float dsilu_from_sigmoid(float x, float s) { return s * __builtin_fmaf
 // SAVED (stage A only, round 5): the forward pass kept pre2 (k_edge with HD_EDGE_SAVE, 32 H floats per tile in accumulator order); the
 // accumulators are loaded instead of recomputed - no weight stream, no MFMA, 32 16-byte loads per lane up front - and the stage is
 // the HBM-bound element-wise kernel it is at heart (reads pre2 + the gathered gradient rows, writes G2: 2 x 4 H bytes per edge row).
+// PREC 3 (stage B only, round 5, `training_precision = "fp16x3"`): dP = G2 W2 in the two-way FP16 split of the sampler's fp16x3 mode (three
+// v_mfma_f32_32x32x16_f16 per product).  An operand row - the G2 row of one edge - is scaled by s = 2^(13 - E), E = floor(log2(max_c
+// |G2[e][c]|)), the row maximum stage A left in g2max (exact, not a bound), the W2^T image by the power of two that puts its largest
+// element into [2^14, 2^15) (k_pack_w2_f16); the epilogue undoes both in the factor it multiplies a row by anyway.
 template <int H, bool COORD, int STAGE, int PREC = 0, bool SAVED = false>
 __global__ __launch_bounds__(256, 2) void k_edge_bwd(EdgeBwdArgs a) {
     static_assert(!SAVED || STAGE == 0, "only stage A has something to load");
-    constexpr int KC = PREC == 2 ? 16 : 32;                        // K chunk width
-    constexpr int NCT = H / 32, NCH = H / KC, CHF = PREC == 2 ? 24 * H : 32 * H;   // CHF: floats per weight chunk image
+    static_assert(PREC != 3 || (STAGE == 1 && H >= 128), "the fp16x3 contraction exists for stage B at widths 128 / 256");
+    constexpr int KC = (PREC == 2 || PREC == 3) ? 16 : 32;         // K chunk width
+    constexpr int NCT = H / 32, NCH = H / KC, CHF = PREC == 2 ? 24 * H : PREC == 3 ? 16 * H : 32 * H;   // CHF: floats per weight chunk image
     extern __shared__ __attribute__((aligned(16))) float smem_b[];
     float* wbuf0 = smem_b;                       // [2][CHF] two K chunks of the weight image (double buffer)
     float* scr = smem_b + (SAVED ? 0 : 2 * CHF); // per wave: 32 phi + 96 unit dir + 32 ni + 32 nj + 32 radial + 32 d0 + 32 valid
@@ -106,6 +116,15 @@ __global__ __launch_bounds__(256, 2) void k_edge_bwd(EdgeBwdArgs a) {
         }
     }
 
+    // fp16x3 stage B: scale of this lane's operand row and, for the epilogue (by row slot), 1 / (row scale x image scale)
+    float f16_s = 1.0f;
+    if constexpr (PREC == 3) {
+        const float g = fmaxf(a.g2max[e], 7.8886090522101181e-31f);                   // 2^-100: a zero row stays zero under any scale
+        const uint32_t eb = (__builtin_bit_cast(uint32_t, g) >> 23) & 0xffu;          // g in [2^(eb-127), 2^(eb-126))
+        f16_s = __builtin_bit_cast(float, (267u - eb) << 23);                         // 2^(13 - E): g s < 2^14
+        if (hh == 0) phi_s[n] = __builtin_bit_cast(float, (eb - 13u) << 23) * a.w2scal[1];
+    }
+
     // A operand of K chunk c for this lane's edge row (k = 32c + 16hh + 0..15).  The raw rows are requested one chunk ahead
     // (load_raw, in flight under the MFMAs of the current chunk) and finished behind them (finish_P: first-layer
     // pre-activation + SiLU; stage B: the G2 row as it is).
@@ -140,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_bwd(EdgeBwdArgs a) {
                 }
             } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) P[4 * u + j] = w.a[u][j];
+                for (int j = 0; j < 4; ++j) P[4 * u + j] = PREC == 3 ? w.a[u][j] * f16_s : w.a[u][j];
             }
         }
     };
@@ -221,6 +240,33 @@ __global__ __launch_bounds__(256, 2) void k_edge_bwd(EdgeBwdArgs a) {
                 for (int k = 0; k < 6; ++k) fcur[k] = fnxt[k];
                 __builtin_amdgcn_sched_barrier(0);
             }
+        } else if constexpr (PREC == 3) {
+            // one k-step of 16 per chunk; image [hi | lo][column tile][64 lanes] x 16 B (k_pack_w2_f16c).  Per pair of column tiles six
+            // MFMAs on alternating accumulators (h*H, l*H, h*L), fragments requested a pair ahead.
+            u32x4 xh, xl;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { uint32_t hi, lo; f16_split2(P[2 * i], P[2 * i + 1], hi, lo); xh[i] = hi; xl[i] = lo; }
+            const f16x8 A_h = __builtin_bit_cast(f16x8, xh), A_l = __builtin_bit_cast(f16x8, xl);
+            const f16x8* wf = reinterpret_cast<const f16x8*>(wbuf) + lane;          // [piece][ct][64 lanes] x 16 B
+            f16x8 fcur[4], fnxt[4];
+            auto load_f = [&](int g, f16x8 (&f)[4]) {
+                f[0] = wf[(2 * g) * 64]; f[1] = wf[(NCT + 2 * g) * 64]; f[2] = wf[(2 * g + 1) * 64]; f[3] = wf[(NCT + 2 * g + 1) * 64];
+            };
+            load_f(0, fcur);
+#pragma unroll
+            for (int g = 0; g < NCT / 2; ++g) {
+                if (g + 1 < NCT / 2) load_f(g + 1, fnxt);
+                const int c0 = 2 * g, c1 = 2 * g + 1;
+                acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_h, fcur[0], acc[c0], 0, 0, 0);       // h * H
+                acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_h, fcur[2], acc[c1], 0, 0, 0);
+                acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_l, fcur[0], acc[c0], 0, 0, 0);       // l * H
+                acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_l, fcur[2], acc[c1], 0, 0, 0);
+                acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_h, fcur[1], acc[c0], 0, 0, 0);       // h * L
+                acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_h, fcur[3], acc[c1], 0, 0, 0);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) fcur[k] = fnxt[k];
+                __builtin_amdgcn_sched_barrier(0);
+            }
         } else {
             // eight groups of (k-quad q, half of the column tiles); the B fragments of group g+1 are requested before the
             // MFMAs of group g.  sched_barrier keeps hipcc from hoisting more fragment reads than that (it spills otherwise).
@@ -275,6 +321,9 @@ __global__ __launch_bounds__(256, 2) void k_edge_bwd(EdgeBwdArgs a) {
     // worth of gathered values are live (left alone hipcc hoists all 128-256 gathers to the top and spills).
 
     if constexpr (STAGE == 0) {
+        float gm[16];                                   // SAVED: running max_c |G2| of this lane's 16 rows
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gm[r] = 0.f;
         // per-tile partials of d(wa) / d(w7) and of d(b2): the two halves of the wavefront added, one row of H per tile
         auto store_partials = [&](int ct, float cs, float bs) {
             const float cst = cs + __shfl_xor(cs, 32), bst = bs + __shfl_xor(bs, 32);
@@ -348,6 +397,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_bwd(EdgeBwdArgs a) {
                     const float dM = __builtin_fmaf(qr[r], wav, gval(gc, r) * attr[r]);     // d(msg)*att + (d(msg).M) att(1-att) wa
                     const float g2 = dM * dsilu_from_sigmoid(x, s);                          // zero for padding rows (g, qr)
                     g2p[(size_t)((r & 3) + 8 * (r >> 2)) * H] = g2;
+                    if constexpr (SAVED) gm[r] = fmaxf(gm[r], fabsf(g2));
                     cs = __builtin_fmaf(qr[r], m, cs);
                     bs += g2;
                 }
@@ -403,6 +453,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_bwd(EdgeBwdArgs a) {
                     const float s = sigmoid_f(x);
                     const float g2 = dphir[r] * wav * dsilu_from_sigmoid(x, s);     // dphi is zero for padding rows
                     g2p[(size_t)((r & 3) + 8 * (r >> 2)) * H] = g2;
+                    if constexpr (SAVED) gm[r] = fmaxf(gm[r], fabsf(g2));
                     cs = __builtin_fmaf(dphir[r], x * s, cs);
                     bs += g2;
                 }
@@ -410,11 +461,34 @@ __global__ __launch_bounds__(256, 2) void k_edge_bwd(EdgeBwdArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        if constexpr (SAVED) {
+            // row maxima of G2 (the range of stage B's fp16x3 operand rows): the transposed reduction of the row dots with max for +
+            float v8[8], v4[4], v2[2];
+            const bool b4 = n & 16, b3 = n & 8, b2_ = n & 4, b1 = n & 2;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v8[k] = fmaxf(b4 ? gm[k + 8] : gm[k], __shfl_xor(b4 ? gm[k] : gm[k + 8], 16));
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v4[k] = fmaxf(b3 ? v8[k + 4] : v8[k], __shfl_xor(b3 ? v8[k] : v8[k + 4], 8));
+#pragma unroll
+            for (int k = 0; k < 2; ++k) v2[k] = fmaxf(b2_ ? v4[k + 2] : v4[k], __shfl_xor(b2_ ? v4[k] : v4[k + 2], 4));
+            float v = fmaxf(b1 ? v2[1] : v2[0], __shfl_xor(b1 ? v2[0] : v2[1], 2));
+            v = fmaxf(v, __shfl_xor(v, 1));
+            if (a.g2max) {
+                if ((n & 1) == 0) a.g2max[(size_t)tile * 32 + my_rho] = v;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+                __shared__ float wgm[4];
+                if (lane == 0) wgm[wave] = v;
+                __syncthreads();
+                if (tid == 0) a.g2wgmax[blockIdx.x] = fmaxf(fmaxf(wgm[0], wgm[1]), fmaxf(wgm[2], wgm[3]));
+            }
+        }
     } else {
         // stage B: row by row (the two AB rows of an edge are gathered once per row, one row ahead); a row's two dots with
         // w_r / w_d are reduced over its half-wave on the spot (keeping 2 x 16 running dots for a transposed reduction at
         // the end costs the registers that make the difference between one and two wavefronts per SIMD)
         float wrp[NCT], wdp[NCT];
+        float pmx = 0.f;                                            // PREC 3: max |P| over this lane's share of the tile
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) { wrp[ct] = 0.f; wdp[ct] = 0.f; }
         auto load_ab = [&](int r, float (&ai)[NCT], float (&bj)[NCT]) {
@@ -429,9 +503,10 @@ __global__ __launch_bounds__(256, 2) void k_edge_bwd(EdgeBwdArgs a) {
         for (int r = 0; r < 16; ++r) {
             if (r + 1 < 16) load_ab(r + 1, ain, bjn);
             const float rad = rrad_s[rho(r)], dd0 = rd0_s[rho(r)], vrr = rval_s[rho(r)];
+            const float vrs = PREC == 3 ? vrr * phi_s[rho(r)] : vrr;       // fp16x3: the accumulators carry row scale x image scale
             float* po = a.Pout + ((size_t)tile * 32 + rho(r)) * H + n;
             float* go = a.G1 + ((size_t)tile * 32 + rho(r)) * H + n;
-            float dr = 0.f, dd = 0.f;
+            float dr = 0.f, dd = 0.f, pmr = 0.f;
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
                 const int col = 32 * ct + n;
@@ -440,8 +515,11 @@ __global__ __launch_bounds__(256, 2) void k_edge_bwd(EdgeBwdArgs a) {
                 pre = __builtin_fmaf(rad, wr, pre);
                 pre = __builtin_fmaf(dd0, wd, pre);
                 const float s = sigmoid_f(pre);
-                const float g1 = vrr * acc[ct][r] * dsilu_from_sigmoid(pre, s);
-                po[32 * ct] = vrr * pre * s;
+                const float g1 = vrs * acc[ct][r] * dsilu_from_sigmoid(pre, s);
+                const float pv = vrr * pre * s;
+                po[32 * ct] = pv;
+                // (opaque: as plain fmaxf hipcc re-associates the maximum over the whole tile into a tree and spills 83 registers)
+                if constexpr (PREC == 3) asm("v_max_f32 %0, %0, |%1|" : "+v"(pmr) : "v"(pv));
                 go[32 * ct] = g1;
                 dr = __builtin_fmaf(g1, wr, dr);
                 dd = __builtin_fmaf(g1, wd, dd);
@@ -450,6 +528,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_bwd(EdgeBwdArgs a) {
             }
 #pragma unroll
             for (int o = 16; o > 0; o >>= 1) { dr += __shfl_xor(dr, o); dd += __shfl_xor(dd, o); }
+            if constexpr (PREC == 3) pmx = fmaxf(pmx, pmr);
             if (n == 0) {                                            // d(radial), d(d0) of row rho(r)
                 float* es = a.escal + ((size_t)tile * 32 + rho(r)) * 8;
                 es[4] = dr; es[5] = dd;
@@ -465,6 +544,14 @@ __global__ __launch_bounds__(256, 2) void k_edge_bwd(EdgeBwdArgs a) {
                 a.wrdpart[((size_t)tile * 2) * H + 32 * ct + n] = wrt;
                 a.wrdpart[((size_t)tile * 2 + 1) * H + 32 * ct + n] = wdt;
             }
+        }
+        if constexpr (PREC == 3) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) pmx = fmaxf(pmx, __shfl_xor(pmx, o));
+            __shared__ float wpm[4];
+            if (lane == 0) wpm[wave] = pmx;
+            __syncthreads();
+            if (tid == 0) a.pwgmax[blockIdx.x] = fmaxf(fmaxf(wpm[0], wpm[1]), fmaxf(wpm[2], wpm[3]));
         }
     }
 }

@@ -345,13 +345,16 @@ class EGNN_dynamics_QM9(nn.Module):
         MFMAs per product, fp32 accumulation; hidden_nf >= 128) while everything around them - first-layer recomputation,
         SiLU and its derivative, the node-level GEMMs and the loss - stays exact fp32: this implementation's counterpart of the reference's
         mixed-precision training (apex O2, conf/trainer/default.yaml:4-5), without its loss of accuracy: gradients agree with
-        the exact-fp32 step to ~1e-6 (tests/test_gpu_training.py)."""
+        the exact-fp32 step to ~1e-6 (tests/test_gpu_training.py).  "fp16x3" (round 5): the same four contraction sites in the
+        sampler's two-way FP16 split (three MFMAs per product; operand rows / arrays ranged by exact powers of two computed on the
+        device from the data itself) on top of the kept pre-activations (`keep_edge_activations`); a layer whose batch is too
+        small to keep them runs in bf16x6."""
         return getattr(self, "_training_precision", "fp32")
 
     @training_precision.setter
     def training_precision(self, name: str) -> None:
-        if name not in ("fp32", "bf16x6"):
-            raise ValueError('training_precision must be "fp32" or "bf16x6"')
+        if name not in ("fp32", "bf16x6", "fp16x3"):
+            raise ValueError('training_precision must be "fp32", "bf16x6" or "fp16x3"')
         object.__setattr__(self, "_training_precision", name)
 
     #: Training forward keeps the second-layer pre-activations W2 P + b2 of every edge row for its backward pass where the

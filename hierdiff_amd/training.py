@@ -210,6 +210,21 @@ class _NodeMLP(torch.autograd.Function):
         return dX[:, :H] + g, dX[:, H:], dW3, db3, dW4, db4, None
 
 
+_PREC_CODE = {"fp32": 0, "bf16x6": 2, "fp16x3": 3}          # `precision` of hd_edge_layer_forward_s / _backward_s
+_F16WS = {}
+
+
+def _f16_workspace(dev: torch.device, n: int) -> torch.Tensor:
+    """Workspace of the fp16x3 backward (image scalars, maxima): one grow-only buffer per device, reused by every edge layer - the
+    backward calls of a step are stream-ordered and each reads only what its own stages wrote."""
+    key = (dev.type, dev.index)
+    buf = _F16WS.get(key)
+    if buf is None or buf.numel() < n:
+        buf = torch.empty(max(n, 1024), device=dev, dtype=torch.float32)
+        _F16WS[key] = buf
+    return buf
+
+
 class _EdgeLayer(torch.autograd.Function):
     """out = neighbour sum of the edge model of one GCL ([M, H]) or EquivariantUpdate ([M, 4], xyz0), from the node features:
     the factorised first edge Linear [A | B] = h [W1a ; W1b]^T + [b1 | 0] (one GEMM over the stacked halves of `W1`
@@ -230,26 +245,28 @@ class _EdgeLayer(torch.autograd.Function):
         x4, x04, W2, b2, wa = (v.detach().contiguous() for v in (x4, x04, W2, b2, wa))
         ba_c = None if ba is None else ba.detach().contiguous()
         out = torch.empty((max(1, tr.M), 4 if coord else tr.H), device=AB.device, dtype=torch.float32)
-        x6 = getattr(dyn, "training_precision", "fp32") == "bf16x6"
+        prec = _PREC_CODE[getattr(dyn, "training_precision", "fp32")]
         # keep W2 P + b2 of every edge row for the backward pass where the library says it pays (large batches) and a gradient
         # will be asked for: [rows, H] fp32 per edge layer, 4.1 GB for the 18 layers of the headline shape at B = 256
         pre2 = None
         if getattr(dyn, "keep_edge_activations", True) and any(ctx.needs_input_grad):
-            rows = int(lib.hd_edge_layer_save_rows(dyn._handle(), topo.ptr, 2 if x6 else 0))
+            rows = int(lib.hd_edge_layer_save_rows(dyn._handle(), topo.ptr, prec))
             if rows > 0:
                 pre2 = torch.empty((rows, tr.H), device=AB.device, dtype=torch.float32)
-        _lib.check(lib.hd_edge_layer_forward_s(dyn._handle(), topo.ptr, int(coord), 2 if x6 else 0, AB.data_ptr(), x4.data_ptr(),
+        if prec == 3 and pre2 is None and any(ctx.needs_input_grad):
+            prec = 2        # the fp16x3 backward exists on top of the kept pre2 only: this layer runs in bf16x6 (equally fp32-accurate)
+        _lib.check(lib.hd_edge_layer_forward_s(dyn._handle(), topo.ptr, int(coord), prec, AB.data_ptr(), x4.data_ptr(),
                                                x04.data_ptr(), wrd.data_ptr(), W2.data_ptr(), b2.data_ptr(), wa.data_ptr(),
                                                None if ba_c is None else ba_c.data_ptr(), out.data_ptr(),
                                                None if pre2 is None else pre2.data_ptr(), _stream(AB.device)),
                    "hd_edge_layer_forward_s")
         ctx.save_for_backward(AB, x4, x04, wrd, W2, b2, wa, hd, Wst, *([] if ba_c is None else [ba_c]), *([] if pre2 is None else [pre2]))
-        ctx.misc = (dyn, topo, tr, coord, ba_c is not None, pre2 is not None)
+        ctx.misc = (dyn, topo, tr, coord, ba_c is not None, pre2 is not None, prec)
         return out[:tr.M]
 
     @staticmethod
     def backward(ctx, gout):
-        dyn, topo, tr, coord, has_ba, has_pre2 = ctx.misc
+        dyn, topo, tr, coord, has_ba, has_pre2, prec = ctx.misc
         saved = ctx.saved_tensors
         AB, x4, x04, wrd, W2, b2, wa, hd, Wst = saved[:9]
         ba = saved[9] if has_ba else None
@@ -265,16 +282,29 @@ class _EdgeLayer(torch.autograd.Function):
         dAB = torch.empty((M, 2 * tr.H), device=dev, dtype=torch.float32)
         dx = torch.empty((M, 4), device=dev, dtype=torch.float32)
         dx0 = torch.empty((M, 4), device=dev, dtype=torch.float32)
-        x6 = getattr(dyn, "training_precision", "fp32") == "bf16x6"
+        f16 = prec == 3 and tr.H in (128, 256)
+        f16ws, n_wg = None, 0
+        if f16:
+            nw = C.c_int(0)
+            f16ws = _f16_workspace(dev, int(lib.hd_edge_layer_f16ws_floats(dyn._handle(), topo.ptr, C.byref(nw))))
+            n_wg = nw.value
         _lib.check(lib.hd_edge_layer_backward_s(
-            dyn._handle(), topo.ptr, int(coord), 2 if x6 else 0, AB.data_ptr(), x4.data_ptr(), x04.data_ptr(), wrd.data_ptr(), W2.data_ptr(),
+            dyn._handle(), topo.ptr, int(coord), prec, AB.data_ptr(), x4.data_ptr(), x04.data_ptr(), wrd.data_ptr(), W2.data_ptr(),
             b2.data_ptr(), wa.data_ptr(), None if ba is None else ba.data_ptr(), g.data_ptr(),
-            None if pre2 is None else pre2.data_ptr(), ws["G2"].data_ptr(),
+            None if pre2 is None else pre2.data_ptr(), None if f16ws is None else f16ws.data_ptr(), ws["G2"].data_ptr(),
             ws["P"].data_ptr(), ws["G1"].data_ptr(), ws["escal"].data_ptr(), ws["colpart"].data_ptr(), ws["bapart"].data_ptr(),
             ws["b2part"].data_ptr(), ws["wrdpart"].data_ptr(), dAB.data_ptr(), dx.data_ptr(), dx0.data_ptr(), _stream(dev)),
             "hd_edge_layer_backward_s")
         # the one dense reduction over all edge rows: dL/dW2[c][k] = sum_e G2[e][c] P[e][k] (K = edge rows, split-K in slab order)
-        if getattr(dyn, "training_precision", "fp32") == "bf16x6" and tr.H in (128, 256):
+        if f16:
+            # fp16x3: two FP16 pieces per operand, each ranged by one power of two from the maxima the backward stages left in f16ws
+            dW2 = torch.empty((tr.H, tr.H), device=dev, dtype=torch.float32)
+            slabs = max(1, min(256, tr.rows // 128))
+            w6 = _splitk_workspace(dev, slabs * tr.H * tr.H)
+            _lib.check(lib.hd_dw2_f16(_dev_index(dev), tr.rows, tr.H, ws["G2"].data_ptr(), ws["P"].data_ptr(), f16ws.data_ptr() + 16,
+                                      f16ws.data_ptr() + 16 + 4 * n_wg, n_wg, dW2.data_ptr(), tr.H, w6.data_ptr(), slabs * tr.H * tr.H,
+                                      _stream(dev)), "hd_dw2_f16")
+        elif prec == 2 and tr.H in (128, 256):
             # opt-in: the same reduction on a three-way bf16 split of both operands (hd_dw2_x6: fp32-accurate, every row read once)
             dW2 = torch.empty((tr.H, tr.H), device=dev, dtype=torch.float32)
             slabs = max(1, min(256, tr.rows // 128))

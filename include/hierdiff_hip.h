@@ -229,19 +229,29 @@ int hd_edge_layer_backward_p(hd_handle* h, hd_topology* topo, int coord, int pre
                              const float* ba, const float* gout, float* G2, float* P, float* G1, float* escal, float* colpart,
                              float* bapart, float* b2part, float* wrdpart, float* dAB, float* dx, float* dx0, void* stream);
 /* Round 5 (ABI 10): keep the second-layer pre-activations instead of recomputing them.  hd_edge_layer_save_rows = rows of a
- * [rows][hidden_nf] fp32 buffer the forward of this topology can fill (0: the batch is small enough for the column-split / mixed
+ * [rows][hidden_nf] fp32 buffer the forward of this topology can fill (the table's rows plus one spare tile; 0: the batch is small enough for the column-split / mixed
  * edge kernels, which keep their faster forward - pass pre2 = NULL and the backward recomputes as before).  hd_edge_layer_forward_s
  * with pre2 != NULL writes W2 P + b2 of every edge row into it (accumulator order per 32-row tile, opaque to the caller; 228 MB per
  * layer at B = 256, N = 30, H = 256 - sized for this GPU's HBM, not for a 16 GB card); hd_edge_layer_backward_s with the same
  * buffer runs stage A as an element-wise kernel over it (no weight stream, no matrix instruction).  pre2 = NULL in either call is
  * exactly the _p function.  Same results to the bit as the recomputing path in the same arithmetic (tests/test_gpu_training.py). */
+/* precision 3 = "fp16x3" (hidden_nf >= 128; narrower layers run the fp32 kernels): the sampler's two-way FP16 split in the training
+ * path - forward contraction (the fp16x3 edge kernel on the unscaled parameters; images, image scale and row ranges made on the device
+ * per call), stage B's dP = G2 W2 (operand rows ranged by their exact maxima, which stage A leaves in f16ws) and dW2 (hd_dw2_f16).
+ * It exists only together with the kept pre2 (whose spare tile carries the image scalars from the forward to the backward call):
+ * hd_edge_layer_backward_s(precision 3) needs the pre2 of a precision-3 forward and f16ws
+ * (hd_edge_layer_f16ws_floats floats, *n_wg = the number of per-workgroup maxima hd_dw2_f16 reads at f16ws + 4 and f16ws + 4 + n_wg);
+ * where hd_edge_layer_save_rows(.., 3) is 0 the caller runs the layer in precision 2. */
+long long hd_edge_layer_f16ws_floats(hd_handle* h, hd_topology* topo, int* n_wg);
+int hd_dw2_f16(int device, int rows, int H, const float* G2, const float* P, const float* gmax, const float* pmax, int n,
+               float* dW2, int ldc, float* ws, long long ws_floats, void* stream);
 long long hd_edge_layer_save_rows(hd_handle* h, hd_topology* topo, int precision);
 int hd_edge_layer_forward_s(hd_handle* h, hd_topology* topo, int coord, int precision, const float* AB, const float* x,
                             const float* x0, const float* wrd, const float* W2, const float* b2, const float* wa,
                             const float* ba, float* out, float* pre2, void* stream);
 int hd_edge_layer_backward_s(hd_handle* h, hd_topology* topo, int coord, int precision, const float* AB, const float* x,
                              const float* x0, const float* wrd, const float* W2, const float* b2, const float* wa,
-                             const float* ba, const float* gout, const float* pre2, float* G2, float* P, float* G1, float* escal,
+                             const float* ba, const float* gout, const float* pre2, float* f16ws, float* G2, float* P, float* G1, float* escal,
                              float* colpart, float* bapart, float* b2part, float* wrdpart, float* dAB, float* dx, float* dx0,
                              void* stream);
 /* Backward of hd_edge_layer_forward given gout = dL/d(out).  Per-edge activations are recomputed; the caller provides

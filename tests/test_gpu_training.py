@@ -460,6 +460,56 @@ def test_training_precision_bf16x6_gradients(H):
         dyn.training_precision = "bf16x3"
 
 
+@pytest.mark.parametrize("H", [256, 128])
+def test_training_precision_fp16x3_gradients(H, monkeypatch):
+    """`dynamics.training_precision = "fp16x3"` (round 5): forward contraction, stage B's dP = G2 W2 and dW2 = G2^T P in the two-way
+    FP16 split (hd_edge_layer_forward_s / _backward_s with precision 3, hd_dw2_f16), ranges computed on the device from the data; the
+    mode lives on top of the kept pre-activations, so the batch is one that keeps them (870 tiles) - and a 5-molecule batch falls
+    back to bf16x6 layer by layer.  Same bars as the bf16x6 mode: 1e-4 against the oracle's autograd, 1e-5 against the exact-fp32 step."""
+    from hierdiff_amd import _lib
+    from hierdiff_amd.weights import synthetic_state_dict
+    L = 2
+    lib = _lib.load()
+    calls = {"fwd": [], "dw2": 0}
+    of, od = lib.hd_edge_layer_forward_s, lib.hd_dw2_f16
+    monkeypatch.setattr(lib, "hd_edge_layer_forward_s", lambda *a: (calls["fwd"].append(a[3]), of(*a))[1])
+    monkeypatch.setattr(lib, "hd_dw2_f16", lambda *a: (calls.__setitem__("dw2", calls["dw2"] + 1), od(*a))[1])
+    for n_list, expect in (([30] * 30 + [17, 9], 3), ([30, 30, 17, 30, 9], 2)):
+        sd_np = synthetic_state_dict(9, 0, H, L, 2, True, 79, 0.5)
+        cfg = orc.DynCfg(in_node_nf=9, hidden_nf=H, n_layers=L, normalization_factor=10.0)
+        xh, nm, em = orc.random_inputs(n_list, 8, 74)
+        B, N = xh.shape[:2]
+        t = torch.linspace(0.1, 0.9, B).view(B, 1)
+        w = torch.randn(B, N, 11, generator=torch.Generator().manual_seed(8))
+        sd = _oracle_sd(sd_np)
+        xo = xh.clone().requires_grad_(True)
+        ref = orc.dynamics_forward(sd, cfg, t, xo, nm, em, None, None, prefix="dynamics.egnn.")
+        (ref * w).sum().backward()
+        grads = {}
+        for mode in ("fp32", "fp16x3"):
+            calls["fwd"].clear(); calls["dw2"] = 0
+            dyn = build_dynamics(sd_np, H, L)
+            dyn.precision = "fp32"
+            dyn.training_precision = mode
+            xg = xh.to(DEV).requires_grad_(True)
+            out = dyn._forward(t.to(DEV), xg, nm.to(DEV), em.to(DEV), None, None)
+            assert rel_l2(out.detach().cpu().numpy(), ref.detach().numpy()) < 1e-5
+            (out * w.to(DEV)).sum().backward()
+            if mode == "fp16x3":
+                assert calls["fwd"] and all(p == expect for p in calls["fwd"]), calls
+                assert calls["dw2"] == (len(calls["fwd"]) if expect == 3 else 0)
+            worst, n = _compare_grads(dyn.egnn.named_parameters(), sd, "dynamics.egnn.", f"H={H} training_precision={mode}")
+            valid = nm.numpy()[..., 0]
+            assert rel_l2(xg.grad.cpu().double().numpy()[valid], xo.grad.double().numpy()[valid]) < GRAD_TOL
+            grads[mode] = {k: p.grad.detach().clone() for k, p in dyn.egnn.named_parameters()}
+            print(f"H={H} B={B} training_precision={mode}: {n} tensors, worst grad rel-L2 vs oracle {worst:.2e}")
+        between = max(float((grads["fp16x3"][k] - grads["fp32"][k]).norm() / grads["fp32"][k].norm().clamp_min(1e-30))
+                      for k in grads["fp32"] if float(grads["fp32"][k].norm()) > 1e-6)
+        print(f"H={H} B={B}: fp16x3 step (layers in precision {expect}) vs exact-fp32 step, worst parameter-gradient rel-L2 {between:.2e}")
+        # (the 5-molecule batch at width 128 has tensors whose exact-fp32 gradient is itself 1.6e-5 from the float64 oracle's)
+        assert between < (1e-5 if expect == 3 else 5e-5)
+
+
 @pytest.mark.parametrize("H,B,mode", [(32, 5, "fp32"), (64, 7, "fp32"), (128, 32, "fp32"), (128, 32, "bf16x6"), (256, 32, "fp32"),
                                       (256, 32, "bf16x6"), (256, 6, "fp32")])
 def test_kept_edge_activations_equal_the_recomputing_backward(H, B, mode, monkeypatch):
