@@ -496,12 +496,26 @@ def next_rows(dev) -> dict:
             step()
         torch.cuda.synchronize(dev)
         d6 = (time.perf_counter() - t0) / 5
+        # round 5: the same four sites in the two-way FP16 split, on top of the kept second-layer pre-activations
+        m.dynamics.training_precision = "fp16x3"
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize(dev)
+        d3 = (time.perf_counter() - t0) / 5
         m.dynamics.training_precision = "fp32"
         out[f"training_step_B{B}_N30_L6_bf16x6_contractions"] = {
             "ms_per_step": round(d6 * 1e3, 2), "molecules_per_s": round(B / d6, 1),
-            "what": "the same step with training_precision = 'bf16x6': hd_edge_layer_forward_p / hd_edge_layer_backward_p (precision 2) "
+            "what": "the same step with training_precision = 'bf16x6': hd_edge_layer_forward_s / hd_edge_layer_backward_s (precision 2) "
                     "+ hd_dw2_x6; node GEMMs, first-layer GEMMs and loss exact fp32; gradients within 6e-6 of the oracle's "
                     "(tests/test_gpu_training.py)"}
+        out[f"training_step_B{B}_N30_L6_fp16x3_contractions"] = {
+            "ms_per_step": round(d3 * 1e3, 2), "molecules_per_s": round(B / d3, 1),
+            "what": "training_precision = 'fp16x3' (precision 3 + hd_dw2_f16; layers of a batch too small to keep pre2 run in bf16x6): "
+                    "gradients within 2e-6 of the exact-fp32 step's (tests/test_gpu_training.py)"}
         # what a real training loop sees: NEW masks every step, i.e. one topology build per step inside the timed region.  Same
         # WORK in the rows below: one multiset of ragged sizes (12 .. 30 nodes, mean 21), either the same batch every step
         # (topology cached) or the sizes permuted over the batch positions every step (never-seen masks, identical edge / node

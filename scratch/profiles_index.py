@@ -27,6 +27,8 @@ RULES = [
     (r"r03_node_phase_trace\.log|r04_node_first_loads_reorder_ab\.log", "phase stamps of k_node_f32 / a reorder A-B (null)", "DESIGN 4 k_node_f32, 12a"),
     (r"r03_power_clock\.log", "rocm-smi clock / power during sustained forwards", "DESIGN 4 (power-limited clock)"),
     (r"r\d+_pmc_tgemm.*\.log|r\d+_pmc_train\.log", "counters of the training GEMM kernels", "DESIGN 10"),
+    (r"r05_train_kept_pre2\.log", "training step + kernel tables with the kept second-layer pre-activations (fp32 27.0 ms, bf16x6 21.9 ms)", "DESIGN 10 round 5, second half"),
+    (r"r05_train_fp16x3\.log", "training step + kernel table with training_precision = fp16x3 (20.4 ms)", "DESIGN 10 round 5, second half"),
     (r"r05_train_kstats\.log", "kernel tables of the training step in both arithmetics after the k_edge_dx rewrite", "DESIGN 10 round 5"),
     (r"r\d+_train.*\.log|r02_loss_host_profile_before\.log|r02_topology_and_loss_host\.log|r03_topology_time\.log|r04_fresh_masks\.log", "training step: per-kernel / per-op times, host-side costs, fresh-mask staging", "DESIGN 10; r05: 10 'round 5'"),
     (r"r04_edge_res_.*", "register-resident persistent fp32 edge kernel k_edge_res (rejected), versions v1-v5 and the A/B", "DESIGN 12a, EXPERIMENTS D"),
