@@ -1968,10 +1968,9 @@ extern "C" int hd_edge_layer_backward_s(hd_handle* h, hd_topology* t, int coord,
     std::memset(&cs, 0, sizeof(cs));
     cs.G = G1; cs.out = dAB; cs.M = M; cs.H = H; cs.ldo = 2 * H;
     const long long total = (long long)M * (H / 4);
-    cs.ptr = t->rptr; cs.rows = t->rrows; cs.col0 = 0;
-    hipLaunchKernelGGL(k_csr_sum, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, cs);
-    cs.ptr = t->sptr; cs.rows = t->srows; cs.col0 = H;
-    hipLaunchKernelGGL(k_csr_sum, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, cs);
+    cs.ptr = t->rptr; cs.rows = t->rrows; cs.col0 = 0;                   // rows by receiving node -> dA
+    cs.ptr_b = t->sptr; cs.rows_b = t->srows; cs.col0_b = H;            // rows by sending node   -> dB   (blockIdx.y = 1)
+    hipLaunchKernelGGL(k_csr_sum, dim3((unsigned)((total + 255) / 256), 2), dim3(256), 0, s, cs);
     EdgeDxArgs d;
     d.escal = escal; d.ei = t->ei; d.ej = t->ej; d.rptr = t->rptr; d.rrows = t->rrows; d.sptr = t->sptr; d.srows = t->srows;
     d.xcur = x; d.x0 = x0; d.dx = dx; d.dx0 = dx0; d.norm_constant = c.norm_constant; d.M = M; d.coord = coord ? 1 : 0;

@@ -570,6 +570,9 @@ struct CsrSumArgs {
     const float* x_in;      // optional (with G2; stage 2, round 5): x_out[i][k] = (x_in[i][k] + sum[k]) * xmask[i], k < 3 -
     float* x_out;           // k_egcl_node_out's coordinate expression, saving that launch
     const float* xmask;     // [M] or NULL
+    const int* ptr_b;       // gridDim.y == 2 (the edge layer's backward): blockIdx.y = 1 sums the rows of a second CSR (rows by
+    const int* rows_b;      // sending node) into columns col0_b .. of the same output - both reductions of G1 in one launch
+    int col0_b;
 };
 
 __global__ void k_csr_sum(CsrSumArgs a) {
@@ -581,17 +584,21 @@ __global__ void k_csr_sum(CsrSumArgs a) {
     // rows are added in ascending list order (deterministic; the order every caller's parity rests on), but REQUESTED four at a
     // time: written as one load per iteration the loop is a chain of dependent L2 round trips (index -> row) per edge - 12.3 us
     // for the 12 incoming edges of a stage-2 node (round 5)
-    const int p0 = a.ptr[i], p1 = a.ptr[i + 1];
+    const bool second = blockIdx.y == 1;
+    const int* const ptr = second ? a.ptr_b : a.ptr;
+    const int* const rows = second ? a.rows_b : a.rows;
+    const int col0 = second ? a.col0_b : a.col0;
+    const int p0 = ptr[i], p1 = ptr[i + 1];
     const float* base = (c4 == q) ? a.G2 : a.G + 4 * c4;
     const size_t ld = (c4 == q) ? 4 : (size_t)a.H;
     int p = p0;
     for (; p + 4 <= p1; p += 4) {
-        const int r0 = a.rows[p], r1 = a.rows[p + 1], r2 = a.rows[p + 2], r3 = a.rows[p + 3];
+        const int r0 = rows[p], r1 = rows[p + 1], r2 = rows[p + 2], r3 = rows[p + 3];
         const f32x4 g0 = *reinterpret_cast<const f32x4*>(base + (size_t)r0 * ld), g1 = *reinterpret_cast<const f32x4*>(base + (size_t)r1 * ld);
         const f32x4 g2 = *reinterpret_cast<const f32x4*>(base + (size_t)r2 * ld), g3 = *reinterpret_cast<const f32x4*>(base + (size_t)r3 * ld);
         v += g0; v += g1; v += g2; v += g3;
     }
-    for (; p < p1; ++p) v += *reinterpret_cast<const f32x4*>(base + (size_t)a.rows[p] * ld);
+    for (; p < p1; ++p) v += *reinterpret_cast<const f32x4*>(base + (size_t)rows[p] * ld);
     if (c4 == q) {
         *reinterpret_cast<f32x4*>(a.out2 + (size_t)i * 4) = v;
         if (a.x_out) {
@@ -599,7 +606,7 @@ __global__ void k_csr_sum(CsrSumArgs a) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) a.x_out[(size_t)i * 3 + k] = (a.x_in[(size_t)i * 3 + k] + v[k]) * m;
         }
-    } else *reinterpret_cast<f32x4*>(a.out + (size_t)i * a.ldo + a.col0 + 4 * c4) = v;
+    } else *reinterpret_cast<f32x4*>(a.out + (size_t)i * a.ldo + col0 + 4 * c4) = v;
 }
 
 // Coordinate gradients of one edge layer from the per-edge scalars: radial = |x_i - x_j|^2 (d(radial) from stage B), the
