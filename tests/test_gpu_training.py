@@ -342,6 +342,13 @@ def test_randomised_gradient_sweep():
     tail = "\n".join(proc.stdout.splitlines()[-4:])
     assert proc.returncode == 0, tail + proc.stderr[-2000:]
     assert "failures 0" in tail, tail
+    # round 5: widths 128 / 256 on 20-36 molecules - kept pre-activations, training_precision fp32 / bf16x6 / fp16x3 drawn per case
+    # (a 24-case run: profiles/r05_fuzz_grads_big.log)
+    proc = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_grads.py"), "8", "13", "big"], cwd=root,
+                          capture_output=True, text=True, timeout=600)
+    tail = "\n".join(proc.stdout.splitlines()[-4:])
+    assert proc.returncode == 0, tail + proc.stderr[-2000:]
+    assert "failures 0" in tail, tail
 
 
 def test_trainer_ddp_step_equals_the_manual_sequence():
