@@ -96,7 +96,16 @@ __global__ __launch_bounds__(256, 2) void k_edge_bwd(EdgeBwdArgs a) {
     for (int k = tid; k < 2 * H; k += 256) wrd_s[k] = a.wrd[k];
     for (int k = tid; k < H; k += 256) { wrd_s[2 * H + k] = a.b2[k]; wrd_s[3 * H + k] = a.wa[k]; }
 
-    const int tile = blockIdx.x * 4 + wave;                    // every tile of the (padded) table exists
+    // XCD-aware placement as in k_edge (round 5): block b runs on XCD b % 8 and takes the (b / 8)-th workgroup-tile of that XCD's
+    // contiguous share of the edge list, so the AB / gradient rows of a molecule are gathered into ONE L2 (dealt round-robin, stage B
+    // read 364 MB for 228 MB of G2: profiles/r05_pmc_train_hbm.log)
+    int wt;
+    {
+        const int bid = blockIdx.x, nwt = gridDim.x, xcd = bid & 7, slot = bid >> 3;
+        const int q = nwt >> 3, r = nwt & 7;
+        wt = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;        // a bijection of [0, nwt): slot < q + (xcd < r) always
+    }
+    const int tile = wt * 4 + wave;                            // every tile of the (padded) table exists
     const int e = tile * 32 + n;
     const int ni = a.ei[e], nj = a.ej[e];
     const float valid = (a.eseg[e] != 255) ? 1.0f : 0.0f;

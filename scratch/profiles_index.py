@@ -28,6 +28,8 @@ RULES = [
     (r"r03_power_clock\.log", "rocm-smi clock / power during sustained forwards", "DESIGN 4 (power-limited clock)"),
     (r"r\d+_pmc_tgemm.*\.log|r\d+_pmc_train\.log", "counters of the training GEMM kernels", "DESIGN 10"),
     (r"r05_fuzz_grads_big\.log", "random gradient sweep at widths 128 / 256 on 20-36 molecules: kept pre-activations, fp32 / bf16x6 / fp16x3 per case; 24 cases, no failure", "DESIGN 10 round 5, second half"),
+    (r"r05_pmc_train_hbm\.log", "HBM bytes per launch of the training kernels (FETCH_SIZE / WRITE_SIZE passes) against their algorithmic bytes, before / after the XCD-aware placement of the backward stages", "DESIGN 10 round 5, second half"),
+    (r"r05_train_xcd_placement\.log", "training step + kernel tables after the XCD-aware placement of the backward stages (fp32 26.5 ms, fp16x3 19.5 ms)", "DESIGN 10 round 5, second half"),
     (r"r05_train_kept_pre2\.log", "training step + kernel tables with the kept second-layer pre-activations (fp32 27.0 ms, bf16x6 21.9 ms)", "DESIGN 10 round 5, second half"),
     (r"r05_train_fp16x3\.log", "training step + kernel table with training_precision = fp16x3 (20.4 ms)", "DESIGN 10 round 5, second half"),
     (r"r05_train_kstats\.log", "kernel tables of the training step in both arithmetics after the k_edge_dx rewrite", "DESIGN 10 round 5"),
