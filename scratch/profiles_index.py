@@ -30,6 +30,7 @@ RULES = [
     (r"r05_fuzz_grads_big\.log", "random gradient sweep at widths 128 / 256 on 20-36 molecules: kept pre-activations, fp32 / bf16x6 / fp16x3 per case; 24 cases, no failure", "DESIGN 10 round 5, second half"),
     (r"r05_pmc_train_hbm\.log", "HBM bytes per launch of the training kernels (FETCH_SIZE / WRITE_SIZE passes) against their algorithmic bytes, before / after the XCD-aware placement of the backward stages", "DESIGN 10 round 5, second half"),
     (r"r05_train_xcd_placement\.log", "training step + kernel tables after the XCD-aware placement of the backward stages (fp32 26.5 ms, fp16x3 19.5 ms)", "DESIGN 10 round 5, second half"),
+    (r"r05_ab_rebuild_p\.log", "same-box A/B of the fp16x3 training step: P materialised vs rebuilt inside the dW2 kernel (null)", "EXPERIMENTS L"),
     (r"r05_train_kept_pre2\.log", "training step + kernel tables with the kept second-layer pre-activations (fp32 27.0 ms, bf16x6 21.9 ms)", "DESIGN 10 round 5, second half"),
     (r"r05_train_fp16x3\.log", "training step + kernel table with training_precision = fp16x3 (20.4 ms)", "DESIGN 10 round 5, second half"),
     (r"r05_train_kstats\.log", "kernel tables of the training step in both arithmetics after the k_edge_dx rewrite", "DESIGN 10 round 5"),

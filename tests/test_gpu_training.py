@@ -426,6 +426,50 @@ def test_dw2_matches_a_float64_product(H, rows, fname):
     assert fn(0, rows, 64, G2.data_ptr(), P.data_ptr(), again.data_ptr(), 64, ws.data_ptr(), ws.numel(), None) != 0
 
 
+@pytest.mark.parametrize("H,rows", [(256, 4096), (256, 32 * 173), (128, 2048), (128, 32)])
+def test_dw2_f16_matches_a_float64_product(H, rows):
+    """k_dw2_f16 (round 5): dW2 = G2^T P on a two-way FP16 split of both operands, each ranged by ONE power of two taken from
+    per-workgroup maxima.  The operands span what a backward pass produces - columns over four decades and ROWS over six (gradient
+    rows of gated-off edges next to the ones that matter): an element far below its array's maximum loses bits in proportion to how
+    little it contributes, so the reduction stays within 2e-6 of a float64 product, like the bf16x6 kernel; an all-zero operand, any
+    number of maxima, deterministic."""
+    from hierdiff_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(H + rows + 1)
+    G2 = (torch.randn(rows, H, generator=g) * torch.logspace(-3, 1, H)[None, :] * torch.logspace(-6, 0, rows)[torch.randperm(rows, generator=g)][:, None]).to(DEV)
+    P = (torch.randn(rows, H, generator=g) * 3.0).to(DEV)
+    ref = G2.double().t() @ P.double()
+    st = torch.cuda.current_stream().cuda_stream
+    outs = []
+    for slabs, nmax in ((256, max(1, rows // 128)), (7, 1), (1, 3)):
+        # maxima per group of rows, as the backward stages leave them (any partition of the rows works: only the overall maximum matters)
+        gm = torch.stack([c.abs().max() for c in G2.chunk(nmax)]).contiguous()
+        pm = torch.stack([c.abs().max() for c in P.chunk(nmax)]).contiguous()
+        dW2 = torch.full((H, H), float("nan"), device=DEV)
+        ws = torch.empty(slabs * H * H, device=DEV)
+        _lib.check(lib.hd_dw2_f16(0, rows, H, G2.data_ptr(), P.data_ptr(), gm.data_ptr(), pm.data_ptr(), gm.numel(), dW2.data_ptr(), H,
+                                  ws.data_ptr(), ws.numel(), st), "hd_dw2_f16")
+        err = float((dW2.double() - ref).norm() / ref.norm())
+        f32 = float(((G2.t() @ P).double() - ref).norm() / ref.norm())
+        print(f"hd_dw2_f16 H={H} rows={rows} slabs<={slabs} maxima {gm.numel()}: rel-L2 vs float64 {err:.2e} (torch fp32 matmul {f32:.2e})")
+        assert err < 2e-6
+        outs.append(dW2)
+    again = torch.empty_like(outs[0])
+    ws = torch.empty(256 * H * H, device=DEV)
+    gm = torch.stack([c.abs().max() for c in G2.chunk(max(1, rows // 128))]).contiguous()
+    pm = torch.stack([c.abs().max() for c in P.chunk(max(1, rows // 128))]).contiguous()
+    _lib.check(lib.hd_dw2_f16(0, rows, H, G2.data_ptr(), P.data_ptr(), gm.data_ptr(), pm.data_ptr(), gm.numel(), again.data_ptr(), H,
+                              ws.data_ptr(), ws.numel(), st), "hd_dw2_f16")
+    assert torch.equal(again, outs[0])
+    zero = torch.zeros_like(G2)
+    zm = torch.zeros(1, device=DEV)
+    _lib.check(lib.hd_dw2_f16(0, rows, H, zero.data_ptr(), P.data_ptr(), zm.data_ptr(), pm.data_ptr(), 1, again.data_ptr(), H,
+                              ws.data_ptr(), ws.numel(), st), "hd_dw2_f16")
+    assert float(again.abs().max()) == 0.0
+    assert lib.hd_dw2_f16(0, 48, H, G2.data_ptr(), P.data_ptr(), gm.data_ptr(), pm.data_ptr(), 1, again.data_ptr(), H, ws.data_ptr(), ws.numel(), None) != 0
+    assert lib.hd_dw2_f16(0, rows, H, G2.data_ptr(), P.data_ptr(), None, pm.data_ptr(), 1, again.data_ptr(), H, ws.data_ptr(), ws.numel(), None) != 0
+
+
 @pytest.mark.parametrize("H", [256, 128])
 def test_training_precision_bf16x6_gradients(H):
     """`dynamics.training_precision = "bf16x6"`: the edge layer's H x H contractions - forward (hd_edge_layer_forward_p, precision 2),
