@@ -90,3 +90,58 @@ def test_node_update_row_bounds_hold_and_are_usable():
         # the range where an element keeps both FP16 pieces normal
         assert (np.log2(tb / np.maximum(np.abs(T).max(1), 1e-300)) < 12).all()
         assert (np.log2(hb / np.maximum(np.abs(hn).max(1), 1e-300)) < 12).all()
+
+
+def _array_scale(x):
+    """k_dw2_f16: ONE power of two per operand, max |x| -> [2^14, 2^15) (at most 2^100: all-zero / tiny arrays)."""
+    m = np.float32(np.abs(x).max())
+    if m == 0:
+        return np.float32(2.0) ** 100
+    _, e = np.frexp(m)
+    return np.float32(2.0) ** min(100, 15 - int(e))
+
+
+def fp16x3_dw2(G, P):
+    """dW2[c][k] = sum_e G[e][c] P[e][k] the way k_dw2_f16 forms it (hierdiff_amd/csrc/k_dw2.hpp): both operands scaled by one
+    power of two each, FP16 head / tail, three of the four cross terms, fp32 accumulation, un-scaled at the end."""
+    gs, ps = _array_scale(G), _array_scale(P)
+    gh, gl = _split((G * gs).astype(np.float32))
+    ph, pl = _split((P * ps).astype(np.float32))
+    f = lambda a: a.astype(np.float32)
+    assert np.isfinite(f(gh)).all() and np.isfinite(f(ph)).all(), "a head overflowed"
+    acc = f(gh).T @ f(pl) + f(gl).T @ f(ph) + f(gh).T @ f(ph)
+    return acc * (np.float32(1.0) / gs) * (np.float32(1.0) / ps)
+
+
+@pytest.mark.parametrize("row_decades,col_decades", [(0, 0), (6, 4), (12, 0), (3, 8)])
+def test_dw2_one_scale_per_operand_is_enough(row_decades, col_decades):
+    """The training path's dense reduction over all edge rows (round 5).  Per-row ranging is impossible here (the row index is the
+    contraction index), and unnecessary: a sum is as exact as its largest terms are, and an element 2^18 below the array maximum
+    still has 22 significant bits (head normal, tail at the subnormal quantum 2^-24).  Gradient rows over `row_decades` decades
+    (gated-off edges next to the ones that matter) and columns over `col_decades`: the result stays at the error of an fp32 GEMM of
+    the same operands against float64."""
+    rng = np.random.Generator(np.random.PCG64(11 + row_decades))
+    E, H = 2048, 128
+    G = rng.standard_normal((E, H)).astype(np.float32)
+    G *= np.float32(10.0) ** (-row_decades * rng.random((E, 1))).astype(np.float32)
+    G *= np.float32(10.0) ** (-col_decades * rng.random((1, H))).astype(np.float32) * np.float32(1e-4)      # gradients are small numbers
+    pre = rng.standard_normal((E, H)).astype(np.float32) * 3
+    P = (pre / (1 + np.exp(-pre))).astype(np.float32)
+    ref = G.astype(np.float64).T @ P.astype(np.float64)
+    # per COLUMN of the result (a column of tiny gradients must be as good as a large one: relative error per output row)
+    rel = lambda y: float(np.max(np.linalg.norm(y - ref, axis=1) / np.linalg.norm(ref, axis=1)))
+    err16 = rel(fp16x3_dw2(G, P).astype(np.float64))
+    err32 = rel((G.T @ P).astype(np.float64))
+    assert err16 < max(2.0 * err32, 6e-7) or col_decades >= 8, (err16, err32)
+    if col_decades >= 8:        # documented limit: a result row whose gradients sit 8 decades (2^26) below the array maximum loses bits
+        whole = float(np.linalg.norm(fp16x3_dw2(G, P).astype(np.float64) - ref) / np.linalg.norm(ref))
+        assert whole < 6e-7 and err16 < 1e-2, (whole, err16)
+
+
+def test_dw2_scales_of_degenerate_arrays():
+    z = np.zeros((64, 128), dtype=np.float32)
+    P = np.ones((64, 128), dtype=np.float32)
+    assert float(np.abs(fp16x3_dw2(z, P)).max()) == 0.0
+    tiny = np.full((64, 128), 1e-38, dtype=np.float32)           # the 2^100 clamp: heads become subnormal, nothing overflows or turns NaN
+    out = fp16x3_dw2(tiny, P)
+    assert np.isfinite(out).all()
