@@ -450,7 +450,8 @@ def next_rows(dev) -> dict:
     m = DiffusionQM9(default_config(hidden_nf=H, n_layers=L))
     m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in synthetic_state_dict(9, 0, H, L, 2, True, 0, 0.5).items()})
     m = m.to(dev).train()
-    opt = torch.optim.AdamW(m.parameters(), lr=1e-4)
+    from hierdiff_amd.trainer import configure_optimizers
+    opt, _ = configure_optimizers(m, lr=1e-4)          # the package's own factory: AdamW with the reference's values, fused on the GPU
     for B in (256, 64):
         g = torch.Generator().manual_seed(0)
         x = torch.randn(B, N, 3, generator=g)

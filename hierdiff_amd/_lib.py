@@ -62,6 +62,9 @@ SIGNATURES = {
     "hd_dw2_x6": (C.c_int, [C.c_int, C.c_int, C.c_int, _FP, _FP, _FP, C.c_int, _FP, C.c_longlong, _VP]),
     "hd_edge_layer_backward": (C.c_int, [_VP, _VP, C.c_int] + [_FP] * 20 + [_VP]),
     "hd_edge_layer_backward_p": (C.c_int, [_VP, _VP, C.c_int, C.c_int] + [_FP] * 20 + [_VP]),
+    "hd_vlb_loss_forward": (C.c_int, [C.c_int] * 7 + [C.c_float] * 4 + [_FP] * 9 + [_VP]),
+    "hd_vlb_loss_backward": (C.c_int, [C.c_int] * 7 + [C.c_float] * 4 + [_FP] * 11 + [_VP]),
+    "hd_vlb_zt": (C.c_int, [C.c_int] * 3 + [_FP] * 6 + [_VP]),
     "hd_edge_layer_save_rows": (C.c_longlong, [_VP, _VP, C.c_int]),
     "hd_edge_layer_forward_s": (C.c_int, [_VP, _VP, C.c_int, C.c_int] + [_FP] * 10 + [_VP]),
     "hd_edge_layer_backward_s": (C.c_int, [_VP, _VP, C.c_int, C.c_int] + [_FP] * 22 + [_VP]),
@@ -124,3 +127,29 @@ def require_gpu() -> None:
     if lib.hd_device_count() < 1:
         raise HierDiffHipError("no HIP device visible: the HierDiff hot path runs only on an MI355X "
                                "(there is no CPU fallback)")
+
+
+# ----------------------------------------------------------------------------- "did an optimizer run since?" (round 5)
+# The packed weight images of the HIP handles and the schedule table are cached against the parameters' (address, in-place version)
+# pairs.  torch's FUSED optimizers (`torch.optim.AdamW(..., fused=True)`, the form hierdiff_amd.trainer.configure_optimizers picks on
+# the GPU) update the parameters WITHOUT bumping their version counters (measured on this torch build: version (2, 2) before and after
+# a step that changed the values), so the version alone would leave an evaluation after a training step on stale weights.  A global
+# post-step hook counts optimizer steps instead; every such cache key carries the count.
+_OPT_STEPS = [0]
+_HOOKED = [False]
+
+
+def optimizer_generation() -> int:
+    """Number of `torch.optim.Optimizer.step` calls seen in this process (any optimizer: an over-approximation that costs a
+    re-pack, never a stale image)."""
+    if not _HOOKED[0]:
+        try:
+            from torch.optim.optimizer import register_optimizer_step_post_hook
+
+            def _count(_opt, _args, _kwargs):
+                _OPT_STEPS[0] += 1
+            register_optimizer_step_post_hook(_count)
+        except Exception:           # a torch without global hooks: fused optimizers then need sync_weights(force=True)
+            pass
+        _HOOKED[0] = True
+    return _OPT_STEPS[0]

@@ -37,7 +37,7 @@ class TwoStreamSampler:
 
     def _sync_twin(self):
         m = self.model
-        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in m.state_dict(keep_vars=True).values())
+        key = (_lib.optimizer_generation(),) + tuple((p.data_ptr(), p._version, str(p.device)) for p in m.state_dict(keep_vars=True).values())
         if self._twin is None:
             self._twin = type(m)(m.cfg)
         t = self._twin

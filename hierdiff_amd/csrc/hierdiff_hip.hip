@@ -1828,12 +1828,14 @@ extern "C" long long hd_edge_layer_f16ws_floats(hd_handle* h, hd_topology* t, in
 }
 
 // Rows of the pre2 buffer a training forward may keep for its backward pass (hd_edge_layer_forward_s), or 0 where keeping does
-// not pay: batches small enough for the column-split / mixed edge kernels keep their faster forward and recompute.
+// not pay: batches small enough for the column-split edge kernel keep their faster forward and recompute.
 extern "C" long long hd_edge_layer_save_rows(hd_handle* h, hd_topology* t, int precision) {
     if (!h || !t || t->h != h || t->n_wg == 0 || t->M == 0) return 0;
     if (precision != 0 && precision != 2 && precision != 3) return 0;
     const int mode = h->H >= 128 ? precision : 0;
-    if (h->H >= 128 && (edge_runs_split(h, t->n_tiles, mode) || edge_runs_mixed(h, t->n_tiles, mode))) return 0;
+    // (the mix of whole and column-split tiles gains 2-5 % on a forward; the kept pre-activations save the backward a whole contraction:
+    // only the pure column-split regime - B <= 18 at N = 30, where that forward is 2 x faster - keeps recomputing)
+    if (h->H >= 128 && edge_runs_split(h, t->n_tiles, mode)) return 0;
     return (long long)t->n_wg * 4 * 32 + 32;        // one tile more than the table has: the fp16x3 forward parks its image scalars there
 }
 
@@ -2497,6 +2499,58 @@ extern "C" int hd_dw2_f16(int device, int rows, int H, const float* G2, const fl
     if (H == 256) hipLaunchKernelGGL((k_dw2_f16<256>), dim3(slabs), dim3(512), dw2_f16_lds_bytes<256>(), s, a);
     else hipLaunchKernelGGL((k_dw2_f16<128>), dim3(slabs), dim3(512), dw2_f16_lds_bytes<128>(), s, a);
     hipLaunchKernelGGL(k_dw2_reduce, dim3((H * H + 255) / 256), dim3(256), 0, s, ws, dW2, H * H, H, ldc, slabs);
+    HIP_TRY(hipGetLastError());
+    return HD_OK;
+}
+
+// ----------------------------------------------------------------------------- training loss (k_loss.hpp)
+static int vlb_check(const char* who, int device, int B, int N, int D, int int_nf, int cont_nf) {
+    if (B < 1 || N < 1 || D < 4 || int_nf < 0 || cont_nf < 0 || 3 + int_nf + cont_nf > D)
+        return fail(HD_E_INVALID, std::string(who) + ": bad shape (B, N >= 1, D >= 4, 3 + int_nf + cont_nf <= D)");
+    if (hd_device_count() <= device || device < 0) return fail(HD_E_HIP, std::string(who) + ": no such HIP device (is a GPU visible?)");
+    HIP_TRY(hipSetDevice(device));
+    return HD_OK;
+}
+
+extern "C" int hd_vlb_loss_forward(int device, int B, int N, int D, int int_nf, int cont_nf, int l2_train, float T, float nv2, float nb2,
+                                   float log_nv0, const float* net, const float* zt, const float* xh, const float* eps, const float* nm,
+                                   const float* gam, const float* t_int, float* loss, float* err, void* stream) {
+    HD_TRY(vlb_check("hd_vlb_loss_forward", device, B, N, D, int_nf, cont_nf));
+    if (!net || !zt || !xh || !eps || !nm || !gam || !t_int || !loss || !err) return fail(HD_E_INVALID, "hd_vlb_loss_forward: null tensor");
+    VlbArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.net = net; a.zt = zt; a.xh = xh; a.eps = eps; a.nm = nm; a.gam = gam; a.t_int = t_int; a.loss = loss; a.err = err;
+    a.B = B; a.N = N; a.D = D; a.int_nf = int_nf; a.cont_nf = cont_nf; a.l2_train = l2_train; a.T = T; a.nv2 = nv2; a.nb2 = nb2; a.log_nv0 = log_nv0;
+    hipLaunchKernelGGL((k_vlb<false>), dim3(B), dim3(256), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return HD_OK;
+}
+
+extern "C" int hd_vlb_loss_backward(int device, int B, int N, int D, int int_nf, int cont_nf, int l2_train, float T, float nv2, float nb2,
+                                    float log_nv0, const float* net, const float* zt, const float* xh, const float* eps, const float* nm,
+                                    const float* gam, const float* t_int, const float* gout, float* dnet, float* dzt, float* dgam,
+                                    void* stream) {
+    HD_TRY(vlb_check("hd_vlb_loss_backward", device, B, N, D, int_nf, cont_nf));
+    if (!net || !zt || !xh || !eps || !nm || !gam || !t_int || !gout || !dnet || !dzt || !dgam)
+        return fail(HD_E_INVALID, "hd_vlb_loss_backward: null tensor");
+    VlbArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.net = net; a.zt = zt; a.xh = xh; a.eps = eps; a.nm = nm; a.gam = gam; a.t_int = t_int; a.gout = gout; a.dnet = dnet; a.dzt = dzt; a.dgam = dgam;
+    a.B = B; a.N = N; a.D = D; a.int_nf = int_nf; a.cont_nf = cont_nf; a.l2_train = l2_train; a.T = T; a.nv2 = nv2; a.nb2 = nb2; a.log_nv0 = log_nv0;
+    hipLaunchKernelGGL((k_vlb<true>), dim3(B), dim3(256), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return HD_OK;
+}
+
+// z_t = alpha(g_t) xh + sigma(g_t) eps per molecule (dzt = NULL), or its gradient with respect to g_t (dzt given: dgt [B] written)
+extern "C" int hd_vlb_zt(int device, int B, int ND, const float* xh, const float* eps, const float* gt, float* zt, const float* dzt,
+                         float* dgt, void* stream) {
+    if (B < 1 || ND < 1 || !xh || !eps || !gt || (!dzt && !zt) || (dzt && !dgt)) return fail(HD_E_INVALID, "hd_vlb_zt: bad argument");
+    if (hd_device_count() <= device || device < 0) return fail(HD_E_HIP, "hd_vlb_zt: no such HIP device (is a GPU visible?)");
+    HIP_TRY(hipSetDevice(device));
+    VlbZtArgs a{xh, eps, gt, zt, dzt, dgt, B, ND};
+    if (dzt) hipLaunchKernelGGL((k_vlb_zt<true>), dim3(B), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((k_vlb_zt<false>), dim3(B), dim3(256), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return HD_OK;
 }

@@ -162,6 +162,11 @@ class DiffusionQM9(_Base):
         self.merge_batches = 4096
         self.merge_edges = 900_000
         self.debug_checks = False       # True re-enables the reference's host-synchronising asserts
+        #: training-mode loss around the network call as two fused launches per direction (csrc/k_loss.hpp) instead of ~350 torch
+        #: launches; False = the torch-op path (same arithmetic; what evaluation, pocket models and the CPU run)
+        self.fused_loss = True
+        self._fused_log_nv0 = 0.0
+        self._fused_took = False
         self.schedule_gammas = None     # optional [T+1] gamma grid overriding the network (replay a run)
         # "fp64" (default): the schedule network is evaluated once in float64 on the host and rounded - the same table on
         # every machine.  "fp32": evaluated like the reference (float32, a [B,1] column per grid value, CPU BLAS): agrees
@@ -236,7 +241,7 @@ class DiffusionQM9(_Base):
         # batch gives the same NLL whatever the grad mode
         if torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.gamma.parameters()):
             return self.gamma(t).view(-1, 1)
-        ver = (self.T, str(t.device)) + tuple((p.data_ptr(), p._version) for p in self.gamma.state_dict(keep_vars=True).values())
+        ver = (self.T, str(t.device), _lib.optimizer_generation()) + tuple((p.data_ptr(), p._version) for p in self.gamma.state_dict(keep_vars=True).values())
         if getattr(self, "_gamma_grid_key", None) != ver:
             k = torch.arange(-1, self.T + 1, dtype=torch.float32).view(-1, 1)
             self._gamma_grid = evaluate_gamma(self.gamma, k / self.T).view(-1).to(t.device)
@@ -327,6 +332,24 @@ class DiffusionQM9(_Base):
             eps = self.sample_combined_position_feature_noise(B, mol, node_mask)
         eps = torch.as_tensor(eps, dtype=torch.float32, device=dev)
         xh = torch.cat([x, h], dim=2).to(torch.float32)
+        if (self.fused_loss and not t0_always and mol_shape is None and x.is_cuda and torch.is_grad_enabled() and self.training
+                and xh.shape[2] == self.n_dims + self.in_node_nf):
+            # the training loss around the network call as one launch per direction (training.vlb_zt / vlb_loss, csrc/k_loss.hpp);
+            # everything this branch skips below is the same arithmetic in ~350 element-wise launches, kept for every other case
+            # (evaluation, pocket models, CPU) and as the oracle of tests/test_gpu_training.py
+            from .training import vlb_loss, vlb_zt
+            self._check_mean_zero(x, node_mask)
+            gam = torch.stack([gamma_s.reshape(B), gamma_t.reshape(B), gamma_0.reshape(B), gamma_T.reshape(B)])
+            xh, eps = xh.contiguous(), eps.contiguous()
+            z_t = vlb_zt(xh, eps, gam[1])
+            net_out = self.phi(z_t, t, node_mask_all, edge_mask, context, mol_shape=mol)
+            int_nf, cont_nf = (5, 3) if self.node_coarse_type == 'prop' else (3, 0)
+            l2_train = self.loss_type == 'l2'
+            consts = (int_nf, cont_nf, l2_train, float(self.T), float(self.norm_values[2]), float(self.norm_biases[2]),
+                      float(self._fused_log_nv0))
+            loss, error = vlb_loss(net_out, z_t, gam, xh, eps, nm.reshape(B, mol).contiguous(), t_int.reshape(B).contiguous(), consts)
+            self._fused_took = True
+            return loss, {'t': t_int.squeeze(), 'loss_t': loss.squeeze(), 'error': error.squeeze()}
         xh_fix = torch.cat([x_fix, h_fix], dim=2).to(torch.float32)
         self._check_mean_zero(x, node_mask)
         z_t = self.alpha(gamma_t, x) * xh + self.sigma(gamma_t, x) * eps
@@ -361,8 +384,14 @@ class DiffusionQM9(_Base):
         x, h, delta_log_px = self.normalize(x, h, node_mask.to(torch.float32))
         if self.training and self.loss_type == 'l2':
             delta_log_px = torch.zeros_like(delta_log_px)
+        # (the fused training loss returns loss - delta_log_px itself: log(norm_values[0]) travels in; 0 keeps compute_loss's own value)
+        self._fused_log_nv0 = math.log(self.norm_values[0])
+        self._fused_took = False
         loss, _ = self.compute_loss(x, h, node_mask, edge_mask, context, t0_always=not self.training,
                                     mol_shape=mol_shape, **replay)
+        self._fused_log_nv0 = 0.0
+        if self._fused_took:
+            return loss
         return loss - delta_log_px
 
     def forward(self, batch, **replay):
@@ -444,7 +473,7 @@ class DiffusionQM9(_Base):
         """Tabulated schedule, uploaded to the handle (hd_set_schedule); recomputed when gamma changes."""
         handle = self._lib_handle()          # creates the handle if needed: its generation is part of the key (a new
         # handle - other precision, other device - has no schedule yet, even if it re-uses a freed handle's address)
-        key = (self.T, self.dynamics._handle_gen) + tuple(
+        key = (self.T, self.dynamics._handle_gen, _lib.optimizer_generation()) + tuple(
             (p.data_ptr(), p._version) for p in self.gamma.parameters()) + (
                 id(self.schedule_gammas), self.schedule_eval, rows if self.schedule_eval == "fp32" else 0)
         if key != self._sched_key:

@@ -293,7 +293,7 @@ class EGNN_dynamics_QM9(nn.Module):
         object.__setattr__(self, "_arith", arith)
 
     def _sync_gnn_engine(self):
-        key = tuple((p.data_ptr(), p._version) for p in self.gnn.parameters())
+        key = (_lib.optimizer_generation(),) + tuple((p.data_ptr(), p._version) for p in self.gnn.parameters())
         if key == self._engine_key:
             return
         eg, gn = self._engine.egnn, self.gnn
@@ -443,7 +443,8 @@ class EGNN_dynamics_QM9(nn.Module):
             self._handle_gen = self._arith._handle_gen
             return
         h = self._handle()
-        key = tuple((p.data_ptr(), p._version) for p in self.egnn.parameters())
+        # (+ the optimizer-step count: fused optimizers do not bump `_version`, _lib.optimizer_generation)
+        key = (_lib.optimizer_generation(),) + tuple((p.data_ptr(), p._version) for p in self.egnn.parameters())
         if not force and key == self._weights_key:
             return
         blob = self.canonical_blob().contiguous()

@@ -157,7 +157,8 @@ def _fp64_twin(gamma_module: torch.nn.Module) -> torch.nn.Module:
     per-step API calls evaluate_gamma twice per diffusion step)."""
     import copy
     import weakref
-    key = tuple((p.data_ptr(), p._version, p.device) for p in gamma_module.state_dict(keep_vars=True).values())
+    from ._lib import optimizer_generation          # fused optimizers change values without bumping `_version`
+    key = (optimizer_generation(),) + tuple((p.data_ptr(), p._version, p.device) for p in gamma_module.state_dict(keep_vars=True).values())
     hit = _TWINS.get(id(gamma_module))
     if hit is not None and hit[0]() is gamma_module and hit[1] == key:
         return hit[2]

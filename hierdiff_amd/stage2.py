@@ -142,7 +142,7 @@ class E_GCL(nn.Module):
         h = self._handle()
         if self._plist is None:                  # the module-tree walk of .parameters() costs more than a beam-sized layer
             self._plist = list(self.parameters())
-        key = tuple((p.data_ptr(), p._version) for p in self._plist)
+        key = (_lib.optimizer_generation(),) + tuple((p.data_ptr(), p._version) for p in self._plist)     # (fused optimizers: no version bump)
         if key == self._weights_key:
             return
         blob = torch.cat([p.detach().reshape(-1).to(torch.float32) for p in self._plist]).contiguous()

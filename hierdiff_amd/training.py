@@ -403,3 +403,75 @@ def dynamics_forward_train(dyn: EGNN_dynamics_QM9, t, xh, node_mask, edge_mask, 
     nmf = node_mask.reshape(B, N, 1).to(torch.float32)
     vel = vel - (vel.sum(1, keepdim=True) / nmf.sum(1, keepdim=True)) * nmf
     return torch.cat([vel, out[..., 3:]], dim=2)
+
+
+# ----------------------------------------------------------------------------- the variational loss around the network call, fused
+class _VlbZt(torch.autograd.Function):
+    """z_t = alpha(g_t) xh + sigma(g_t) eps (diffusion_qm9.py:566-571) as one launch per direction (`hd_vlb_zt`); differentiable
+    with respect to g_t [B] - the learned schedule is part of the graph - not to the data or the noise."""
+
+    @staticmethod
+    def forward(ctx, xh, eps, gt):
+        lib = _lib.load()
+        B = xh.shape[0]
+        zt = torch.empty_like(xh)
+        _lib.check(lib.hd_vlb_zt(_dev_index(xh.device), B, xh.numel() // B, xh.data_ptr(), eps.data_ptr(), gt.data_ptr(), zt.data_ptr(),
+                                 None, None, _stream(xh.device)), "hd_vlb_zt")
+        ctx.save_for_backward(xh, eps, gt)
+        return zt
+
+    @staticmethod
+    def backward(ctx, dzt):
+        xh, eps, gt = ctx.saved_tensors
+        lib = _lib.load()
+        B = xh.shape[0]
+        dgt = torch.empty_like(gt)
+        dz = dzt.contiguous()
+        _lib.check(lib.hd_vlb_zt(_dev_index(xh.device), B, xh.numel() // B, xh.data_ptr(), eps.data_ptr(), gt.data_ptr(), None,
+                                 dz.data_ptr(), dgt.data_ptr(), _stream(xh.device)), "hd_vlb_zt")
+        return None, None, dgt
+
+
+class _VlbLoss(torch.autograd.Function):
+    """compute_loss of the reference in training mode (t0_always = False) from the network output on: error, SNR weight, KL to the
+    prior, log constants, the t = 0 likelihood, the estimator - `hd_vlb_loss_forward` / `_backward`, one launch each (the torch ops
+    they replace: ~350 launches of [B, N, 11] tensors per step).  Differentiable with respect to the network output, z_t and the four
+    schedule values."""
+
+    @staticmethod
+    def forward(ctx, net, zt, gam, xh, eps, nm, t_int, consts):
+        lib = _lib.load()
+        B, N, D = net.shape
+        net, zt, gam = net.contiguous(), zt.contiguous(), gam.contiguous()
+        loss = torch.empty(B, device=net.device, dtype=torch.float32)
+        err = torch.empty(B, device=net.device, dtype=torch.float32)
+        int_nf, cont_nf, l2, T, nv2, nb2, log_nv0 = consts
+        _lib.check(lib.hd_vlb_loss_forward(_dev_index(net.device), B, N, D, int_nf, cont_nf, int(l2), T, nv2, nb2, log_nv0, net.data_ptr(),
+                                           zt.data_ptr(), xh.data_ptr(), eps.data_ptr(), nm.data_ptr(), gam.data_ptr(), t_int.data_ptr(),
+                                           loss.data_ptr(), err.data_ptr(), _stream(net.device)), "hd_vlb_loss_forward")
+        ctx.save_for_backward(net, zt, gam, xh, eps, nm, t_int)
+        ctx.consts = consts
+        ctx.mark_non_differentiable(err)
+        return loss, err
+
+    @staticmethod
+    def backward(ctx, gout, _gerr):
+        net, zt, gam, xh, eps, nm, t_int = ctx.saved_tensors
+        lib = _lib.load()
+        B, N, D = net.shape
+        int_nf, cont_nf, l2, T, nv2, nb2, log_nv0 = ctx.consts
+        dnet, dzt, dgam = torch.empty_like(net), torch.empty_like(net), torch.empty_like(gam)
+        go = gout.contiguous()
+        _lib.check(lib.hd_vlb_loss_backward(_dev_index(net.device), B, N, D, int_nf, cont_nf, int(l2), T, nv2, nb2, log_nv0, net.data_ptr(),
+                                            zt.data_ptr(), xh.data_ptr(), eps.data_ptr(), nm.data_ptr(), gam.data_ptr(), t_int.data_ptr(),
+                                            go.data_ptr(), dnet.data_ptr(), dzt.data_ptr(), dgam.data_ptr(), _stream(net.device)),
+                   "hd_vlb_loss_backward")
+        return dnet, dzt, dgam, None, None, None, None, None
+
+
+def vlb_zt(xh, eps, gt):
+    return _VlbZt.apply(xh, eps, gt)
+
+
+def vlb_loss(net, zt, gam, xh, eps, nm, t_int, consts):
+    return _VlbLoss.apply(net, zt, gam, xh, eps, nm, t_int, consts)

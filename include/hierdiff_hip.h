@@ -229,7 +229,7 @@ int hd_edge_layer_backward_p(hd_handle* h, hd_topology* topo, int coord, int pre
                              const float* ba, const float* gout, float* G2, float* P, float* G1, float* escal, float* colpart,
                              float* bapart, float* b2part, float* wrdpart, float* dAB, float* dx, float* dx0, void* stream);
 /* Round 5 (ABI 10): keep the second-layer pre-activations instead of recomputing them.  hd_edge_layer_save_rows = rows of a
- * [rows][hidden_nf] fp32 buffer the forward of this topology can fill (the table's rows plus one spare tile; 0: the batch is small enough for the column-split / mixed
+ * [rows][hidden_nf] fp32 buffer the forward of this topology can fill (the table's rows plus one spare tile; 0: the batch is small enough for the column-split
  * edge kernels, which keep their faster forward - pass pre2 = NULL and the backward recomputes as before).  hd_edge_layer_forward_s
  * with pre2 != NULL writes W2 P + b2 of every edge row into it (accumulator order per 32-row tile, opaque to the caller; 228 MB per
  * layer at B = 256, N = 30, H = 256 - sized for this GPU's HBM, not for a 16 GB card); hd_edge_layer_backward_s with the same
@@ -325,6 +325,23 @@ int hd_gemm_f32(int device, int M, int N, int K, const float* A, long long a_m_s
  * into min(256, ws_floats / H^2, rows / 128) slabs whose partial results are added in a fixed order (deterministic). */
 int hd_dw2_x6(int device, int rows, int H, const float* G2, const float* P, float* dW2, int ldc, float* ws,
               long long ws_floats, void* stream);
+/* The variational training loss around the network call as one kernel per direction (round 5; reference: compute_loss with
+ * t0_always = False, diffusion_qm9.py:530-673, and what it calls - compute_error :160-172, kl_prior :206-239, the log constants
+ * :241-262, log_pxh_given_z0_without_constants :460-528).  All tensors fp32 on the device: net / zt / xh / eps [B][N][D] (network
+ * output, noised input, normalised data [x | h], noise), nm [B][N], gam [4][B] = gamma at (s, t, 0, 1), t_int [B].  int_nf / cont_nf:
+ * integer / continuous feature columns of the t = 0 likelihood (5 / 3 for node_coarse_type 'prop', 3 / 0 otherwise); l2_train: the
+ * `l2` training loss; T timesteps; nv2 / nb2 = norm_values[2] / norm_biases[2]; log_nv0 = log(norm_values[0]).
+ * forward: loss [B] (= nll per molecule), err [B] (= the `error` of the reference's info dict).
+ * backward: given gout = dL/d(loss) [B]: dnet, dzt [B][N][D] and dgam [4][B] (the schedule network is trained).
+ * hd_vlb_zt: z_t = sqrt(sigmoid(-g_t)) xh + sqrt(sigmoid(g_t)) eps (dzt = NULL), or dgt[b] = d/dg_t of that against dzt. */
+int hd_vlb_loss_forward(int device, int B, int N, int D, int int_nf, int cont_nf, int l2_train, float T, float nv2, float nb2,
+                        float log_nv0, const float* net, const float* zt, const float* xh, const float* eps, const float* nm,
+                        const float* gam, const float* t_int, float* loss, float* err, void* stream);
+int hd_vlb_loss_backward(int device, int B, int N, int D, int int_nf, int cont_nf, int l2_train, float T, float nv2, float nb2,
+                         float log_nv0, const float* net, const float* zt, const float* xh, const float* eps, const float* nm,
+                         const float* gam, const float* t_int, const float* gout, float* dnet, float* dzt, float* dgam, void* stream);
+int hd_vlb_zt(int device, int B, int ND, const float* xh, const float* eps, const float* gt, float* zt, const float* dzt, float* dgt,
+              void* stream);
 /* Column sums of n <= 4 device arrays src[i] [rows][width[i]] into dst[i] [width[i]] in two launches, rows added in a fixed
  * order (32 ascending row ranges, then the ranges ascending): the reductions hd_edge_layer_backward leaves to its caller
  * (db2, d(wa), d(w_r) / d(w_d), d(ba) from the per-tile partial sums).  src / width / dst are HOST arrays of n entries;

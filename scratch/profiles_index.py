@@ -31,6 +31,10 @@ RULES = [
     (r"r05_pmc_train_hbm\.log", "HBM bytes per launch of the training kernels (FETCH_SIZE / WRITE_SIZE passes) against their algorithmic bytes, before / after the XCD-aware placement of the backward stages", "DESIGN 10 round 5, second half"),
     (r"r05_train_xcd_placement\.log", "training step + kernel tables after the XCD-aware placement of the backward stages (fp32 26.5 ms, fp16x3 19.5 ms)", "DESIGN 10 round 5, second half"),
     (r"r05_ab_rebuild_p\.log", "same-box A/B of the fp16x3 training step: P materialised vs rebuilt inside the dW2 kernel (null)", "EXPERIMENTS L"),
+    (r"r05_train_host_time_before\.log", "host enqueue time by section and launch count of a B = 16 training step before the fused loss / fused AdamW (12.07 ms, 1,122 launches)", "DESIGN 10 round 5, third part"),
+    (r"r05_train_b16_kstats_before\.log", "kernel launch counts of the B = 16 training step before the fused loss", "DESIGN 10 round 5, third part"),
+    (r"r05_train_fused_loss_times\.log", "training step by batch size with the fused loss and fused AdamW (B = 16: 8.3-9.7 ms, 867 launches)", "DESIGN 10 round 5, third part"),
+    (r"r05_train_keep_ab\.log", "same-box A/B by batch size and arithmetic: pre-activations kept vs recomputed", "DESIGN 10 round 5, second half"),
     (r"r05_train_kept_pre2\.log", "training step + kernel tables with the kept second-layer pre-activations (fp32 27.0 ms, bf16x6 21.9 ms)", "DESIGN 10 round 5, second half"),
     (r"r05_train_fp16x3\.log", "training step + kernel table with training_precision = fp16x3 (20.4 ms)", "DESIGN 10 round 5, second half"),
     (r"r05_train_kstats\.log", "kernel tables of the training step in both arithmetics after the k_edge_dx rewrite", "DESIGN 10 round 5"),

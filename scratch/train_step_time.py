@@ -17,7 +17,8 @@ x = torch.randn(B, N, 3, generator=g); x = x - x.mean(1, keepdim=True)
 h = torch.cat([torch.randint(0, 5, (B, N, 5), generator=g).float(), torch.randn(B, N, 3, generator=g)], 2)
 nm = torch.ones(B, N, 1, dtype=torch.bool); em = ~torch.eye(N, dtype=torch.bool)[None].expand(B, N, N)
 batch = {"positions": x.to(DEV), "atom_mask": nm.to(DEV), "edge_mask": em.contiguous().to(DEV), "node_feature": h.to(DEV)}
-opt = torch.optim.AdamW(m.parameters(), lr=1e-4)
+from hierdiff_amd.trainer import configure_optimizers
+opt, _ = configure_optimizers(m, lr=1e-4)
 def step():
     opt.zero_grad(set_to_none=True)
     loss = m.training_step(batch, 0)

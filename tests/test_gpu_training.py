@@ -119,6 +119,88 @@ def test_training_loss_gradients_on_reference_fixtures(name):
     print(f"{name}: {n} parameter tensors, worst grad rel-L2 {worst:.2e}")
 
 
+@pytest.mark.parametrize("loss_type,schedule,coarse,nv", [("vlb", "learned", "prop", (1.0, 1.0, 1.0)), ("l2", "polynomial_2", "prop", (1.0, 1.0, 1.0)),
+                                                          ("vlb", "polynomial_2", "prop", (1.0, 1.0, 1.0)), ("vlb", "learned", "elem", (1.0, 1.0, 1.0)),
+                                                          ("vlb", "learned", "prop", (2.0, 4.0, 1.0))])
+def test_fused_training_loss_equals_the_torch_op_path(loss_type, schedule, coarse, nv):
+    """Round 5: compute_loss in training mode as two fused launches per direction (csrc/k_loss.hpp: z_t, then everything behind the
+    network call) against the torch-op path it replaces (`model.fused_loss = False`, itself pinned to the reference by fixtures F9)
+    on the same draws: per-molecule loss values, the `error` entry, and the gradient of the mean loss with respect to EVERY
+    parameter - dynamics and schedule network - over the config branches the kernel carries (vlb / l2, learned / fixed schedule,
+    5 + 3 / 3 + 0 feature columns, non-unit norm_values), ragged molecules, rows with t = 0 (the integer likelihood) among the others."""
+    from hierdiff_amd import DiffusionQM9, default_config
+    from hierdiff_amd.weights import synthetic_state_dict
+    H, L, B, N = 64, 2, 7, 11
+    cfg = default_config(hidden_nf=H, n_layers=L, timesteps=50)
+    cfg.loss_type, cfg.noise_schedule, cfg.node_coarse_type = loss_type, schedule, coarse
+    cfg.pre_noise.noise_schedule = schedule
+    cfg.norm_values = list(nv)
+    g = torch.Generator().manual_seed(3)
+    sizes = [11, 7, 1, 9, 4, 11, 2]
+    nm = torch.zeros(B, N, 1, dtype=torch.bool)
+    for b, n in enumerate(sizes):
+        nm[b, :n] = True
+    em = (nm.float() @ nm.float().transpose(1, 2)).bool() & ~torch.eye(N, dtype=torch.bool)[None]
+    x = torch.randn(B, N, 3, generator=g) * nm
+    x = x - (x.sum(1, keepdim=True) / nm.sum(1, keepdim=True)) * nm
+    F_ = 8 if coarse == "prop" else 3
+    hi = torch.randint(0, 5, (B, N, 5 if coarse == "prop" else 3), generator=g).float()
+    h = (torch.cat([hi, torch.randn(B, N, 3, generator=g)], 2) if coarse == "prop" else hi) * nm
+    batch = {"positions": x.to(DEV), "atom_mask": nm.to(DEV), "edge_mask": em.to(DEV), "node_feature": h.to(DEV)}
+    t_int = torch.tensor([[0.], [17.], [3.], [0.], [50.], [1.], [29.]])
+    res = {}
+    for fused in (True, False):
+        torch.manual_seed(11)
+        m = DiffusionQM9(cfg)
+        sd = synthetic_state_dict(3 + F_ + 1 - 3, 0, H, L, 2, True, 41, 0.5)
+        own = m.state_dict()
+        m.load_state_dict({k: (torch.from_numpy(sd[k].copy()) if k in sd and tuple(sd[k].shape) == tuple(v.shape) else v) for k, v in own.items()})
+        m = m.to(DEV).train()
+        m.fused_loss = fused
+        eps = m.sample_combined_position_feature_noise(B, N, nm.to(DEV)) if "eps" not in res else res["eps"]
+        res["eps"] = eps
+        xs, hs, dl = m.normalize(batch["positions"], batch["node_feature"], nm.to(DEV).float())
+        per, info = m.compute_loss(xs, hs, nm.to(DEV), em.reshape(B, N * N).to(DEV), None, t0_always=False, t_int=t_int, eps=eps)
+        out = m.forward(batch, t_int=t_int, eps=eps)["loss"]
+        out.backward()
+        res[fused] = (per.detach().clone(), info["error"].detach().clone(), out.detach().clone(),
+                      {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None})
+        # the four schedule values as leaves: their gradients element by element (the schedule network's parameter gradients are
+        # sums of these 1e4-1e5-sized numbers with opposite signs - one rounding of a term is visible in such a sum)
+        with torch.no_grad():
+            tt = t_int.to(DEV)
+            gv = m.gamma(torch.cat([(tt - 1) / m.T, tt / m.T, torch.zeros_like(tt), torch.ones_like(tt)], 0)).view(4, B, 1)
+        leaves = {k: gv[i].clone().requires_grad_(True) for i, k in enumerate(("gamma_s", "gamma_t", "gamma_0", "gamma_T"))}
+        m.zero_grad(set_to_none=True)
+        per2, _ = m.compute_loss(xs, hs, nm.to(DEV), em.reshape(B, N * N).to(DEV), None, t0_always=False, t_int=t_int, eps=eps, gammas=leaves)
+        per2.mean().backward()
+        res[("dgam", fused)] = torch.stack([(leaves[k].grad if leaves[k].grad is not None else torch.zeros(B, 1, device=DEV)).view(B)
+                                            for k in ("gamma_s", "gamma_t", "gamma_0", "gamma_T")])      # (l2: g_s, g_0 do not enter)
+    dga, dgb = res[("dgam", True)], res[("dgam", False)]
+    np.testing.assert_allclose(dga.cpu().numpy(), dgb.cpu().numpy(), rtol=1e-4, atol=1e-5 * float(dgb.abs().max()))
+    scale_g = float(dgb.abs().max())
+    a, b = res[True], res[False]
+    assert torch.isfinite(a[0]).all() and torch.isfinite(a[2])
+    np.testing.assert_allclose(a[0].cpu().numpy(), b[0].cpu().numpy(), rtol=2e-5, atol=1e-4)
+    np.testing.assert_allclose(a[1].cpu().numpy(), b[1].cpu().numpy(), rtol=2e-5, atol=1e-5)
+    np.testing.assert_allclose(float(a[2]), float(b[2]), rtol=2e-5)
+    assert set(a[3]) == set(b[3]) and len(a[3]) > 40
+    scale = max(float(v.abs().max()) for v in b[3].values())
+    worst = 0.0
+    for k, gb in b[3].items():
+        err = float((a[3][k] - gb).norm())
+        # (the small schedule-network gradients - l3.bias is the plain sum of all 4 B schedule-value gradients, ~0 against terms of
+        # ~1e3 - are rounding noise of those terms in BOTH paths: an absolute bar for them; the tight check is `dgam` above)
+        slack = 2e-5 * scale_g * gb.numel() ** 0.5 if k.startswith("gamma.") else 1e-7 * scale * gb.numel() ** 0.5
+        assert err <= 1e-4 * float(gb.norm()) + slack, (k, err, float(gb.norm()))
+        if not k.startswith("gamma."):
+            worst = max(worst, err / max(float(gb.norm()), 1e-30))
+    sched = [k for k in a[3] if k.startswith("gamma.")]
+    assert (schedule == "learned") == bool(sched)
+    print(f"{loss_type} {schedule} {coarse} nv={nv}: loss {float(a[2]):.4f} / {float(b[2]):.4f}, {len(a[3])} gradients ({len(sched)} of the schedule network), "
+          f"worst dynamics-gradient rel-L2 fused vs torch ops {worst:.2e}; d loss / d gamma values up to {scale_g:.1e}, fused vs torch ops within 1e-4")
+
+
 def test_training_step_with_learned_schedule_and_optimizer():
     """training_step (diffusion_qm9.py:774-777) end to end: learned schedule in the graph, every parameter gets a finite
     gradient; the loss code's gradient with respect to the schedule values equals the oracle's; a few Adam steps reduce
@@ -388,6 +470,44 @@ def test_trainer_ddp_step_equals_the_manual_sequence():
         assert ka == kb and torch.equal(pa, pb), ka
     moved = sum(float((pa.cpu() - torch.from_numpy(sd[k])).abs().max()) > 0 for k, pa in a.state_dict().items() if k in sd and k != "buffer")
     assert moved > 10, "the optimiser must have moved the weights"
+
+
+def test_inference_path_sees_the_weights_a_fused_optimizer_wrote():
+    """torch's fused optimizers (the AdamW `trainer.configure_optimizers` picks on the GPU) change the parameters without bumping their
+    version counters, which the packed weight images of the inference handle and the schedule table are cached against: the cache
+    keys also carry a count of optimizer steps (`_lib.optimizer_generation`).  After a fused step the no-grad forward (packed images,
+    HIP sampler kernels) must equal the differentiable forward (the parameters themselves), and the tabulated schedule the network."""
+    from hierdiff_amd import DiffusionQM9, default_config
+    from hierdiff_amd.trainer import configure_optimizers
+    from hierdiff_amd.weights import synthetic_state_dict
+    H, L, B, N = 64, 2, 5, 9
+    m = DiffusionQM9(default_config(hidden_nf=H, n_layers=L, timesteps=50))
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in synthetic_state_dict(9, 0, H, L, 2, True, 33, 0.5).items()})
+    m = m.to(DEV).train()
+    batch = {k: v.to(DEV) for k, v in _host_batch(5, B, N).items()}
+    opt, _ = configure_optimizers(m, lr=3e-2)
+    assert opt.defaults.get("fused")
+    xh = torch.randn(B, N, 11, device=DEV) * batch["atom_mask"]
+    t = torch.full((B, 1), 0.5, device=DEV)
+    em = batch["edge_mask"].reshape(B, N * N)
+
+    def both():
+        with torch.no_grad():
+            inf = m.dynamics._forward(t, xh, batch["atom_mask"], em, None, None)
+            tab = m._gamma_rows(t, "gamma_t", None)
+        dif = m.dynamics._forward(t, xh.clone().requires_grad_(True), batch["atom_mask"], em, None, None).detach()
+        return inf, dif, tab, m.gamma(t).detach().view(-1, 1)
+    inf0, dif0, tab0, net0 = both()
+    assert rel_l2(inf0.cpu().numpy(), dif0.cpu().numpy()) < 2e-6 and torch.allclose(tab0, net0, rtol=1e-4, atol=1e-4)
+    for _ in range(6):
+        opt.zero_grad(set_to_none=True)
+        m.training_step(batch, 0).backward()
+        opt.step()
+    inf1, dif1, tab1, net1 = both()
+    assert rel_l2(dif1.cpu().numpy(), dif0.cpu().numpy()) > 1e-4, "the optimiser must have moved the weights"
+    assert rel_l2(inf1.cpu().numpy(), dif1.cpu().numpy()) < 2e-6, "the inference handle runs on stale weights"
+    moved = float((net1 - net0).abs().max())
+    assert moved > 0 and float((tab1 - net1).abs().max()) < 0.25 * moved, "the schedule table is stale"
 
 
 # ----------------------------------------------------------------------------- opt-in bf16x6 arithmetic of the training path
