@@ -64,6 +64,7 @@ SIGNATURES = {
     "hd_edge_layer_backward_p": (C.c_int, [_VP, _VP, C.c_int, C.c_int] + [_FP] * 20 + [_VP]),
     "hd_vlb_loss_forward": (C.c_int, [C.c_int] * 7 + [C.c_float] * 4 + [_FP] * 9 + [_VP]),
     "hd_vlb_loss_backward": (C.c_int, [C.c_int] * 7 + [C.c_float] * 4 + [_FP] * 11 + [_VP]),
+    "hd_edge_prep": (C.c_int, [C.c_int, C.c_int, C.c_int] + [_FP] * 5 + [_VP]),
     "hd_vlb_zt": (C.c_int, [C.c_int] * 3 + [_FP] * 6 + [_VP]),
     "hd_edge_layer_save_rows": (C.c_longlong, [_VP, _VP, C.c_int]),
     "hd_edge_layer_forward_s": (C.c_int, [_VP, _VP, C.c_int, C.c_int] + [_FP] * 10 + [_VP]),

@@ -1854,8 +1854,11 @@ extern "C" int hd_edge_layer_forward_s(hd_handle* h, hd_topology* t, int coord, 
     const hd_config& c = h->cfg;
     const int H = h->H, M = t->M;
     const int ow = coord ? 4 : H;
-    HIP_TRY(hipMemsetAsync(out, 0, (size_t)std::max(1, M) * ow * sizeof(float), s));
-    if (t->n_wg == 0 || M == 0) return HD_OK;
+    // (k_agg below writes every row of `out`; only a layer without edges needs the fill)
+    if (t->n_wg == 0 || M == 0) {
+        HIP_TRY(hipMemsetAsync(out, 0, (size_t)std::max(1, M) * ow * sizeof(float), s));
+        return HD_OK;
+    }
     EdgeArgs e;
     std::memset(&e, 0, sizeof(e));
     if (f16) {
@@ -2376,7 +2379,7 @@ extern "C" int hd_gemm_f32(int device, int M, int N, int K, const float* A, long
         return fail(HD_E_INVALID, "hd_gemm_f32: the epilogue's second tensor is missing");
     if (split_k < 1) split_k = 1;
     if (split_k > 1 && (!ws || epi != TG_EPI_BIAS)) return fail(HD_E_INVALID, "hd_gemm_f32: split-K needs a workspace and the plain epilogue");
-    if (colsum && (split_k < 2 || a_m_stride != 1 || a_k_stride == 1)) return fail(HD_E_INVALID, "hd_gemm_f32: column sums ride on a split-K GEMM with an m-contiguous A");
+    if (colsum && (a_m_stride != 1 || a_k_stride == 1)) return fail(HD_E_INVALID, "hd_gemm_f32: column sums ride on a GEMM with an m-contiguous A (dW = dY^T X)");
     if (hd_device_count() <= device || device < 0) return fail(HD_E_HIP, "hd_gemm_f32: no such HIP device (is a GPU visible?)");
     if (M == 0 || N == 0) return HD_OK;
     HIP_TRY(hipSetDevice(device));
@@ -2397,7 +2400,9 @@ extern "C" int hd_gemm_f32(int device, int M, int N, int K, const float* A, long
     }
     g.kslab = kslab;
     g.ws = splitting ? ws : nullptr;
-    g.colsum_ws = (splitting && colsum) ? ws + (size_t)split_k * M * N : nullptr;
+    // (one slab: the n-tile-0 workgroups' sums over k ARE the column sums - no workspace, no reduce launch; short K, i.e. the node-level
+    // dW of a small batch, where a training step is bound by the number of launches)
+    g.colsum_ws = colsum ? (splitting ? ws + (size_t)split_k * M * N : colsum) : nullptr;
     auto aligned = [](const float* p, long long ld) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && (ld & 3) == 0; };
     g.avec = aligned(A, a_kc ? a_m_stride : a_k_stride) ? 1 : 0;
     g.bvec = aligned(B, b_kc ? b_n_stride : b_k_stride) ? 1 : 0;
@@ -2551,6 +2556,19 @@ extern "C" int hd_vlb_zt(int device, int B, int ND, const float* xh, const float
     VlbZtArgs a{xh, eps, gt, zt, dzt, dgt, B, ND};
     if (dzt) hipLaunchKernelGGL((k_vlb_zt<true>), dim3(B), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((k_vlb_zt<false>), dim3(B), dim3(256), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return HD_OK;
+}
+
+// W1 [H][2H + 2], b1 [H] -> Wst [2H][H], bst [2H], wrd [2][H] (dir 0); dWst, dwrd -> dW1 (dir 1: W1 is written, b1 / bst unused)
+extern "C" int hd_edge_prep(int device, int H, int dir, float* W1, const float* b1, float* Wst, float* bst, float* wrd, void* stream) {
+    if (H < 1 || !W1 || !Wst || !wrd || (dir == 0 && (!b1 || !bst))) return fail(HD_E_INVALID, "hd_edge_prep: bad argument");
+    if (hd_device_count() <= device || device < 0) return fail(HD_E_HIP, "hd_edge_prep: no such HIP device (is a GPU visible?)");
+    HIP_TRY(hipSetDevice(device));
+    EdgePrepArgs a{W1, b1, Wst, bst, wrd, H};
+    const dim3 grid((H * (2 * H + 2) + 255) / 256);
+    if (dir == 0) hipLaunchKernelGGL((k_edge_prep<0>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((k_edge_prep<1>), grid, dim3(256), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return HD_OK;
 }

@@ -175,3 +175,25 @@ __global__ __launch_bounds__(256) void k_vlb_zt(VlbZtArgs a) {
     vlb_block_sum<1>(v, red);
     if (tid == 0) a.dgt[b] = v[0];
 }
+
+// ----------------------------------------------------------------------------- small layout kernels of the training path (launch count)
+// The first edge Linear W1 [H][2H + 2] (columns: h_row | h_col | radial | d0) as the operands the edge layer wants, in ONE launch
+// instead of torch's cat / cat / transpose: Wst [2H][H] = [W1[:, :H] ; W1[:, H:2H]], bst [2H] = [b1 | 0], wrd [2][H] = the two distance
+// columns.  DIR 1 is the way back: dW1 [H][2H + 2] from dWst [2H][H] and dwrd [2][H].
+struct EdgePrepArgs { const float* W1; const float* b1; float* Wst; float* bst; float* wrd; int H; };
+template <int DIR>
+__global__ __launch_bounds__(256) void k_edge_prep(EdgePrepArgs a) {
+    const int H = a.H, ld = 2 * H + 2;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= H * ld) return;
+    const int r = idx / ld, c = idx - r * ld;                 // element (r, c) of W1 / dW1
+    float* w1 = const_cast<float*>(a.W1);
+    if (c < 2 * H) {
+        float* st = a.Wst + ((size_t)(c < H ? r : H + r)) * H + (c < H ? c : c - H);
+        if (DIR == 0) *st = w1[idx]; else w1[idx] = *st;
+    } else {
+        float* wd = a.wrd + (size_t)(c - 2 * H) * H + r;
+        if (DIR == 0) *wd = w1[idx]; else w1[idx] = *wd;
+    }
+    if (DIR == 0 && idx < 2 * H) a.bst[idx] = idx < H ? a.b1[idx] : 0.0f;
+}

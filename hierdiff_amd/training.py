@@ -148,6 +148,8 @@ def _split_for(m_out, n_out, k):
     """Slabs of a dW = dY^T X GEMM: enough workgroups to fill the chip (the result is only 8 - 16 tiles), at least eight
     K chunks per slab, and a workspace (slabs x result) that stays a few times the operands' size."""
     tiles = ((m_out + 63) // 64) * ((n_out + 127) // 128)
+    if k < 512:
+        return 1        # a short reduction (node rows of a small batch): one launch, no split-K reduce behind it
     return int(max(2, min(64, (512 + tiles - 1) // tiles, k // 256)))
 
 
@@ -237,11 +239,15 @@ class _EdgeLayer(torch.autograd.Function):
     def forward(ctx, dyn, topo, tr, coord, h, W1, b1, zero_h, x4, x04, W2, b2, wa, ba):
         lib = _lib.load()
         H = tr.H
-        W1d = W1.detach()
+        W1d = W1.detach().contiguous()
         hd = _rows(h.detach())
-        Wst = torch.cat([W1d[:, :H], W1d[:, H:2 * H]], dim=0)                     # [2H, H]
-        AB = _linear_fwd(hd, Wst, torch.cat([b1.detach(), zero_h]))
-        wrd = W1d[:, 2 * H:2 * H + 2].t().contiguous()                             # [2, H]
+        # [W1a ; W1b] [2H, H], [b1 | 0] [2H] and the two distance columns [2, H] in one launch (hd_edge_prep)
+        Wst = torch.empty((2 * H, H), device=W1d.device, dtype=torch.float32)
+        bst = torch.empty((2 * H,), device=W1d.device, dtype=torch.float32)
+        wrd = torch.empty((2, H), device=W1d.device, dtype=torch.float32)
+        _lib.check(lib.hd_edge_prep(_dev_index(W1d.device), H, 0, W1d.data_ptr(), b1.detach().contiguous().data_ptr(), Wst.data_ptr(),
+                                    bst.data_ptr(), wrd.data_ptr(), _stream(W1d.device)), "hd_edge_prep")
+        AB = _linear_fwd(hd, Wst, bst)
         x4, x04, W2, b2, wa = (v.detach().contiguous() for v in (x4, x04, W2, b2, wa))
         ba_c = None if ba is None else ba.detach().contiguous()
         out = torch.empty((max(1, tr.M), 4 if coord else tr.H), device=AB.device, dtype=torch.float32)
@@ -332,9 +338,9 @@ class _EdgeLayer(torch.autograd.Function):
         dh = _linear_dx(gAB, Wst)
         dWst, dbst = _linear_dw(gAB, hd, True)
         dW1 = torch.empty((H, 2 * H + 2), device=dev, dtype=torch.float32)
-        dW1[:, :H].copy_(dWst[:H])
-        dW1[:, H:2 * H].copy_(dWst[H:])
-        dW1[:, 2 * H:].copy_(dwrd.t())
+        dwrd_c = dwrd.contiguous()
+        _lib.check(lib.hd_edge_prep(_dev_index(dev), H, 1, dW1.data_ptr(), None, dWst.data_ptr(), None, dwrd_c.data_ptr(), _stream(dev)),
+                   "hd_edge_prep")
         return (None, None, None, None, dh, dW1, dbst[:H], None, dx[:tr.M], dx0[:tr.M], dW2, db2, dwa, dba)
 
 

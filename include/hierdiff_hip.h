@@ -312,8 +312,8 @@ int hd_linear(int device, const float* x, int M, int K, int ldx, const float* W,
  * dW2 = G2^T P of hd_edge_layer_backward.  epi: 0 C = acc + bias; 1 C = acc + bias, C2 = SiLU(C); 2 C = (aux + acc + bias) *
  * row_mask[m] (row_mask may be NULL); 3 C = acc * SiLU'(aux).  bias [N] or NULL.  split_k > 1 (epi 0 only): K is cut into
  * slabs whose partial results go to ws ([slabs][M][N] floats, + [slabs][M] when colsum is given) and are added in slab order
- * (deterministic); colsum [M] then receives sum_k A(m,k) (the bias gradient of dW = dY^T X; A must be m-contiguous).  The
- * slab count actually used is ceil(K / (32 * ceil(K / split_k / 32))) <= split_k. */
+ * (deterministic); colsum [M] (any split_k, ABI 10: also 1 - no workspace then) receives sum_k A(m,k) (the bias gradient of
+ * dW = dY^T X; A must be m-contiguous).  The slab count actually used is ceil(K / (32 * ceil(K / split_k / 32))) <= split_k. */
 int hd_gemm_f32(int device, int M, int N, int K, const float* A, long long a_m_stride, long long a_k_stride,
                 const float* B, long long b_k_stride, long long b_n_stride, float* C, int ldc, const float* bias,
                 int epi, const float* aux, const float* row_mask, float* C2, int split_k, float* ws,
@@ -342,6 +342,11 @@ int hd_vlb_loss_backward(int device, int B, int N, int D, int int_nf, int cont_n
                          const float* gam, const float* t_int, const float* gout, float* dnet, float* dzt, float* dgam, void* stream);
 int hd_vlb_zt(int device, int B, int ND, const float* xh, const float* eps, const float* gt, float* zt, const float* dzt, float* dgt,
               void* stream);
+/* Layout of the first edge Linear for the edge layer, one launch (round 5: a training step at the reference's batch size is bound
+ * by the NUMBER of launches): W1 [H][2H + 2] (state_dict layout, columns h_row | h_col | radial | d0), b1 [H] -> Wst [2H][H] (the two
+ * node halves stacked: AB = h Wst^T + bst), bst [2H] = [b1 | 0], wrd [2][H] (hd_edge_layer_forward's wrd).  dir 1: the way back for
+ * the gradient - W1 receives dW1 assembled from Wst = dWst and wrd = dwrd (b1 / bst unused). */
+int hd_edge_prep(int device, int H, int dir, float* W1, const float* b1, float* Wst, float* bst, float* wrd, void* stream);
 /* Column sums of n <= 4 device arrays src[i] [rows][width[i]] into dst[i] [width[i]] in two launches, rows added in a fixed
  * order (32 ascending row ranges, then the ranges ascending): the reductions hd_edge_layer_backward leaves to its caller
  * (db2, d(wa), d(w_r) / d(w_d), d(ba) from the per-tile partial sums).  src / width / dst are HOST arrays of n entries;
