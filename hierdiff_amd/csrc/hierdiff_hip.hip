@@ -1941,7 +1941,7 @@ extern "C" int hd_edge_layer_backward_s(hd_handle* h, hd_topology* t, int coord,
     }
     // every output row is written by the kernels below (all tiles of the padded table exist; the CSR sums and k_edge_dx
     // cover every active node), so nothing is cleared first; escal[:, 0:4] is only defined (and only read) in coordinate layers
-    if (coord) HIP_TRY(hipMemsetAsync(bapart, 0, (size_t)tiles * sizeof(float), s));     // no attention bias in a coordinate layer
+    // (bapart of a coordinate layer - no attention bias - is zeroed by stage A itself)
     // (stage A streams the W2 image only when it has to recompute pre2)
     const float* f16scal = f16 ? pre2 + (size_t)t->n_wg * 128 * H : nullptr;     // {2^k, 2^-k, ..} of W2, left by the precision-3 forward
     if (f16) {
@@ -1951,8 +1951,8 @@ extern "C" int hd_edge_layer_backward_s(hd_handle* h, hd_topology* t, int coord,
         if (!pre2) hipLaunchKernelGGL((k_pack_w2_x6<false>), dim3((H * H / 2 + 255) / 256), dim3(256), 0, s, W2, reinterpret_cast<uint32_t*>(t->w2img), H);
         hipLaunchKernelGGL((k_pack_w2_x6<true>), dim3((H * H / 2 + 255) / 256), dim3(256), 0, s, W2, reinterpret_cast<uint32_t*>(t->w2timg), H);
     } else {
-        if (!pre2) hipLaunchKernelGGL((k_pack_w2<false>), dim3((H * H + 255) / 256), dim3(256), 0, s, W2, t->w2img, H);
-        hipLaunchKernelGGL((k_pack_w2<true>), dim3((H * H + 255) / 256), dim3(256), 0, s, W2, t->w2timg, H);
+        if (!pre2) hipLaunchKernelGGL(k_pack_w2_both, dim3((H * H + 255) / 256), dim3(256), 0, s, W2, t->w2img, t->w2timg, H);
+        else hipLaunchKernelGGL((k_pack_w2<true>), dim3((H * H + 255) / 256), dim3(256), 0, s, W2, t->w2timg, H);
     }
     EdgeBwdArgs a;
     std::memset(&a, 0, sizeof(a));

@@ -427,6 +427,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_bwd(EdgeBwdArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
             }
             const float rowdot = row_reduce(dot);                     // phi of row rho(my_slot)
+            if (lane == 0) a.bapart[tile] = 0.0f;                     // no attention bias in a coordinate layer (saves the host a fill)
             if ((n & 1) == 0) phi_s[my_rho] = rowdot;
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -694,4 +695,16 @@ __global__ void k_pack_w2(const float* W, float* img, int H) {
     const int ct = rest % NCT, cq = rest / NCT, q = cq & 3, c = cq >> 2;
     const int k = 32 * c + 16 * (lane >> 5) + 4 * q + j, col = 32 * ct + (lane & 31);
     img[idx] = TRANS ? W[(size_t)k * H + col] : W[(size_t)col * H + k];
+}
+// both images of one W in one launch (the recomputing backward needs W2 for stage A and W2^T for stage B)
+__global__ void k_pack_w2_both(const float* W, float* img, float* timg, int H) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= H * H) return;
+    const int NCT = H / 32;
+    const int j = idx & 3, lane = (idx >> 2) & 63;
+    const int rest = idx >> 8;
+    const int ct = rest % NCT, cq = rest / NCT, q = cq & 3, c = cq >> 2;
+    const int k = 32 * c + 16 * (lane >> 5) + 4 * q + j, col = 32 * ct + (lane & 31);
+    img[idx] = W[(size_t)col * H + k];
+    timg[idx] = W[(size_t)k * H + col];
 }

@@ -395,7 +395,10 @@ def dynamics_forward_train(dyn: EGNN_dynamics_QM9, t, xh, node_mask, edge_mask, 
         e = blk.gcl_equiv
         xagg = edge_layer(True, e.coord_mlp[0], e.coord_mlp[2], e.coord_mlp[4].weight.reshape(-1), None, xb)
         x4 = (xb + xagg) * nm
-        h = h * nm
+        # (the reference's `h = h * node_mask` at the end of a block, egnn_new.py:143: h leaves _NodeMLP already multiplied by the
+        # 0 / 1 mask in the GEMM epilogue, so the product is the identity bit for bit - skipped with its backward, 12 launches a step)
+        if S == 0:
+            h = h * nm
     hout = _Linear.apply(h, egnn.embedding_out.weight, egnn.embedding_out.bias) * nm
     x_final = x4[:, :3]
     if mol_shape is not None:
