@@ -443,3 +443,32 @@ def test_sample_broadcasts_context_like_the_reference():
     assert torch.equal(seen["ctx"], torch.full((4, max(sizes), 1), 2.0))
     with pytest.raises((ValueError, RuntimeError)):
         m.sample(4, "cpu", context=torch.zeros(3, 1, 1))
+
+
+def test_optimizer_generation_counts_steps_of_any_optimizer():
+    """Round 5: torch's fused optimizers change parameters without bumping their `_version`, which the packed-weight / schedule caches
+    of the package were keyed by; the keys now also carry `_lib.optimizer_generation()`, a process-wide count of optimizer steps from
+    a global post-step hook.  The count must move with every step of every optimizer (an over-approximation costs a re-pack, a
+    missed step would leave an evaluation on stale weights)."""
+    import torch
+    from hierdiff_amd import _lib
+    g0 = _lib.optimizer_generation()
+    p, q = torch.nn.Parameter(torch.ones(3)), torch.nn.Parameter(torch.ones(2))
+    o1, o2 = torch.optim.SGD([p], lr=0.1), torch.optim.AdamW([q], lr=0.1)
+    p.grad, q.grad = torch.ones(3), torch.ones(2)
+    o1.step()
+    assert _lib.optimizer_generation() == g0 + 1
+    o2.step(); o1.step()
+    assert _lib.optimizer_generation() == g0 + 3
+    # and the schedule twin of the noise model is rebuilt on it even when no version moved
+    from hierdiff_amd.noise_model import GammaNetwork, _fp64_twin
+    net = GammaNetwork()
+    t1 = _fp64_twin(net)
+    assert _fp64_twin(net) is t1
+    v0 = net.gamma_0._version
+    net.gamma_0.data.add_(1.0)          # an in-place write that bumps no version counter of the parameter (what a fused optimizer does)
+    assert net.gamma_0._version == v0
+    assert _fp64_twin(net) is t1, "without an optimizer step or a version bump the cache is expected to hold (documented limit)"
+    o1.step()
+    t2 = _fp64_twin(net)
+    assert t2 is not t1 and float(t2.gamma_0) == float(net.gamma_0)
