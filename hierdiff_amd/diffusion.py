@@ -165,8 +165,6 @@ class DiffusionQM9(_Base):
         #: training-mode loss around the network call as two fused launches per direction (csrc/k_loss.hpp) instead of ~350 torch
         #: launches; False = the torch-op path (same arithmetic; what evaluation, pocket models and the CPU run)
         self.fused_loss = True
-        self._fused_log_nv0 = 0.0
-        self._fused_took = False
         self.schedule_gammas = None     # optional [T+1] gamma grid overriding the network (replay a run)
         # "fp64" (default): the schedule network is evaluated once in float64 on the host and rounded - the same table on
         # every machine.  "fp32": evaluated like the reference (float32, a [B,1] column per grid value, CPU BLAS): agrees
@@ -345,10 +343,8 @@ class DiffusionQM9(_Base):
             net_out = self.phi(z_t, t, node_mask_all, edge_mask, context, mol_shape=mol)
             int_nf, cont_nf = (5, 3) if self.node_coarse_type == 'prop' else (3, 0)
             l2_train = self.loss_type == 'l2'
-            consts = (int_nf, cont_nf, l2_train, float(self.T), float(self.norm_values[2]), float(self.norm_biases[2]),
-                      float(self._fused_log_nv0))
+            consts = (int_nf, cont_nf, l2_train, float(self.T), float(self.norm_values[2]), float(self.norm_biases[2]), 0.0)
             loss, error = vlb_loss(net_out, z_t, gam, xh, eps, nm.reshape(B, mol).contiguous(), t_int.reshape(B).contiguous(), consts)
-            self._fused_took = True
             return loss, {'t': t_int.squeeze(), 'loss_t': loss.squeeze(), 'error': error.squeeze()}
         xh_fix = torch.cat([x_fix, h_fix], dim=2).to(torch.float32)
         self._check_mean_zero(x, node_mask)
@@ -384,14 +380,8 @@ class DiffusionQM9(_Base):
         x, h, delta_log_px = self.normalize(x, h, node_mask.to(torch.float32))
         if self.training and self.loss_type == 'l2':
             delta_log_px = torch.zeros_like(delta_log_px)
-        # (the fused training loss returns loss - delta_log_px itself: log(norm_values[0]) travels in; 0 keeps compute_loss's own value)
-        self._fused_log_nv0 = math.log(self.norm_values[0])
-        self._fused_took = False
         loss, _ = self.compute_loss(x, h, node_mask, edge_mask, context, t0_always=not self.training,
                                     mol_shape=mol_shape, **replay)
-        self._fused_log_nv0 = 0.0
-        if self._fused_took:
-            return loss
         return loss - delta_log_px
 
     def forward(self, batch, **replay):
