@@ -33,6 +33,7 @@ RULES = [
     (r"r05_ab_rebuild_p\.log", "same-box A/B of the fp16x3 training step: P materialised vs rebuilt inside the dW2 kernel (null)", "EXPERIMENTS L"),
     (r"r05_train_b16_kstats_after\.log", "kernel launch counts of the B = 16 training step with the fused loss, fused AdamW and single-slab node dW", "DESIGN 10 round 5, third part"),
     (r"r05_train_b16_after_prep\.log", "B = 16 / 256 training step after hd_edge_prep (733 launches per step at B = 16)", "DESIGN 10 round 5, third part"),
+    (r"r05_train_launch_census_b16\.log", "the 701 device launches of one B = 16 training step by kernel and by issuing op, after the round's cuts", "DESIGN 10 round 5, third part; 12"),
     (r"r05_train_host_time_before\.log", "host enqueue time by section and launch count of a B = 16 training step before the fused loss / fused AdamW (12.07 ms, 1,122 launches)", "DESIGN 10 round 5, third part"),
     (r"r05_train_b16_kstats_before\.log", "kernel launch counts of the B = 16 training step before the fused loss", "DESIGN 10 round 5, third part"),
     (r"r05_train_fused_loss_times\.log", "training step by batch size with the fused loss and fused AdamW (B = 16: 8.3-9.7 ms, 867 launches)", "DESIGN 10 round 5, third part"),
