@@ -252,6 +252,8 @@ class _EdgeLayer(torch.autograd.Function):
         ba_c = None if ba is None else ba.detach().contiguous()
         out = torch.empty((max(1, tr.M), 4 if coord else tr.H), device=AB.device, dtype=torch.float32)
         prec = _PREC_CODE[getattr(dyn, "training_precision", "fp32")]
+        if tr.H < 128:
+            prec = 0        # the split arithmetics exist from width 128 up: narrower layers run the exact-fp32 kernels, as in sampling
         # keep W2 P + b2 of every edge row for the backward pass where the library says it pays (large batches) and a gradient
         # will be asked for: [rows, H] fp32 per edge layer, 4.1 GB for the 18 layers of the headline shape at B = 256
         pre2 = None

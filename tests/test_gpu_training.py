@@ -681,6 +681,29 @@ def test_training_precision_fp16x3_gradients(H, monkeypatch):
         assert between < (1e-5 if expect == 3 else 5e-5)
 
 
+@pytest.mark.parametrize("mode", ["bf16x6", "fp16x3"])
+def test_training_precision_below_width_128_is_the_fp32_step(mode):
+    """The split arithmetics exist from width 128 up; a narrower model asked for `training_precision = "bf16x6"` / "fp16x3" runs the
+    exact-fp32 kernels (as `precision` does in sampling): same output and gradient bits as the fp32 step."""
+    from hierdiff_amd.weights import synthetic_state_dict
+    H, L = 64, 2
+    sd_np = synthetic_state_dict(9, 0, H, L, 2, True, 80, 0.5)
+    xh, nm, em = orc.random_inputs([9, 4, 12, 7], 8, 75)
+    B = xh.shape[0]
+    t = torch.linspace(0.1, 0.9, B).view(B, 1)
+    res = {}
+    for m_ in ("fp32", mode):
+        dyn = build_dynamics(sd_np, H, L)
+        dyn.precision = "fp32"
+        dyn.training_precision = m_
+        xg = xh.to(DEV).requires_grad_(True)
+        out = dyn._forward(t.to(DEV), xg, nm.to(DEV), em.to(DEV), None, None)
+        out.square().sum().backward()
+        res[m_] = (out.detach().clone(), xg.grad.clone(), [p.grad.clone() for p in dyn.egnn.parameters()])
+    assert torch.equal(res["fp32"][0], res[mode][0]) and torch.equal(res["fp32"][1], res[mode][1])
+    assert all(torch.equal(a, b) for a, b in zip(res["fp32"][2], res[mode][2]))
+
+
 @pytest.mark.parametrize("H,B,mode", [(32, 5, "fp32"), (64, 7, "fp32"), (128, 32, "fp32"), (128, 32, "bf16x6"), (256, 32, "fp32"),
                                       (256, 32, "bf16x6"), (256, 6, "fp32")])
 def test_kept_edge_activations_equal_the_recomputing_backward(H, B, mode, monkeypatch):
