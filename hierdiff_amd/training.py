@@ -217,9 +217,10 @@ _F16WS = {}
 
 
 def _f16_workspace(dev: torch.device, n: int) -> torch.Tensor:
-    """Workspace of the fp16x3 backward (image scalars, maxima): one grow-only buffer per device, reused by every edge layer - the
-    backward calls of a step are stream-ordered and each reads only what its own stages wrote."""
-    key = (dev.type, dev.index)
+    """Workspace of the fp16x3 backward (image scalars, maxima): one grow-only buffer per device AND stream, reused by every edge
+    layer - the backward calls of a step are stream-ordered and each reads only what its own stages wrote (two models training on two
+    streams of one device get two buffers)."""
+    key = (dev.type, dev.index, int(_stream(dev) or 0))
     buf = _F16WS.get(key)
     if buf is None or buf.numel() < n:
         buf = torch.empty(max(n, 1024), device=dev, dtype=torch.float32)
