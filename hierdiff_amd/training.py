@@ -233,7 +233,7 @@ class _EdgeLayer(torch.autograd.Function):
     the factorised first edge Linear [A | B] = h [W1a ; W1b]^T + [b1 | 0] (one GEMM over the stacked halves of `W1`
     [H, 2H + 2]; its last two columns are the distance weights w_r, w_d) and the edge kernels of include/hierdiff_hip.h
     `hd_edge_layer_forward` / `hd_edge_layer_backward`.  One Function for both, so that the gradient of `W1` is assembled once
-    (three strided copies) instead of through autograd's slice / cat / transpose nodes (a zero-filled [H, 2H + 2] tensor, a copy
+    (one launch, hd_edge_prep; round 5 - three strided copies before) instead of through autograd's slice / cat / transpose nodes (a zero-filled [H, 2H + 2] tensor, a copy
     and an accumulation per slice: ~10 small launches per edge layer)."""
 
     @staticmethod
