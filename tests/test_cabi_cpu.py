@@ -472,3 +472,19 @@ def test_optimizer_generation_counts_steps_of_any_optimizer():
     o1.step()
     t2 = _fp64_twin(net)
     assert t2 is not t1 and float(t2.gamma_0) == float(net.gamma_0)
+
+
+def test_configure_optimizers_picks_the_fused_form_only_on_the_gpu():
+    """trainer.configure_optimizers: the reference's AdamW / StepLR values (conf/optim/adamw.yaml, conf/scheduler/step.yaml); torch's fused
+    multi-tensor update only when every parameter lives on the GPU (a CPU model gets the default form), and on request."""
+    import torch
+    from hierdiff_amd.trainer import configure_optimizers
+    m = torch.nn.Linear(4, 3)
+    opt, sched = configure_optimizers(m)
+    assert isinstance(opt, torch.optim.AdamW) and not opt.defaults.get("fused")
+    assert opt.defaults["lr"] == 4.0e-4 and opt.defaults["weight_decay"] == 4.0e-8
+    assert isinstance(sched, torch.optim.lr_scheduler.StepLR) and sched.step_size == 15 and sched.gamma == 0.1
+    opt2, _ = configure_optimizers(m, fused=False)
+    assert not opt2.defaults.get("fused")
+    m(torch.ones(2, 4)).sum().backward()
+    opt.step()          # the CPU form runs
