@@ -486,5 +486,6 @@ def test_configure_optimizers_picks_the_fused_form_only_on_the_gpu():
     assert isinstance(sched, torch.optim.lr_scheduler.StepLR) and sched.step_size == 15 and sched.gamma == 0.1
     opt2, _ = configure_optimizers(m, fused=False)
     assert not opt2.defaults.get("fused")
-    m(torch.ones(2, 4)).sum().backward()
+    with torch.enable_grad():
+        m(torch.ones(2, 4)).sum().backward()
     opt.step()          # the CPU form runs
