@@ -2408,6 +2408,17 @@ extern "C" int hd_gemm_f32(int device, int M, int N, int K, const float* A, long
     g.bvec = aligned(B, b_kc ? b_n_stride : b_k_stride) ? 1 : 0;
     dim3 grid((M + TG_BM - 1) / TG_BM, (N + TG_BN - 1) / TG_BN, split_k);
     const dim3 block(256);
+    // a result of fewer than 128 tiles (a small training batch) as 32 x 32 tiles with the K quarters on the four wavefronts
+    if (!splitting && (long long)grid.x * grid.y < 128 && K >= 32) {
+        g.colsum = colsum;
+        const dim3 sg((M + 31) / 32, (N + 31) / 32);
+        if (a_kc && b_kc) hipLaunchKernelGGL((k_tgemm_small<true, true>), sg, block, 0, s, g);
+        else if (a_kc) hipLaunchKernelGGL((k_tgemm_small<true, false>), sg, block, 0, s, g);
+        else if (b_kc) hipLaunchKernelGGL((k_tgemm_small<false, true>), sg, block, 0, s, g);
+        else hipLaunchKernelGGL((k_tgemm_small<false, false>), sg, block, 0, s, g);
+        HIP_TRY(hipGetLastError());
+        return HD_OK;
+    }
     if (splitting) {                                   // 1-D, XCD-aware: the tiles of a slab share an XCD's L2 (k_tgemm.hpp)
         g.nx = grid.x; g.ny = grid.y; g.nz = split_k;
         grid = dim3(g.nx * g.ny * 8 * ((split_k + 7) / 8));

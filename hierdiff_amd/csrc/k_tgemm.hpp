@@ -33,6 +33,7 @@ struct TGemmArgs {
     const float* rmask;     // RESID_MASK: [M] row mask or null
     float* ws;              // split-K: [z][M][N] partial results (null: one slab, epilogue applied here)
     float* colsum_ws;       // non-null: [z][M] partial sums over k of A(m, k) (written by the n-tile-0 workgroups)
+    float* colsum;          // k_tgemm_small: [M] the column sums themselves
     long long sam, sak, sbk, sbn;
     int M, N, K, ldc, kslab, epi, avec, bvec;
     int nx, ny, nz;         // nz > 0: 1-D XCD-aware launch of nx x ny tiles x nz slabs (split-K)
@@ -243,6 +244,82 @@ __global__ __launch_bounds__(256, 2) void k_tgemm(TGemmArgs g) {
             else if (g.epi == TG_EPI_MUL_DSILU) g.C[o] = v * dsilu_f(g.aux[o]);
             else g.C[o] = v;
         }
+    }
+}
+
+// Small results (round 5): when the 64 x 128 tiling gives the chip fewer than ~128 workgroups - the node-level Linears of a small
+// training batch: 480 rows at the reference's batch size of 16 are 16-32 workgroups, ~25 us per GEMM whatever its size - the same
+// product runs as 32 x 32 output tiles, one workgroup each, the four wavefronts taking the four QUARTERS OF K: operands straight from
+// global memory / L2 into the MFMA operand registers (a wave's share is 32 rows x K/4: no LDS staging, next step's loads in flight under
+// the current step's four MFMAs), the four partial tiles added through LDS in wave order (deterministic), every epilogue of k_tgemm,
+// and the bias gradient (column sums of an m-contiguous A) on the way.  Lane (n, hh) of a step of eight k values holds k0 + 4 hh + j
+// for MFMA j of both operands - a float4 along a k-contiguous source, four coalesced loads along an m- / n-contiguous one.
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void k_tgemm_small(TGemmArgs g) {
+    __shared__ float red[4][16 * 64];
+    __shared__ float cred[4][32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, n = lane & 31;
+    const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    const int row = m0 + n, col = n0 + n;
+    const int kq = ((g.K + 3) / 4 + 7) / 8 * 8;                 // K quarter, whole steps of eight
+    const int kbeg = wave * kq, kend = min(g.K, kbeg + kq);
+    const bool rok = row < g.M, cok = col < g.N;
+    const float* Ap = A_KC ? g.A + (long long)row * g.sam : g.A + row;
+    const float* Bp = B_KC ? g.B + (long long)col * g.sbn : g.B + col;
+    auto load = [&](int k0, f32x4& a, f32x4& b) {
+        const int k = k0 + 4 * hh;
+        a = f32x4{0.f, 0.f, 0.f, 0.f}; b = a;
+        if (rok) {
+            if (A_KC) {
+                if (g.avec && k + 3 < kend) a = *reinterpret_cast<const f32x4*>(Ap + k);
+                else { for (int j = 0; j < 4; ++j) if (k + j < kend) a[j] = Ap[k + j]; }
+            } else { for (int j = 0; j < 4; ++j) if (k + j < kend) a[j] = Ap[(long long)(k + j) * g.sak]; }
+        }
+        if (cok) {
+            if (B_KC) {
+                if (g.bvec && k + 3 < kend) b = *reinterpret_cast<const f32x4*>(Bp + k);
+                else { for (int j = 0; j < 4; ++j) if (k + j < kend) b[j] = Bp[k + j]; }
+            } else { for (int j = 0; j < 4; ++j) if (k + j < kend) b[j] = Bp[(long long)(k + j) * g.sbk]; }
+        }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float csum = 0.f;
+    f32x4 a0, b0, a1, b1;
+    if (kbeg < kend) load(kbeg, a0, b0);
+    for (int k0 = kbeg; k0 < kend; k0 += 8) {
+        if (k0 + 8 < kend) load(k0 + 8, a1, b1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[j], acc, 0, 0, 0);
+        csum += (a0[0] + a0[1]) + (a0[2] + a0[3]);
+        a0 = a1; b0 = b1;
+    }
+    // partial tiles -> LDS [wave][r][lane]; acc[r]: row m0 + rho(r) (+ 4 hh), column n0 + n
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][r * 64 + lane] = acc[r];
+    const bool do_colsum = !A_KC && g.colsum != nullptr && blockIdx.y == 0;
+    if (do_colsum) {
+        csum += __shfl_xor(csum, 32);
+        if (hh == 0) cred[wave][n] = csum;
+    }
+    __syncthreads();
+    if (do_colsum && tid < 32 && m0 + tid < g.M) g.colsum[m0 + tid] = (cred[0][tid] + cred[1][tid]) + (cred[2][tid] + cred[3][tid]);
+    const int l2 = tid & 63, h2 = l2 >> 5, n2 = l2 & 31, c2 = n0 + n2;
+    if (c2 >= g.N) return;
+    const float bias = g.bias ? g.bias[c2] : 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = (tid >> 6) * 4 + q;
+        const int rw = m0 + (r & 3) + 8 * (r >> 2) + 4 * h2;
+        if (rw >= g.M) continue;
+        float v = ((red[0][r * 64 + l2] + red[1][r * 64 + l2]) + red[2][r * 64 + l2]) + red[3][r * 64 + l2];
+        v += bias;
+        const size_t o = (size_t)rw * g.ldc + c2;
+        if (g.epi == TG_EPI_BIAS_SILU2) { g.C[o] = v; g.C2[o] = silu_f(v); }
+        else if (g.epi == TG_EPI_RESID_MASK) { v += g.aux[o]; if (g.rmask) v *= g.rmask[rw]; g.C[o] = v; }
+        else if (g.epi == TG_EPI_MUL_DSILU) g.C[o] = v * dsilu_f(g.aux[o]);
+        else g.C[o] = v;
     }
 }
 

@@ -32,6 +32,8 @@ RULES = [
     (r"r05_train_xcd_placement\.log", "training step + kernel tables after the XCD-aware placement of the backward stages (fp32 26.5 ms, fp16x3 19.5 ms)", "DESIGN 10 round 5, second half"),
     (r"r05_ab_fused_gamma\.log", "same-box A/B of the B = 16 / 256 training step: schedule network fused vs torch ops (null), loss fused vs torch ops (-1.9 ms at B = 16)", "EXPERIMENTS N"),
     (r"r05_splitk_last_workgroup\.log", "training step with split-K finished by the last workgroup of a tile instead of a reduce launch (2x slower; removed)", "EXPERIMENTS O"),
+    (r"r05_ab_small_gemm\.log", "same-box A/B of the training step by batch size: library before / after k_tgemm_small (B = 64: -3 %, B = 128: -3.5 %, B <= 32 host-bound)", "DESIGN 10 round 5, third part"),
+    (r"r05_small_gemm_first_run\.log", "training steps B = 16..128 and the host / device split of a B = 16 step with k_tgemm_small (device time 8.76 -> 6.82 ms)", "DESIGN 10 round 5, third part"),
     (r"r05_ab_rebuild_p\.log", "same-box A/B of the fp16x3 training step: P materialised vs rebuilt inside the dW2 kernel (null)", "EXPERIMENTS L"),
     (r"r05_train_b16_kstats_after\.log", "kernel launch counts of the B = 16 training step with the fused loss, fused AdamW and single-slab node dW", "DESIGN 10 round 5, third part"),
     (r"r05_train_b16_after_prep\.log", "B = 16 / 256 training step after hd_edge_prep (733 launches per step at B = 16)", "DESIGN 10 round 5, third part"),
