@@ -6,6 +6,7 @@ import os, re, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RULES = [
     (r"edge_kernel_traffic\.json", "HBM bytes of the edge kernel by counter, round 1", "DESIGN 4 (roofline table, traffic column)"),
+    (r"r05_bench_default_slow_box2\.json", "default bench line of the FINAL library on a box with a slow host and a 16-bit MFMA clock ~10 % down (fp32 47.06, fp16x3 101.7, bf16x3 109.3; training B = 64 rows all ~9.7 ms = that host's enqueue floor); same run as r05_counters.json", "DESIGN 6 (box-to-box spread)"),
     (r"r05_bench_default_slow_box\.json", "default bench line mid-round on a box whose 16-bit MFMA clock was ~6 % lower (fp16 22.2 ns per MFMA)", "DESIGN 6 (box-to-box spread)"),
     (r"r\d+_bench_default.*\.json|r\d+_bench_\d+steps.*\.json|r\d+_bench_(fp32|bf16x3|first_path)\.json|r\d+_bench_3steps\.json",
      "complete JSON line of a `python bench.py` run on a gpurun box", "DESIGN 6 (bench numbers of that round); the `configs` / `next_rows` blocks the driver's tail truncates"),
