@@ -43,6 +43,7 @@ RULES = [
     (r"r05_train_b16_kstats_before\.log", "kernel launch counts of the B = 16 training step before the fused loss", "DESIGN 10 round 5, third part"),
     (r"r05_train_fused_loss_times\.log", "training step by batch size with the fused loss and fused AdamW (B = 16: 8.3-9.7 ms, 867 launches)", "DESIGN 10 round 5, third part"),
     (r"r05_train_keep_ab\.log", "same-box A/B by batch size and arithmetic: pre-activations kept vs recomputed", "DESIGN 10 round 5, second half"),
+    (r"r05_train_kstats_final\.log", "kernel tables of the training step on the FINAL library: B = 256 fp16x3, B = 256 fp32, B = 16 fp32 (k_tgemm_small 9-14 us)", "DESIGN 10 round 5"),
     (r"r05_train_kept_pre2\.log", "training step + kernel tables with the kept second-layer pre-activations (fp32 27.0 ms, bf16x6 21.9 ms)", "DESIGN 10 round 5, second half"),
     (r"r05_train_fp16x3\.log", "training step + kernel table with training_precision = fp16x3 (20.4 ms)", "DESIGN 10 round 5, second half"),
     (r"r05_train_kstats\.log", "kernel tables of the training step in both arithmetics after the k_edge_dx rewrite", "DESIGN 10 round 5"),
