@@ -40,6 +40,11 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
+# dmabuf IPC (RCCL between the per-GPU ranks fails with `hipIpcGetMemHandle: invalid argument` without it on this driver): set
+# in-process before torch / HIP load, so that a rank started by the driver's own launcher line - not only by self_launch() below -
+# has it.  hierdiff_amd/__init__.py does the same for every other entry point.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 

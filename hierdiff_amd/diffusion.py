@@ -1,4 +1,4 @@
-"""Sampling half of the reference's `DiffusionQM9` (endiffusion/train_module/diffusion_qm9.py) on MI355X.
+"""The reference's `DiffusionQM9` (endiffusion/train_module/diffusion_qm9.py) on MI355X: sampling, loss / NLL, training hooks.
 
 Same entry points and result format as the reference:
   DiffusionQM9.sample(num_samples, device, context=None, pocket_cond=None)        :347-395
@@ -453,6 +453,99 @@ class DiffusionQM9(_Base):
         return self.forward(batch)
 
     test_step = validation_step
+
+    # ------------------------------------------------------------------ epoch-end hooks and optimiser (Lightning side of the module)
+    # diffusion_qm9.py:753-801, 871-879.  With pytorch_lightning installed the base class provides `log`, `all_gather`,
+    # `global_rank`; without it (this image) the same hooks work over torch.distributed, or on one process.
+    def _rank(self) -> int:
+        if _Base is not nn.Module:
+            return int(self.global_rank)
+        import torch.distributed as dist
+        return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+    def _gather_ranks(self, value: torch.Tensor) -> torch.Tensor:
+        """[world, ...] stack of `value` from every rank (LightningModule.all_gather's shape; [1, ...] on one process).  Every
+        rank must hold the same shape, as under Lightning."""
+        if _Base is not nn.Module:
+            out = self.all_gather(value)
+            return out if out.dim() > value.dim() else out.unsqueeze(0)
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return value.unsqueeze(0)
+        parts = [torch.empty_like(value) for _ in range(dist.get_world_size())]
+        dist.all_gather(parts, value.contiguous())
+        return torch.stack(parts)
+
+    def _gather_result(self, result):
+        """List of per-step dicts -> one dict of tensors: first the steps are joined (tensors concatenated, scalars stacked into
+        a vector), then the ranks (diffusion_qm9.py:753-766)."""
+        keys = list(result[0].keys())
+        steps = {}
+        for key in keys:
+            first = result[0][key]
+            if first.dim() > 0:
+                steps[key] = torch.cat([r[key] for r in result])
+            else:
+                steps[key] = torch.stack([r[key].detach() for r in result]).to(first)
+        return {key: torch.cat(list(self._gather_ranks(steps[key]))) for key in keys}
+
+    def _compute_metrics(self, result):
+        """diffusion_qm9.py:768-772: the epoch metric is the mean of the gathered per-step losses."""
+        return {'loss': result['loss'].mean()}
+
+    def _log(self, name, value, **kw):
+        if _Base is not nn.Module:
+            self.log(name, value, **kw)
+        else:                                   # no Lightning: the last logged values stay readable on the module
+            self.logged = getattr(self, "logged", {})
+            self.logged[name] = value
+
+    def validation_epoch_end(self, result):
+        """diffusion_qm9.py:787-795."""
+        metrics = self._compute_metrics(self._gather_result(result))
+        self._log("val_loss", metrics["loss"], on_epoch=True, prog_bar=True)
+
+    def test_epoch_end(self, result):
+        """diffusion_qm9.py:797-800 (logged by rank 0 only)."""
+        metrics = self._compute_metrics(self._gather_result(result))
+        if self._rank() == 0:
+            self._log("test/ppl", metrics["loss"], on_epoch=True)
+
+    def configure_optimizers(self):
+        """diffusion_qm9.py:871-879: `[optimizer], [scheduler]` from `cfg.optim` / `cfg.scheduler` (hydra nodes with a `_target_`,
+        conf/optim/adamw.yaml, conf/scheduler/step.yaml).  hydra's `instantiate` is used when the package exists; otherwise the
+        `_target_` is resolved here - only names under `torch.optim` are accepted - and a cfg without these nodes gets the
+        reference's shipped values (AdamW 4e-4 / 4e-8, StepLR 15 / 0.1: hierdiff_amd.trainer.configure_optimizers, fused update
+        on the GPU).  A scheduler node that asks for `num_training_steps` needs the Lightning trainer and is not supported
+        without it."""
+        from .trainer import configure_optimizers as _defaults
+        optim_cfg, sched_cfg = _get(self.cfg, "optim", None), _get(self.cfg, "scheduler", None)
+        if optim_cfg is None:
+            opt, sched = _defaults(self)
+            if sched_cfg is not None:
+                sched = self._instantiate(sched_cfg, opt)
+            return [opt], [sched]
+        opt = self._instantiate(optim_cfg, self.parameters())
+        sched = self._instantiate(sched_cfg, opt) if sched_cfg is not None else torch.optim.lr_scheduler.StepLR(opt, step_size=15, gamma=0.1)
+        return [opt], [sched]
+
+    @staticmethod
+    def _instantiate(node, *args):
+        node = dict(node)
+        if "num_training_steps" in node:
+            raise NotImplementedError("schedulers keyed on num_training_steps need the Lightning trainer (diffusion_qm9.py:804-869)")
+        try:
+            from hydra.utils import instantiate  # type: ignore
+            return instantiate(node, *args)
+        except ImportError:
+            pass
+        target = str(node.pop("_target_"))
+        if not target.startswith("torch.optim."):
+            raise ValueError(f"_target_ {target!r}: only torch.optim.* optimisers / lr_schedulers are resolved without hydra")
+        obj = torch.optim
+        for part in target.split(".")[2:]:
+            obj = getattr(obj, part)
+        return obj(*args, **node)
 
     # ------------------------------------------------------------------ HIP plumbing
     def _lib_handle(self):

@@ -6,7 +6,8 @@ gradient_clip_algorithm norm, accumulate_grad_batches 1; `conf/optim/adamw.yaml`
 
     loss = model.training_step(batch)      # forward + loss on this rank's shard of the batch
     loss.backward()
-    <DDP: gradients averaged over ranks>   # here: ONE flat all-reduce (hierdiff_amd.sharding.allreduce_gradients, RCCL over xGMI)
+    <DDP: gradients averaged over ranks>   # here: one all-reduce per EGNN block, launched from backward hooks as the block's
+                                           # gradients land (hierdiff_amd.sharding.GradientBuckets, RCCL over xGMI)
     clip_grad_norm_(parameters, 2.0)
     optimizer.step()
 
@@ -20,7 +21,7 @@ from typing import Dict, Iterable, Optional
 
 import torch
 
-from .sharding import allreduce_gradients
+from .sharding import GradientBuckets, allreduce_gradients
 
 
 def configure_optimizers(model: torch.nn.Module, lr: float = 4.0e-4, weight_decay: float = 4.0e-8, step_size: int = 15,
@@ -41,13 +42,22 @@ def _world() -> int:
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
-def _launch_step(model, batch: Dict[str, torch.Tensor], optimizer: torch.optim.Optimizer, clip_val: Optional[float]):
+def _launch_step(model, batch: Dict[str, torch.Tensor], optimizer: torch.optim.Optimizer, clip_val: Optional[float],
+                 overlap: bool = True):
     """Everything of one optimisation step that is queued on the GPU; returns the (loss, grad norm) device scalars."""
     model.train()
     optimizer.zero_grad(set_to_none=True)
+    buckets = None
+    if _world() > 1 and overlap:
+        buckets = getattr(model, "_grad_buckets", None)
+        if buckets is None:                      # hooks registered once per model; they stay silent at world size 1
+            buckets = GradientBuckets(model, average=True)
+            model._grad_buckets = buckets
     loss = model.training_step(batch, 0)
     loss.backward()
-    if _world() > 1:
+    if buckets is not None:
+        buckets.finish()
+    elif _world() > 1:
         allreduce_gradients(model, average=True)
     params = [p for p in model.parameters() if p.grad is not None]
     if clip_val is not None:
@@ -58,10 +68,12 @@ def _launch_step(model, batch: Dict[str, torch.Tensor], optimizer: torch.optim.O
     return loss.detach(), norm
 
 
-def ddp_step(model, batch: Dict[str, torch.Tensor], optimizer: torch.optim.Optimizer, clip_val: Optional[float] = 2.0) -> Dict[str, float]:
+def ddp_step(model, batch: Dict[str, torch.Tensor], optimizer: torch.optim.Optimizer, clip_val: Optional[float] = 2.0,
+             overlap: bool = True) -> Dict[str, float]:
     """One optimisation step on this rank's batch; returns {"loss", "grad_norm"} (the norm BEFORE clipping, like Lightning's
-    track_grad_norm: 2).  Every rank must call it the same number of times (the all-reduce is collective)."""
-    loss, norm = _launch_step(model, batch, optimizer, clip_val)
+    track_grad_norm: 2).  Every rank must call it the same number of times (the all-reduce is collective).  `overlap=False`
+    averages with one flat all-reduce after backward instead of the per-block buckets (same bits)."""
+    loss, norm = _launch_step(model, batch, optimizer, clip_val, overlap)
     return {"loss": float(loss), "grad_norm": float(norm)}
 
 

@@ -243,3 +243,157 @@ def test_bench_line_keeps_the_creditable_blocks_in_the_drivers_tail():
     assert i_f32 >= 0, "the fp32 configs block fell out of the tail"
     assert '"fp16x3": {"value"' in tail and '"metric"' in tail and '"cpu_baseline"' in tail and '"roofline"' in tail
     assert '"next_rows"' not in tail                      # the rows outside the hot path go first
+
+
+# ----------------------------------------------------------------------------- round 6: environment, overlapped buckets, epoch-end hooks
+
+@pytest.mark.parametrize("entry", ["import hierdiff_amd", "import bench", "import hierdiff_amd.sharding"])
+def test_every_entry_point_sets_dmabuf_ipc_before_hip_loads(entry):
+    """RCCL between the per-GPU ranks needs HSA_ENABLE_IPC_MODE_LEGACY=0 on the MI355X boxes' driver.  A rank started by ANY launcher
+    (not only bench.py's own) must have it: importing the package or bench.py sets it in-process; a caller's own value is kept."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import os; assert 'HSA_ENABLE_IPC_MODE_LEGACY' not in os.environ; " + entry +
+            "; print('IPC=' + os.environ['HSA_ENABLE_IPC_MODE_LEGACY'])")
+    env = {k: v for k, v in os.environ.items() if k != "HSA_ENABLE_IPC_MODE_LEGACY"}
+    out = subprocess.run([sys.executable, "-c", code], cwd=repo, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "IPC=0" in out.stdout
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "1"
+    code = entry + "; import os; print('IPC=' + os.environ['HSA_ENABLE_IPC_MODE_LEGACY'])"
+    out = subprocess.run([sys.executable, "-c", code], cwd=repo, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "IPC=1" in out.stdout
+
+
+class _Block(torch.nn.Module):
+    def __init__(self, w):
+        super().__init__()
+        self.a = torch.nn.Linear(w, w)
+        self.b = torch.nn.Linear(w, w)
+
+    def forward(self, h):
+        return h + self.b(torch.tanh(self.a(h)))
+
+
+class _BlockedToy(torch.nn.Module):
+    """Parameter names shaped like the product's (`egnn.e_block_<i>.*` + embedding / output layer / an unused parameter), differentiated
+    on the CPU: blocks finish back to front in backward, as the EGNN's do."""
+
+    def __init__(self, w=5, blocks=3):
+        super().__init__()
+        self.egnn = torch.nn.Module()
+        self.egnn.embedding = torch.nn.Linear(4, w)
+        for i in range(blocks):
+            self.egnn.add_module(f"e_block_{i}", _Block(w))
+        self.egnn.embedding_out = torch.nn.Linear(w, 2)
+        self.unused = torch.nn.Parameter(torch.ones(3))
+        self.blocks = blocks
+
+    def training_step(self, batch, batch_idx=0):
+        h = self.egnn.embedding(batch["x"])
+        for i in range(self.blocks):
+            h = getattr(self.egnn, f"e_block_{i}")(h)
+        return ((self.egnn.embedding_out(h) - batch["y"]) ** 2).mean()
+
+
+def _bucket_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    assert os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") == "0"        # set by importing the package inside this rank
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hierdiff_amd.sharding import GradientBuckets, allreduce_gradients
+    res = {}
+    for mode in ("flat", "buckets"):
+        torch.manual_seed(5)
+        model = _BlockedToy()
+        g = torch.Generator().manual_seed(70 + rank)
+        batch = {"x": torch.randn(16, 4, generator=g), "y": torch.randn(16, 2, generator=g)}
+        if mode == "buckets":
+            bk = GradientBuckets(model)
+            model.training_step(batch).backward()
+            early = list(bk.launch_order)             # what was already on the wire when backward returned
+            n = bk.finish()
+            res["early"], res["order"], res["n_b"] = early, list(bk.launch_order), n
+            # a second step through the same object: state is reset, same result for the same batch
+            model.zero_grad(set_to_none=True)
+            model.training_step(batch).backward()
+            bk.finish()
+            bk.remove()
+        else:
+            model.training_step(batch).backward()
+            res["n_f"] = allreduce_gradients(model)
+        res[mode] = [p.grad.clone() for p in model.parameters()]
+    torch.save(res, os.path.join(out_dir, f"b{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.autograd
+def test_world2_overlapped_buckets_equal_the_flat_allreduce(tmp_path):
+    """GradientBuckets (one all-reduce per EGNN block, issued from backward hooks back to front) gives bit for bit the gradients of the
+    single flat all-reduce, on both ranks, with a parameter that never receives a gradient riding along as zeros."""
+    world, port = 2, _free_port()
+    mp.spawn(_bucket_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(tmp_path / f"b{k}.pt") for k in range(world)]
+    for k in range(world):
+        assert r[k]["n_b"] == r[k]["n_f"] > 0
+        assert r[k]["early"] == [0, 1, 2], "the three block buckets (highest block first) must be launched DURING backward"
+        assert r[k]["order"] == [0, 1, 2, 3]           # the remainder (embedding, output layer, unused) at finish()
+        for a, b in zip(r[k]["flat"], r[k]["buckets"]):
+            assert torch.equal(a, b)
+    for a, b in zip(r[0]["buckets"], r[1]["buckets"]):
+        assert torch.equal(a, b)
+    assert torch.equal(r[0]["buckets"][-1], torch.zeros(3)) or torch.equal(r[0]["buckets"][0], torch.zeros(3))
+
+
+def _epoch_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hierdiff_amd import DiffusionQM9, default_config
+    model = DiffusionQM9(default_config(hidden_nf=32, n_layers=1))
+    steps = [{"loss": torch.tensor(1.0 + rank + 10 * k)} for k in range(3)]
+    model.validation_epoch_end(steps)
+    model.test_epoch_end(steps)
+    gathered = model._gather_result([{"loss": torch.tensor(float(rank))}, {"loss": torch.tensor(5.0)}])
+    torch.save({"logged": {k: float(v) for k, v in model.logged.items()}, "gathered": gathered["loss"]}, os.path.join(out_dir, f"e{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_epoch_end_hooks_and_configure_optimizers(tmp_path):
+    """The Lightning-side hooks of the reference module (diffusion_qm9.py:753-801, 871-879) exist on DiffusionQM9 and work without
+    Lightning: steps are joined, ranks gathered, the mean logged (test metric on rank 0 only); configure_optimizers returns
+    ([optimizer], [scheduler]) from cfg.optim / cfg.scheduler or the reference's shipped values."""
+    from hierdiff_amd import DiffusionQM9, default_config
+    model = DiffusionQM9(default_config(hidden_nf=32, n_layers=1))
+    # one process: vector-valued and scalar step outputs
+    out = model._gather_result([{"loss": torch.tensor([1.0, 2.0])}, {"loss": torch.tensor([6.0])}])
+    assert torch.equal(out["loss"], torch.tensor([1.0, 2.0, 6.0]))
+    model.validation_epoch_end([{"loss": torch.tensor(2.0)}, {"loss": torch.tensor(4.0)}])
+    assert float(model.logged["val_loss"]) == 3.0
+    model.test_epoch_end([{"loss": torch.tensor(2.0)}, {"loss": torch.tensor(8.0)}])
+    assert float(model.logged["test/ppl"]) == 5.0
+    opts, scheds = model.configure_optimizers()
+    assert isinstance(opts, list) and isinstance(scheds, list) and len(opts) == len(scheds) == 1
+    assert isinstance(opts[0], torch.optim.AdamW) and opts[0].defaults["lr"] == 4.0e-4 and opts[0].defaults["weight_decay"] == 4.0e-8
+    assert isinstance(scheds[0], torch.optim.lr_scheduler.StepLR) and scheds[0].step_size == 15 and scheds[0].gamma == 0.1
+    assert sum(p.numel() for g in opts[0].param_groups for p in g["params"]) == sum(p.numel() for p in model.parameters())
+    # hydra-style nodes (conf/optim/sgd.yaml-like, conf/scheduler/step.yaml)
+    cfg = default_config(hidden_nf=32, n_layers=1)
+    cfg["optim"] = {"_target_": "torch.optim.SGD", "lr": 0.1, "momentum": 0.9}
+    cfg["scheduler"] = {"_target_": "torch.optim.lr_scheduler.StepLR", "step_size": 3, "gamma": 0.5}
+    opts, scheds = DiffusionQM9(cfg).configure_optimizers()
+    assert isinstance(opts[0], torch.optim.SGD) and opts[0].defaults["momentum"] == 0.9 and scheds[0].step_size == 3
+    cfg["optim"] = {"_target_": "os.system", "command": "true"}
+    with pytest.raises(ValueError):
+        DiffusionQM9(cfg).configure_optimizers()
+    # two ranks: the gather joins the ranks' steps, both ranks see the same mean, only rank 0 logs the test metric
+    world, port = 2, _free_port()
+    mp.spawn(_epoch_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(tmp_path / f"e{k}.pt") for k in range(world)]
+    want = np.mean([1.0, 11.0, 21.0, 2.0, 12.0, 22.0])
+    assert r[0]["logged"]["val_loss"] == r[1]["logged"]["val_loss"] == pytest.approx(want)
+    assert r[0]["logged"]["test/ppl"] == pytest.approx(want) and "test/ppl" not in r[1]["logged"]
+    assert torch.equal(r[0]["gathered"], torch.tensor([0.0, 5.0, 1.0, 5.0])) and torch.equal(r[0]["gathered"], r[1]["gathered"])
