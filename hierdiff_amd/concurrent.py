@@ -37,13 +37,16 @@ class TwoStreamSampler:
 
     def _sync_twin(self):
         m = self.model
-        key = (_lib.optimizer_generation(),) + tuple((p.data_ptr(), p._version, str(p.device)) for p in m.state_dict(keep_vars=True).values())
+        tensors = list(m.state_dict(keep_vars=True).values())
+        key = (_lib.optimizer_generation(),) + tuple((p.data_ptr(), p._version, str(p.device)) for p in tensors)
         if self._twin is None:
             self._twin = type(m)(m.cfg)
+            self._twin_guard = _lib.ImageGuard()
         t = self._twin
-        if key != self._twin_key:
+        if not self._twin_guard.valid(key, tensors):          # key AND content of the model's tensors (_lib.ImageGuard)
             t.load_state_dict(m.state_dict())
             t.to(next(m.parameters()).device)
+            self._twin_guard.store(key, tensors)
             self._twin_key = key
         t.dynamics.precision = m.dynamics.precision
         for knob in ("noise_mode", "seed", "use_graph", "debug_checks", "schedule_gammas"):

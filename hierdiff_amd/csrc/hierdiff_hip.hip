@@ -2605,6 +2605,27 @@ extern "C" int hd_colsum_f32(int device, int rows, int n, const float* const* sr
     return HD_OK;
 }
 
+extern "C" int hd_params_digest(int device, const void* const* ptrs_dev, const long long* prefix_dev, int n, long long total,
+                                unsigned long long* scratch_dev, unsigned long long* digest_host, void* stream) {
+    if (!ptrs_dev || !prefix_dev || !scratch_dev || !digest_host) return fail(HD_E_INVALID, "hd_params_digest: null argument");
+    if (n < 1 || total < 0) return fail(HD_E_INVALID, "hd_params_digest: n < 1 or total < 0");
+    if (hd_device_count() <= device || device < 0) return fail(HD_E_HIP, "hd_params_digest: no such HIP device (is a GPU visible?)");
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(scratch_dev, 0, sizeof(unsigned long long), s));
+    if (total > 0) {
+        DigestArgs a;
+        a.ptrs = reinterpret_cast<const uint32_t* const*>(ptrs_dev); a.prefix = prefix_dev; a.n = n; a.total = total; a.out = scratch_dev;
+        const long long groups = (total + DIGEST_CHUNK - 1) / DIGEST_CHUNK;
+        hipLaunchKernelGGL(k_params_digest, dim3((unsigned)groups), dim3(256), 0, s, a);
+        HIP_TRY(hipGetLastError());
+    }
+    // the one host wait of the check: 8 bytes, in stream order behind the writes the digest must see
+    HIP_TRY(hipMemcpyAsync(digest_host, scratch_dev, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return HD_OK;
+}
+
 // ----------------------------------------------------------------------------- sampling maths
 
 static NoiseSrc make_noise(const float* raw_x, const float* raw_h, int rows, uint64_t seed, uint64_t base,

@@ -13,7 +13,7 @@
 //   * the whole row-local node chain (neighbour-sum reduction, node MLP, residual, the next layers' first edge Linear) is
 //     one launch in every mode (k_node for the bf16 splits, k_node_f32).
 // Files: k_gemm_r16.hpp (fp32 node GEMMs of small / medium batches), common.hpp (types, helpers, RNG), k_node.hpp, k_edge.hpp, k_edge_split.hpp (fp32 edge kernel of very small batches), k_edge_bwd.hpp (training: backward of an edge layer),
-// k_sampling.hpp (output stage, posterior step, decode, noise), k_egcl.hpp (stage-2 layer E_GCL, forward), k_tgemm.hpp (training: general fp32 GEMM of the node-level Linears, forward / dX / dW split-K), k_loss.hpp (training: the variational loss around the network call, one kernel per direction).  (The one-wave-per-SIMD edge-kernel experiments live in scratch/experiments/.)
+// k_sampling.hpp (output stage, posterior step, decode, noise), k_egcl.hpp (stage-2 layer E_GCL, forward), k_tgemm.hpp (training: general fp32 GEMM of the node-level Linears, forward / dX / dW split-K), k_loss.hpp (training: the variational loss around the network call, one kernel per direction), k_digest.hpp (content digest of the parameter tensors: guards the packed weight images against silent staleness).  (The one-wave-per-SIMD edge-kernel experiments live in scratch/experiments/.)
 #pragma once
 #include "common.hpp"
 #include "k_node.hpp"
@@ -27,3 +27,4 @@
 #include "k_tgemm.hpp"
 #include "k_dw2.hpp"
 #include "k_loss.hpp"
+#include "k_digest.hpp"

@@ -239,11 +239,13 @@ class DiffusionQM9(_Base):
         # batch gives the same NLL whatever the grad mode
         if torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.gamma.parameters()):
             return self.gamma(t).view(-1, 1)
-        ver = (self.T, str(t.device), _lib.optimizer_generation()) + tuple((p.data_ptr(), p._version) for p in self.gamma.state_dict(keep_vars=True).values())
-        if getattr(self, "_gamma_grid_key", None) != ver:
+        gparams = list(self.gamma.state_dict(keep_vars=True).values())
+        ver = (self.T, str(t.device), _lib.optimizer_generation()) + tuple((p.data_ptr(), p._version) for p in gparams)
+        guard = self.__dict__.setdefault("_gamma_grid_guard", _lib.ImageGuard())
+        if not guard.valid(ver, gparams):             # key AND content of the schedule parameters (_lib.ImageGuard)
             k = torch.arange(-1, self.T + 1, dtype=torch.float32).view(-1, 1)
             self._gamma_grid = evaluate_gamma(self.gamma, k / self.T).view(-1).to(t.device)
-            self._gamma_grid_key = ver
+            guard.store(ver, gparams)
         idx = torch.round(t.to(torch.float32) * self.T).long().view(-1) + 1
         return self._gamma_grid[idx].view(-1, 1)
 
@@ -559,7 +561,11 @@ class DiffusionQM9(_Base):
         key = (self.T, self.dynamics._handle_gen, _lib.optimizer_generation()) + tuple(
             (p.data_ptr(), p._version) for p in self.gamma.parameters()) + (
                 id(self.schedule_gammas), self.schedule_eval, rows if self.schedule_eval == "fp32" else 0)
-        if key != self._sched_key:
+        gparams = list(self.gamma.parameters())
+        guard = self.__dict__.setdefault("_sched_guard", _lib.ImageGuard())
+        if self._sched_key is None:
+            guard.clear()
+        if not guard.valid(key, gparams):             # key AND content of the schedule parameters (_lib.ImageGuard)
             tabs = schedule_tables(self.gamma, self.T, self.schedule_gammas, self.schedule_eval, rows)
             tau = tabs["tau"].numpy().astype(np.float32)
             coef = tabs["coef"].numpy().astype(np.float32).reshape(-1)
@@ -567,6 +573,7 @@ class DiffusionQM9(_Base):
                 handle, self.T, tau.ctypes.data_as(C.POINTER(C.c_float)),
                 coef.ctypes.data_as(C.POINTER(C.c_float))), "hd_set_schedule")
             self._sched = tabs
+            guard.store(key, gparams)
             self._sched_key = key
         return self._sched
 

@@ -293,8 +293,12 @@ class EGNN_dynamics_QM9(nn.Module):
         object.__setattr__(self, "_arith", arith)
 
     def _sync_gnn_engine(self):
-        key = (_lib.optimizer_generation(),) + tuple((p.data_ptr(), p._version) for p in self.gnn.parameters())
-        if key == self._engine_key:
+        params = list(self.gnn.parameters())
+        key = (_lib.optimizer_generation(),) + tuple((p.data_ptr(), p._version) for p in params)
+        guard = self.__dict__.setdefault("_engine_guard", _lib.ImageGuard())
+        if self._engine_key is None:
+            guard.clear()
+        if guard.valid(key, params):
             return
         eg, gn = self._engine.egnn, self.gnn
         H = gn.embedding.weight.shape[0]
@@ -313,6 +317,7 @@ class EGNN_dynamics_QM9(nn.Module):
                     dst.att_mlp[0].weight.copy_(src.att_mlp[0].weight); dst.att_mlp[0].bias.copy_(src.att_mlp[0].bias)
             for p in blk.gcl_equiv.parameters():
                 p.zero_()
+        guard.store(key, params)
         self._engine_key = key
 
     def _forward_gnn(self, t, xh, node_mask, edge_mask, context):
@@ -443,9 +448,16 @@ class EGNN_dynamics_QM9(nn.Module):
             self._handle_gen = self._arith._handle_gen
             return
         h = self._handle()
-        # (+ the optimizer-step count: fused optimizers do not bump `_version`, _lib.optimizer_generation)
-        key = (_lib.optimizer_generation(),) + tuple((p.data_ptr(), p._version) for p in self.egnn.parameters())
-        if not force and key == self._weights_key:
+        # cheap key: (address, in-place version) of every parameter + the optimizer-step count (fused optimizers do not bump
+        # `_version`, _lib.optimizer_generation).  A key hit is then CONFIRMED by content (_lib.ImageGuard: one digest launch
+        # over the parameters, 8 bytes read back), so a writer that bumps nothing - `p.data.copy_`, an external kernel - cannot
+        # leave the handle on a stale image either.
+        params = list(self.egnn.parameters())
+        key = (_lib.optimizer_generation(),) + tuple((p.data_ptr(), p._version) for p in params)
+        guard = self.__dict__.setdefault("_weights_guard", _lib.ImageGuard())
+        if self._weights_key is None:
+            guard.clear()
+        if not force and guard.valid(key, params):
             return
         blob = self.canonical_blob().contiguous()
         lib = _lib.load()
@@ -453,6 +465,7 @@ class EGNN_dynamics_QM9(nn.Module):
         if blob.numel() != expect:
             raise HierDiffHipError(f"parameter count {blob.numel()} != library layout {expect}")
         _lib.check(lib.hd_set_weights(h, blob.data_ptr(), blob.numel(), 1, _stream(blob.device)), "hd_set_weights")
+        guard.store(key, params)
         self._weights_key = key
 
     # ------------------------------------------------------------------ topology

@@ -157,15 +157,18 @@ def _fp64_twin(gamma_module: torch.nn.Module) -> torch.nn.Module:
     per-step API calls evaluate_gamma twice per diffusion step)."""
     import copy
     import weakref
-    from ._lib import optimizer_generation          # fused optimizers change values without bumping `_version`
-    key = (optimizer_generation(),) + tuple((p.data_ptr(), p._version, p.device) for p in gamma_module.state_dict(keep_vars=True).values())
+    from ._lib import ImageGuard, optimizer_generation          # fused optimizers change values without bumping `_version`
+    tensors = list(gamma_module.state_dict(keep_vars=True).values())
+    key = (optimizer_generation(),) + tuple((p.data_ptr(), p._version, p.device) for p in tensors)
     hit = _TWINS.get(id(gamma_module))
-    if hit is not None and hit[0]() is gamma_module and hit[1] == key:
+    if hit is not None and hit[0]() is gamma_module and hit[1].valid(key, tensors):      # key AND content (ImageGuard)
         return hit[2]
     twin = copy.deepcopy(gamma_module).to("cpu").double()
     if len(_TWINS) > 16:
         _TWINS.clear()
-    _TWINS[id(gamma_module)] = (weakref.ref(gamma_module), key, twin)
+    guard = ImageGuard()
+    guard.store(key, tensors)
+    _TWINS[id(gamma_module)] = (weakref.ref(gamma_module), guard, twin)
     return twin
 
 

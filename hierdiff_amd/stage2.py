@@ -143,7 +143,12 @@ class E_GCL(nn.Module):
         if self._plist is None:                  # the module-tree walk of .parameters() costs more than a beam-sized layer
             self._plist = list(self.parameters())
         key = (_lib.optimizer_generation(),) + tuple((p.data_ptr(), p._version) for p in self._plist)     # (fused optimizers: no version bump)
-        if key == self._weights_key:
+        guard = self.__dict__.setdefault("_weights_guard", _lib.ImageGuard())
+        if self._weights_key is None:
+            guard.clear()
+        # key AND content (_lib.ImageGuard: one digest launch + an 8-byte read per check; Edge_denoise freezes its layers for the
+        # length of a call, so a model pays it once per layer per call, not once per layer application)
+        if guard.valid(key, self._plist):
             return
         blob = torch.cat([p.detach().reshape(-1).to(torch.float32) for p in self._plist]).contiguous()
         lib = _lib.load()
@@ -151,6 +156,7 @@ class E_GCL(nn.Module):
             raise HierDiffHipError(f"parameter count {blob.numel()} != library layout {lib.hd_egcl_weight_count(h)}")
         _lib.check(lib.hd_egcl_set_weights(h, blob.data_ptr(), blob.numel(), 1, torch.cuda.current_stream(blob.device).cuda_stream),
                    "hd_egcl_set_weights")
+        guard.store(key, self._plist)
         self._weights_key = key
 
     def _apply(self, fn, *a, **k):

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define HD_ABI_VERSION 10
+#define HD_ABI_VERSION 11
 
 #define HD_OK 0
 #define HD_E_INVALID (-1)      /* bad argument / unsupported configuration */
@@ -353,6 +353,15 @@ int hd_edge_prep(int device, int H, int dir, float* W1, const float* b1, float* 
  * ws: 32 * sum(width) device floats. */
 int hd_colsum_f32(int device, int rows, int n, const float* const* src, const int* width, float* const* dst, float* ws,
                   void* stream);
+
+/* 64-bit content digest of n device tensors of 32-bit words (the parameters a packed image was made from): the Python wrapper
+ * compares it with the digest taken when it last called hd_set_weights / hd_set_schedule / hd_egcl_set_weights, so that a writer
+ * which bumps no version counter (a fused optimizer, `.data` writes, an external kernel) can never leave the inference path on a
+ * stale image.  The reference has no counterpart: it evaluates its modules in place (en_dynamics.py:49-122).
+ * ptrs_dev [n] device pointers, prefix_dev [n + 1] word offsets (prefix_dev[n] == total), both DEVICE arrays; scratch_dev: one
+ * device uint64.  One launch + an 8-byte copy; WAITS for `stream`.  The value is independent of the launch geometry. */
+int hd_params_digest(int device, const void* const* ptrs_dev, const long long* prefix_dev, int n, long long total,
+                     unsigned long long* scratch_dev, unsigned long long* digest_host, void* stream);
 
 /* Host implementation of the library's normal generator (same bits as the device one up to libm
  * round-off); used by tests and by callers that want to reproduce a draw on the CPU. */

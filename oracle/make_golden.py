@@ -817,7 +817,18 @@ def fixture_elem(DiffusionQM9, name, hidden_nf, n_layers, seed, T, n_list):
     got, err = orc.nll_forward(sd, ocfg, 1000, x, h, nm, em, None, t_int, draws[0], draws[1], training=False, gammas=gam,
                                node_coarse_type="elem")
     check(f"{name} nll", got.numpy(), loss.numpy(), tol=5e-6)
-    save(name, xh=xh.numpy(), t_rows=t.numpy(), out_row_t=ref.numpy(), node_mask=nm.numpy(), edge_mask=em.numpy(),
+    # round 6: the TRAINING-mode loss of the same model (one network call, rows with t = 0 among the others) - the number the
+    # product's fused loss kernel (csrc/k_loss.hpp, 3 + 0 feature columns) is compared with
+    model.train(True)
+    tloss, tinfo, tdraws, tgam, tt_int = _record_loss(model, x, h, nm, em.view(B, N * N), True, seed + 302, preset_t=[0, 1, 500, 1000])
+    tgot, terr = orc.nll_forward(sd, ocfg, 1000, x, h, nm, em, None, tt_int, tdraws[0], None, training=True, gammas=tgam,
+                                 node_coarse_type="elem")
+    check(f"{name} training loss", tgot.numpy(), tloss.numpy(), tol=5e-6)
+    check(f"{name} training error", terr.numpy(), tinfo["error"].numpy(), tol=5e-6)
+    model.train(False)
+    train = dict(train_t_int=tt_int.numpy(), train_eps=tdraws[0].numpy(), train_loss=tloss.numpy(), train_error=tinfo["error"].numpy(),
+                 **{"train_" + k: v.numpy() for k, v in tgam.items()})
+    save(name, xh=xh.numpy(), t_rows=t.numpy(), out_row_t=ref.numpy(), node_mask=nm.numpy(), edge_mask=em.numpy(), **train,
          raw_x=np.stack([r[0].numpy() for r in raws]), raw_h=np.stack([r[1].numpy() for r in raws]),
          n_list=np.array(n_list), x=x_ref, h=h_ref, T=T, gamma_grid=gamma_grid, hidden_nf=hidden_nf, n_layers=n_layers,
          weight_seed=seed, coord_gain=1.0, loss_x=x.numpy(), loss_h=h.numpy(), t_int=t_int.numpy(),

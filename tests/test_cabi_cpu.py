@@ -28,7 +28,7 @@ def test_header_symbols_all_exported(lib):
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.hd_version() == _lib.ABI_VERSION == 10
+    assert lib.hd_version() == _lib.ABI_VERSION == 11
 
 
 def test_no_gpu_fails_loudly(lib):
@@ -468,10 +468,13 @@ def test_optimizer_generation_counts_steps_of_any_optimizer():
     v0 = net.gamma_0._version
     net.gamma_0.data.add_(1.0)          # an in-place write that bumps no version counter of the parameter (what a fused optimizer does)
     assert net.gamma_0._version == v0
-    assert _fp64_twin(net) is t1, "without an optimizer step or a version bump the cache is expected to hold (documented limit)"
-    o1.step()
+    # round 6: such a write is seen too (the key hit is confirmed by a content digest, _lib.ImageGuard) - rounds 2-5 documented
+    # this case as a limit of the cache
     t2 = _fp64_twin(net)
     assert t2 is not t1 and float(t2.gamma_0) == float(net.gamma_0)
+    assert _fp64_twin(net) is t2
+    o1.step()
+    assert _fp64_twin(net) is not t2          # the optimizer-step count is part of the key, whichever optimizer stepped
 
 
 def test_configure_optimizers_picks_the_fused_form_only_on_the_gpu():
@@ -489,3 +492,22 @@ def test_configure_optimizers_picks_the_fused_form_only_on_the_gpu():
     with torch.enable_grad():
         m(torch.ones(2, 4)).sum().backward()
     opt.step()          # the CPU form runs
+
+
+def test_image_guard_confirms_key_hits_by_content():
+    """_lib.ImageGuard (round 6): a cached image is valid only if the cheap key AND the content digest of the tensors it was made
+    from are unchanged; on the CPU the digest is a host hash (cuda tensors: csrc/k_digest.hpp, tests/test_gpu_training.py)."""
+    import torch
+    a = [torch.arange(12, dtype=torch.float32).view(3, 4), torch.zeros(0), torch.ones(5, dtype=torch.float64)]
+    g = _lib.ImageGuard()
+    assert not g.valid(("k",), a)
+    g.store(("k",), a)
+    assert g.valid(("k",), a) and not g.valid(("other",), a)
+    ver = a[0]._version
+    a[0].data[2, 3] += 1.0                                   # `.data`: the tensor's own version counter does not move
+    assert a[0]._version == ver and not g.valid(("k",), a)
+    a[0].data[2, 3] -= 1.0
+    assert g.valid(("k",), a)
+    assert _lib.params_digest([torch.zeros(2, 3)]) != _lib.params_digest([torch.zeros(3, 2)])      # shape is part of the host hash
+    g.clear()
+    assert not g.valid(("k",), a)

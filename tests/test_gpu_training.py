@@ -119,6 +119,93 @@ def test_training_loss_gradients_on_reference_fixtures(name):
     print(f"{name}: {n} parameter tensors, worst grad rel-L2 {worst:.2e}")
 
 
+def _fused_calls(monkeypatch):
+    """Counts the launches of the fused loss (hierdiff_amd.training.vlb_loss) so a test can assert WHICH path produced its numbers."""
+    import hierdiff_amd.training as tr
+    calls = []
+    real = tr.vlb_loss
+
+    def spy(*a, **k):
+        calls.append(1)
+        return real(*a, **k)
+    monkeypatch.setattr(tr, "vlb_loss", spy)
+    return calls
+
+
+@pytest.mark.parametrize("case", ["f12_l2_poly2", "f20_norm_values", "f13_elem", "f9_vlb_batch_entry"])
+def test_fused_training_loss_meets_reference_fixtures(case, monkeypatch):
+    """Round 6: the fused training loss (csrc/k_loss.hpp, the default training path on the GPU) against
+    numbers the REFERENCE produced in training mode, under autograd, branch by branch: `l2` + predefined schedule with a t = 0 row
+    (F12), non-unit norm_values / norm_biases through `nll` (F20), 3 + 0 `elem` feature columns (F13, training-mode loss added to
+    the generator this round), and the vlb / learned-schedule case through the batch-level entry `forward(batch)` (F9).  Each case
+    asserts that the fused kernel - not the torch-op path - produced the value, and that the value is differentiable."""
+    from hierdiff_amd import DiffusionQM9, default_config
+    from hierdiff_amd.weights import synthetic_state_dict
+    calls = _fused_calls(monkeypatch)
+    if case == "f12_l2_poly2":
+        fx = load("f12_poly2_l2_h32_l2")
+        H, L, T = int(fx["hidden_nf"]), int(fx["n_layers"]), int(fx["T"])
+        cfg = default_config(hidden_nf=H, n_layers=L, timesteps=T)
+        cfg["noise_schedule"], cfg["loss_type"] = "polynomial_2", "l2"
+        cfg["pre_noise"] = dict(noise_schedule="polynomial_2", timesteps=T, precision=1e-4)
+        model = DiffusionQM9(cfg)
+        sd_np = {k: v for k, v in synthetic_state_dict(9, 0, H, L, 2, True, int(fx["weight_seed"]), 1.0).items() if not k.startswith("gamma.")}
+        sd_np["gamma.gamma"] = fx["gamma_table"]
+        model.load_state_dict({k: torch.from_numpy(np.asarray(v).copy()) for k, v in sd_np.items()})
+        model = model.to(DEV).train()
+        nm, em = orc.canonical_masks([int(v) for v in fx["n_list"]])
+        assert float(fx["t_int"][0, 0]) == 0.0
+        loss, info = model.compute_loss(torch.from_numpy(fx["loss_x"]).to(DEV), torch.from_numpy(fx["loss_h"]).to(DEV), nm.to(DEV),
+                                        em.to(DEV), None, t0_always=False, t_int=fx["t_int"], eps=fx["eps"])
+        np.testing.assert_allclose(loss.detach().cpu().numpy(), fx["loss"], rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(info["error"].detach().cpu().numpy(), fx["error"], rtol=1e-4, atol=1e-5)
+    elif case == "f20_norm_values":
+        fx = load("f20_norm_h64_l2")
+        sd_np, _, _ = fixture_model(fx)
+        cfg = default_config(hidden_nf=int(fx["hidden_nf"]), n_layers=int(fx["n_layers"]), timesteps=int(fx["T"]))
+        cfg.norm_values = [float(v) for v in fx["norm_values"]]
+        cfg.norm_biases = [None] + [float(v) for v in fx["norm_biases"][1:]]
+        model = DiffusionQM9(cfg)
+        model.load_state_dict({k: torch.from_numpy(np.asarray(v).copy()) for k, v in sd_np.items()})
+        model = model.to(DEV).train()
+        nm, em = orc.canonical_masks([int(v) for v in fx["n_list"]])
+        gam = {k: fx[f"train_{k}"] for k in ("gamma_s", "gamma_t", "gamma_0", "gamma_T")}
+        loss = model.nll(torch.from_numpy(fx["x"]).to(DEV), torch.from_numpy(fx["h"]).to(DEV), nm.to(DEV), em.to(DEV), None,
+                         t_int=fx["train_t_int"], eps=fx["train_eps"], gammas=gam)
+        np.testing.assert_allclose(loss.detach().cpu().numpy(), fx["train_nll"], rtol=1e-4, atol=1e-3)
+    elif case == "f13_elem":
+        fx = load("f13_elem_h64_l2")
+        H, L = int(fx["hidden_nf"]), int(fx["n_layers"])
+        cfg = default_config(hidden_nf=H, n_layers=L, timesteps=1000)
+        cfg["node_coarse_type"] = "elem"
+        model = DiffusionQM9(cfg)
+        model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in synthetic_state_dict(4, 0, H, L, 2, True, int(fx["weight_seed"]), 1.0).items()})
+        model = model.to(DEV).train()
+        nm, em = torch.from_numpy(fx["node_mask"]), torch.from_numpy(fx["edge_mask"])
+        gam = {k: fx[f"train_{k}"] for k in ("gamma_s", "gamma_t", "gamma_0", "gamma_T")}
+        assert float(fx["train_t_int"][0, 0]) == 0.0
+        loss, info = model.compute_loss(torch.from_numpy(fx["loss_x"]).to(DEV), torch.from_numpy(fx["loss_h"]).to(DEV), nm.to(DEV),
+                                        em.to(DEV), None, t0_always=False, t_int=fx["train_t_int"], eps=fx["train_eps"], gammas=gam)
+        np.testing.assert_allclose(loss.detach().cpu().numpy(), fx["train_loss"], rtol=1e-4, atol=1e-3)
+        np.testing.assert_allclose(info["error"].detach().cpu().numpy(), fx["train_error"], rtol=1e-4, atol=1e-4)
+    else:
+        fx = load("f9_nll_train_h64_l2")
+        sd_np, _, _ = fixture_model(fx)
+        model = build_diffusion(sd_np, int(fx["hidden_nf"]), int(fx["n_layers"]), T=int(fx["T"]), precision="fp32").train()
+        nm, em = orc.canonical_masks([int(v) for v in fx["n_list"]])
+        x, h = torch.from_numpy(fx["x"]).to(DEV), torch.from_numpy(fx["h"]).to(DEV)
+        B, N = x.shape[:2]
+        batch = {"positions": x, "atom_mask": nm.to(DEV), "edge_mask": em.to(DEV).view(B, N, N), "node_feature": h}
+        gam = {k: fx[k] for k in ("gamma_s", "gamma_t", "gamma_0", "gamma_T")}
+        loss = model(batch, t_int=fx["t_int"], eps=fx["eps"], gammas=gam)["loss"]
+        assert abs(loss.item() - float(np.mean(fx["loss"]))) <= 1e-4 * abs(float(np.mean(fx["loss"]))) + 1e-3
+    assert len(calls) == 1, "the value above must come from the fused loss kernel"
+    assert loss.requires_grad
+    loss.mean().backward()
+    grads = [p.grad for p in model.dynamics.parameters() if p.grad is not None]
+    assert grads and all(torch.isfinite(g).all() for g in grads) and any(float(g.abs().max()) > 0 for g in grads)
+
+
 @pytest.mark.parametrize("loss_type,schedule,coarse,nv", [("vlb", "learned", "prop", (1.0, 1.0, 1.0)), ("l2", "polynomial_2", "prop", (1.0, 1.0, 1.0)),
                                                           ("vlb", "polynomial_2", "prop", (1.0, 1.0, 1.0)), ("vlb", "learned", "elem", (1.0, 1.0, 1.0)),
                                                           ("vlb", "learned", "prop", (2.0, 4.0, 1.0))])
@@ -508,6 +595,60 @@ def test_inference_path_sees_the_weights_a_fused_optimizer_wrote():
     assert rel_l2(inf1.cpu().numpy(), dif1.cpu().numpy()) < 2e-6, "the inference handle runs on stale weights"
     moved = float((net1 - net0).abs().max())
     assert moved > 0 and float((tab1 - net1).abs().max()) < 0.25 * moved, "the schedule table is stale"
+
+
+def test_inference_path_sees_writes_that_bump_no_version():
+    """Round 6: a writer that is not a torch optimizer and bumps no version counter - `p.data.copy_`,
+    `torch._foreach_add_` on `.data` - used to leave the packed weight image, the schedule table and the two-stream twin stale with
+    no error (this test fails on the round-5 library).  Every key hit is now confirmed by a content digest of the parameters
+    (csrc/k_digest.hpp, _lib.ImageGuard)."""
+    from hierdiff_amd import DiffusionQM9, _lib, default_config
+    from hierdiff_amd.weights import synthetic_state_dict
+    H, L, B, N = 64, 2, 5, 9
+    m = DiffusionQM9(default_config(hidden_nf=H, n_layers=L, timesteps=50))
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in synthetic_state_dict(9, 0, H, L, 2, True, 33, 0.5).items()})
+    m = m.to(DEV).eval()
+    batch = {k: v.to(DEV) for k, v in _host_batch(5, B, N).items()}
+    xh = torch.randn(B, N, 11, device=DEV) * batch["atom_mask"]
+    t = torch.full((B, 1), 0.5, device=DEV)
+    em = batch["edge_mask"].reshape(B, N * N)
+
+    def both():
+        with torch.no_grad():
+            inf = m.dynamics._forward(t, xh, batch["atom_mask"], em, None, None)
+            tab = m._gamma_rows(t, "gamma_t", None)
+        m.dynamics.differentiable = True
+        dif = m.dynamics._forward(t, xh.clone().requires_grad_(True), batch["atom_mask"], em, None, None).detach()
+        m.dynamics.differentiable = None
+        return inf, dif, tab, m.gamma(t).detach().view(-1, 1)
+    inf0, dif0, tab0, net0 = both()
+    assert rel_l2(inf0.cpu().numpy(), dif0.cpu().numpy()) < 2e-6
+    gen = _lib.optimizer_generation()
+    versions = [p._version for p in m.parameters()]
+    w = m.dynamics.egnn.e_block_1.gcl_0.edge_mlp[2].weight
+    w.data.mul_(1.5)                                                   # .data: a separate version counter
+    torch._foreach_add_([p.data for p in m.gamma.parameters()], 0.25)
+    assert [p._version for p in m.parameters()] == versions and _lib.optimizer_generation() == gen, "the writes must bump nothing"
+    inf1, dif1, tab1, net1 = both()
+    assert rel_l2(dif1.cpu().numpy(), dif0.cpu().numpy()) > 1e-4, "the write must have moved the output"
+    assert rel_l2(inf1.cpu().numpy(), dif1.cpu().numpy()) < 2e-6, "the inference handle runs on a stale weight image"
+    moved = float((net1 - net0).abs().max())
+    assert moved > 0 and float((tab1 - net1).abs().max()) < 0.25 * moved, "the schedule table is stale"
+    # one ulp in one weight is seen; the digest does not depend on how the words are cut into tensors
+    p0 = m.dynamics.egnn.embedding.weight
+    d0 = _lib.params_digest([p0])
+    flat = p0.detach().reshape(-1)
+    assert _lib.params_digest([flat[:100], flat[100:]]) == d0 and _lib.params_digest([flat]) == d0
+    bits = p0.data.view(torch.int32)
+    bits[3, 2] += 1
+    assert _lib.params_digest([p0]) != d0
+    bits[3, 2] -= 1
+    assert _lib.params_digest([p0]) == d0
+    host = np.frombuffer(flat.cpu().numpy().tobytes(), dtype=np.uint32).astype(np.uint64)
+    x = host + np.uint64(0x9E3779B97F4A7C15) * (np.arange(host.size, dtype=np.uint64) + np.uint64(1))
+    x ^= x >> np.uint64(30); x *= np.uint64(0xBF58476D1CE4E5B9); x ^= x >> np.uint64(27); x *= np.uint64(0x94D049BB133111EB); x ^= x >> np.uint64(31)
+    want = int(np.sum(x, dtype=np.uint64))
+    assert d0 == (want + 1) & 0xFFFFFFFFFFFFFFFF          # the kernel against a numpy restatement of csrc/k_digest.hpp
 
 
 # ----------------------------------------------------------------------------- opt-in bf16x6 arithmetic of the training path

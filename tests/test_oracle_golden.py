@@ -219,6 +219,13 @@ def test_elem_matches_reference():
         loss, _ = orc.nll_forward(sd, cfg, 1000, fx["loss_x"], fx["loss_h"], nm, em, None, fx["t_int"], fx["eps"], fx["eps0"],
                                   training=False, gammas=gam, node_coarse_type="elem")
     np.testing.assert_allclose(loss.numpy(), fx["loss"], rtol=2e-6, atol=1e-4)
+    with torch.no_grad():          # round 6: the training-mode loss (one network call, a t = 0 row)
+        tgam = {k: torch.from_numpy(fx["train_" + k]) for k in ("gamma_s", "gamma_t", "gamma_0", "gamma_T")}
+        tloss, terr = orc.nll_forward(sd, cfg, 1000, fx["loss_x"], fx["loss_h"], nm, em, None, fx["train_t_int"], fx["train_eps"], None,
+                                      training=True, gammas=tgam, node_coarse_type="elem")
+    np.testing.assert_allclose(tloss.numpy(), fx["train_loss"], rtol=2e-6, atol=1e-4)
+    np.testing.assert_allclose(terr.numpy(), fx["train_error"], rtol=2e-6, atol=1e-5)
+    assert float(fx["train_t_int"][0, 0]) == 0.0
 
 
 def test_pocket_loss_matches_reference():
