@@ -12,12 +12,11 @@ point sets, counter-based Gaussian noise) and deterministic random-init weights:
 checkpoint and there is no network.
 
 The JSON line's headline (`value`, `dtype`, `roofline`) is the EXACT-fp32 path (v_mfma_f32_32x32x2_f32), the
-arithmetic the reference computes in.  The three opt-in modes are timed in the same invocation over the same K steps and
-reported as sibling blocks with their own rooflines and their measured deviation from the fp32 path: `"fp16x3"`
-(per-edge contraction on a two-way FP16 split of operands ranged by exact powers of two, 3 fp16 MFMAs per product) and
-`"bf16x6"` (three-way bf16 split, 6 bf16 MFMAs) - both fp32-ACCURATE: as far from a float64 evaluation as the exact-fp32
-path and the float32 reference themselves, tests/test_gpu_parity.py - and `"bf16x3"` (two-way bf16 split, 3 MFMAs,
-~1e-5 rel-L2).  At N=1 the line also carries
+arithmetic the reference computes in.  The one opt-in mode is timed in the same invocation over the same K steps and
+reported as a sibling block with its own roofline and its measured deviation from the fp32 path: `"fp16x3"`
+(per-edge and node contractions on a two-way FP16 split of operands ranged by exact powers of two, 3 fp16 MFMAs per product;
+fp32-ACCURATE: as far from a float64 evaluation as the exact-fp32 path and the float32 reference themselves,
+tests/test_gpu_parity.py).  (The bf16 splits of rounds 1-5 were retired in round 6.)  At N=1 the line also carries
 `cpu_baseline` (the oracle timed on this host) and `configs` (BASELINE.json configs 2, 3, 5 and the reference's
 default B=2 job, timed on short chains).
 
@@ -49,15 +48,15 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 # /opt/skills/guides/MI355X_MICROARCH.md, dense matrix peaks: v_mfma_f32_32x32x2_f32 157.3 TFLOP/s,
-# bf16 MFMA ~2.5 PFLOP/s; HBM3E 8 TB/s.  The bf16x3 path executes 3 bf16 MFMA flops per algorithmic flop.
-MFMA_PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0, "bf16x6": 2500.0, "fp16x3": 2500.0}
-MFMAS_PER_PRODUCT = {"fp32": 1, "bf16x3": 3, "bf16x6": 6, "fp16x3": 3}
+# fp16 MFMA ~2.5 PFLOP/s; HBM3E 8 TB/s.  The fp16x3 path executes 3 fp16 MFMA flops per algorithmic flop.
+MFMA_PEAK_TFLOPS = {"fp32": 157.3, "fp16x3": 2500.0}
+MFMAS_PER_PRODUCT = {"fp32": 1, "fp16x3": 3}
 HBM_PEAK_GBPS = 8000.0
-DTYPE = {"fp32": "f32", "bf16x3": "bf16x3", "bf16x6": "bf16x6", "fp16x3": "fp16x3"}
+DTYPE = {"fp32": "f32", "fp16x3": "fp16x3"}
 # PMC figures are NOT measured by this process (counter passes need rocprofv3 around the run): they are replayed from the
 # newest committed summary of scratch/round_profiles.sh + summarize_profiles.py, and only when that summary was collected
 # on the very library that is loaded now (sha256 of libhierdiff_hip.so) and on this workload's shape.
-COUNTER_FILES = [os.path.join(REPO, "profiles", f) for f in ("r05_counters.json", "r04_counters.json", "r03_counters.json",
+COUNTER_FILES = [os.path.join(REPO, "profiles", f) for f in ("r06_counters.json", "r05_counters.json", "r04_counters.json", "r03_counters.json",
                                                               os.path.join("history", "r02_counters.json"))]
 
 
@@ -223,12 +222,12 @@ def timed_headline(model, precision, args, dev, rank, world, dist):
             else:
                 roofline["pmc"] = {"replayed_from": None, "refused": pmc.get("stale", "no entry for this precision")}
             if precision != "fp32":
-                # fp32 operands are split into bf16 pieces: each algorithmic flop costs 3 (6) bf16 MFMA flops
+                # fp32 operands are split into two fp16 pieces: each algorithmic flop costs 3 fp16 MFMA flops
                 m = MFMAS_PER_PRODUCT[precision]
                 roofline["executed_mfma_tflops"] = round(m * achieved, 2)
                 roofline["executed_frac"] = round(m * achieved / peak, 4)
                 roofline["vs_fp32_mfma_peak"] = round(achieved / MFMA_PEAK_TFLOPS["fp32"], 4)
-                roofline["note"] = (f"contraction on {m} {'fp16' if precision == 'fp16x3' else 'bf16'} MFMAs per product ({precision}); achieved counts algorithmic "
+                roofline["note"] = (f"contraction on {m} fp16 MFMAs per product ({precision}); achieved counts algorithmic "
                                     "flops, executed_* the issued MFMA flops; vs_fp32_mfma_peak = achieved / 157.3")
         if cnt[1] > 0:
             # the node side (family 1: the fused k_node_f32 / k_node launches, or k_gemm_r16 below HD_FUSE_MIN_ROWS): algorithmic
@@ -281,7 +280,7 @@ def sustained_mfma(precision: str, dev) -> dict:
     from hierdiff_amd import _lib
     try:
         lib = _lib.load()
-        kind = {"fp32": 0, "fp16x3": 1, "bf16x3": 2, "bf16x6": 2}[precision]
+        kind = {"fp32": 0, "fp16x3": 1}[precision]
         g = torch.Generator().manual_seed(11)
         data = (torch.rand(1024, generator=g) * 2 - 1).to(dev)
         n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
@@ -293,7 +292,7 @@ def sustained_mfma(precision: str, dev) -> dict:
                                      torch.cuda.current_stream(dev).cuda_stream), "hd_mfma_probe")
         flop_per_mfma = 2.0 * 32 * 32 * (2 if kind == 0 else 16)
         tf = flop_per_mfma / (ns.value * 1e-9) * 4 * n_cu / 1e12
-        return {"instruction": ["v_mfma_f32_32x32x2_f32", "v_mfma_f32_32x32x16_f16", "v_mfma_f32_32x32x16_bf16"][kind],
+        return {"instruction": ["v_mfma_f32_32x32x2_f32", "v_mfma_f32_32x32x16_f16"][kind],
                 "ns_per_mfma_per_simd": round(ns.value, 2), "tflops": round(tf, 1),
                 "what": "register-operand MFMA loop on every SIMD, 2 wavefronts per SIMD, random operands, measured in this process"}
     except Exception:               # a measurement aid must never fail the bench
@@ -301,7 +300,7 @@ def sustained_mfma(precision: str, dev) -> dict:
 
 
 @torch.no_grad()
-def precision_gap(model, args, dev, mode="bf16x3") -> dict:
+def precision_gap(model, args, dev, mode="fp16x3") -> dict:
     """rel-L2 between a split mode and the exact-fp32 mode on one headline-shaped forward (the fp32 path is the yardstick
     here; every mode is checked against the reference-generated golden vectors in tests/)."""
     B, N = args.batch, args.nodes
@@ -317,11 +316,8 @@ def precision_gap(model, args, dev, mode="bf16x3") -> dict:
             model.dynamics.precision = p
             outs[p] = model.dynamics._forward(t, xh, nm, None, None, None).double()
         worst = max(worst, float(torch.linalg.norm(outs[mode] - outs["fp32"]) / torch.linalg.norm(outs["fp32"])))
-    bound = {"bf16x3": "<= 1.3e-5 rel-L2 per forward on every golden fixture (tests/, bar 1e-4)",
-             "bf16x6": "<= 7e-7 rel-L2 per forward on every golden fixture, the exact-fp32 mode's own figure; distance to a "
-                       "float64 evaluation 3.6e-7 vs 3.8e-7 (exact fp32) and 3.0e-7 (float32 reference), tests/test_gpu_parity.py",
-             "fp16x3": "<= 8e-7 rel-L2 per forward on every golden fixture, the exact-fp32 mode's own figure; distance to a float64 "
-                       "evaluation 3.5e-7 vs 3.8e-7 (exact fp32), 3.2e-7 (bf16x6) and 3.0e-7 (float32 reference), "
+    bound = {"fp16x3": "<= 8e-7 rel-L2 per forward on every golden fixture, the exact-fp32 mode's own figure; distance to a float64 "
+                       "evaluation 3.5e-7 vs 3.8e-7 (exact fp32) and 3.0e-7 (float32 reference), "
                        "tests/test_gpu_parity.py; operands ranged per matrix / per edge row by exact powers of two: no range assumption"}
     return {"max_rel_l2_vs_fp32_path": float(f"{worst:.3e}"), "bound_vs_reference": bound[mode]}
 
@@ -390,7 +386,7 @@ def other_configs(args, dev) -> dict:
     m9 = build_model(256, 9, 1000, dev, 0, 1)
     m6 = build_model(256, 6, 1000, dev, 0, 1)
     m5 = build_model(256, 6, 1000, dev, 0, 1, context_nf=1, cls=EnVariationalDiffusion)
-    for prec in ("fp32", "fp16x3", "bf16x6", "bf16x3"):
+    for prec in ("fp32", "fp16x3"):
         for m in (m9s, m6s, m9, m6, m5):
             m.dynamics.precision = prec
         blk = {}
@@ -492,17 +488,8 @@ def next_rows(dev) -> dict:
                                                  "loss_value_no_grad_ms": round(dv * 1e3, 2),
                                                  "what": "DiffusionQM9.training_step + backward + AdamW.step, the same batch every step "
                                                          "(its topology is cached); every kernel exact fp32"}
-        # opt-in mixed mode (dynamics.training_precision = "bf16x6"): the edge layer's four H x H contraction sites in the fp32-accurate bf16 split
-        m.dynamics.training_precision = "bf16x6"
-        for _ in range(2):
-            step()
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for _ in range(5):
-            step()
-        torch.cuda.synchronize(dev)
-        d6 = (time.perf_counter() - t0) / 5
-        # round 5: the same four sites in the two-way FP16 split, on top of the kept second-layer pre-activations
+        # opt-in mixed mode (dynamics.training_precision = "fp16x3"): the edge layer's contraction sites in the two-way FP16 split, on top
+        # of the kept second-layer pre-activations
         m.dynamics.training_precision = "fp16x3"
         for _ in range(2):
             step()
@@ -513,14 +500,9 @@ def next_rows(dev) -> dict:
         torch.cuda.synchronize(dev)
         d3 = (time.perf_counter() - t0) / 5
         m.dynamics.training_precision = "fp32"
-        out[f"training_step_B{B}_N30_L6_bf16x6_contractions"] = {
-            "ms_per_step": round(d6 * 1e3, 2), "molecules_per_s": round(B / d6, 1),
-            "what": "the same step with training_precision = 'bf16x6': hd_edge_layer_forward_s / hd_edge_layer_backward_s (precision 2) "
-                    "+ hd_dw2_x6; node GEMMs, first-layer GEMMs and loss exact fp32; gradients within 6e-6 of the oracle's "
-                    "(tests/test_gpu_training.py)"}
         out[f"training_step_B{B}_N30_L6_fp16x3_contractions"] = {
             "ms_per_step": round(d3 * 1e3, 2), "molecules_per_s": round(B / d3, 1),
-            "what": "training_precision = 'fp16x3' (precision 3 + hd_dw2_f16; layers of a batch too small to keep pre2 run in bf16x6): "
+            "what": "training_precision = 'fp16x3' (precision 3 + hd_dw2_f16; layers of a batch too small to keep pre2 run in exact fp32): "
                     "gradients within 2e-6 of the exact-fp32 step's (tests/test_gpu_training.py)"}
         # what a real training loop sees: NEW masks every step, i.e. one topology build per step inside the timed region.  Same
         # WORK in the rows below: one multiset of ragged sizes (12 .. 30 nodes, mean 21), either the same batch every step
@@ -608,6 +590,7 @@ def next_rows(dev) -> dict:
     lay = lay.to(dev)
     for _ in range(3):
         lay(hh, [row, col], xx, edge_attr=ea, node_mask=nmask, edge_mask=emask)
+    lay._frozen = True          # as inside Edge_denoise: parameters verified once per model call (key + content digest), not per layer
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for _ in range(20):
@@ -674,14 +657,14 @@ def self_launch(n_gpus: int, argv) -> int:
 
 def driver_visible_order(out: dict) -> dict:
     """Key order of the JSON line.  The driver's record keeps the last ~8 KB of the line, so the
-    blocks this tier credits go LAST: the rows outside the hot path (training, stage 2) and the superseded bf16 modes first,
+    blocks this tier credits go LAST: the rows outside the hot path (training, stage 2) first,
     then `configs` with the exact-fp32 block as its last entry, the fp16x3 headline block, and finally the contract's own
     keys with `roofline` and `cpu_baseline`.  A JSON object is unordered for every parser; this is about the truncated copy."""
-    first = ["next_rows", "bf16x3", "bf16x6", "configs", "fp16x3"]
+    first = ["next_rows", "configs", "fp16x3"]
     ordered = {k: out[k] for k in first if k in out}
     if isinstance(ordered.get("configs"), dict):
         c = ordered["configs"]
-        inner = [k for k in c if k not in ("bf16x3", "bf16x6", "fp16x3", "f32")] + [k for k in ("bf16x3", "bf16x6", "fp16x3", "f32") if k in c]
+        inner = [k for k in c if k not in ("fp16x3", "f32")] + [k for k in ("fp16x3", "f32") if k in c]
         ordered["configs"] = {k: c[k] for k in inner}
     last = ["config", "roofline", "cpu_baseline"]
     for k, v in out.items():
@@ -694,12 +677,9 @@ def driver_visible_order(out: dict) -> dict:
 
 
 NOTES = {"fp32": "exact fp32 MFMA (v_mfma_f32_32x32x2_f32), the reference's arithmetic",
-         "bf16x6": "fp32-accurate: per-edge H x H contraction on a three-way bf16 split (24 significant bits), 6 bf16 MFMAs per "
-                   "product, fp32 accumulate; node-level GEMMs exact fp32",
          "fp16x3": "fp32-accurate: per-edge H x H contraction on a two-way fp16 split (22 significant bits, operands ranged by exact "
                    "powers of two), 3 fp16 MFMAs per product, fp32 accumulate; node update in the same two-piece fp16 arithmetic "
-                   "from width 128 up (k_node<..., F16>), exact fp32 node kernels below",
-         "bf16x3": "fp32 operands split into bf16 head + tail, 3 bf16 MFMAs per product, fp32 accumulate"}
+                   "from width 128 up (k_node<..., F16>), exact fp32 node kernels below"}
 
 
 def main() -> None:
@@ -712,8 +692,8 @@ def main() -> None:
     ap.add_argument("--layers", type=int, default=6)
     ap.add_argument("--hidden", type=int, default=256)
     ap.add_argument("--timesteps", type=int, default=1000)
-    ap.add_argument("--precision", choices=["all", "fp32", "fp16x3", "bf16x6", "bf16x3"], default="all",
-                    help="'all' (default): headline = exact fp32, plus the bf16x6 and bf16x3 sibling blocks; a single mode "
+    ap.add_argument("--precision", choices=["all", "fp32", "fp16x3"], default="all",
+                    help="'all' (default): headline = exact fp32, plus the fp16x3 sibling block; a single mode "
                          "times only that mode (profiling runs)")
     ap.add_argument("--graph", action="store_true", help="replay each diffusion step from a captured hipGraph")
     ap.add_argument("--event-stride", type=int, default=8,
@@ -752,7 +732,7 @@ def main() -> None:
 
     H, L, B, N, T = args.hidden, args.layers, args.batch, args.nodes, args.timesteps
     model = build_model(H, L, T, dev, rank, world, dist_on=dist is not None)
-    modes = ["fp32", "fp16x3", "bf16x6", "bf16x3"] if args.precision == "all" else [args.precision]
+    modes = ["fp32", "fp16x3"] if args.precision == "all" else [args.precision]
     blocks = {p: timed_headline(model, p, args, dev, rank, world, dist) for p in modes}
 
     if rank != 0:
@@ -786,7 +766,7 @@ def main() -> None:
                                       "the timed region; none on the data path"}
     if "roofline" in hb:
         out["roofline"] = hb["roofline"]
-    for mode in ("fp16x3", "bf16x6", "bf16x3"):
+    for mode in ("fp16x3",):
         if mode in blocks and head != mode:
             sib = dict(blocks[mode])
             sib["precision_note"] = "opt-in mode: " + NOTES[mode] + "; same K steps, same workload, same process as the headline"

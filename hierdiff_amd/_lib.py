@@ -58,10 +58,7 @@ SIGNATURES = {
     "hd_topology_nodes": (C.c_int, [_VP, _VP]),
     "hd_topology_nodes_device": (C.c_int, [_VP, _VP, _VP]),
     "hd_edge_layer_forward": (C.c_int, [_VP, _VP, C.c_int] + [_FP] * 9 + [_VP]),
-    "hd_edge_layer_forward_p": (C.c_int, [_VP, _VP, C.c_int, C.c_int] + [_FP] * 9 + [_VP]),
-    "hd_dw2_x6": (C.c_int, [C.c_int, C.c_int, C.c_int, _FP, _FP, _FP, C.c_int, _FP, C.c_longlong, _VP]),
     "hd_edge_layer_backward": (C.c_int, [_VP, _VP, C.c_int] + [_FP] * 20 + [_VP]),
-    "hd_edge_layer_backward_p": (C.c_int, [_VP, _VP, C.c_int, C.c_int] + [_FP] * 20 + [_VP]),
     "hd_vlb_loss_forward": (C.c_int, [C.c_int] * 7 + [C.c_float] * 4 + [_FP] * 9 + [_VP]),
     "hd_vlb_loss_backward": (C.c_int, [C.c_int] * 7 + [C.c_float] * 4 + [_FP] * 11 + [_VP]),
     "hd_edge_prep": (C.c_int, [C.c_int, C.c_int, C.c_int] + [_FP] * 5 + [_VP]),
@@ -90,7 +87,7 @@ SIGNATURES = {
     "hd_debug_edge_trace": (C.c_int, [_VP, C.c_void_p, C.c_int]),
 }
 
-ABI_VERSION = 11          # HD_ABI_VERSION of include/hierdiff_hip.h
+ABI_VERSION = 12          # HD_ABI_VERSION of include/hierdiff_hip.h
 _lib: Optional[C.CDLL] = None
 
 
@@ -196,7 +193,7 @@ def params_digest(tensors) -> int:
             for t in ts:
                 prefix.append(prefix[-1] + t.numel())
             tab = (torch.tensor([t.data_ptr() for t in ts], dtype=torch.int64, device=dev),
-                   torch.tensor(prefix, dtype=torch.int64, device=dev), torch.zeros(1, dtype=torch.int64, device=dev), prefix[-1])
+                   torch.tensor(prefix, dtype=torch.int64, device=dev), torch.zeros(2, dtype=torch.int64, device=dev), prefix[-1])
             _DIGEST_TABLES[key] = tab
         out = C.c_uint64(0)
         with torch.cuda.device(idx):

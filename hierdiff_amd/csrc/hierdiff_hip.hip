@@ -66,12 +66,11 @@ struct hd_handle {
     int device;
     int H, fin, F, D, NS;       // NS: 32-column sub-tiles per k_gemm workgroup tile
     // arithmetic of the two kernel families, derived from cfg.precision and the width (hd_create):
-    //   edge_mode 0 fp32 | 1 bf16x3 | 2 bf16x6 | 3 fp16x3      node_mode 0 fp32 (k_node_f32 / k_gemm_r16) | 1 bf16 two-piece | 2 bf16 three-piece | 3 fp16 two-piece
-    //   precision 0: 0 / 0;  1: 1 / 1;  2: 2 / 2 (H >= 128, else 0 / 0);  3: 3 / 3 (H >= 128), else 3 / 0
-    // `scaled`: the edge model runs in the domain scaled by -log2(e) (two-way modes, silu_scaled in common.hpp)
+    //   edge_mode 0 fp32 | 3 fp16x3      node_mode 0 fp32 (k_node_f32 / k_node_split_f32 / k_gemm_r16) | 3 fp16 two-piece
+    //   precision 0: 0 / 0;  3: 3 / 3 (H >= 128), else 3 / 0        (1 = bf16x3 and 2 = bf16x6 were retired in ABI 12)
+    // `scaled`: the edge model runs in the domain scaled by -log2(e) (fp16x3, silu_scaled in common.hpp)
     int edge_mode, node_mode;
     bool scaled;
-    bool x6;                    // edge_mode == 2
     long long n_weights;
     bool weights_set;
     float* dw;                  // packed weights
@@ -224,7 +223,8 @@ extern "C" int hd_create(const hd_config* cfg, int device, hd_handle** out) {
     const int F = cfg->in_node_nf - (cfg->condition_time ? 1 : 0);
     if (F < 1) return fail(HD_E_INVALID, "hd_create: in_node_nf must leave at least one feature column");
     if (cfg->context_node_nf < 0) return fail(HD_E_INVALID, "hd_create: context_node_nf < 0");
-    if (cfg->precision < 0 || cfg->precision > 3) return fail(HD_E_INVALID, "hd_create: precision must be 0 (fp32), 1 (bf16x3), 2 (bf16x6) or 3 (fp16x3)");
+    if (cfg->precision != 0 && cfg->precision != 3)
+        return fail(HD_E_INVALID, "hd_create: precision must be 0 (fp32) or 3 (fp16x3); 1 (bf16x3) and 2 (bf16x6) were retired in ABI 12");
     if (!cfg->aggregation_mean && !(cfg->normalization_factor != 0.0f)) return fail(HD_E_INVALID, "hd_create: normalization_factor == 0");
     if (hd_device_count() <= device || device < 0)
         return fail(HD_E_HIP, "hd_create: no such HIP device (is a GPU visible?)");
@@ -239,13 +239,10 @@ extern "C" int hd_create(const hd_config* cfg, int device, hd_handle** out) {
     {
         const bool wide = cfg->hidden_nf >= 128;
         switch (cfg->precision) {
-            case 1: h->edge_mode = 1; h->node_mode = 1; break;
-            case 2: h->edge_mode = wide ? 2 : 0; h->node_mode = wide ? 2 : 0; break;
             case 3: h->edge_mode = 3; h->node_mode = wide ? 3 : 0; break;
             default: h->edge_mode = 0; h->node_mode = 0; break;
         }
-        h->scaled = h->edge_mode == 1 || h->edge_mode == 3;
-        h->x6 = h->edge_mode == 2;
+        h->scaled = h->edge_mode == 3;
     }
     h->NS = (cfg->hidden_nf == 32) ? 1 : 2;
     h->n_weights = weight_count(*cfg);
@@ -371,46 +368,9 @@ static void pack_edge_w2(std::vector<float>& dst, size_t off, int H, const float
                     }
 }
 
-// bf16 round-to-nearest-even of an fp32 value (bit pattern in the low 16 bits)
-static inline uint16_t bf16_rne(float v) {
-    uint32_t u;
-    std::memcpy(&u, &v, 4);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
-}
-static inline float bf16_to_f32(uint16_t b) {
-    uint32_t u = (uint32_t)b << 16;
-    float v;
-    std::memcpy(&v, &u, 4);
-    return v;
-}
-static inline void bf16_split(float v, uint16_t& hi, uint16_t& lo) {
-    hi = bf16_rne(v);
-    lo = bf16_rne(v - bf16_to_f32(hi));
-}
-
-// bf16x3 images (same byte size as the fp32 ones: 2 B head + 2 B tail per weight).
-// fused node kernel (k_node): [k-step s][column tile ct][hi|lo][64 lanes][8], k = 16s + 8*(lane>>5) + i, col = 32ct + (lane&31).
-template <typename Fn>
-static void pack_node_b(std::vector<float>& dstf, size_t off, int K, int Nc, Fn W, int NP = 2) {
-    uint16_t* dst = reinterpret_cast<uint16_t*>(dstf.data() + off);
-    const int nct = Nc / 32;
-    for (int st = 0; st < K / 16; ++st)
-        for (int ct = 0; ct < nct; ++ct)
-            for (int lane = 0; lane < 64; ++lane)
-                for (int i = 0; i < 8; ++i) {
-                    float v = W(32 * ct + (lane & 31), 16 * st + 8 * (lane >> 5) + i);
-                    const size_t base = ((size_t)(st * nct + ct) * NP) * 512;
-                    for (int p = 0; p < NP; ++p) {                    // NP = 2: head, tail; 3 (bf16x6): head, middle, tail
-                        const uint16_t piece = bf16_rne(v);
-                        dst[base + (size_t)p * 512 + (size_t)lane * 8 + i] = piece;
-                        v -= bf16_to_f32(piece);
-                    }
-                }
-}
-
-// FP16 node kernel: pack_node_b's two-piece layout with FP16 pieces of W x 2^k (largest |element| in [2^14, 2^15)).  Returns 2^k;
+// FP16 node kernel (k_node<..., F16>): [k-step s][column tile ct][hi|lo][64 lanes][8] halves, k = 16s + 8*(lane>>5) + i,
+// col = 32ct + (lane&31) - the same byte size as an fp32 image - holding the two FP16 pieces of W x 2^k (largest |element| in
+// [2^14, 2^15)).  Returns 2^k;
 // *l1 = max over output columns of sum_k |W[col][k]| (the constant of the kernel's row bounds).
 template <typename Fn>
 static float pack_node_b_f16(std::vector<float>& dstf, size_t off, int K, int Nc, Fn W, float* l1) {
@@ -439,25 +399,6 @@ static float pack_node_b_f16(std::vector<float>& dstf, size_t off, int K, int Nc
     return sw;
 }
 
-// bf16x6 edge kernel: per 16-wide K chunk [head|middle|tail][H/32 ct][64 lanes][8], k = 16c + 8*(lane>>5) + i
-// (1.5x the bytes of the fp32 image: three bf16 pieces per weight).
-static void pack_edge_w2_x6(std::vector<float>& dstf, size_t off, int H, const float* W2) {
-    uint16_t* dst = reinterpret_cast<uint16_t*>(dstf.data() + off);
-    const int NCT = H / 32;
-    for (int c = 0; c < H / 16; ++c)
-        for (int ct = 0; ct < NCT; ++ct)
-            for (int lane = 0; lane < 64; ++lane)
-                for (int i = 0; i < 8; ++i) {
-                    const float v = W2[(size_t)(32 * ct + (lane & 31)) * H + 16 * c + 8 * (lane >> 5) + i];
-                    const uint16_t hi = bf16_rne(v);
-                    const float r = v - bf16_to_f32(hi);
-                    const uint16_t mi = bf16_rne(r);
-                    const uint16_t lo = bf16_rne(r - bf16_to_f32(mi));
-                    const size_t base = (size_t)c * 3 * NCT * 512 + (size_t)ct * 512 + (size_t)lane * 8 + i;
-                    dst[base] = hi; dst[base + (size_t)NCT * 512] = mi; dst[base + (size_t)2 * NCT * 512] = lo;
-                }
-}
-
 // fused fp32 node kernel (k_node_f32): [32-wide K chunk s][column tile ct][4 q][64 lanes][4 j] floats,
 // k = 32s + 16*(lane>>5) + 4q + j, col = 32ct + (lane&31).
 template <typename Fn>
@@ -472,26 +413,8 @@ static void pack_node_b_f32(std::vector<float>& dst, size_t off, int K, int Nc, 
                             W(32 * ct + (lane & 31), 32 * st + 16 * (lane >> 5) + 4 * q + j);
 }
 
-// edge kernel: per K chunk [hi|lo][2 k-steps][H/32 ct][64 lanes][8], k = 32c + 16*(lane>>5) + 8s + i.
-static void pack_edge_w2_bf(std::vector<float>& dstf, size_t off, int H, const float* W2) {
-    uint16_t* dst = reinterpret_cast<uint16_t*>(dstf.data() + off);
-    const int NCT = H / 32;
-    for (int c = 0; c < H / 32; ++c)
-        for (int st = 0; st < 2; ++st)
-            for (int ct = 0; ct < NCT; ++ct)
-                for (int lane = 0; lane < 64; ++lane)
-                    for (int i = 0; i < 8; ++i) {
-                        const int k = 32 * c + 16 * (lane >> 5) + 8 * st + i;
-                        const int col = 32 * ct + (lane & 31);
-                        uint16_t hi, lo;
-                        bf16_split(W2[(size_t)col * H + k], hi, lo);
-                        const size_t blk = (size_t)c * 32 * H * 2;
-                        dst[blk + (((size_t)(0 * 2 + st) * NCT + ct) * 64 + lane) * 8 + i] = hi;
-                        dst[blk + (((size_t)(1 * 2 + st) * NCT + ct) * 64 + lane) * 8 + i] = lo;
-                    }
-}
-
-// fp16x3 edge kernel: pack_edge_w2_bf's layout with fp16 pieces of W2 x 2^k, 2^k the power of two that puts the largest
+// fp16x3 edge kernel: per K chunk [hi|lo][2 k-steps][H/32 ct][64 lanes][8] halves, k = 32c + 16*(lane>>5) + 8s + i, holding the two
+// fp16 pieces of W2 x 2^k, 2^k the power of two that puts the largest
 // |element| into [2^14, 2^15) (so heads stay finite and the tails of all but negligible elements normal).  Returns 2^k.
 static float pack_edge_w2_f16(std::vector<float>& dstf, size_t off, int H, const float* W2) {
     float wmax = 0.0f;
@@ -536,9 +459,8 @@ extern "C" int hd_set_weights(hd_handle* h, const float* blob, long long n, int 
     const int H = h->H, fin = h->fin;
     const int L = c.n_layers, S = c.inv_sublayers;
     const bool bf = h->scaled;                                // two-way edge modes: scaled domain
-    const size_t w2_floats = h->x6 ? (size_t)H * H * 3 / 2 : (size_t)H * H;
-    const size_t gx = h->node_mode == 2 ? 3 : 2;              // node weight images: x gx / 2 (three bf16 pieces per weight)
-    const int NPc = h->node_mode == 2 ? 3 : 2;
+    const size_t w2_floats = (size_t)H * H;
+    const size_t gx = 2;                                      // node weight images: two fp16 pieces (or one fp32 word) per weight
     const bool nodef32 = h->node_mode == 0;                   // k_node_f32 / k_gemm_r16
     // layout of the packed buffer
     size_t off = 0;
@@ -577,7 +499,7 @@ extern "C" int hd_set_weights(hd_handle* h, const float* blob, long long n, int 
         std::copy(Wo, Wo + (size_t)fin * H, pk.begin() + h->outW);
         std::copy(bo, bo + fin, pk.begin() + h->out_b);
     }
-    // bf16x3 mode runs the edge model in a scaled domain (see silu_scaled in common.hpp): everything feeding a
+    // fp16x3 mode runs the edge model in a scaled domain (see silu_scaled in common.hpp): everything feeding a
     // SiLU / sigmoid of the edge kernel carries c = -log2(e), its consumers carry 1/c.  One rounding per weight.
     const double cs = bf ? -1.4426950408889634074 : 1.0, cs_inv = 1.0 / cs;
     auto sc = [&](float v) { return (float)((double)v * cs); };
@@ -590,8 +512,7 @@ extern "C" int hd_set_weights(hd_handle* h, const float* blob, long long n, int 
         };
         w.abs_ = 1.0f;
         if (nodef32) { pack_node_b_f32(pk, w.ab_img, H, 2 * H, wab); pack_gemm_b16(pk, w.ab_gimg, H, 2 * H, wab); }
-        else if (h->node_mode == 3) w.abs_ = pack_node_b_f16(pk, w.ab_img, H, 2 * H, wab, nullptr);
-        else pack_node_b(pk, w.ab_img, H, 2 * H, wab, NPc);
+        else w.abs_ = pack_node_b_f16(pk, w.ab_img, H, 2 * H, wab, nullptr);
         for (int k = 0; k < H; ++k) {
             pk[w.ab_bias + k] = sc(b1[k]);
             pk[w.ab_bias + H + k] = 0.0f;
@@ -606,12 +527,9 @@ extern "C" int hd_set_weights(hd_handle* h, const float* blob, long long n, int 
     };
     // second edge Linear in the image of the handle's edge mode; returns the scale S its accumulators carry (1 but for fp16x3)
     auto pack_w2 = [&](LayerW& w, const float* W2) -> float {
-        switch (h->edge_mode) {
-            case 1: pack_edge_w2_bf(pk, w.w2_img, H, W2); return 1.0f;
-            case 2: pack_edge_w2_x6(pk, w.w2_img, H, W2); return 1.0f;
-            case 3: return pack_edge_w2_f16(pk, w.w2_img, H, W2);
-            default: pack_edge_w2(pk, w.w2_img, H, W2); return 1.0f;
-        }
+        if (h->edge_mode == 3) return pack_edge_w2_f16(pk, w.w2_img, H, W2);
+        pack_edge_w2(pk, w.w2_img, H, W2);
+        return 1.0f;
     };
     for (int i = 0; i < L; ++i) {
         for (int j = 0; j < S; ++j) {
@@ -630,14 +548,11 @@ extern "C" int hd_set_weights(hd_handle* h, const float* blob, long long n, int 
                 pack_node_b_f32(pk, w.w4_img, H, H, w4);
                 pack_gemm_b16(pk, w.w3_gimg, 2 * H, H, w3);
                 pack_gemm_b16(pk, w.w4_gimg, H, H, w4);
-            } else if (h->node_mode == 3) {
+            } else {
                 w.w3s = pack_node_b_f16(pk, w.w3_img, 2 * H, H, w3, &w.w3l1);
                 w.w4s = pack_node_b_f16(pk, w.w4_img, H, H, w4, &w.w4l1);
                 w.b3max = w.b4max = 0.0f;
                 for (int k = 0; k < H; ++k) { w.b3max = std::max(w.b3max, std::fabs(b3[k])); w.b4max = std::max(w.b4max, std::fabs(b4[k])); }
-            } else {
-                pack_node_b(pk, w.w3_img, 2 * H, H, w3, NPc);
-                pack_node_b(pk, w.w4_img, H, H, w4, NPc);
             }
             for (int k = 0; k < H; ++k) pk[w.b2 + k] = sc(b2[k]);
             std::copy(b3, b3 + H, pk.begin() + w.b3);
@@ -986,7 +901,7 @@ extern "C" int hd_topology_create_s(hd_handle* h, const uint8_t* node_mask, cons
     const size_t f_part = carve((size_t)std::max(1, n_parts) * H), f_xpart = carve((size_t)std::max(1, n_parts) * 4);
     const size_t f_abmax = carve((size_t)M_pad * 2), f_abmax2 = carve((size_t)M_pad * 2), f_rowinfo = carve((size_t)M_pad * 2);
     const size_t f_eps = carve(BN * h->D), f_z = carve(BN * h->D), f_ctx = carve(BN * (size_t)std::max(1, h->cfg.context_node_nf));
-    const size_t f_w2 = carve((size_t)H * H * 3 / 2), f_w2t = carve((size_t)H * H * 3 / 2);      // fp32 images or the 1.5 x bf16x6 ones
+    const size_t f_w2 = carve((size_t)H * H * 3 / 2), f_w2t = carve((size_t)H * H * 3 / 2);      // fp32 / fp16 images (H^2 floats) + room behind them: the fp16x3 training forward parks its image scalars there
     auto build = [&]() -> int {
         ArenaSlot sl;
         HD_TRY(arena_acquire(h->device, table_bytes + ws_floats * sizeof(float), table_bytes, sl));
@@ -1132,9 +1047,9 @@ static void gemm_r16(hd_handle* h, int epi, bool agg, const R16Args& g, hipStrea
     launch_r16<1>(epi, agg, g, s);      // 32-row workgroups (RT = 2) were measured: slower up to B = 64, equal above (profiles/r03_r16_sweep2.log)
 }
 
-// Fused node update (bf16x3 only): min(4, H/32) wavefronts per 32-row workgroup.
+// Fused node update in two-piece FP16 arithmetic (k_node<..., F16>), 32-row workgroups.
 template <int H>
-static int node_lds_bytes(bool upd, int np = 2) {        // region 0: the np bf16 pieces of X; region 1: those of T / the fp32 staging tile
+static int node_lds_bytes(bool upd, int np = 2) {        // region 0: the two fp16 pieces of X; region 1: those of T / the fp32 staging tile
     const int r1 = std::max(32 * (H + 8) * 2 * np, 32 * (H + 4) * 4);
     return 32 * ((upd ? 2 * H : H) + 8) * 2 * np + r1;
 }
@@ -1143,10 +1058,9 @@ template <int H>
 static int node_f32_lds_bytes(bool upd) { return 32 * ((upd ? 2 * H : H) + 4) * 4 + 32 * (H + 4) * 4; }
 
 template <int H, int NW>
-static void launch_node_hw(bool upd, int nab, int mode, const NodeArgs& a, hipStream_t s) {      // mode: 0 fp32, 1 bf16x3, 2 bf16x6
+static void launch_node_hw(bool upd, int nab, int mode, const NodeArgs& a, hipStream_t s) {      // mode: 0 fp32, 3 fp16 two-piece
     const int nrt = (a.M + 31) / 32;
     const dim3 grid(8 * ((nrt + 7) / 8)), block(64 * NW);
-    const bool x6 = mode == 2;
     if (mode == 0) {
         const int ldsf = node_f32_lds_bytes<H>(upd);
         if (!upd) hipLaunchKernelGGL((k_node_f32<H, NW, false, 1>), grid, block, ldsf, s, a);
@@ -1154,34 +1068,16 @@ static void launch_node_hw(bool upd, int nab, int mode, const NodeArgs& a, hipSt
         else hipLaunchKernelGGL((k_node_f32<H, NW, true, 2>), grid, block, ldsf, s, a);
         return;
     }
-    if constexpr (H >= 128) {
-        if (x6) {
-            const int lds6 = node_lds_bytes<H>(upd, 3);
-            if (!upd) hipLaunchKernelGGL((k_node<H, NW, false, 1, 3>), grid, block, lds6, s, a);
-            else if (nab == 1) hipLaunchKernelGGL((k_node<H, NW, true, 1, 3>), grid, block, lds6, s, a);
-            else hipLaunchKernelGGL((k_node<H, NW, true, 2, 3>), grid, block, lds6, s, a);
-            return;
-        }
+    if constexpr (H >= 128) {                              // two-piece FP16 (fp16x3 mode; narrower widths run the fp32 node kernels)
+        const int lds = node_lds_bytes<H>(upd);
+        if (!upd) hipLaunchKernelGGL((k_node<H, NW, false, 1, 2, true>), grid, block, lds, s, a);
+        else if (nab == 1) hipLaunchKernelGGL((k_node<H, NW, true, 1, 2, true>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((k_node<H, NW, true, 2, 2, true>), grid, block, lds, s, a);
     }
-    const int lds = node_lds_bytes<H>(upd);
-    if constexpr (H >= 128) {
-        if (mode == 3) {                                   // two-piece FP16 (fp16x3 mode)
-            if (!upd) hipLaunchKernelGGL((k_node<H, NW, false, 1, 2, true>), grid, block, lds, s, a);
-            else if (nab == 1) hipLaunchKernelGGL((k_node<H, NW, true, 1, 2, true>), grid, block, lds, s, a);
-            else hipLaunchKernelGGL((k_node<H, NW, true, 2, 2, true>), grid, block, lds, s, a);
-            return;
-        }
-    }
-    if (!upd) hipLaunchKernelGGL((k_node<H, NW, false, 1>), grid, block, lds, s, a);
-    else if (nab == 1) hipLaunchKernelGGL((k_node<H, NW, true, 1>), grid, block, lds, s, a);
-    else hipLaunchKernelGGL((k_node<H, NW, true, 2>), grid, block, lds, s, a);
 }
 
 template <int H, int NW>
 static int prepare_node_hw() {
-    HIP_TRY(hipFuncSetAttribute((const void*)k_node<H, NW, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, node_lds_bytes<H>(false)));
-    HIP_TRY(hipFuncSetAttribute((const void*)k_node<H, NW, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, node_lds_bytes<H>(true)));
-    HIP_TRY(hipFuncSetAttribute((const void*)k_node<H, NW, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, node_lds_bytes<H>(true)));
     HIP_TRY(hipFuncSetAttribute((const void*)k_node_f32<H, NW, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, node_f32_lds_bytes<H>(false)));
     HIP_TRY(hipFuncSetAttribute((const void*)k_node_f32<H, NW, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, node_f32_lds_bytes<H>(true)));
     HIP_TRY(hipFuncSetAttribute((const void*)k_node_f32<H, NW, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, node_f32_lds_bytes<H>(true)));
@@ -1189,11 +1085,6 @@ static int prepare_node_hw() {
         HIP_TRY(hipFuncSetAttribute((const void*)k_node<H, NW, false, 1, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, node_lds_bytes<H>(false)));
         HIP_TRY(hipFuncSetAttribute((const void*)k_node<H, NW, true, 1, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, node_lds_bytes<H>(true)));
         HIP_TRY(hipFuncSetAttribute((const void*)k_node<H, NW, true, 2, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, node_lds_bytes<H>(true)));
-    }
-    if constexpr (H >= 128) {
-        HIP_TRY(hipFuncSetAttribute((const void*)k_node<H, NW, false, 1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, node_lds_bytes<H>(false, 3)));
-        HIP_TRY(hipFuncSetAttribute((const void*)k_node<H, NW, true, 1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, node_lds_bytes<H>(true, 3)));
-        HIP_TRY(hipFuncSetAttribute((const void*)k_node<H, NW, true, 2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, node_lds_bytes<H>(true, 3)));
     }
     return HD_OK;
 }
@@ -1270,13 +1161,13 @@ static int prepare_node_split_h() {
 }
 
 template <int H>
-static int edge_lds_bytes(bool x6 = false) {       // dynamic part: W2 double buffer + wave scratch (w_r/w_d/b2/wa are static)
-    return (2 * (x6 ? 24 : 32) * H + 2 * H + 4 * 136) * 4;
+static int edge_lds_bytes() {       // dynamic part: W2 double buffer + wave scratch (w_r/w_d/b2/wa are static)
+    return (2 * 32 * H + 2 * H + 4 * 136) * 4;
 }
 
 #ifdef HD_DEBUG_KERNELS
 // Measurement build only (python -m hierdiff_amd.build --debug-kernels): HD_ABLATE=<bits> selects an ablated
-// instantiation of the H=256 bf16x3 GCL edge kernel; bit 16 records per-wave cycle stamps (hd_debug_edge_trace).
+// instantiation of the H=256 GCL edge kernel; bit 16 records per-wave cycle stamps (hd_debug_edge_trace).
 // Not compiled into the product library: the variants change results and allocate on first use.
 extern "C" int hd_debug_edge_trace(hd_handle* h, long long* out, int max_wg) {
     if (!h || !h->d_trace) return 0;
@@ -1296,7 +1187,7 @@ extern "C" int hd_debug_node_trace(long long* out, int max_ll) {
 
 template <int PREC>
 static bool launch_edge_ablated(hd_handle* h, const EdgeArgs& a, hipStream_t s) {
-    const int lds = edge_lds_bytes<256>(PREC == 2);
+    const int lds = edge_lds_bytes<256>();
     const dim3 grid(a.n_wg), block(256);
     auto run = [&](auto Abl) {
         constexpr int ABL = decltype(Abl)::value;
@@ -1345,14 +1236,13 @@ static bool edge_runs_mixed(const hd_handle* h, int n_tiles, int mode) {
     return n_tiles > per_round && n_tiles < h->mix_max_tiles && (pays || h->mix_rounds >= 0);
 }
 
-// `mode_override` >= 0 selects the arithmetic of THIS launch (0 fp32, 1 bf16x3, 2 bf16x6) instead of the handle's: the opt-in
-// bf16x6 forward of the training path (hd_edge_layer_forward_p) on a handle whose other kernels stay exact fp32
+// `mode_override` >= 0 selects the arithmetic of THIS launch (0 fp32, 3 fp16x3) instead of the handle's: the opt-in fp16x3
+// forward of the training path (hd_edge_layer_forward_s) on a handle whose other kernels stay exact fp32
 template <int H>
 static int launch_edge_h(hd_handle* h, bool coord, const EdgeArgs& a, hipStream_t s, int mode_override = -1) {
     const int lds = edge_lds_bytes<H>();
-    // kernel family of this launch: 0 fp32, 1 bf16x3, 2 bf16x6, 3 fp16x3
-    const int prec = mode_override >= 0 ? ((mode_override == 2 && H < 128) ? 0 : mode_override) : h->edge_mode;
-    const bool x6 = prec == 2;
+    // kernel family of this launch: 0 fp32, 3 fp16x3
+    const int prec = mode_override >= 0 ? mode_override : h->edge_mode;
     const dim3 grid(a.n_wg), block(256);
     if constexpr (H >= 128) {
         if (a.dscal) {
@@ -1370,43 +1260,29 @@ static int launch_edge_h(hd_handle* h, bool coord, const EdgeArgs& a, hipStream_
     if (a.pre2) {
         // training forward that keeps pre2 for the backward pass (HD_EDGE_SAVE): always the whole-tile kernel, whose accumulator
         // layout is the saved layout (the caller offers the buffer only where this kernel would run anyway: edge_layer_saves)
-        if constexpr (H >= 128) {
-            if (x6) {
-                const int lds6 = edge_lds_bytes<H>(true);
-                if (coord) hipLaunchKernelGGL((k_edge<H, true, 2, HD_EDGE_SAVE>), grid, block, lds6, s, a);
-                else hipLaunchKernelGGL((k_edge<H, false, 2, HD_EDGE_SAVE>), grid, block, lds6, s, a);
-                return HD_OK;
-            }
-        }
         if (coord) hipLaunchKernelGGL((k_edge<H, true, 0, HD_EDGE_SAVE>), grid, block, lds, s, a);
         else hipLaunchKernelGGL((k_edge<H, false, 0, HD_EDGE_SAVE>), grid, block, lds, s, a);
         return HD_OK;
     }
 #ifdef HD_DEBUG_KERNELS
     if constexpr (H == 256) {
-        if (h->ablate && !coord && (x6 ? launch_edge_ablated<2>(h, a, s) : prec == 1 ? launch_edge_ablated<1>(h, a, s) : prec == 3 ? launch_edge_ablated<3>(h, a, s) : launch_edge_ablated<0>(h, a, s))) return HD_OK;
+        if (h->ablate && !coord && (prec == 3 ? launch_edge_ablated<3>(h, a, s) : launch_edge_ablated<0>(h, a, s))) return HD_OK;
     }
 #endif
     if constexpr (H >= 128) {
         // at most 512 tiles: one tile per workgroup, columns split over its four wavefronts (k_edge_split.hpp; bit-identical
         // to k_edge in every precision mode, a quarter of the serial MFMA chain per wavefront)
         const int mode = prec;
-        // measured break-even (profiles/history/r02_split_sweep.log): between 490 and 654 tiles in the bf16 modes, between 654 and 870
+        // measured break-even (profiles/history/r02_split_sweep.log): between 490 and 654 tiles in the 16-bit split modes, between 654 and 870
         // in fp32 (the longer MFMA chain has more to gain from the split)
         if (edge_runs_split(h, a.n_tiles, mode)) {
             const dim3 sgrid(a.n_tiles);
             if (mode == 0) {
                 if (coord) hipLaunchKernelGGL((k_edge_split<H, true, 0>), sgrid, block, 0, s, a);
                 else hipLaunchKernelGGL((k_edge_split<H, false, 0>), sgrid, block, 0, s, a);
-            } else if (mode == 1) {
-                if (coord) hipLaunchKernelGGL((k_edge_split<H, true, 1>), sgrid, block, 0, s, a);
-                else hipLaunchKernelGGL((k_edge_split<H, false, 1>), sgrid, block, 0, s, a);
-            } else if (mode == 3) {
+            } else {
                 if (coord) hipLaunchKernelGGL((k_edge_split<H, true, 3>), sgrid, block, 0, s, a);
                 else hipLaunchKernelGGL((k_edge_split<H, false, 3>), sgrid, block, 0, s, a);
-            } else {
-                if (coord) hipLaunchKernelGGL((k_edge_split<H, true, 2>), sgrid, block, 0, s, a);
-                else hipLaunchKernelGGL((k_edge_split<H, false, 2>), sgrid, block, 0, s, a);
             }
             return HD_OK;
         }
@@ -1417,50 +1293,33 @@ static int launch_edge_h(hd_handle* h, bool coord, const EdgeArgs& a, hipStream_
         const int mode = prec;
         const int per_round = 4 * h->n_cu;
         // Measured (profiles/r03_mix_sweep*.log, ms per forward, plain -> mixed): fp32 B = 40 1.89 -> 1.45, 64 1.93 -> 1.88,
-        // 96 2.66 -> 2.60, 128 3.29 -> 3.17, 160 4.15 -> 3.89, 192 4.79 -> 4.40, 256 5.41 -> 5.51; the bf16 modes gain only
+        // 96 2.66 -> 2.60, 128 3.29 -> 3.17, 160 4.15 -> 3.89, 192 4.79 -> 4.40, 256 5.41 -> 5.51; the 16-bit split modes gain only
         // while few tiles are left over (B = 40: -14 %; B = 64 ... 256: +2 ... +8 %).  A column-split tile costs about 1.5 x a
         // whole one in SIMD time, so the mix pays when it replaces a badly filled last round: at most 2.9 left-over tiles per
-        // CU in fp32, 1.0 in the bf16 modes.
+        // CU in fp32, 1.0 in fp16x3.
         int R = a.n_tiles / per_round;
         if (edge_runs_mixed(h, a.n_tiles, mode)) {
             if (h->mix_rounds >= 0) R = std::min(R, h->mix_rounds);
             EdgeArgs m = a;
             m.n_wg = R * h->n_cu;
             const dim3 mgrid(m.n_wg + (a.n_tiles - 4 * m.n_wg));
-            const int ldsm = std::max(edge_lds_bytes<H>(mode == 2), mode == 2 ? edge_split_lds_bytes<H, 2>() : edge_split_lds_bytes<H, 0>());
+            const int ldsm = std::max(edge_lds_bytes<H>(), edge_split_lds_bytes<H, 0>());
             if (mode == 0) {
                 if (coord) hipLaunchKernelGGL((k_edge_mixed<H, true, 0>), mgrid, block, ldsm, s, m);
                 else hipLaunchKernelGGL((k_edge_mixed<H, false, 0>), mgrid, block, ldsm, s, m);
-            } else if (mode == 1) {
-                if (coord) hipLaunchKernelGGL((k_edge_mixed<H, true, 1>), mgrid, block, ldsm, s, m);
-                else hipLaunchKernelGGL((k_edge_mixed<H, false, 1>), mgrid, block, ldsm, s, m);
-            } else if (mode == 3) {
+            } else {
                 if (coord) hipLaunchKernelGGL((k_edge_mixed<H, true, 3>), mgrid, block, ldsm, s, m);
                 else hipLaunchKernelGGL((k_edge_mixed<H, false, 3>), mgrid, block, ldsm, s, m);
-            } else {
-                if (coord) hipLaunchKernelGGL((k_edge_mixed<H, true, 2>), mgrid, block, ldsm, s, m);
-                else hipLaunchKernelGGL((k_edge_mixed<H, false, 2>), mgrid, block, ldsm, s, m);
             }
-            return HD_OK;
-        }
-    }
-    if constexpr (H >= 128) {
-        if (x6) {
-            const int lds6 = edge_lds_bytes<H>(true);
-            if (coord) hipLaunchKernelGGL((k_edge<H, true, 2>), grid, block, lds6, s, a);
-            else hipLaunchKernelGGL((k_edge<H, false, 2>), grid, block, lds6, s, a);
             return HD_OK;
         }
     }
     if (prec == 3) {
         if (coord) hipLaunchKernelGGL((k_edge<H, true, 3>), grid, block, lds, s, a);
         else hipLaunchKernelGGL((k_edge<H, false, 3>), grid, block, lds, s, a);
-    } else if (prec != 1) {
+    } else {
         if (coord) hipLaunchKernelGGL((k_edge<H, true, 0>), grid, block, lds, s, a);
         else hipLaunchKernelGGL((k_edge<H, false, 0>), grid, block, lds, s, a);
-    } else {
-        if (coord) hipLaunchKernelGGL((k_edge<H, true, 1>), grid, block, lds, s, a);
-        else hipLaunchKernelGGL((k_edge<H, false, 1>), grid, block, lds, s, a);
     }
     return HD_OK;
 }
@@ -1472,8 +1331,6 @@ static int prepare_edge_h() {
     const int lds = edge_lds_bytes<H>();
     HIP_TRY(hipFuncSetAttribute((const void*)k_edge<H, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIP_TRY(hipFuncSetAttribute((const void*)k_edge<H, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    HIP_TRY(hipFuncSetAttribute((const void*)k_edge<H, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    HIP_TRY(hipFuncSetAttribute((const void*)k_edge<H, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIP_TRY(hipFuncSetAttribute((const void*)k_edge<H, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIP_TRY(hipFuncSetAttribute((const void*)k_edge<H, false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIP_TRY(hipFuncSetAttribute((const void*)k_edge<H, true, 0, HD_EDGE_SAVE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -1483,19 +1340,11 @@ static int prepare_edge_h() {
         HIP_TRY(hipFuncSetAttribute((const void*)k_edge<H, false, 3, HD_EDGE_SAVE | HD_EDGE_UNSCALED>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_edge<H, true, 3, HD_EDGE_UNSCALED>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_edge<H, false, 3, HD_EDGE_UNSCALED>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        HIP_TRY(hipFuncSetAttribute((const void*)k_edge<H, true, 2, HD_EDGE_SAVE>, hipFuncAttributeMaxDynamicSharedMemorySize, edge_lds_bytes<H>(true)));
-        HIP_TRY(hipFuncSetAttribute((const void*)k_edge<H, false, 2, HD_EDGE_SAVE>, hipFuncAttributeMaxDynamicSharedMemorySize, edge_lds_bytes<H>(true)));
-        HIP_TRY(hipFuncSetAttribute((const void*)k_edge<H, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, edge_lds_bytes<H>(true)));
-        HIP_TRY(hipFuncSetAttribute((const void*)k_edge<H, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, edge_lds_bytes<H>(true)));
-        const int m0 = std::max(edge_lds_bytes<H>(false), edge_split_lds_bytes<H, 0>()), m2 = std::max(edge_lds_bytes<H>(true), edge_split_lds_bytes<H, 2>());
+        const int m0 = std::max(edge_lds_bytes<H>(), edge_split_lds_bytes<H, 0>());
         HIP_TRY(hipFuncSetAttribute((const void*)k_edge_mixed<H, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, m0));
         HIP_TRY(hipFuncSetAttribute((const void*)k_edge_mixed<H, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, m0));
-        HIP_TRY(hipFuncSetAttribute((const void*)k_edge_mixed<H, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, m0));
-        HIP_TRY(hipFuncSetAttribute((const void*)k_edge_mixed<H, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, m0));
         HIP_TRY(hipFuncSetAttribute((const void*)k_edge_mixed<H, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, m0));
         HIP_TRY(hipFuncSetAttribute((const void*)k_edge_mixed<H, false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, m0));
-        HIP_TRY(hipFuncSetAttribute((const void*)k_edge_mixed<H, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, m2));
-        HIP_TRY(hipFuncSetAttribute((const void*)k_edge_mixed<H, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, m2));
     }
     return HD_OK;
 }
@@ -1749,7 +1598,7 @@ extern "C" int hd_topology_nodes(const hd_topology* t, int* node_of) {
 }
 
 template <int H>
-static int edge_bwd_lds_bytes(bool x6 = false) { return (2 * (x6 ? 24 : 32) * H + 4 * 288) * 4; }      // two weight chunks + per-wave scratch
+static int edge_bwd_lds_bytes() { return (2 * 32 * H + 4 * 288) * 4; }      // two weight chunks + per-wave scratch
 
 template <int H>
 static int prepare_edge_bwd_h() {
@@ -1759,11 +1608,6 @@ static int prepare_edge_bwd_h() {
     HIP_TRY(hipFuncSetAttribute((const void*)k_edge_bwd<H, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIP_TRY(hipFuncSetAttribute((const void*)k_edge_bwd<H, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     if constexpr (H >= 128) {
-        const int lds6 = edge_bwd_lds_bytes<H>(true);
-        HIP_TRY(hipFuncSetAttribute((const void*)k_edge_bwd<H, false, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds6));
-        HIP_TRY(hipFuncSetAttribute((const void*)k_edge_bwd<H, false, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds6));
-        HIP_TRY(hipFuncSetAttribute((const void*)k_edge_bwd<H, true, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds6));
-        HIP_TRY(hipFuncSetAttribute((const void*)k_edge_bwd<H, true, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds6));
         HIP_TRY(hipFuncSetAttribute((const void*)k_edge_bwd<H, false, 1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_edge_bwd<H, true, 1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     }
@@ -1773,7 +1617,6 @@ static int prepare_edge_bwd_h() {
 template <int H>
 static void launch_edge_bwd_h(bool coord, int stage, int prec, const EdgeBwdArgs& a, int n_wg, hipStream_t s) {
     const dim3 grid(n_wg), block(256);
-    const bool x6 = prec == 2;
     if (stage == 0 && a.pre2) {                     // pre2 kept by the forward pass: stage A loads it (one kernel for both arithmetics)
         const int ldss = 4 * 288 * 4;
         if (coord) hipLaunchKernelGGL((k_edge_bwd<H, true, 0, 0, true>), grid, block, ldss, s, a);
@@ -1785,14 +1628,6 @@ static void launch_edge_bwd_h(bool coord, int stage, int prec, const EdgeBwdArgs
             const int lds = (2 * 16 * H + 4 * 288) * 4;
             if (coord) hipLaunchKernelGGL((k_edge_bwd<H, true, 1, 3>), grid, block, lds, s, a);
             else hipLaunchKernelGGL((k_edge_bwd<H, false, 1, 3>), grid, block, lds, s, a);
-            return;
-        }
-        if (x6) {
-            const int lds6 = edge_bwd_lds_bytes<H>(true);
-            if (!coord && stage == 0) hipLaunchKernelGGL((k_edge_bwd<H, false, 0, 2>), grid, block, lds6, s, a);
-            else if (!coord) hipLaunchKernelGGL((k_edge_bwd<H, false, 1, 2>), grid, block, lds6, s, a);
-            else if (stage == 0) hipLaunchKernelGGL((k_edge_bwd<H, true, 0, 2>), grid, block, lds6, s, a);
-            else hipLaunchKernelGGL((k_edge_bwd<H, true, 1, 2>), grid, block, lds6, s, a);
             return;
         }
     }
@@ -1831,7 +1666,7 @@ extern "C" long long hd_edge_layer_f16ws_floats(hd_handle* h, hd_topology* t, in
 // not pay: batches small enough for the column-split edge kernel keep their faster forward and recompute.
 extern "C" long long hd_edge_layer_save_rows(hd_handle* h, hd_topology* t, int precision) {
     if (!h || !t || t->h != h || t->n_wg == 0 || t->M == 0) return 0;
-    if (precision != 0 && precision != 2 && precision != 3) return 0;
+    if (precision != 0 && precision != 3) return 0;
     const int mode = h->H >= 128 ? precision : 0;
     // (the mix of whole and column-split tiles gains 2-5 % on a forward; the kept pre-activations save the backward a whole contraction:
     // only the pure column-split regime - B <= 18 at N = 30, where that forward is 2 x faster - keeps recomputing)
@@ -1843,10 +1678,9 @@ extern "C" int hd_edge_layer_forward_s(hd_handle* h, hd_topology* t, int coord, 
                                        const float* x0, const float* wrd, const float* W2, const float* b2,
                                        const float* wa, const float* ba, float* out, float* pre2, void* stream) {
     HD_TRY(check_train(h, t, "hd_edge_layer_forward"));
-    if (precision != 0 && precision != 2 && precision != 3)
-        return fail(HD_E_INVALID, "hd_edge_layer_forward: precision must be 0 (fp32), 2 (bf16x6) or 3 (fp16x3)");
-    const bool x6 = precision == 2 && h->H >= 128;          // narrower widths run the exact-fp32 kernels, as in sampling
-    const bool f16 = precision == 3 && h->H >= 128;
+    if (precision != 0 && precision != 3)
+        return fail(HD_E_INVALID, "hd_edge_layer_forward_s: precision must be 0 (fp32) or 3 (fp16x3); 2 (bf16x6) was retired in ABI 12");
+    const bool f16 = precision == 3 && h->H >= 128;         // narrower widths run the exact-fp32 kernels, as in sampling
     topo_use(t, (hipStream_t)stream);
     if (!AB || !x || !x0 || !wrd || !W2 || !b2 || !wa || !out) return fail(HD_E_INVALID, "hd_edge_layer_forward: null tensor");
     HIP_TRY(hipSetDevice(h->device));
@@ -1871,8 +1705,7 @@ extern "C" int hd_edge_layer_forward_s(hd_handle* h, hd_topology* t, int coord, 
         AbMaxArgs am{AB, t->abmax, M, H};
         hipLaunchKernelGGL(k_ab_rowmax, dim3((M + 3) / 4), dim3(256), 0, s, am);
         e.dscal = scal; e.abmax = t->abmax;
-    } else if (x6) hipLaunchKernelGGL((k_pack_w2_x6<false>), dim3((H * H / 2 + 255) / 256), dim3(256), 0, s, W2, reinterpret_cast<uint32_t*>(t->w2img), H);
-    else hipLaunchKernelGGL((k_pack_w2<false>), dim3((H * H + 255) / 256), dim3(256), 0, s, W2, t->w2img, H);
+    } else hipLaunchKernelGGL((k_pack_w2<false>), dim3((H * H + 255) / 256), dim3(256), 0, s, W2, t->w2img, H);
     e.AB = AB; e.wrd = wrd; e.W2img = t->w2img; e.b2 = b2; e.wa = wa;
     e.w2s_inv = 1.0f; e.wrmax = e.wdmax = 0.0f;
     e.ei = t->ei; e.ej = t->ej; e.eseg = t->eseg; e.seg_part = t->seg_part; e.tile_nseg = t->tile_nseg;
@@ -1880,7 +1713,7 @@ extern "C" int hd_edge_layer_forward_s(hd_handle* h, hd_topology* t, int coord, 
     e.norm_constant = c.norm_constant; e.coords_range = c.coords_range / (float)c.n_layers; e.attention = c.attention;
     e.use_tanh = c.tanh; e.n_tiles = t->n_tiles; e.n_wg = t->n_wg;
     e.pre2 = pre2;
-    HD_TRY(edge(h, coord != 0, e, s, f16 ? 3 : x6 ? 2 : 0));
+    HD_TRY(edge(h, coord != 0, e, s, f16 ? 3 : 0));
     AggArgs ag;
     ag.part = coord ? t->xpart : t->part; ag.pstart = t->pstart; ag.agg = out; ag.norm = agg_norm(c, t);
     ag.M = M; ag.H = ow;
@@ -1890,17 +1723,10 @@ extern "C" int hd_edge_layer_forward_s(hd_handle* h, hd_topology* t, int coord, 
     return HD_OK;
 }
 
-extern "C" int hd_edge_layer_forward_p(hd_handle* h, hd_topology* t, int coord, int precision, const float* AB, const float* x,
-                                       const float* x0, const float* wrd, const float* W2, const float* b2,
-                                       const float* wa, const float* ba, float* out, void* stream) {
-    if (precision == 3) return fail(HD_E_INVALID, "hd_edge_layer_forward_p: precision must be 0 (fp32) or 2 (bf16x6)");
-    return hd_edge_layer_forward_s(h, t, coord, precision, AB, x, x0, wrd, W2, b2, wa, ba, out, nullptr, stream);
-}
-
 extern "C" int hd_edge_layer_forward(hd_handle* h, hd_topology* t, int coord, const float* AB, const float* x,
                                      const float* x0, const float* wrd, const float* W2, const float* b2,
                                      const float* wa, const float* ba, float* out, void* stream) {
-    return hd_edge_layer_forward_p(h, t, coord, 0, AB, x, x0, wrd, W2, b2, wa, ba, out, stream);
+    return hd_edge_layer_forward_s(h, t, coord, 0, AB, x, x0, wrd, W2, b2, wa, ba, out, nullptr, stream);
 }
 
 extern "C" int hd_edge_layer_backward_s(hd_handle* h, hd_topology* t, int coord, int precision, const float* AB, const float* x,
@@ -1910,11 +1736,10 @@ extern "C" int hd_edge_layer_backward_s(hd_handle* h, hd_topology* t, int coord,
                                       float* escal, float* colpart, float* bapart, float* b2part, float* wrdpart,
                                       float* dAB, float* dx, float* dx0, void* stream) {
     HD_TRY(check_train(h, t, "hd_edge_layer_backward"));
-    if (precision != 0 && precision != 2 && precision != 3)
-        return fail(HD_E_INVALID, "hd_edge_layer_backward: precision must be 0 (fp32), 2 (bf16x6) or 3 (fp16x3)");
+    if (precision != 0 && precision != 3)
+        return fail(HD_E_INVALID, "hd_edge_layer_backward_s: precision must be 0 (fp32) or 3 (fp16x3); 2 (bf16x6) was retired in ABI 12");
     if (precision == 3 && (!pre2 || !f16ws))
         return fail(HD_E_INVALID, "hd_edge_layer_backward_s: precision 3 (fp16x3) needs the kept pre2 and the f16ws workspace");
-    const bool x6 = precision == 2 && h->H >= 128;
     const bool f16 = precision == 3 && h->H >= 128;
     topo_use(t, (hipStream_t)stream);
     if (!AB || !x || !x0 || !wrd || !W2 || !b2 || !wa || !gout || !G2 || !P || !G1 || !escal || !colpart || !bapart ||
@@ -1947,9 +1772,6 @@ extern "C" int hd_edge_layer_backward_s(hd_handle* h, hd_topology* t, int coord,
     if (f16) {
         hipLaunchKernelGGL((k_pack_w2_f16c<true>), dim3((H * H / 8 + 255) / 256), dim3(256), 0, s, W2, f16scal,
                            reinterpret_cast<f16x8*>(t->w2timg), H);
-    } else if (x6) {
-        if (!pre2) hipLaunchKernelGGL((k_pack_w2_x6<false>), dim3((H * H / 2 + 255) / 256), dim3(256), 0, s, W2, reinterpret_cast<uint32_t*>(t->w2img), H);
-        hipLaunchKernelGGL((k_pack_w2_x6<true>), dim3((H * H / 2 + 255) / 256), dim3(256), 0, s, W2, reinterpret_cast<uint32_t*>(t->w2timg), H);
     } else {
         if (!pre2) hipLaunchKernelGGL(k_pack_w2_both, dim3((H * H + 255) / 256), dim3(256), 0, s, W2, t->w2img, t->w2timg, H);
         else hipLaunchKernelGGL((k_pack_w2<true>), dim3((H * H + 255) / 256), dim3(256), 0, s, W2, t->w2timg, H);
@@ -1964,7 +1786,7 @@ extern "C" int hd_edge_layer_backward_s(hd_handle* h, hd_topology* t, int coord,
     if (f16) {      // f16ws: {2^k, 2^-k, -, -} | per-workgroup maxima of |G2|, |P| | row maxima of G2  (hd_edge_layer_f16ws_floats)
         a.w2scal = f16scal; a.g2wgmax = f16ws + 4; a.pwgmax = f16ws + 4 + t->n_wg; a.g2max = f16ws + 4 + 2 * (size_t)t->n_wg;
     }
-    const int prec = f16 ? 3 : x6 ? 2 : 0;
+    const int prec = f16 ? 3 : 0;
     a.Wimg = t->w2img;
     launch_edge_bwd(h, coord != 0, 0, prec, a, t->n_wg, s);
     a.Wimg = t->w2timg;
@@ -1984,23 +1806,13 @@ extern "C" int hd_edge_layer_backward_s(hd_handle* h, hd_topology* t, int coord,
     return HD_OK;
 }
 
-extern "C" int hd_edge_layer_backward_p(hd_handle* h, hd_topology* t, int coord, int precision, const float* AB, const float* x,
-                                      const float* x0, const float* wrd, const float* W2, const float* b2,
-                                      const float* wa, const float* ba, const float* gout, float* G2, float* P, float* G1,
-                                      float* escal, float* colpart, float* bapart, float* b2part, float* wrdpart,
-                                      float* dAB, float* dx, float* dx0, void* stream) {
-    if (precision == 3) return fail(HD_E_INVALID, "hd_edge_layer_backward_p: precision must be 0 (fp32) or 2 (bf16x6)");
-    return hd_edge_layer_backward_s(h, t, coord, precision, AB, x, x0, wrd, W2, b2, wa, ba, gout, nullptr, nullptr, G2, P, G1, escal, colpart,
-                                    bapart, b2part, wrdpart, dAB, dx, dx0, stream);
-}
-
 extern "C" int hd_edge_layer_backward(hd_handle* h, hd_topology* t, int coord, const float* AB, const float* x,
                                       const float* x0, const float* wrd, const float* W2, const float* b2,
                                       const float* wa, const float* ba, const float* gout, float* G2, float* P, float* G1,
                                       float* escal, float* colpart, float* bapart, float* b2part, float* wrdpart,
                                       float* dAB, float* dx, float* dx0, void* stream) {
-    return hd_edge_layer_backward_p(h, t, coord, 0, AB, x, x0, wrd, W2, b2, wa, ba, gout, G2, P, G1, escal, colpart, bapart, b2part,
-                                    wrdpart, dAB, dx, dx0, stream);
+    return hd_edge_layer_backward_s(h, t, coord, 0, AB, x, x0, wrd, W2, b2, wa, ba, gout, nullptr, nullptr, G2, P, G1, escal, colpart,
+                                    bapart, b2part, wrdpart, dAB, dx, dx0, stream);
 }
 
 // ----------------------------------------------------------------------------- stage-2 layer E_GCL (forward)
@@ -2443,47 +2255,6 @@ extern "C" int hd_gemm_f32(int device, int M, int N, int K, const float* A, long
     return HD_OK;
 }
 
-// dW2 = G2^T P in bf16x6 arithmetic (k_dw2.hpp): one workgroup per slab of edge rows owns the whole H x H result
-static int dw2_impl(const char* who, int device, int rows, int H, const float* G2, const float* P, float* dW2, int ldc,
-                    float* ws, long long ws_floats, void* stream) {
-    if (!G2 || !P || !dW2 || !ws) return fail(HD_E_INVALID, std::string(who) + ": null tensor");
-    if (H != 128 && H != 256) return fail(HD_E_INVALID, std::string(who) + ": H must be 128 or 256 (narrower layers use hd_gemm_f32)");
-    if (rows <= 0 || rows % 32 != 0 || ldc < H) return fail(HD_E_INVALID, std::string(who) + ": rows must be a positive multiple of 32 (whole edge tiles), ldc >= H");
-    if (hd_device_count() <= device || device < 0) return fail(HD_E_HIP, std::string(who) + ": no such HIP device (is a GPU visible?)");
-    HIP_TRY(hipSetDevice(device));
-    hipStream_t s = (hipStream_t)stream;
-    // as many slabs as the workspace holds, at most one per CU (256) and at least four chunks each
-    int slabs = (int)std::min<long long>(256, ws_floats / ((long long)H * H));
-    slabs = std::max(1, std::min(slabs, rows / 128));
-    if ((long long)slabs * H * H > ws_floats) return fail(HD_E_INVALID, std::string(who) + ": workspace smaller than one H x H slab");
-    const int kslab = ((rows / 32 + slabs - 1) / slabs) * 32;
-    slabs = (rows + kslab - 1) / kslab;
-    Dw2Args a;
-    a.G = G2; a.P = P; a.ws = ws; a.rows = rows; a.kslab = kslab;
-    {   // the dynamic-LDS limit is a per-DEVICE attribute: prepared once per device, under a lock (autograd's backward threads
-        // may call this concurrently)
-        static std::mutex mu;
-        static unsigned long long prepared_mask = 0;
-        std::lock_guard<std::mutex> lk(mu);
-        const unsigned long long bit = 1ull << (device & 63);
-        if (!(prepared_mask & bit)) {
-            HIP_TRY(hipFuncSetAttribute((const void*)k_dw2_x6<256>, hipFuncAttributeMaxDynamicSharedMemorySize, dw2_lds_bytes<256>()));
-            HIP_TRY(hipFuncSetAttribute((const void*)k_dw2_x6<128>, hipFuncAttributeMaxDynamicSharedMemorySize, dw2_lds_bytes<128>()));
-            prepared_mask |= bit;
-        }
-    }
-    if (H == 256) hipLaunchKernelGGL((k_dw2_x6<256>), dim3(slabs), dim3(512), dw2_lds_bytes<256>(), s, a);
-    else hipLaunchKernelGGL((k_dw2_x6<128>), dim3(slabs), dim3(512), dw2_lds_bytes<128>(), s, a);
-    hipLaunchKernelGGL(k_dw2_reduce, dim3((H * H + 255) / 256), dim3(256), 0, s, ws, dW2, H * H, H, ldc, slabs);
-    HIP_TRY(hipGetLastError());
-    return HD_OK;
-}
-
-extern "C" int hd_dw2_x6(int device, int rows, int H, const float* G2, const float* P, float* dW2, int ldc, float* ws,
-                         long long ws_floats, void* stream) {
-    return dw2_impl("hd_dw2_x6", device, rows, H, G2, P, dW2, ldc, ws, ws_floats, stream);
-}
-
 // dW2 = G2^T P in fp16x3 arithmetic (k_dw2_f16): gmax / pmax = the n per-workgroup maxima the fp16x3 backward left in its workspace
 extern "C" int hd_dw2_f16(int device, int rows, int H, const float* G2, const float* P, const float* gmax, const float* pmax, int n,
                           float* dW2, int ldc, float* ws, long long ws_floats, void* stream) {
@@ -2605,24 +2376,30 @@ extern "C" int hd_colsum_f32(int device, int rows, int n, const float* const* sr
     return HD_OK;
 }
 
+// one pinned, device-visible result word per device (hipHostMalloc is mapped by default); calls are serialised by the lock, which is
+// held for the few microseconds a call lasts
+static std::mutex g_digest_mu;
+static unsigned long long* g_digest_host[64] = {nullptr};
+
 extern "C" int hd_params_digest(int device, const void* const* ptrs_dev, const long long* prefix_dev, int n, long long total,
-                                unsigned long long* scratch_dev, unsigned long long* digest_host, void* stream) {
-    if (!ptrs_dev || !prefix_dev || !scratch_dev || !digest_host) return fail(HD_E_INVALID, "hd_params_digest: null argument");
+                                unsigned long long* state_dev, unsigned long long* digest_host, void* stream) {
+    if (!ptrs_dev || !prefix_dev || !state_dev || !digest_host) return fail(HD_E_INVALID, "hd_params_digest: null argument");
     if (n < 1 || total < 0) return fail(HD_E_INVALID, "hd_params_digest: n < 1 or total < 0");
-    if (hd_device_count() <= device || device < 0) return fail(HD_E_HIP, "hd_params_digest: no such HIP device (is a GPU visible?)");
+    if (hd_device_count() <= device || device < 0 || device >= 64) return fail(HD_E_HIP, "hd_params_digest: no such HIP device (is a GPU visible?)");
     HIP_TRY(hipSetDevice(device));
     hipStream_t s = (hipStream_t)stream;
-    HIP_TRY(hipMemsetAsync(scratch_dev, 0, sizeof(unsigned long long), s));
-    if (total > 0) {
-        DigestArgs a;
-        a.ptrs = reinterpret_cast<const uint32_t* const*>(ptrs_dev); a.prefix = prefix_dev; a.n = n; a.total = total; a.out = scratch_dev;
-        const long long groups = (total + DIGEST_CHUNK - 1) / DIGEST_CHUNK;
-        hipLaunchKernelGGL(k_params_digest, dim3((unsigned)groups), dim3(256), 0, s, a);
-        HIP_TRY(hipGetLastError());
-    }
-    // the one host wait of the check: 8 bytes, in stream order behind the writes the digest must see
-    HIP_TRY(hipMemcpyAsync(digest_host, scratch_dev, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    if (total == 0) { *digest_host = 0; return HD_OK; }
+    std::lock_guard<std::mutex> lk(g_digest_mu);
+    if (!g_digest_host[device]) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&g_digest_host[device]), 64, hipHostMallocDefault));
+    DigestArgs a;
+    a.ptrs = reinterpret_cast<const uint32_t* const*>(ptrs_dev); a.prefix = prefix_dev; a.n = n; a.total = total;
+    a.state = state_dev; a.host_out = g_digest_host[device];
+    const long long groups = (total + DIGEST_CHUNK - 1) / DIGEST_CHUNK;
+    hipLaunchKernelGGL(k_params_digest, dim3((unsigned)groups), dim3(256), 0, s, a);
+    HIP_TRY(hipGetLastError());
+    // the one host wait of the check, in stream order behind the writes the digest must see
     HIP_TRY(hipStreamSynchronize(s));
+    *digest_host = *reinterpret_cast<volatile unsigned long long*>(g_digest_host[device]);
     return HD_OK;
 }
 
@@ -2818,7 +2595,7 @@ extern "C" int hd_sample_loop(hd_handle* h, hd_topology* topo, float* z, const f
 extern "C" int hd_mfma_probe(int device, int kind, const float* in1024, float* scratch, int iters, double* ns_per_mfma_per_simd,
                              void* stream) {
     if (!in1024 || !scratch || !ns_per_mfma_per_simd) return fail(HD_E_INVALID, "hd_mfma_probe: null argument");
-    if (kind < 0 || kind > 2 || iters < 1) return fail(HD_E_INVALID, "hd_mfma_probe: kind must be 0 (fp32), 1 (fp16) or 2 (bf16), iters >= 1");
+    if (kind < 0 || kind > 1 || iters < 1) return fail(HD_E_INVALID, "hd_mfma_probe: kind must be 0 (fp32) or 1 (fp16), iters >= 1");
     if (hd_device_count() <= device || device < 0) return fail(HD_E_HIP, "hd_mfma_probe: no such HIP device (is a GPU visible?)");
     HIP_TRY(hipSetDevice(device));
     hipStream_t s = (hipStream_t)stream;
@@ -2828,12 +2605,14 @@ extern "C" int hd_mfma_probe(int device, int kind, const float* in1024, float* s
     const dim3 grid(2 * n_cu), block(256);                 // two wavefronts per SIMD: the edge kernels' occupancy
     auto launch = [&](int n) {
         if (kind == 0) hipLaunchKernelGGL((k_mfma_probe<0>), grid, block, 0, s, in1024, scratch, n);
-        else if (kind == 1) hipLaunchKernelGGL((k_mfma_probe<1>), grid, block, 0, s, in1024, scratch, n);
-        else hipLaunchKernelGGL((k_mfma_probe<2>), grid, block, 0, s, in1024, scratch, n);
+        else hipLaunchKernelGGL((k_mfma_probe<1>), grid, block, 0, s, in1024, scratch, n);
     };
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
+    {
+        const hipError_t ce = hipEventCreate(&e1);
+        if (ce != hipSuccess) { (void)hipEventDestroy(e0); return fail(HD_E_HIP, std::string("hd_mfma_probe: ") + hipGetErrorString(ce)); }
+    }
     launch(iters);                                          // warm-up (clocks, code)
     (void)hipEventRecord(e0, s);
     launch(iters);

@@ -23,16 +23,25 @@ from . import _lib
 from ._lib import HdConfig, HierDiffHipError
 
 
-PRECISIONS = {"fp32": 0, "bf16x3": 1, "bf16x6": 2, "fp16x3": 3}
+PRECISIONS = {"fp32": 0, "fp16x3": 3}
+RETIRED_PRECISIONS = ("bf16x3", "bf16x6")
 # Arithmetic of the H x H contractions.  The drop-in default is "fp32": exact fp32 matrix instructions
 # (v_mfma_f32_32x32x2_f32), the arithmetic the reference computes in (en_dynamics.py has no notion of reduced
-# precision; per-forward error vs the reference ~5e-7 rel-L2).  "bf16x3" is opt-in (`model.precision = "bf16x3"`
-# or HIERDIFF_PRECISION=bf16x3): fp32 operands split into bf16 head + tail, three bf16 matrix instructions with fp32
-# accumulation, ~1e-5 rel-L2 per forward (bar 1e-4) and ~2.6x faster end to end.  "fp16x3" and "bf16x6"
-# are the fp32-ACCURATE opt-ins (two-way FP16 split with operands ranged by exact powers of two, three MFMAs per product /
-# three-way bf16 split, six MFMAs): as far from a float64 evaluation as exact fp32, 2.4x / 1.7x faster; "fp16x3" is the one to use
-# for sampling.
+# precision; per-forward error vs the reference ~5e-7 rel-L2).  "fp16x3" is the one opt-in (`model.precision = "fp16x3"` or
+# HIERDIFF_PRECISION=fp16x3): fp32-ACCURATE on the matrix cores proper - a two-way FP16 split with operands ranged by exact powers
+# of two, three MFMAs per product, as far from a float64 evaluation as exact fp32, 2.4x faster end to end; the mode to use for
+# sampling.  The bf16 splits of rounds 1-5 were retired in round 6: "bf16x6" (same accuracy, 1.6x slower than fp16x3) and
+# "bf16x3" (4 % faster at 20x the error) were dominated on both axes.
 DEFAULT_PRECISION = "fp32"
+
+def _checked_precision(name: str) -> str:
+    if name in RETIRED_PRECISIONS:
+        raise ValueError(f'precision {name!r} was retired in round 6 (ABI 12): use "fp16x3" - as accurate as "bf16x6" and exact fp32, '
+                         f'at the speed of "bf16x3" - or "fp32"')
+    if name not in PRECISIONS:
+        raise ValueError(f"precision must be one of {sorted(PRECISIONS)}")
+    return name
+
 
 # ----------------------------------------------------------------------------- parameter holders
 # Mirrors of the reference module tree; they are never called, only hold tensors so that
@@ -243,7 +252,7 @@ class EGNN_dynamics_QM9(nn.Module):
                              attention=int(bool(attention)), tanh=int(bool(tanh)),
                              condition_time=int(bool(condition_time)), norm_constant=float(norm_constant),
                              normalization_factor=float(normalization_factor), coords_range=30.0,
-                             precision=PRECISIONS[os.environ.get("HIERDIFF_PRECISION", DEFAULT_PRECISION)],
+                             precision=PRECISIONS[_checked_precision(os.environ.get("HIERDIFF_PRECISION", DEFAULT_PRECISION))],
                              aggregation_mean=int(aggregation_method == 'mean'))
         self.aggregation_method = aggregation_method
         self._hd = None              # (handle, device index)
@@ -344,22 +353,22 @@ class EGNN_dynamics_QM9(nn.Module):
     # ------------------------------------------------------------------ arithmetic of the TRAINING path
     @property
     def training_precision(self) -> str:
-        """"fp32" (default): every kernel of a training step is exact fp32.  "bf16x6" (opt-in): the forward's per-edge H x H
-        contraction, BOTH backward stages' contractions (the recomputed W2 P and dP = G2 W2) and the dense reduction
-        dW2 = G2^T P run on the matrix cores proper in the fp32-ACCURATE three-way bf16 split of the sampler's bf16x6 mode (six
-        MFMAs per product, fp32 accumulation; hidden_nf >= 128) while everything around them - first-layer recomputation,
-        SiLU and its derivative, the node-level GEMMs and the loss - stays exact fp32: this implementation's counterpart of the reference's
-        mixed-precision training (apex O2, conf/trainer/default.yaml:4-5), without its loss of accuracy: gradients agree with
-        the exact-fp32 step to ~1e-6 (tests/test_gpu_training.py).  "fp16x3" (round 5): the same four contraction sites in the
-        sampler's two-way FP16 split (three MFMAs per product; operand rows / arrays ranged by exact powers of two computed on the
-        device from the data itself) on top of the kept pre-activations (`keep_edge_activations`); a layer whose batch is too
-        small to keep them runs in bf16x6."""
+        """"fp32" (default): every kernel of a training step is exact fp32.  "fp16x3" (opt-in; hidden_nf >= 128): the forward's
+        per-edge H x H contraction, stage B's dP = G2 W2 and the dense reduction dW2 = G2^T P run on the matrix cores proper in the
+        sampler's fp32-ACCURATE two-way FP16 split (three MFMAs per product; operand rows / arrays ranged by exact powers of two
+        computed on the device from the data itself) on top of the kept pre-activations (`keep_edge_activations`), while everything
+        around them - first-layer recomputation, SiLU and its derivative, the node-level GEMMs and the loss - stays exact fp32:
+        this implementation's counterpart of the reference's mixed-precision training (apex O2, conf/trainer/default.yaml:4-5)
+        without its loss of accuracy (gradients agree with the exact-fp32 step to ~1e-6, tests/test_gpu_training.py).  A layer
+        whose batch is too small to keep its pre-activations runs in exact fp32 (a one-time warning says so)."""
         return getattr(self, "_training_precision", "fp32")
 
     @training_precision.setter
     def training_precision(self, name: str) -> None:
-        if name not in ("fp32", "bf16x6", "fp16x3"):
-            raise ValueError('training_precision must be "fp32", "bf16x6" or "fp16x3"')
+        if name == "bf16x6":
+            raise ValueError('training_precision "bf16x6" was retired in round 6 (ABI 12): "fp16x3" is as accurate and faster')
+        if name not in ("fp32", "fp16x3"):
+            raise ValueError('training_precision must be "fp32" or "fp16x3"')
         object.__setattr__(self, "_training_precision", name)
 
     #: Training forward keeps the second-layer pre-activations W2 P + b2 of every edge row for its backward pass where the
@@ -377,14 +386,10 @@ class EGNN_dynamics_QM9(nn.Module):
 
     @precision.setter
     def precision(self, name: str) -> None:
-        """"fp32": exact fp32 matrix instructions.  "bf16x3": fp32 operands split into bf16 head+tail, three
-        bf16 matrix instructions with fp32 accumulation (error ~1e-6 per contraction, ~5x the throughput).  "bf16x6": the
-        per-edge contraction on a three-way bf16 split, six bf16 matrix instructions per product - truncation below the
-        rounding of the fp32 accumulation, everything else as in "fp32".  "fp16x3": edge and node contractions on a two-way FP16
-        split (three fp16 matrix instructions per product), every operand ranged by an exact power of two per matrix / per row -
-        as accurate as "fp32" and "bf16x6", at "bf16x3"'s cost; the recommended sampling mode."""
-        if name not in PRECISIONS:
-            raise ValueError(f"precision must be one of {sorted(PRECISIONS)}")
+        """"fp32": exact fp32 matrix instructions.  "fp16x3": edge and node contractions on a two-way FP16 split (three fp16 matrix
+        instructions per product), every operand ranged by an exact power of two per matrix / per row - as accurate as "fp32" at
+        2.4x its speed; the recommended sampling mode."""
+        _checked_precision(name)
         if self.mode == 'gnn_dynamics':
             self._engine.precision = name
             return

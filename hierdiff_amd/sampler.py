@@ -117,9 +117,9 @@ def main(argv=None) -> int:
     ap.add_argument("--timesteps", type=int, default=1000)
     ap.add_argument("--context", type=float, nargs="*", default=None,
                     help="context values cycled over batches (needs a model with context_node_nf=1)")
-    ap.add_argument("--precision", choices=["fp32", "fp16x3", "bf16x6", "bf16x3"], default="fp32",
-                    help="fp32: exact fp32 matrix instructions (the reference's arithmetic); bf16x3: 3-term bf16 split, "
-                         "~1e-5 rel-L2 per forward, ~2.7x faster")
+    ap.add_argument("--precision", choices=["fp32", "fp16x3"], default="fp32",
+                    help="fp32: exact fp32 matrix instructions (the reference's arithmetic); fp16x3: fp32-accurate two-way FP16 "
+                         "split on the matrix cores, ~2.4x faster (recommended for sampling)")
     ap.add_argument("--trust-checkpoint", action="store_true",
                     help="allow the unrestricted unpickler for checkpoints that weights_only=True rejects")
     ap.add_argument("--seed", type=int, default=2022)

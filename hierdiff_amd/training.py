@@ -212,7 +212,8 @@ class _NodeMLP(torch.autograd.Function):
         return dX[:, :H] + g, dX[:, H:], dW3, db3, dW4, db4, None
 
 
-_PREC_CODE = {"fp32": 0, "bf16x6": 2, "fp16x3": 3}          # `precision` of hd_edge_layer_forward_s / _backward_s
+_PREC_CODE = {"fp32": 0, "fp16x3": 3}          # `precision` of hd_edge_layer_forward_s / _backward_s
+_WARNED = set()
 _F16WS = {}
 
 
@@ -263,7 +264,12 @@ class _EdgeLayer(torch.autograd.Function):
             if rows > 0:
                 pre2 = torch.empty((rows, tr.H), device=AB.device, dtype=torch.float32)
         if prec == 3 and pre2 is None and any(ctx.needs_input_grad):
-            prec = 2        # the fp16x3 backward exists on top of the kept pre2 only: this layer runs in bf16x6 (equally fp32-accurate)
+            prec = 0        # the fp16x3 backward exists on top of the kept pre2 only: this layer runs in exact fp32
+            if "fp16x3-fallback" not in _WARNED:
+                _WARNED.add("fp16x3-fallback")
+                import warnings
+                warnings.warn('training_precision "fp16x3": an edge layer whose pre-activations are not kept (keep_edge_activations off, '
+                              "out of the memory budget, or a batch small enough for the column-split edge kernel) runs in exact fp32")
         _lib.check(lib.hd_edge_layer_forward_s(dyn._handle(), topo.ptr, int(coord), prec, AB.data_ptr(), x4.data_ptr(),
                                                x04.data_ptr(), wrd.data_ptr(), W2.data_ptr(), b2.data_ptr(), wa.data_ptr(),
                                                None if ba_c is None else ba_c.data_ptr(), out.data_ptr(),
@@ -313,13 +319,6 @@ class _EdgeLayer(torch.autograd.Function):
             _lib.check(lib.hd_dw2_f16(_dev_index(dev), tr.rows, tr.H, ws["G2"].data_ptr(), ws["P"].data_ptr(), f16ws.data_ptr() + 16,
                                       f16ws.data_ptr() + 16 + 4 * n_wg, n_wg, dW2.data_ptr(), tr.H, w6.data_ptr(), slabs * tr.H * tr.H,
                                       _stream(dev)), "hd_dw2_f16")
-        elif prec == 2 and tr.H in (128, 256):
-            # opt-in: the same reduction on a three-way bf16 split of both operands (hd_dw2_x6: fp32-accurate, every row read once)
-            dW2 = torch.empty((tr.H, tr.H), device=dev, dtype=torch.float32)
-            slabs = max(1, min(256, tr.rows // 128))
-            w6 = _splitk_workspace(dev, slabs * tr.H * tr.H)
-            _lib.check(lib.hd_dw2_x6(_dev_index(dev), tr.rows, tr.H, ws["G2"].data_ptr(), ws["P"].data_ptr(), dW2.data_ptr(), tr.H,
-                                     w6.data_ptr(), slabs * tr.H * tr.H, _stream(dev)), "hd_dw2_x6")
         else:
             dW2, _ = _linear_dw(ws["G2"], ws["P"], False, rows=tr.rows)                                       # [H, H]
         # everything else left the kernels as per-tile partial sums: one two-launch column sum over the four arrays

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define HD_ABI_VERSION 11
+#define HD_ABI_VERSION 12
 
 #define HD_OK 0
 #define HD_E_INVALID (-1)      /* bad argument / unsupported configuration */
@@ -74,20 +74,15 @@ typedef struct hd_config {
     int32_t precision;           /* matrix-core arithmetic of the H x H contractions:
                                     0 = exact fp32 (v_mfma_f32_32x32x2_f32) - what the reference computes in,
                                         and the default of the Python mirror,
-                                    1 = "bf16x3" (opt-in): fp32 operands split into bf16 head + tail, 3 bf16 MFMAs
-                                        with fp32 accumulation (~1e-6 relative on a 256-term dot product),
-                                    2 = "bf16x6" (opt-in): the per-edge H x H contraction on a three-way bf16 split,
-                                        6 bf16 MFMAs per product, fp32 accumulation - truncation <= 2^-26 per product,
-                                        below the rounding of the fp32 accumulation itself; everything else as in
-                                        mode 0 (hidden_nf < 128 runs mode 0's kernels),
                                     3 = "fp16x3" (opt-in): the per-edge contraction on a two-way FP16 split (11 + 11 significant
                                         bits per operand), 3 fp16 MFMAs per product, fp32 accumulation - truncation <= 2^-21 per
                                         product, at the rounding of the fp32 accumulation (measured 1.9e-7 rel-L2 on a 256-term
-                                        contraction, bf16x6 2.4e-7, bf16x3 4.1e-6) at mode 1's cost.  Operands are ranged by
-                                        exact powers of two - W2 per matrix, the activations per edge row from a bound on the
-                                        pre-activation known before the contraction starts - so FP16's exponent range imposes
-                                        no assumption on the network.  The node GEMMs run the same arithmetic (hidden_nf >= 128;
-                                        narrower: mode 0's node kernels) */
+                                        contraction).  Operands are ranged by exact powers of two - W2 per matrix, the
+                                        activations per edge row from a bound on the pre-activation known before the contraction
+                                        starts - so FP16's exponent range imposes no assumption on the network.  The node GEMMs
+                                        run the same arithmetic (hidden_nf >= 128; narrower: mode 0's node kernels).
+                                    1 ("bf16x3") and 2 ("bf16x6") existed up to ABI 11 and are rejected since ABI 12: fp16x3
+                                    is as accurate as 2 at the cost of 1 */
     int32_t aggregation_mean;    /* 0: aggregation_method 'sum' - neighbour sums / normalization_factor (egnn_new.py:280-282);
                                     1: 'mean' (:283-288) - sums / number of edge-list entries of the receiving node.  The
                                        reference's edge list holds all N x N pairs of a molecule, masked or not
@@ -196,7 +191,7 @@ int hd_sample_loop(hd_handle* h, hd_topology* topo, float* z, const float* conte
                    int s_hi, int s_lo, const float* raw_x, const float* raw_h, int noise_rows,
                    uint64_t seed, uint64_t sample_id_base, int use_graph, void* stream);
 
-/* ---- Training primitives (exact fp32 only; hd_config.precision must be 0).
+/* ---- Training primitives (the handle's hd_config.precision must be 0; the fp16x3 contractions are chosen per call below).
  * One "edge layer" is the part of a GCL / EquivariantUpdate that works on edges (egnn_new.py:35-56 / :91-104 with the
  * first Linear factorised): per unmasked edge (i, j)
  *     pre1 = A_i + B_j + |x_i - x_j|^2 w_r + |x0_i - x0_j|^2 w_d,   P = SiLU(pre1),   M = SiLU(W2 P + b2),
@@ -213,35 +208,23 @@ int hd_topology_nodes_device(hd_topology* t, long long* index, void* stream);
 int hd_edge_layer_forward(hd_handle* h, hd_topology* topo, int coord, const float* AB, const float* x,
                           const float* x0, const float* wrd, const float* W2, const float* b2, const float* wa,
                           const float* ba, float* out, void* stream);
-/* The same forward with the arithmetic of the per-edge H x H contraction chosen per call: precision 0 = exact fp32 (what
- * hd_edge_layer_forward runs), 2 = "bf16x6" (three-way bf16 split of both operands, six MFMAs per product, fp32 accumulation:
- * the fp32-ACCURATE mode of the sampler, hd_config.precision; hidden_nf < 128 runs the fp32 kernels).  The opt-in mixed mode of
- * the training path: the reference trains with apex O2 (endiffusion/conf/trainer/default.yaml:4-5); here the forward contraction
- * and the dense reduction dW2 (hd_dw2_x6) may run on the matrix cores proper while the backward stages stay exact fp32. */
-int hd_edge_layer_forward_p(hd_handle* h, hd_topology* topo, int coord, int precision, const float* AB, const float* x,
-                            const float* x0, const float* wrd, const float* W2, const float* b2, const float* wa,
-                            const float* ba, float* out, void* stream);
-/* hd_edge_layer_backward (below) with the arithmetic of its two H x H contractions - stage A recomputes pre2 = W2 P, stage B forms
- * dP = G2 W2 - chosen per call like hd_edge_layer_forward_p: 0 exact fp32, 2 bf16x6 (hidden_nf >= 128).  Everything around the
- * contractions (recomputed first layer, SiLU and its derivative, gate / head, G2 / P / G1, per-tile partial sums) is fp32 either way. */
-int hd_edge_layer_backward_p(hd_handle* h, hd_topology* topo, int coord, int precision, const float* AB, const float* x,
-                             const float* x0, const float* wrd, const float* W2, const float* b2, const float* wa,
-                             const float* ba, const float* gout, float* G2, float* P, float* G1, float* escal, float* colpart,
-                             float* bapart, float* b2part, float* wrdpart, float* dAB, float* dx, float* dx0, void* stream);
-/* Round 5 (ABI 10): keep the second-layer pre-activations instead of recomputing them.  hd_edge_layer_save_rows = rows of a
- * [rows][hidden_nf] fp32 buffer the forward of this topology can fill (the table's rows plus one spare tile; 0: the batch is small enough for the column-split
- * edge kernels, which keep their faster forward - pass pre2 = NULL and the backward recomputes as before).  hd_edge_layer_forward_s
- * with pre2 != NULL writes W2 P + b2 of every edge row into it (accumulator order per 32-row tile, opaque to the caller; 228 MB per
- * layer at B = 256, N = 30, H = 256 - sized for this GPU's HBM, not for a 16 GB card); hd_edge_layer_backward_s with the same
- * buffer runs stage A as an element-wise kernel over it (no weight stream, no matrix instruction).  pre2 = NULL in either call is
- * exactly the _p function.  Same results to the bit as the recomputing path in the same arithmetic (tests/test_gpu_training.py). */
-/* precision 3 = "fp16x3" (hidden_nf >= 128; narrower layers run the fp32 kernels): the sampler's two-way FP16 split in the training
- * path - forward contraction (the fp16x3 edge kernel on the unscaled parameters; images, image scale and row ranges made on the device
- * per call), stage B's dP = G2 W2 (operand rows ranged by their exact maxima, which stage A leaves in f16ws) and dW2 (hd_dw2_f16).
- * It exists only together with the kept pre2 (whose spare tile carries the image scalars from the forward to the backward call):
- * hd_edge_layer_backward_s(precision 3) needs the pre2 of a precision-3 forward and f16ws
- * (hd_edge_layer_f16ws_floats floats, *n_wg = the number of per-workgroup maxima hd_dw2_f16 reads at f16ws + 4 and f16ws + 4 + n_wg);
- * where hd_edge_layer_save_rows(.., 3) is 0 the caller runs the layer in precision 2. */
+/* The same forward / backward with two per-call choices (hd_edge_layer_forward / _backward are the (precision 0, pre2 NULL) case).
+ * (1) Keep the second-layer pre-activations instead of recomputing them: hd_edge_layer_save_rows = rows of a [rows][hidden_nf] fp32
+ * buffer the forward of this topology can fill (the table's rows plus one spare tile; 0: the batch is small enough for the
+ * column-split edge kernels, which keep their faster forward - pass pre2 = NULL and the backward recomputes).
+ * hd_edge_layer_forward_s with pre2 != NULL writes W2 P + b2 of every edge row into it (accumulator order per 32-row tile, opaque to
+ * the caller; 228 MB per layer at B = 256, N = 30, H = 256 - sized for this GPU's HBM, not for a 16 GB card);
+ * hd_edge_layer_backward_s with the same buffer runs stage A as an element-wise kernel over it (no weight stream, no matrix
+ * instruction).  Same results to the bit as the recomputing path (tests/test_gpu_training.py).
+ * (2) precision: 0 = exact fp32; 3 = "fp16x3" (hidden_nf >= 128; narrower layers run the fp32 kernels): the sampler's two-way FP16
+ * split in the training path - the reference trains with apex O2 (endiffusion/conf/trainer/default.yaml:4-5); here the forward
+ * contraction (the fp16x3 edge kernel on the unscaled parameters; images, image scale and row ranges made on the device per call),
+ * stage B's dP = G2 W2 (operand rows ranged by their exact maxima, which stage A leaves in f16ws) and dW2 (hd_dw2_f16) run on the
+ * matrix cores proper, fp32-accurately, while everything around them stays exact fp32.  It exists only together with the kept pre2
+ * (whose spare tile carries the image scalars from the forward to the backward call): hd_edge_layer_backward_s(precision 3) needs
+ * the pre2 of a precision-3 forward and f16ws (hd_edge_layer_f16ws_floats floats, *n_wg = the number of per-workgroup maxima
+ * hd_dw2_f16 reads at f16ws + 4 and f16ws + 4 + n_wg); where hd_edge_layer_save_rows(.., 3) is 0 the caller runs the layer in
+ * precision 0.  (precision 2 = "bf16x6", the _p entry points and hd_dw2_x6 existed up to ABI 11.) */
 long long hd_edge_layer_f16ws_floats(hd_handle* h, hd_topology* topo, int* n_wg);
 int hd_dw2_f16(int device, int rows, int H, const float* G2, const float* P, const float* gmax, const float* pmax, int n,
                float* dW2, int ldc, float* ws, long long ws_floats, void* stream);
@@ -319,12 +302,10 @@ int hd_gemm_f32(int device, int M, int N, int K, const float* A, long long a_m_s
                 int epi, const float* aux, const float* row_mask, float* C2, int split_k, float* ws,
                 float* colsum, void* stream);
 
-/* dW2 [H][ldc] = G2^T P over `rows` edge rows (G2, P [rows][H] as hd_edge_layer_backward leaves them; rows a multiple of 32,
- * H = 128 or 256) in bf16x6 arithmetic (csrc/k_dw2.hpp): the fp32-accurate form of the one dense reduction over all edge rows,
- * ~2.5 x faster than the exact-fp32 split-K product of hd_gemm_f32.  ws: ws_floats >= H * H device floats; the product is cut
- * into min(256, ws_floats / H^2, rows / 128) slabs whose partial results are added in a fixed order (deterministic). */
-int hd_dw2_x6(int device, int rows, int H, const float* G2, const float* P, float* dW2, int ldc, float* ws,
-              long long ws_floats, void* stream);
+/* (hd_dw2_f16, declared with the edge-layer functions above: dW2 [H][ldc] = G2^T P over `rows` edge rows - G2, P [rows][H] as
+ * hd_edge_layer_backward_s leaves them, rows a multiple of 32, H = 128 or 256 - in fp16x3 arithmetic, csrc/k_dw2.hpp: the
+ * fp32-accurate form of the one dense reduction over all edge rows.  ws: ws_floats >= H * H device floats; the product is cut into
+ * min(256, ws_floats / H^2, rows / 128) slabs whose partial results are added in a fixed order: deterministic.) */
 /* The variational training loss around the network call as one kernel per direction (round 5; reference: compute_loss with
  * t0_always = False, diffusion_qm9.py:530-673, and what it calls - compute_error :160-172, kl_prior :206-239, the log constants
  * :241-262, log_pxh_given_z0_without_constants :460-528).  All tensors fp32 on the device: net / zt / xh / eps [B][N][D] (network
@@ -358,10 +339,11 @@ int hd_colsum_f32(int device, int rows, int n, const float* const* src, const in
  * compares it with the digest taken when it last called hd_set_weights / hd_set_schedule / hd_egcl_set_weights, so that a writer
  * which bumps no version counter (a fused optimizer, `.data` writes, an external kernel) can never leave the inference path on a
  * stale image.  The reference has no counterpart: it evaluates its modules in place (en_dynamics.py:49-122).
- * ptrs_dev [n] device pointers, prefix_dev [n + 1] word offsets (prefix_dev[n] == total), both DEVICE arrays; scratch_dev: one
- * device uint64.  One launch + an 8-byte copy; WAITS for `stream`.  The value is independent of the launch geometry. */
+ * ptrs_dev [n] device pointers, prefix_dev [n + 1] word offsets (prefix_dev[n] == total), both DEVICE arrays; state_dev: two
+ * device uint64 that are ZERO on entry (the kernel leaves them zero again).  One launch - the last workgroup publishes the sum to a
+ * pinned host word - and one wait for `stream`.  The value is independent of the launch geometry. */
 int hd_params_digest(int device, const void* const* ptrs_dev, const long long* prefix_dev, int n, long long total,
-                     unsigned long long* scratch_dev, unsigned long long* digest_host, void* stream);
+                     unsigned long long* state_dev, unsigned long long* digest_host, void* stream);
 
 /* Host implementation of the library's normal generator (same bits as the device one up to libm
  * round-off); used by tests and by callers that want to reproduce a draw on the CPU. */
@@ -379,14 +361,14 @@ int hd_profile_read(hd_handle* h, double* ms3, long long* launches3);
 /* Measurement aid (no reference counterpart; bench.py's `roofline.sustained`): the rate at which THIS chip, under its power budget,
  * issues one matrix instruction when every SIMD streams it from register operands at the edge kernels' occupancy (two wavefronts per
  * SIMD, eight accumulators, operands taken from `in1024` - pass random data, zeros clock higher).  kind 0: v_mfma_f32_32x32x2_f32,
- * 1: v_mfma_f32_32x32x16_f16, 2: v_mfma_f32_32x32x16_bf16.  `scratch`: 2 * 256 * (number of CUs) device floats.  Runs the loop twice
+ * 1: v_mfma_f32_32x32x16_f16.  `scratch`: 2 * 256 * (number of CUs) device floats.  Runs the loop twice
  * (warm-up, timed with HIP events on `stream`) and waits for it.  *ns_per_mfma_per_simd = elapsed / (MFMAs issued per SIMD). */
 int hd_mfma_probe(int device, int kind, const float* in1024, float* scratch, int iters, double* ns_per_mfma_per_simd, void* stream);
 
 /* Debug aid (no reference counterpart), live only in a measurement build of the library
  * (python -m hierdiff_amd.build --debug-kernels; the product build returns 0): per-wave cycle stamps of the
  * handle's most recent traced edge-kernel launch (environment HD_ABLATE with bit 16 set at hd_create; H = 256,
- * bf16x3, GCL variant).  32 int64 per workgroup = 4 waves x {start|HW_ID<<48, loop start|XCC_ID<<48, loop end,
+ * GCL variant).  32 int64 per workgroup = 4 waves x {start|HW_ID<<48, loop start|XCC_ID<<48, loop end,
  * end, 3 epilogue stamps, segments}.  Returns the number of workgroups copied (0 if nothing was traced). */
 int hd_debug_edge_trace(hd_handle* h, long long* out, int max_wg);
 

@@ -1,7 +1,7 @@
 """Randomised gradient sweep of the training path: d(sum(out * w)) / d(every parameter, xh) of the HIP dynamics (hierdiff_amd.training) against
 torch.autograd through the CPU oracle, on random model shapes / options / masks.  usage: fuzz_grads.py [cases] [seed] [big]
 "big": widths 128 / 256 on batches of 20-36 molecules (where the whole-tile edge kernel runs and the forward keeps its
-pre-activations), `training_precision` drawn from fp32 / bf16x6 / fp16x3 and `keep_edge_activations` on / off (round 5)."""
+pre-activations), `training_precision` drawn from fp32 / fp16x3 and `keep_edge_activations` on / off (round 5)."""
 import sys, time, numpy as np, torch
 sys.path.insert(0, '.')
 from oracle import egnn_oracle as orc
@@ -26,7 +26,7 @@ for case in range(cases):
         H = int(rng.choice([128, 256])); L = 1; S = int(rng.integers(1, 3))
         B = int(rng.integers(20, 37)); nmax = int(rng.choice([30, 34]))
         n_list = [int(rng.integers(nmax - 6, nmax + 1)) for _ in range(B)]
-        tp = str(rng.choice(["fp32", "bf16x6", "fp16x3", "fp16x3"])); keep = bool(rng.random() < 0.8)
+        tp = str(rng.choice(["fp32", "fp16x3", "fp16x3"])); keep = bool(rng.random() < 0.8)
     sd_np = synthetic_state_dict(9, C_, H, L, S, att, 5000 + case, 0.5)
     cfg = orc.DynCfg(in_node_nf=9, context_node_nf=C_, hidden_nf=H, n_layers=L, inv_sublayers=S, attention=att, tanh=tanh,
                      norm_constant=nc, normalization_factor=nf, aggregation_method=agg)

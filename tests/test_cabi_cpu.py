@@ -28,7 +28,7 @@ def test_header_symbols_all_exported(lib):
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.hd_version() == _lib.ABI_VERSION == 11
+    assert lib.hd_version() == _lib.ABI_VERSION == 12
 
 
 def test_no_gpu_fails_loudly(lib):
@@ -258,9 +258,9 @@ def test_no_register_spills_in_production_kernels():
     assert build.audit(res) == []
     prod = {k: v for k, v in res.items() if build._production(k)}
     edge = [v for k, v in prod.items() if k.startswith("_Z6k_edgeILi256")]
-    assert len(edge) == 8 and all(v["Occupancy"] >= 2 and v["ScratchSize"] == 0 for v in edge)
+    assert len(edge) == 4 and all(v["Occupancy"] >= 2 and v["ScratchSize"] == 0 for v in edge)
     node = [v for k, v in prod.items() if k.startswith("_Z6k_nodeILi256")]
-    assert len(node) == 9 and all(v["ScratchSize"] == 0 for v in node)          # 3 variants x {bf16 two-piece, bf16 three-piece, fp16 two-piece}
+    assert len(node) == 3 and all(v["ScratchSize"] == 0 for v in node)          # {no update, one AB image, two AB images} x fp16 two-piece
 
 
 def test_nodes_distribution_draws_equal_reference():

@@ -47,7 +47,7 @@ FORWARD_FIXTURES = ["f1_cfg1_h256_l3", "f1b_cfg1_h256_l3_gain1", "f7_h32_l2", "f
                     "f6_b16_n30_h256_l9", "f6b_n48_h256_l6"]
 
 
-PRECISIONS = ["fp32", "bf16x3", "bf16x6", "fp16x3"]     # exact-fp32 matrix path / 3- and 6-term bf16 splits / 3-term fp16 split; one bar
+PRECISIONS = ["fp32", "fp16x3"]     # exact-fp32 matrix path / two-way FP16 split (three MFMAs per product); one bar
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
@@ -217,11 +217,10 @@ def test_saturating_activations_vs_oracle(scale, precision):
     assert_parity(out.numpy(), ref.numpy(), f"saturating scale={scale} {precision}")
 
 
-def test_bf16x6_is_fp32_accurate():
-    """The 6-term bf16 split is offered as an fp32-ACCURATE mode (the fp32 MFMA is not a matrix-core instruction on gfx950,
+def test_fp16x3_is_fp32_accurate():
+    """The two-way FP16 split is offered as an fp32-ACCURATE mode (the fp32 MFMA is not a matrix-core instruction on gfx950,
     DESIGN.md section 4b): its distance to the float64 evaluation of the oracle must be that of the exact-fp32 mode and of
-    the float32 reference itself (all three are dominated by fp32 accumulation, ~2e-7), an order of magnitude below
-    bf16x3's, on the headline width."""
+    the float32 reference itself (all three are dominated by fp32 accumulation, ~2e-7), on the headline width."""
     sd_np, sd, cfg, xh, nm, em = _oracle_case([30] * 6 + [17, 9], 256, 3, seed=404)
     t = torch.full((8, 1), 0.3)
     with torch.no_grad():
@@ -236,10 +235,27 @@ def test_bf16x6_is_fp32_accurate():
         err[precision] = rel_l2(out, ref64)
     err["float32 reference"] = rel_l2(ref32, ref64)
     print("distance to the float64 oracle:", {k: f"{v:.2e}" for k, v in err.items()})
-    assert err["bf16x6"] < 1.5 * max(err["fp32"], err["float32 reference"]), err
-    assert err["fp16x3"] < 1.5 * max(err["fp32"], err["float32 reference"]), err      # the 3-term FP16 split: same claim
-    assert err["bf16x6"] < 2e-6 and err["fp32"] < 2e-6 and err["fp16x3"] < 2e-6
-    assert err["bf16x3"] > 3 * err["bf16x6"] and err["bf16x3"] > 3 * err["fp16x3"], err   # the modes are really different arithmetic
+    assert err["fp16x3"] < 1.5 * max(err["fp32"], err["float32 reference"]), err
+    assert err["fp32"] < 2e-6 and err["fp16x3"] < 2e-6
+
+
+def test_retired_precisions_are_rejected_with_a_pointer():
+    """Round 6: "bf16x3" / "bf16x6" no longer exist (ABI 12); the Python mirror says what to use instead, and the library rejects
+    the old codes at hd_create."""
+    import ctypes as C
+    from hierdiff_amd import _lib
+    sd_np, _, _, _, _, _ = _oracle_case([5, 3], 32, 1, seed=1)
+    dyn = build_dynamics(sd_np, 32, 1)
+    for name in ("bf16x3", "bf16x6"):
+        with pytest.raises(ValueError, match="fp16x3"):
+            dyn.precision = name
+    with pytest.raises(ValueError):
+        dyn.training_precision = "bf16x6"
+    lib = _lib.load()
+    for code in (1, 2):
+        cfg = _lib.HdConfig(9, 0, 3, 32, 1, 2, 1, 1, 1, 0.0, 10.0, 30.0, code, 0)
+        h = C.c_void_p()
+        assert lib.hd_create(C.byref(cfg), 0, C.byref(h)) == -1 and b"retired" in lib.hd_last_error()
 
 
 @pytest.mark.parametrize("w2_gain,first_gain", [(2.0 ** -9 * 0.7, 1.0), (2.0 ** 7 * 1.3, 1.0), (1.0, 2.0 ** -8), (1.0, 40.0)])
@@ -345,7 +361,7 @@ def test_general_edge_mask_and_options_vs_oracle():
     assert_parity(out.numpy(), ref.numpy(), "general edge mask")
 
 
-@pytest.mark.parametrize("precision,H", [("fp32", 64), ("bf16x6", 64), ("fp16x3", 64), ("fp16x3", 128), ("bf16x3", 64)])
+@pytest.mark.parametrize("precision,H", [("fp32", 64), ("fp16x3", 64), ("fp16x3", 128)])
 def test_pocket_sized_graph_vs_oracle(precision, H):
     """Pocket-conditioned jobs put the ligand fragments AND the pocket residues into one graph (diffusion_qm9.py:362-371):
     N in the hundreds, a node's edges span 7 tiles, ligand rows fixed through mol_shape.  N = 200 / 137, dense edges plus
@@ -752,7 +768,7 @@ def test_pocket_public_api():
 def test_full_length_chain_vs_oracle(precision):
     """The workload's real length: T = 1000 posterior steps + decode with injected normals, HIP path vs the CPU
     oracle (H=32, L=2 so the oracle's 1001 forwards take well under a minute).  Trajectory-level bar: rel-L2 < 1e-3
-    on the final x and h (the per-forward bar stays 1e-4; measured here 2e-5 / 5e-6 in fp32, 3e-5 / 6e-5 in bf16x3)."""
+    on the final x and h (the per-forward bar stays 1e-4; measured here 2e-5 / 5e-6 in fp32)."""
     import copy
     from hierdiff_amd.weights import synthetic_state_dict
     from hierdiff_amd.noise_model import evaluate_gamma
@@ -838,7 +854,7 @@ def test_norm_values_chain_and_nll_golden(precision):
     raws = [(torch.from_numpy(fx["raw_x"][i]), torch.from_numpy(fx["raw_h"][i])) for i in range(T + 2)]
     x, h = model.sample_from_masks(nm.to(DEV), em.to(DEV), None, raw_noises=raws)
     nmf = nm.float().numpy()
-    tol = 1e-3 if precision == "bf16x3" else 1e-4           # three chained steps of an untrained net amplify the per-forward error
+    tol = 1e-4
     assert_parity(x.cpu().numpy() * nmf, fx["chain_x"], "F20 chain x", tol, 10 * tol)
     assert_parity(h.cpu().numpy(), fx["chain_h"], "F20 chain h", tol, 10 * tol)
     model = build(int(fx["T"]))
@@ -909,7 +925,7 @@ def test_gnn_dynamics_sampling_chain_golden(precision):
     nm, em = orc.canonical_masks([int(v) for v in fx["n_list"]])
     raws = [(torch.from_numpy(fx["raw_x"][i]), torch.from_numpy(fx["raw_h"][i])) for i in range(T + 2)]
     x, h = model.sample_from_masks(nm.to(DEV), em.to(DEV), None, raw_noises=raws)
-    tol = 1e-3 if precision == "bf16x3" else 1e-4
+    tol = 1e-4
     assert_parity(x.cpu().numpy() * nm.float().numpy(), fx["x"], "F21c x", tol, 10 * tol)
     assert_parity(h.cpu().numpy(), fx["h"], "F21c h", tol, 10 * tol)
     # the public entry point (torch-generator noise in this mode): finite molecules of the drawn sizes

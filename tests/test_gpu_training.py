@@ -354,10 +354,10 @@ def test_training_step_with_learned_schedule_and_optimizer():
     assert torch.isfinite(loss) and loss.requires_grad
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "fp16x3"])
+@pytest.mark.parametrize("precision", ["fp32", "fp16x3"])
 def test_eval_mode_nll_does_not_depend_on_grad_mode(precision):
     """an evaluation call made WITHOUT torch.no_grad() (this test runs with autograd recording) takes the
-    inference kernels of the configured precision - it neither raises in the bf16 modes nor switches the schedule from the
+    inference kernels of the configured precision - it neither raises in the fp16x3 mode nor switches the schedule from the
     float64 table to the on-device fp32 network - and returns the bits of the same call under no_grad."""
     from hierdiff_amd.weights import synthetic_state_dict
     H, L = 64, 2
@@ -511,7 +511,7 @@ def test_randomised_gradient_sweep():
     tail = "\n".join(proc.stdout.splitlines()[-4:])
     assert proc.returncode == 0, tail + proc.stderr[-2000:]
     assert "failures 0" in tail, tail
-    # round 5: widths 128 / 256 on 20-36 molecules - kept pre-activations, training_precision fp32 / bf16x6 / fp16x3 drawn per case
+    # round 5: widths 128 / 256 on 20-36 molecules - kept pre-activations, training_precision fp32 / fp16x3 drawn per case
     # (a 24-case run: profiles/r05_fuzz_grads_big.log)
     proc = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_grads.py"), "8", "13", "big"], cwd=root,
                           capture_output=True, text=True, timeout=600)
@@ -651,48 +651,14 @@ def test_inference_path_sees_writes_that_bump_no_version():
     assert d0 == (want + 1) & 0xFFFFFFFFFFFFFFFF          # the kernel against a numpy restatement of csrc/k_digest.hpp
 
 
-# ----------------------------------------------------------------------------- opt-in bf16x6 arithmetic of the training path
-
-@pytest.mark.parametrize("fname", ["hd_dw2_x6"])
-@pytest.mark.parametrize("H,rows", [(256, 4096), (256, 32 * 173), (128, 2048), (128, 32)])
-def test_dw2_matches_a_float64_product(H, rows, fname):
-    """csrc/k_dw2.hpp: dW2 = G2^T P with one workgroup per slab of edge rows owning the whole H x H result, on a three-way bf16
-    split of both operands, six MFMAs per product - closer to a float64 product than torch's fp32 GEMM of the same operands (the
-    split drops terms below 2^-26 of a product); slab counts that do and do not divide the rows; deterministic."""
-    import ctypes as C
-    from hierdiff_amd import _lib
-    lib = _lib.load()
-    fn = getattr(lib, fname)
-    g = torch.Generator().manual_seed(H + rows)
-    G2 = (torch.randn(rows, H, generator=g) * torch.logspace(-3, 1, H)[None, :]).to(DEV)       # columns of very different scale
-    P = torch.randn(rows, H, generator=g).to(DEV)
-    ref = G2.double().t() @ P.double()
-    outs = []
-    for slabs in (256, 7, 1):
-        dW2 = torch.full((H, H), float("nan"), device=DEV)
-        ws = torch.empty(slabs * H * H, device=DEV)
-        _lib.check(fn(0, rows, H, G2.data_ptr(), P.data_ptr(), dW2.data_ptr(), H, ws.data_ptr(), ws.numel(),
-                                 torch.cuda.current_stream().cuda_stream), fname)
-        err = float((dW2.double() - ref).norm() / ref.norm())
-        f32 = float(((G2.t() @ P).double() - ref).norm() / ref.norm())
-        print(f"{fname} H={H} rows={rows} slabs<={slabs}: rel-L2 vs float64 {err:.2e} (torch fp32 matmul {f32:.2e})")
-        assert err < 2e-6
-        outs.append(dW2)
-    again = torch.empty_like(outs[0])
-    ws = torch.empty(256 * H * H, device=DEV)
-    _lib.check(fn(0, rows, H, G2.data_ptr(), P.data_ptr(), again.data_ptr(), H, ws.data_ptr(), ws.numel(),
-                             torch.cuda.current_stream().cuda_stream), fname)
-    assert torch.equal(again, outs[0])                                   # no atomics: bit-reproducible
-    assert fn(0, 48, H, G2.data_ptr(), P.data_ptr(), again.data_ptr(), H, ws.data_ptr(), ws.numel(), None) != 0   # rows % 32
-    assert fn(0, rows, 64, G2.data_ptr(), P.data_ptr(), again.data_ptr(), 64, ws.data_ptr(), ws.numel(), None) != 0
-
+# ----------------------------------------------------------------------------- opt-in fp16x3 arithmetic of the training path
 
 @pytest.mark.parametrize("H,rows", [(256, 4096), (256, 32 * 173), (128, 2048), (128, 32)])
 def test_dw2_f16_matches_a_float64_product(H, rows):
     """k_dw2_f16 (round 5): dW2 = G2^T P on a two-way FP16 split of both operands, each ranged by ONE power of two taken from
     per-workgroup maxima.  The operands span what a backward pass produces - columns over four decades and ROWS over six (gradient
     rows of gated-off edges next to the ones that matter): an element far below its array's maximum loses bits in proportion to how
-    little it contributes, so the reduction stays within 2e-6 of a float64 product, like the bf16x6 kernel; an all-zero operand, any
+    little it contributes, so the reduction stays within 2e-6 of a float64 product; an all-zero operand, any
     number of maxima, deterministic."""
     from hierdiff_amd import _lib
     lib = _lib.load()
@@ -732,52 +698,13 @@ def test_dw2_f16_matches_a_float64_product(H, rows):
 
 
 @pytest.mark.parametrize("H", [256, 128])
-def test_training_precision_bf16x6_gradients(H):
-    """`dynamics.training_precision = "bf16x6"`: the edge layer's H x H contractions - forward (hd_edge_layer_forward_p, precision 2),
-    both backward stages (hd_edge_layer_backward_p, precision 2) and dW2 (hd_dw2_x6) - in the fp32-accurate bf16 split, everything
-    else exact fp32.  Every parameter gradient and the input gradient
-    meet the SAME bar against the oracle's autograd as the exact-fp32 step (1e-4) and agree with the exact-fp32 step itself to
-    1e-5 - mixed precision without a loss of accuracy (the reference's own mixed mode is apex O2, conf/trainer/default.yaml:4-5)."""
-    from hierdiff_amd.weights import synthetic_state_dict
-    n_list, L = [30, 30, 17, 30, 9], 2
-    sd_np = synthetic_state_dict(9, 0, H, L, 2, True, 77, 0.5)
-    cfg = orc.DynCfg(in_node_nf=9, hidden_nf=H, n_layers=L, normalization_factor=10.0)
-    xh, nm, em = orc.random_inputs(n_list, 8, 72)
-    B, N = xh.shape[:2]
-    t = torch.linspace(0.1, 0.9, B).view(B, 1)
-    w = torch.randn(B, N, 11, generator=torch.Generator().manual_seed(6))
-    sd = _oracle_sd(sd_np)
-    xo = xh.clone().requires_grad_(True)
-    ref = orc.dynamics_forward(sd, cfg, t, xo, nm, em, None, None, prefix="dynamics.egnn.")
-    (ref * w).sum().backward()
-    grads = {}
-    for mode in ("fp32", "bf16x6"):
-        dyn = build_dynamics(sd_np, H, L)
-        dyn.precision = "fp32"
-        dyn.training_precision = mode
-        xg = xh.to(DEV).requires_grad_(True)
-        out = dyn._forward(t.to(DEV), xg, nm.to(DEV), em.to(DEV), None, None)
-        assert rel_l2(out.detach().cpu().numpy(), ref.detach().numpy()) < 1e-5
-        (out * w.to(DEV)).sum().backward()
-        worst, n = _compare_grads(dyn.egnn.named_parameters(), sd, "dynamics.egnn.", f"H={H} training_precision={mode}")
-        valid = nm.numpy()[..., 0]
-        assert rel_l2(xg.grad.cpu().double().numpy()[valid], xo.grad.double().numpy()[valid]) < GRAD_TOL
-        grads[mode] = {k: p.grad.detach().clone() for k, p in dyn.egnn.named_parameters()}
-        print(f"H={H} training_precision={mode}: {n} tensors, worst grad rel-L2 vs oracle {worst:.2e}")
-    between = max(float((grads["bf16x6"][k] - grads["fp32"][k]).norm() / grads["fp32"][k].norm().clamp_min(1e-30))
-                  for k in grads["fp32"] if float(grads["fp32"][k].norm()) > 1e-6)
-    print(f"H={H}: bf16x6 step vs exact-fp32 step, worst parameter-gradient rel-L2 {between:.2e}")
-    assert between < 1e-5
-    with pytest.raises(ValueError):
-        dyn.training_precision = "bf16x3"
-
-
-@pytest.mark.parametrize("H", [256, 128])
 def test_training_precision_fp16x3_gradients(H, monkeypatch):
     """`dynamics.training_precision = "fp16x3"` (round 5): forward contraction, stage B's dP = G2 W2 and dW2 = G2^T P in the two-way
     FP16 split (hd_edge_layer_forward_s / _backward_s with precision 3, hd_dw2_f16), ranges computed on the device from the data; the
     mode lives on top of the kept pre-activations, so the batch is one that keeps them (870 tiles) - and a 5-molecule batch falls
-    back to bf16x6 layer by layer.  Same bars as the bf16x6 mode: 1e-4 against the oracle's autograd, 1e-5 against the exact-fp32 step."""
+    back to exact fp32 layer by layer (round 6; bf16x6 before), with a one-time warning.  Bars: 1e-4 against the oracle's autograd,
+    1e-5 against the exact-fp32 step (the fallback IS the exact-fp32 step: bit-equal).  Every parameter gradient and the input
+    gradient - mixed precision without a loss of accuracy (the reference's own mixed mode is apex O2, conf/trainer/default.yaml:4-5)."""
     from hierdiff_amd import _lib
     from hierdiff_amd.weights import synthetic_state_dict
     L = 2
@@ -786,7 +713,10 @@ def test_training_precision_fp16x3_gradients(H, monkeypatch):
     of, od = lib.hd_edge_layer_forward_s, lib.hd_dw2_f16
     monkeypatch.setattr(lib, "hd_edge_layer_forward_s", lambda *a: (calls["fwd"].append(a[3]), of(*a))[1])
     monkeypatch.setattr(lib, "hd_dw2_f16", lambda *a: (calls.__setitem__("dw2", calls["dw2"] + 1), od(*a))[1])
-    for n_list, expect in (([30] * 30 + [17, 9], 3), ([30, 30, 17, 30, 9], 2)):
+    import warnings
+    import hierdiff_amd.training as tr
+    tr._WARNED.discard("fp16x3-fallback")
+    for n_list, expect in (([30] * 30 + [17, 9], 3), ([30, 30, 17, 30, 9], 0)):
         sd_np = synthetic_state_dict(9, 0, H, L, 2, True, 79, 0.5)
         cfg = orc.DynCfg(in_node_nf=9, hidden_nf=H, n_layers=L, normalization_factor=10.0)
         xh, nm, em = orc.random_inputs(n_list, 8, 74)
@@ -804,12 +734,15 @@ def test_training_precision_fp16x3_gradients(H, monkeypatch):
             dyn.precision = "fp32"
             dyn.training_precision = mode
             xg = xh.to(DEV).requires_grad_(True)
-            out = dyn._forward(t.to(DEV), xg, nm.to(DEV), em.to(DEV), None, None)
+            with warnings.catch_warnings(record=True) as caught:
+                warnings.simplefilter("always")
+                out = dyn._forward(t.to(DEV), xg, nm.to(DEV), em.to(DEV), None, None)
             assert rel_l2(out.detach().cpu().numpy(), ref.detach().numpy()) < 1e-5
             (out * w.to(DEV)).sum().backward()
             if mode == "fp16x3":
                 assert calls["fwd"] and all(p == expect for p in calls["fwd"]), calls
                 assert calls["dw2"] == (len(calls["fwd"]) if expect == 3 else 0)
+                assert (expect == 0) == any("runs in exact fp32" in str(c.message) for c in caught)
             worst, n = _compare_grads(dyn.egnn.named_parameters(), sd, "dynamics.egnn.", f"H={H} training_precision={mode}")
             valid = nm.numpy()[..., 0]
             assert rel_l2(xg.grad.cpu().double().numpy()[valid], xo.grad.double().numpy()[valid]) < GRAD_TOL
@@ -818,13 +751,14 @@ def test_training_precision_fp16x3_gradients(H, monkeypatch):
         between = max(float((grads["fp16x3"][k] - grads["fp32"][k]).norm() / grads["fp32"][k].norm().clamp_min(1e-30))
                       for k in grads["fp32"] if float(grads["fp32"][k].norm()) > 1e-6)
         print(f"H={H} B={B}: fp16x3 step (layers in precision {expect}) vs exact-fp32 step, worst parameter-gradient rel-L2 {between:.2e}")
-        # (the 5-molecule batch at width 128 has tensors whose exact-fp32 gradient is itself 1.6e-5 from the float64 oracle's)
-        assert between < (1e-5 if expect == 3 else 5e-5)
+        assert between < 1e-5 if expect == 3 else between == 0.0
+    with pytest.raises(ValueError):
+        dyn.training_precision = "bf16x3"
 
 
-@pytest.mark.parametrize("mode", ["bf16x6", "fp16x3"])
+@pytest.mark.parametrize("mode", ["fp16x3"])
 def test_training_precision_below_width_128_is_the_fp32_step(mode):
-    """The split arithmetics exist from width 128 up; a narrower model asked for `training_precision = "bf16x6"` / "fp16x3" runs the
+    """The split arithmetic exists from width 128 up; a narrower model asked for `training_precision = "fp16x3"` runs the
     exact-fp32 kernels (as `precision` does in sampling): same output and gradient bits as the fp32 step."""
     from hierdiff_amd.weights import synthetic_state_dict
     H, L = 64, 2
@@ -845,14 +779,12 @@ def test_training_precision_below_width_128_is_the_fp32_step(mode):
     assert all(torch.equal(a, b) for a, b in zip(res["fp32"][2], res[mode][2]))
 
 
-@pytest.mark.parametrize("H,B,mode", [(32, 5, "fp32"), (64, 7, "fp32"), (128, 32, "fp32"), (128, 32, "bf16x6"), (256, 32, "fp32"),
-                                      (256, 32, "bf16x6"), (256, 6, "fp32")])
+@pytest.mark.parametrize("H,B,mode", [(32, 5, "fp32"), (64, 7, "fp32"), (128, 32, "fp32"), (256, 32, "fp32"), (256, 6, "fp32")])
 def test_kept_edge_activations_equal_the_recomputing_backward(H, B, mode, monkeypatch):
     """Round 5: the training forward keeps W2 P + b2 of every edge row (hd_edge_layer_forward_s) where the whole-tile edge kernel
     runs, and stage A of the backward pass loads it instead of recomputing it on the matrix cores (hd_edge_layer_backward_s).
     `dynamics.keep_edge_activations = False` is the recomputing path of rounds 2-4: same output bits, gradients equal to the
-    bit in exact fp32 (the kept values ARE the recomputed ones: same arithmetic in the same order; in the bf16x6 mode the
-    recomputation orders its partial products differently - 3e-6 - and the kept values are the forward's own) - and the path under test is the
+    bit in exact fp32 (the kept values ARE the recomputed ones: same arithmetic in the same order) - and the path under test is the
     one that ran: 870 tiles at B = 32 take the whole-tile kernel at widths 128 / 256, every batch does below 128, and the
     6-molecule batch at width 256 (column-split forward) keeps nothing."""
     from hierdiff_amd import _lib
@@ -887,10 +819,7 @@ def test_kept_edge_activations_equal_the_recomputing_backward(H, B, mode, monkey
         worst = max(worst, d)
     dx = float((res[True][1] - res[False][1]).norm() / res[False][1].norm())
     print(f"H={H} B={B} {mode}: kept vs recomputed - worst parameter-gradient rel-L2 {worst:.2e}, d/dxh {dx:.2e}")
-    if mode == "fp32":
-        assert worst == 0.0 and dx == 0.0
-    else:       # bf16x6: stage A's own contraction sums its six partial products in another order than the forward kernel's
-        assert worst < 1e-5 and dx < 1e-5
+    assert worst == 0.0 and dx == 0.0
 
 
 # ----------------------------------------------------------------------------- new masks every step: staged batches, pooled arenas

@@ -229,8 +229,8 @@ def test_bench_line_keeps_the_creditable_blocks_in_the_drivers_tail():
     line = {"metric": "m", "value": 1.0, "unit": "molecules/s", "n_gpus": 1, "steps": 2, "warmup": 1, "ms_per_step": 5.0,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "w"}, "roofline": {"frac": 0.7, "pad": "r" * 600},
-            "fp16x3": {"value": 2.0, "pad": "p" * 1500}, "bf16x6": {"value": 1.5, "pad": "p" * 1800}, "bf16x3": {"value": 2.1, "pad": "p" * 1600},
-            "configs": {"note": "n", "f32": blk(10), "fp16x3": blk(10), "bf16x6": blk(10), "bf16x3": blk(10)},
+            "fp16x3": {"value": 2.0, "pad": "p" * 1500},
+            "configs": {"note": "n", "f32": blk(10), "fp16x3": blk(10)},
             "next_rows": {f"row{i}": {"ms_per_step": 1.0, "what": "y" * 300} for i in range(10)},
             "cpu_baseline": {"value": 0.03, "sample": "s" * 400}}
     out = bench.driver_visible_order(line)
