@@ -161,67 +161,82 @@ def optimizer_generation() -> int:
 # k_params_digest over the parameter tensors where they lie (no concatenation; 23.7 MB at L = 6, a few microseconds) and an
 # 8-byte read.  Cost: one stream wait per confirmed hit - the sampler pays it once per 1001 forwards (hd_sample_loop), a
 # single `_forward` call once per call.
-_DIGEST_TABLES: dict = {}
+class DigestPlan:
+    """Everything `params_digest` needs that does not change while the tensors stay where they are: per device the pointer / offset
+    tables of its cuda fp32 tensors (built once: walking 60-odd parameters in Python costs more than the kernel), plus the tensors
+    that are hashed on the host (CPU tensors, other dtypes: the 3,077-float schedule network before .to(device) - bookkeeping, not
+    compute).  `run()` = one launch of k_params_digest per device + an 8-byte read each."""
 
-
-def params_digest(tensors) -> int:
-    """64-bit digest of the VALUES of `tensors` (any mix of devices).  cuda fp32 tensors go through hd_params_digest in one
-    launch per device; anything else (CPU tensors, other dtypes: the 3,077-float schedule network before .to(device)) is hashed
-    on the host - bookkeeping, not compute."""
-    import hashlib
-    import torch
-    by_dev: dict = {}
-    host, on_host = hashlib.blake2b(digest_size=8), False
-    for t in tensors:
-        t = t.detach()
-        if t.is_cuda and t.dtype == torch.float32 and t.is_contiguous():
-            by_dev.setdefault(t.device.index if t.device.index is not None else torch.cuda.current_device(), []).append(t)
-        else:
-            on_host = True
-            host.update(t.cpu().contiguous().view(torch.uint8).numpy().tobytes() if t.numel() else b"")
-            host.update(str(tuple(t.shape)).encode())
-    parts = [int.from_bytes(host.digest(), "little")] if on_host else []
-    lib = load() if by_dev else None
-    for idx, ts in sorted(by_dev.items()):
-        key = (idx,) + tuple((t.data_ptr(), t.numel()) for t in ts)
-        tab = _DIGEST_TABLES.get(key)
-        if tab is None:
-            if len(_DIGEST_TABLES) > 64:
-                _DIGEST_TABLES.clear()
+    def __init__(self, tensors):
+        import torch
+        by_dev: dict = {}
+        self.host = []
+        for t in tensors:
+            t = t.detach()
+            if t.is_cuda and t.dtype == torch.float32 and t.is_contiguous():
+                by_dev.setdefault(t.device.index if t.device.index is not None else torch.cuda.current_device(), []).append(t)
+            else:
+                self.host.append(t)
+        self.dev = []
+        for idx, ts in sorted(by_dev.items()):
             dev = torch.device("cuda", idx)
             prefix = [0]
             for t in ts:
                 prefix.append(prefix[-1] + t.numel())
-            tab = (torch.tensor([t.data_ptr() for t in ts], dtype=torch.int64, device=dev),
-                   torch.tensor(prefix, dtype=torch.int64, device=dev), torch.zeros(2, dtype=torch.int64, device=dev), prefix[-1])
-            _DIGEST_TABLES[key] = tab
-        out = C.c_uint64(0)
-        with torch.cuda.device(idx):
-            stream = torch.cuda.current_stream().cuda_stream
-            check(lib.hd_params_digest(idx, tab[0].data_ptr(), tab[1].data_ptr(), len(ts), tab[3], tab[2].data_ptr(), C.byref(out), stream),
-                  "hd_params_digest")
-        parts.append(out.value)
-    total = 0
-    for x in parts:                      # one device, no host tensor: the kernel's value + 1
-        total = (total * 0x100000001B3 + x + 1) & 0xFFFFFFFFFFFFFFFF
-    return total
+            self.dev.append((idx, torch.tensor([t.data_ptr() for t in ts], dtype=torch.int64, device=dev),
+                             torch.tensor(prefix, dtype=torch.int64, device=dev), torch.zeros(2, dtype=torch.int64, device=dev),
+                             len(ts), prefix[-1], ts))           # (the tensors are kept alive with their addresses)
+
+    def run(self) -> int:
+        import hashlib
+        import torch
+        parts = []
+        if self.host:
+            h = hashlib.blake2b(digest_size=8)
+            for t in self.host:
+                h.update(t.cpu().contiguous().view(torch.uint8).numpy().tobytes() if t.numel() else b"")
+                h.update(str(tuple(t.shape)).encode())
+            parts.append(int.from_bytes(h.digest(), "little"))
+        if self.dev:
+            lib = load()
+            out = C.c_uint64(0)
+            for idx, ptrs, prefix, state, n, total, _ in self.dev:
+                with torch.cuda.device(idx):
+                    check(lib.hd_params_digest(idx, ptrs.data_ptr(), prefix.data_ptr(), n, total, state.data_ptr(), C.byref(out),
+                                               torch.cuda.current_stream().cuda_stream), "hd_params_digest")
+                parts.append(out.value)
+        total = 0
+        for x in parts:                      # one device, no host tensor: the kernel's value + 1
+            total = (total * 0x100000001B3 + x + 1) & 0xFFFFFFFFFFFFFFFF
+        return total
+
+
+def params_digest(tensors) -> int:
+    """64-bit digest of the VALUES of `tensors` (any mix of devices): cuda fp32 tensors through hd_params_digest, one launch per
+    device; anything else hashed on the host."""
+    return DigestPlan(tensors).run()
 
 
 class ImageGuard:
-    """`valid(key, tensors)` is True only if BOTH the cheap key and the content digest equal those of the last `store`."""
+    """`valid(key, tensors)` is True only if BOTH the cheap key and the content digest equal those of the last `store`.  The key must
+    carry every tensor's address (all call sites key on `(data_ptr, _version)` pairs): a key hit then means the plan built at
+    `store` still points at the right memory, and the confirmation costs one launch and one 8-byte read, no Python per tensor."""
 
     def __init__(self):
         self.key = None
         self.digest = None
+        self.plan = None
 
     def valid(self, key, tensors) -> bool:
         if self.key is None or key != self.key:
             return False
-        return params_digest(tensors) == self.digest
+        return self.plan.run() == self.digest
 
     def store(self, key, tensors) -> None:
+        self.plan = DigestPlan(tensors)
         self.key = key
-        self.digest = params_digest(tensors)
+        self.digest = self.plan.run()
 
     def clear(self) -> None:
         self.key = None
+        self.plan = None

@@ -2220,8 +2220,11 @@ extern "C" int hd_gemm_f32(int device, int M, int N, int K, const float* A, long
     g.bvec = aligned(B, b_kc ? b_n_stride : b_k_stride) ? 1 : 0;
     dim3 grid((M + TG_BM - 1) / TG_BM, (N + TG_BN - 1) / TG_BN, split_k);
     const dim3 block(256);
-    // a result of fewer than 128 tiles (a small training batch) as 32 x 32 tiles with the K quarters on the four wavefronts
-    if (!splitting && (long long)grid.x * grid.y < 128 && K >= 32) {
+    // a result of fewer than 128 tiles (a small training batch) as 32 x 32 tiles with the K quarters on the four wavefronts.  The
+    // tile count bounds M * N below 1 M elements; the kernel re-reads a 32 x K strip of both operands per tile with no LDS reuse, so
+    // K is bounded too: the measured family is the node-level Linears (K <= 2 hidden_nf = 512; profiles/r05_ab_small_gemm.log covers
+    // it up to its upper end, M = 3,840 rows x N = 256 / 512: step 15.9 -> 15.3 ms at B = 128) - longer K takes the LDS-tiled kernel
+    if (!splitting && (long long)grid.x * grid.y < 128 && K >= 32 && K <= 1024) {
         g.colsum = colsum;
         const dim3 sg((M + 31) / 32, (N + 31) / 32);
         if (a_kc && b_kc) hipLaunchKernelGGL((k_tgemm_small<true, true>), sg, block, 0, s, g);

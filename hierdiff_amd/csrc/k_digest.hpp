@@ -1,7 +1,8 @@
 // Content digest of a set of parameter tensors (round 6; no reference counterpart - the reference evaluates its nn.Modules in
 // place, this library evaluates PACKED IMAGES of them, and an image must never outlive the values it was packed from).
 //
-// digest = sum over the virtual concatenation of the tensors' 32-bit words of splitmix64(word + phi64 * (position + 1)), modulo 2^64.
+// digest = sum over the PAIRS (w[i], w[i+1]), i even, of the virtual concatenation of the tensors' 32-bit words (padded with zeros to a
+// multiple of four) of splitmix64((w[i] | w[i+1] << 32) + phi64 * (i + 1)), modulo 2^64.
 // Integer addition is associative, so the value does not depend on the launch geometry or on the order the atomics land in; it
 // changes when any single bit of any word changes (splitmix64 is a bijection of the 64-bit argument, and the argument differs),
 // and two different contents collide with probability 2^-64.  HBM/L2-bound: 16-byte loads where a group of four words is aligned
@@ -56,15 +57,19 @@ __global__ __launch_bounds__(256) void k_params_digest(DigestArgs a) {
         const uint32_t* q = p + (i - t_begin);
         if (i + 4 <= t_end && (reinterpret_cast<uintptr_t>(q) & 15) == 0) {
             const uint4 v = *reinterpret_cast<const uint4*>(q);
-            acc += digest_term(v.x, i) + digest_term(v.y, i + 1) + digest_term(v.z, i + 2) + digest_term(v.w, i + 3);
+            acc += digest_term((unsigned long long)v.x | ((unsigned long long)v.y << 32), i) +
+                   digest_term((unsigned long long)v.z | ((unsigned long long)v.w << 32), i + 2);
         } else {                         // tensor boundary or an unaligned view: word by word, walking on as needed
             int tj = ti;
             long long b = t_begin, e = t_end;
             const uint32_t* pj = p;
+            uint32_t w[4] = {0u, 0u, 0u, 0u};        // (words past the end of the concatenation count as zero: `total` is part of the key)
             for (int d = 0; d < 4 && i + d < a.total; ++d) {
                 while (i + d >= e) { ++tj; b = a.prefix[tj]; e = a.prefix[tj + 1]; pj = a.ptrs[tj]; }
-                acc += digest_term(pj[i + d - b], i + d);
+                w[d] = pj[i + d - b];
             }
+            acc += digest_term((unsigned long long)w[0] | ((unsigned long long)w[1] << 32), i) +
+                   digest_term((unsigned long long)w[2] | ((unsigned long long)w[3] << 32), i + 2);
         }
     }
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);

@@ -158,12 +158,14 @@ def release_cached_memory() -> None:
 
 
 _PIN_RING: Dict[Tuple, list] = {}
-_PIN_DEPTH = 4
+_PIN_DEPTH = 4                      # slots a byte class starts with
+_PIN_CLASS_BYTES = 64 << 20         # ... and may grow to (per class and device) before a staging call waits for a copy
 
 
 def _to_device_async(t: torch.Tensor, device: torch.device) -> torch.Tensor:
     """Host tensor -> device in stream order WITHOUT a host wait: through a pinned staging buffer this module keeps (a ring of
-    _PIN_DEPTH buffers per shape / dtype, each guarded by the event behind its last copy).  What it avoids, all measured in a
+    at least _PIN_DEPTH buffers per byte class, each guarded by the event behind its last copy; a buffer is reused only once that
+    event has completed, the ring grows instead - up to _PIN_CLASS_BYTES - when every buffer is still in flight).  What it avoids, all measured in a
     staged training loop at B = 256 (scratch/fresh_masks_trace.py, scratch/busy_gpu_experiments.py): a pageable source makes torch
     wait for the stream (the host cannot run ahead); `Tensor.pin_memory()` allocates, and with the host ahead of the GPU its cached
     blocks are still in flight, so it falls through to hipHostMalloc, which waits for the device (60 ms stalls); and
@@ -185,14 +187,24 @@ def _to_device_async(t: torch.Tensor, device: torch.device) -> torch.Tensor:
     if ring is None:
         ring = _PIN_RING[key] = [0, []]
     pos, slots = ring
-    if len(slots) < _PIN_DEPTH:
+    slot = None
+    if len(slots) >= _PIN_DEPTH:
+        # oldest slot first; a slot whose copy has not run yet (tensors of ONE batch share a byte class, and their copies queue
+        # behind the training step that is still executing) must not be waited for - that wait is the stall this function exists
+        # to avoid: take the next finished slot, or grow the ring while the class stays under its byte cap
+        for k in range(len(slots)):
+            cand = slots[(pos + k) % len(slots)]
+            if cand[1] is None or cand[1].query():
+                slot = cand
+                ring[0] = (pos + k + 1) % len(slots)
+                break
+        if slot is None and len(slots) * cap >= _PIN_CLASS_BYTES:
+            slot = slots[pos % len(slots)]
+            ring[0] = (pos + 1) % len(slots)
+            slot[1].synchronize()                                   # the cap is reached: wait for the oldest copy
+    if slot is None:
         slots.append([torch.empty(cap, dtype=torch.uint8, pin_memory=True), None])
         slot = slots[-1]
-    else:
-        slot = slots[pos % _PIN_DEPTH]
-        ring[0] = pos + 1
-        if slot[1] is not None:
-            slot[1].synchronize()                                   # copy issued _PIN_DEPTH stagings ago: long done
     src = t.contiguous()
     if nbytes:
         C.memmove(slot[0].data_ptr(), src.data_ptr(), nbytes)
@@ -374,7 +386,8 @@ class EGNN_dynamics_QM9(nn.Module):
     #: Training forward keeps the second-layer pre-activations W2 P + b2 of every edge row for its backward pass where the
     #: whole-tile edge kernel runs (large batches; `hd_edge_layer_save_rows`), so stage A of the backward pass loads them instead
     #: of recomputing them on the matrix cores: [edge rows, hidden_nf] fp32 per edge layer - 228 MB x 18 layers = 4.1 GB at
-    #: B = 256, N = 30, H = 256, a size chosen for this GPU's 288 GB.  False = recompute (rounds 2-4; same gradients to the bit).
+    #: B = 256, N = 30, H = 256, a size chosen for this GPU's 288 GB; it grows as B N^2 H layers, and a layer whose buffer cannot be
+    #: allocated falls back to recomputing (one warning).  False = recompute everywhere (rounds 2-4; same gradients to the bit).
     keep_edge_activations = True
 
     # ------------------------------------------------------------------ precision of the matrix-core path

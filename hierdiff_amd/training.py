@@ -262,7 +262,18 @@ class _EdgeLayer(torch.autograd.Function):
         if getattr(dyn, "keep_edge_activations", True) and any(ctx.needs_input_grad):
             rows = int(lib.hd_edge_layer_save_rows(dyn._handle(), topo.ptr, prec))
             if rows > 0:
-                pre2 = torch.empty((rows, tr.H), device=AB.device, dtype=torch.float32)
+                # [edge rows, H] fp32 per edge layer, alive until the backward pass: B N^2 H layers bytes x 4 in total (4.1 GB at
+                # the headline shape; a pocket model with a few hundred nodes reaches tens of GB).  A layer whose buffer does not
+                # fit is not an error: it recomputes in its backward pass, like every layer did before round 5
+                try:
+                    pre2 = torch.empty((rows, tr.H), device=AB.device, dtype=torch.float32)
+                except torch.cuda.OutOfMemoryError:
+                    pre2 = None
+                    if "keep-oom" not in _WARNED:
+                        _WARNED.add("keep-oom")
+                        import warnings
+                        warnings.warn(f"keep_edge_activations: {rows * tr.H * 4 / 2**20:.0f} MiB for one edge layer's pre-activations do "
+                                      "not fit; this and later such layers recompute them in the backward pass (same gradients)")
         if prec == 3 and pre2 is None and any(ctx.needs_input_grad):
             prec = 0        # the fp16x3 backward exists on top of the kept pre2 only: this layer runs in exact fp32
             if "fp16x3-fallback" not in _WARNED:

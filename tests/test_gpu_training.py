@@ -639,13 +639,16 @@ def test_inference_path_sees_writes_that_bump_no_version():
     d0 = _lib.params_digest([p0])
     flat = p0.detach().reshape(-1)
     assert _lib.params_digest([flat[:100], flat[100:]]) == d0 and _lib.params_digest([flat]) == d0
+    assert _lib.params_digest([flat[:101], flat[101:103], flat[103:]]) == d0          # boundaries inside a group of four words
     bits = p0.data.view(torch.int32)
     bits[3, 2] += 1
     assert _lib.params_digest([p0]) != d0
     bits[3, 2] -= 1
     assert _lib.params_digest([p0]) == d0
     host = np.frombuffer(flat.cpu().numpy().tobytes(), dtype=np.uint32).astype(np.uint64)
-    x = host + np.uint64(0x9E3779B97F4A7C15) * (np.arange(host.size, dtype=np.uint64) + np.uint64(1))
+    host = np.concatenate([host, np.zeros((-host.size) % 4, dtype=np.uint64)])
+    pair = host[0::2] | (host[1::2] << np.uint64(32))
+    x = pair + np.uint64(0x9E3779B97F4A7C15) * (np.arange(0, host.size, 2, dtype=np.uint64) + np.uint64(1))
     x ^= x >> np.uint64(30); x *= np.uint64(0xBF58476D1CE4E5B9); x ^= x >> np.uint64(27); x *= np.uint64(0x94D049BB133111EB); x ^= x >> np.uint64(31)
     want = int(np.sum(x, dtype=np.uint64))
     assert d0 == (want + 1) & 0xFFFFFFFFFFFFFFFF          # the kernel against a numpy restatement of csrc/k_digest.hpp
@@ -875,6 +878,38 @@ def test_stage_batch_builds_the_topology_from_the_host_masks(monkeypatch):
     assert torch.equal(v1, v2)
     with pytest.raises(Exception):
         b.dynamics.stage_masks(host["atom_mask"].to(DEV), host["edge_mask"].to(DEV))
+
+
+def test_staging_many_small_tensors_never_waits_for_the_running_step():
+    """tensors of one batch share a byte class of the pinned staging ring; the fifth of them used to WAIT for the
+    first one's copy - queued behind the training step that is still running - i.e. for the GPU to drain.  A slot is now reused only
+    when its copy has completed and the ring grows instead: a dozen stagings behind ~100 ms of queued GPU work return in
+    milliseconds, and every copy carries its own bytes."""
+    import time
+    from hierdiff_amd.dynamics import _PIN_RING, _to_device_async
+    dev = torch.device(DEV)
+    a = torch.randn(4096, 4096, device=dev)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(4):
+        a @ a
+    torch.cuda.synchronize(dev)
+    per = (time.perf_counter() - t0) / 4
+    reps = max(8, int(0.15 / per))
+    srcs = [torch.full((257,), float(k)) + torch.arange(257) for k in range(12)]
+    for _ in range(reps):
+        a = (a @ a) * 1e-4
+    t1 = time.perf_counter()
+    outs = [_to_device_async(t, dev) for t in srcs]
+    host = time.perf_counter() - t1
+    torch.cuda.synchronize(dev)
+    total = time.perf_counter() - t1
+    assert total > 0.05, "the test needs GPU work in flight while it stages"
+    assert host < 0.25 * total, f"staging waited for the GPU: {host * 1e3:.1f} ms of {total * 1e3:.1f} ms"
+    for src, out in zip(srcs, outs):
+        assert torch.equal(out.cpu(), src)
+    ring = _PIN_RING[(4096, str(dev))]
+    assert 4 <= len(ring[1]) <= 16384
 
 
 def test_recycled_arenas_give_the_same_bits():
