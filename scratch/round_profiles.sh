@@ -8,7 +8,7 @@ cd /root/repo
 TAG=${1:-r02}
 OUT=gpurun_out/prof_$TAG; rm -rf $OUT; mkdir -p $OUT
 SQ="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"
-for prec in ${PRECS:-fp32 fp16x3 bf16x6 bf16x3}; do
+for prec in ${PRECS:-fp32 fp16x3}; do
   rm -rf /tmp/ks
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -o p -- python bench.py --precision $prec --timesteps 50 --steps 2 --warmup 1 --no-cpu-baseline --no-configs > $OUT/bench_${prec}_T50.log 2>&1
   cp $(find /tmp/ks -name "p_kernel_stats.csv" | head -1) $OUT/${TAG}_${prec}_T50_kernel_stats.csv

@@ -56,7 +56,7 @@ def main():
            "correction": "hbm bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE counts 64 B per 128-B request); "
                          "counters include Infinity-Cache hits",
            "edge_kernel": {}, "kernels": {}}
-    for prec, pnum in (("fp32", 0), ("bf16x3", 1), ("bf16x6", 2), ("fp16x3", 3)):
+    for prec, pnum in (("fp32", 0), ("fp16x3", 3)):          # (rounds 2-5 also carried bf16x3 = 1 and bf16x6 = 2)
         stats = {}
         sp = os.path.join(d, f"{tag}_{prec}_T50_kernel_stats.csv")
         if os.path.exists(sp):
