@@ -1,151 +1,22 @@
-// dW2 = G2^T P on the matrix cores proper (training, opt-in bf16x6 arithmetic): the one dense reduction over ALL edge rows of an
-// edge layer's backward, dL/dW2[c][k] = sum_e G2[e][c] P[e][k] (hd_edge_layer_backward leaves G2 = dL/d(pre2) and P = SiLU(pre1)
+// dW2 = G2^T P on the matrix cores proper (training, opt-in fp16x3 arithmetic): the one dense reduction over ALL edge rows of an
+// edge layer's backward, dL/dW2[c][k] = sum_e G2[e][c] P[e][k] (hd_edge_layer_backward_s leaves G2 = dL/d(pre2) and P = SiLU(pre1)
 // as [rows][H] arrays; reference: the autograd of edge_mlp.2 / coord_mlp.2, egnn_new.py:19-23, 83-86).  Included through kernels.hpp.
 //
-// In exact fp32 (k_tgemm) this product is 29 GFLOP per layer at H = 256, B = 256 on an instruction that runs at the vector rate:
-// 298 us, 5.4 ms of a 33 ms training step.  Here both operands are split three ways into bf16 pieces (a = h + m + l, 24
-// significant bits) and the product is formed from six v_mfma_f32_32x32x16_bf16 per k-step with fp32 accumulation - the bf16x6
-// arithmetic of the sampler's edge kernel (k_edge.hpp, PREC 2): truncation <= 2^-26 per product, below the rounding of the fp32
-// accumulation itself.  One workgroup owns the WHOLE H x H result for a slab of edge rows (split-K: partial results in `ws`, streamed,
-// added in a fixed order by k_dw2_reduce - deterministic), so each operand row is read exactly once:
+// In exact fp32 (k_tgemm) this product is 29 GFLOP per layer at H = 256, B = 256 on an instruction that runs at the vector rate.
+// Here (k_dw2_f16, below) both operands are split two ways into FP16 pieces and the product is formed from three
+// v_mfma_f32_32x32x16_f16 per k-step with fp32 accumulation.  One workgroup owns the WHOLE H x H result for a slab of edge rows
+// (split-K: partial results in `ws`, streamed, added in a fixed order by k_dw2_reduce - deterministic), so each operand row is read
+// exactly once:
 //   * 32 edge rows per chunk: every thread loads float4 pieces of two consecutive rows (coalesced), splits the 2 x 4 values
-//     and stores them as packed bf16 pairs into three LDS planes per operand, [column][k] with k contiguous (the MFMA wants 8
+//     and stores them as packed pairs into two LDS planes per operand, [column][k] with k contiguous (the MFMA wants 8
 //     consecutive k of one column per lane; memory has the columns contiguous): row stride 80 B, the four 16-byte k groups of a
 //     row XOR-permuted by (column >> 4) & 3, which makes the transposing ds_write_b32 2-way (free) instead of 8-way conflicted
 //     and keeps the ds_read_b128 fragment reads conflict-free;
-//   * 8 wavefronts as 4 (result rows) x 2 (result columns), H/128 x H/64 accumulators of 32 x 32 each; per k-step and column
-//     tile three fragment reads and 6 H/128 MFMAs (small terms first: h*l, h*m, m*m, h*h, m*h, l*h);
+//   * 8 wavefronts as 4 (result rows) x 2 (result columns), H/128 x H/64 accumulators of 32 x 32 each;
 //   * the next chunk's global loads are in flight under the current chunk's MFMAs (single LDS buffer, two barriers per chunk).
+// (Rounds 4-5 carried a three-way bf16 twin of this kernel, k_dw2_x6; retired in round 6 with the bf16x6 mode.)
 #pragma once
 #include "common.hpp"
-
-struct Dw2Args {
-    const float* G;         // [rows][H]  G2
-    const float* P;         // [rows][H]
-    float* ws;              // [slabs][H][H] partial results
-    int rows, kslab;        // rows: multiple of 32; kslab: rows per workgroup (multiple of 32)
-};
-
-template <int H>
-constexpr int dw2_lds_bytes() { return 2 * 3 * H * 80; }
-
-template <int H>
-__global__ __launch_bounds__(512, 2) void k_dw2_x6(Dw2Args a) {
-    static_assert(H % 128 == 0, "wave grid 4 x 2 of 32 x 32 tiles");
-    constexpr int MT = H / 128, NT = H / 64;            // 32 x 32 tiles per wavefront: rows (G columns), columns (P columns)
-    constexpr int Q = H / 4;                            // float4 per operand row
-    constexpr int NPASS = H / 128;                      // 512 threads cover 512 / Q row pairs per pass, 16 row pairs per chunk
-    constexpr int PLANE = H * 80;                       // bytes per plane
-    extern __shared__ __attribute__((aligned(16))) char lds_d[];
-    char* gpl = lds_d;                                  // G planes h, m, l
-    char* ppl = lds_d + 3 * PLANE;                      // P planes
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;            // wavefront's block: result rows [wr H/4, +H/4), columns [wc H/2, +H/2)
-    const int kg = lane >> 5, i = lane & 31;
-    const int z = blockIdx.x;
-    const int kbeg = z * a.kslab, kend = min(a.rows, kbeg + a.kslab);
-    const int nchunk = (kend - kbeg) / 32;
-
-    // loader geometry: column quad c4, row pair kp (+ 8 or 16 per pass)
-    const int c4 = tid % Q, kp0 = tid / Q;
-    constexpr int KPP = 512 / Q;                        // row pairs per pass
-    f32x4 gr[NPASS][2], pr[NPASS][2];
-    auto load_chunk = [&](int c) {
-        const size_t r0 = (size_t)(kbeg + 32 * c);
-#pragma unroll
-        for (int p = 0; p < NPASS; ++p) {
-            const size_t row = r0 + 2 * (kp0 + KPP * p);
-            gr[p][0] = *reinterpret_cast<const f32x4*>(a.G + row * H + 4 * c4);
-            gr[p][1] = *reinterpret_cast<const f32x4*>(a.G + (row + 1) * H + 4 * c4);
-            pr[p][0] = *reinterpret_cast<const f32x4*>(a.P + row * H + 4 * c4);
-            pr[p][1] = *reinterpret_cast<const f32x4*>(a.P + (row + 1) * H + 4 * c4);
-        }
-    };
-    // column `col`, k pair kp of a plane: byte offset (row stride 80 B, 16-byte k groups XOR-permuted by (col >> 4) & 3)
-    auto slot = [](int col, int kp) { return col * 80 + (((kp >> 2) ^ ((col >> 4) & 3)) << 4) + ((kp & 3) << 2); };
-    auto store_chunk = [&]() {
-#pragma unroll
-        for (int p = 0; p < NPASS; ++p) {
-            const int kp = kp0 + KPP * p;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int off = slot(4 * c4 + j, kp);
-                uint32_t h, m, l;
-                bf16_split3(gr[p][0][j], gr[p][1][j], h, m, l);
-                *reinterpret_cast<uint32_t*>(gpl + off) = h;
-                *reinterpret_cast<uint32_t*>(gpl + PLANE + off) = m;
-                *reinterpret_cast<uint32_t*>(gpl + 2 * PLANE + off) = l;
-                bf16_split3(pr[p][0][j], pr[p][1][j], h, m, l);
-                *reinterpret_cast<uint32_t*>(ppl + off) = h;
-                *reinterpret_cast<uint32_t*>(ppl + PLANE + off) = m;
-                *reinterpret_cast<uint32_t*>(ppl + 2 * PLANE + off) = l;
-            }
-        }
-    };
-    // fragment of k-step s (16 k) for the 32 columns starting at col0: lane (i, kg) takes k = 16 s + 8 kg .. + 7 of column col0 + i
-    auto frag = [&](const char* plane, int col0, int s) -> bf16x8 {
-        const int col = col0 + i;
-        return *reinterpret_cast<const bf16x8*>(plane + col * 80 + (((2 * s + kg) ^ ((col >> 4) & 3)) << 4));
-    };
-
-    f32x16 acc[MT][NT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
-
-    if (nchunk > 0) load_chunk(0);
-    for (int c = 0; c < nchunk; ++c) {
-        store_chunk();                                  // waits for chunk c's loads
-        __syncthreads();
-        if (c + 1 < nchunk) load_chunk(c + 1);          // in flight under the MFMAs below
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            bf16x8 Ah[MT], Am[MT], Al[MT];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const int col0 = wr * (H / 4) + 32 * mt;
-                Ah[mt] = frag(gpl, col0, s); Am[mt] = frag(gpl + PLANE, col0, s); Al[mt] = frag(gpl + 2 * PLANE, col0, s);
-            }
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int col0 = wc * (H / 2) + 32 * nt;
-                const bf16x8 Bh = frag(ppl, col0, s), Bm = frag(ppl + PLANE, col0, s), Bl = frag(ppl + 2 * PLANE, col0, s);
-                // the six terms, small ones first; consecutive MFMAs go to different accumulators (no dependent pair back to back)
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[mt], Bl, acc[mt][nt], 0, 0, 0);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al[mt], Bh, acc[mt][nt], 0, 0, 0);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[mt], Bm, acc[mt][nt], 0, 0, 0);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am[mt], Bh, acc[mt][nt], 0, 0, 0);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am[mt], Bm, acc[mt][nt], 0, 0, 0);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[mt], Bh, acc[mt][nt], 0, 0, 0);
-            }
-        }
-        __syncthreads();                                // every wavefront is done with the planes: the next chunk may overwrite them
-    }
-
-    // partial result of this slab.  acc[mt][nt][r]: row wr H/4 + 32 mt + rho(r), rho(r) = (r & 3) + 8 (r >> 2) + 4 kg; column wc H/2 + 32 nt + i
-    float* out = a.ws + (size_t)z * H * H;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wr * (H / 4) + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * kg;
-                // streamed: 256 slabs x 256 KB of partial results must not push the G2 / P rows of the neighbouring kernels out of the caches
-                __builtin_nontemporal_store(acc[mt][nt][r], out + (size_t)row * H + wc * (H / 2) + 32 * nt + i);
-            }
-}
 
 // dW2[m][n] = sum over the slabs' partial results, in a FIXED order: eight interleaved running sums (slab z goes to sum z % 8,
 // ascending z) added as ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7)) - eight loads in flight per thread instead of a
@@ -161,27 +32,6 @@ __global__ __launch_bounds__(256) void k_dw2_reduce(const float* ws, float* C, i
     }
     for (int k = 0; z + k < nz; ++k) s[k] += __builtin_nontemporal_load(ws + (size_t)(z + k) * total + idx);
     C[(size_t)(idx / N) * ldc + idx % N] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
-}
-
-// W [H][H] (state_dict layout, row = output column of the layer) -> chunk image of the bf16x6 edge kernels (pack_edge_w2_x6 on the
-// device: training runs on the parameter itself): per 16-wide K chunk [head | middle | tail][H/32 column tiles][64 lanes][8 bf16],
-// lane (hh, n) element i = W[32 ct + n][16 c + 8 hh + i] - or, TRANS (second backward stage, dP = G2 W2), of W^T: W[16 c + 8 hh + i][32 ct + n].
-// One thread per (chunk, tile, lane, element pair).
-template <bool TRANS>
-__global__ void k_pack_w2_x6(const float* W, uint32_t* img, int H) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;            // pair index: ((c * NCT + ct) * 64 + lane) * 4 + ip
-    if (idx >= H * H / 2) return;
-    const int NCT = H / 32;
-    const int ip = idx & 3, lane = (idx >> 2) & 63, rest = idx >> 8;
-    const int ct = rest % NCT, c = rest / NCT;
-    const int col = 32 * ct + (lane & 31), k = 16 * c + 8 * (lane >> 5) + 2 * ip;
-    uint32_t h, m, l;
-    if (TRANS) bf16_split3(W[(size_t)k * H + col], W[(size_t)(k + 1) * H + col], h, m, l);
-    else bf16_split3(W[(size_t)col * H + k], W[(size_t)col * H + k + 1], h, m, l);
-    const size_t base = ((size_t)c * 3 * NCT + ct) * 256 + lane * 4 + ip;       // in dwords: 512 bf16 = 256 dwords per (piece, tile)
-    img[base] = h;
-    img[base + (size_t)NCT * 256] = m;
-    img[base + (size_t)2 * NCT * 256] = l;
 }
 
 // ----------------------------------------------------------------------------- fp16x3 arithmetic of the training path (round 5)
@@ -268,8 +118,8 @@ __global__ void k_pack_w2_f16c(const float* W, const float* scal, f16x8* img, in
     img[base + (size_t)NCT * 64] = lo;
 }
 
-// dW2 = G2^T P in fp16x3 arithmetic: k_dw2_x6's structure (one workgroup per slab of edge rows, [column][k] planes in LDS, 4 x 2
-// wavefronts) with two FP16 planes per operand and three MFMAs per product (h*h, l*h, h*l; what is dropped is <= 2^-21 of a product).
+// dW2 = G2^T P in fp16x3 arithmetic (structure: this file's header - one workgroup per slab of edge rows, [column][k] planes in LDS,
+// 4 x 2 wavefronts): two FP16 planes per operand and three MFMAs per product (h*h, l*h, h*l; what is dropped is <= 2^-21 of a product).
 // Both operands are ranged by ONE power of two each - G2 by 2^(14 - E(max |G2|)), P likewise: a sum over all edge rows is as exact as
 // its largest terms are, an element 2^18 below the array's maximum still keeps 22 significant bits (head normal, tail >= the
 // subnormal quantum 2^-24) and smaller ones lose bits in proportion to how little they matter.  The two maxima are per-workgroup

@@ -85,20 +85,16 @@ __global__ void __launch_bounds__(256) k_ab_rowmax(AbMaxArgs a) {
     if (lane == 0) { a.out[2 * (size_t)row] = ma; a.out[2 * (size_t)row + 1] = mb; }
 }
 
-// PREC 0: exact fp32 (v_mfma_f32_32x32x2_f32).  PREC 1: "bf16x3" - both operands are split into a bf16
-// head and a bf16 tail (a = ah + al, |a - ah - al| <= 2^-18 |a|) and the product is formed as
-// ah*bh + al*bh + ah*bl with fp32 accumulation on v_mfma_f32_32x32x16_bf16: 3 matrix instructions at
-// 16x the fp32 rate, per-product error ~1e-5 (the dropped al*bl term), i.e. ~1e-6 on a 256-term dot.
-// PREC 2: "bf16x6" - three-way split a = ah + am + al (24 significant bits), product = ah*bh + ah*bm + am*bh + am*bm +
-// ah*bl + al*bh: six bf16 MFMAs, the dropped terms are <= 2^-26 of the product, i.e. below the rounding of the fp32
-// accumulation that every mode shares (scratch/split_numerics.py: 5e-9 rel-L2 against 2.9e-7 for an fp32 GEMM).  The
-// matrix cores proper only take 16-bit inputs - the fp32 MFMA runs on the SIMD's packed-fp32 datapath and nothing
-// overlaps with it - so this is the fp32-accurate form that leaves the VALU free for the SiLUs.
-// Everything else of the mode is the fp32 one (unscaled domain, compensated SiLU, fp32 node GEMMs); H >= 128.
-// PREC 3: "fp16x3" - PREC 1's structure line for line (two-way split, three MFMAs, scaled domain) on fp16 pieces
-// (v_mfma_f32_32x32x16_f16): 11 + 11 significant bits per operand instead of 8 + 8, so what the three kept terms drop is
-// <= 2^-21 of a product - at the rounding of the fp32 accumulation, like bf16x6 (measured with the real instruction,
-// scratch/mb/f16_denorm.hip: 1.9e-7 rel-L2 against fp64 vs 2.4e-7 for bf16x6, 4.1e-6 for bf16x3), at PREC 1's cost.  fp16 has
+// INSTANTIATED since round 6 (ABI 12): PREC 0 and PREC 3.  The branches for PREC 1 ("bf16x3": the same two-way loop on bf16 pieces,
+// v_mfma_f32_32x32x16_bf16) and PREC 2 ("bf16x6": three-way bf16 split, six MFMAs, 16-wide K chunks) are the retired arithmetics of
+// rounds 1-5; they remain in the templates as the form the fp16x3 path specialises (split2<F16>, mma16<F16>) and are compiled by no
+// launch site (EXPERIMENTS.md sections Q, R describe them).
+// PREC 0: exact fp32 (v_mfma_f32_32x32x2_f32) - the instruction runs on the SIMD's packed-fp32 datapath and nothing overlaps with it
+// (DESIGN.md section 4): unscaled domain, fp32 node GEMMs.
+// PREC 3: "fp16x3" - both operands split into an fp16 head and tail (a = ah + al), the product formed as ah*bh + al*bh + ah*bl with
+// fp32 accumulation on v_mfma_f32_32x32x16_f16 (three matrix instructions at 16x the fp32 rate), scaled domain: 11 + 11 significant
+// bits per operand, so what the three kept terms drop is <= 2^-21 of a product - at the rounding of the fp32 accumulation (measured
+// with the real instruction, scratch/mb/f16_denorm.hip: 1.9e-7 rel-L2 against fp64).  fp16 has
 // 5 exponent bits, so both operands are brought into range by exact powers of two.  The W2 image is stored x 2^k with its
 // largest element in [2^14, 2^15) (per matrix, by the packer).  The activations of an EDGE ROW (i, j) are scaled by
 // s = 2^(13 - E), E = floor(log2(bound)), with bound = max_k|A_i[k]| + max_k|B_j[k]| + radial max|w_r| + d0 max|w_d| >=
@@ -106,7 +102,7 @@ __global__ void __launch_bounds__(256) k_ab_rowmax(AbMaxArgs a) {
 // node kernel next to the AB rows, k_node.hpp phase 3, or by k_ab_rowmax), so s x activation < 2^14 ALWAYS - the mode has no range
 // assumption left, and rows of small activations are scaled up as much as rows of large ones are scaled down.  s rides in the
 // SiLU's reciprocal (`1 + e` becomes fma(e, 1/s, 1/s)); a row of the accumulators holds s 2^k x its pre-activation, and the
-// epilogue undoes it in the fused multiply-add that also adds the bias (one instruction more than PREC 1).  Tails below the
+// epilogue undoes it in the fused multiply-add that also adds the bias.  Tails below the
 // normal range are subnormal fp16 numbers, which the matrix core keeps.
 
 // Four LDS fragment reads / a counted wait that releases them (see k_edge).  The reads are inline asm so

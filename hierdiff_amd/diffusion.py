@@ -550,8 +550,12 @@ class DiffusionQM9(_Base):
         return obj(*args, **node)
 
     # ------------------------------------------------------------------ HIP plumbing
-    def _lib_handle(self):
-        self.dynamics.sync_weights()
+    def _lib_handle(self, synced: bool = False):
+        """The dynamics' handle with its weight image confirmed (key + content digest, `sync_weights`).  `synced`: the caller has just
+        evaluated the network through this handle (`phi`), which confirmed it - the check costs a stream wait, and the step-by-step
+        samplers would pay it twice per diffusion step."""
+        if not (synced and getattr(self.dynamics, "mode", "egnn_dynamics") == "egnn_dynamics"):
+            self.dynamics.sync_weights()
         return self.dynamics._handle()
 
     def _schedule(self, rows: int = 1):
@@ -636,7 +640,7 @@ class DiffusionQM9(_Base):
         topo = self.dynamics.topology(node_mask, edge_mask, B, N)
         zs = torch.empty((B, mol, D), device=dev, dtype=torch.float32)
         _lib.check(_lib.load().hd_posterior_step(
-            self._lib_handle(), topo.ptr, zt_c.data_ptr(), eps.data_ptr(), coef.data_ptr(), coef.shape[0],
+            self._lib_handle(synced=True), topo.ptr, zt_c.data_ptr(), eps.data_ptr(), coef.data_ptr(), coef.shape[0],
             raw_x.data_ptr(), raw_h.data_ptr(), raw_x.shape[0], mol, zs.data_ptr(), _stream(dev)), "hd_posterior_step")
         return zs
 
@@ -674,7 +678,7 @@ class DiffusionQM9(_Base):
         h = torch.empty((B, N, self.in_node_nf), device=dev, dtype=torch.float32)
         c3 = np.ascontiguousarray(coef3, dtype=np.float32)
         _lib.check(_lib.load().hd_final_decode(
-            self._lib_handle(), topo.ptr, z0.data_ptr(), eps.data_ptr(), c3.ctypes.data_as(C.POINTER(C.c_float)),
+            self._lib_handle(synced=True), topo.ptr, z0.data_ptr(), eps.data_ptr(), c3.ctypes.data_as(C.POINTER(C.c_float)),
             _ptr(raw_x), _ptr(raw_h), nb, self.seed, philox[0] if philox else 0, philox[1] if philox else 0,
             int(fix_noise), x.data_ptr(), h.data_ptr(), _stream(dev)), "hd_final_decode")
         if not self._unit_norm:         # `unnormalize` (:174-179); h is already masked: (h nv1 + nb1) mask = h_masked nv1 + nb1 mask

@@ -944,7 +944,7 @@ def test_c_abi_error_codes_and_messages():
 
     def cfg(**kw):
         base = dict(in_node_nf=9, context_node_nf=0, n_dims=3, hidden_nf=32, n_layers=1, inv_sublayers=1, attention=1,
-                    tanh=1, condition_time=1, norm_constant=0.0, normalization_factor=10.0, coords_range=30.0, precision=1)
+                    tanh=1, condition_time=1, norm_constant=0.0, normalization_factor=10.0, coords_range=30.0, precision=3)
         base.update(kw)
         return _lib.HdConfig(**base)
     h = C.c_void_p()
