@@ -194,7 +194,7 @@ class DigestPlan:
         if self.host:
             h = hashlib.blake2b(digest_size=8)
             for t in self.host:
-                h.update(t.cpu().contiguous().view(torch.uint8).numpy().tobytes() if t.numel() else b"")
+                h.update(t.cpu().contiguous().reshape(-1).view(torch.uint8).numpy().tobytes() if t.numel() else b"")
                 h.update(str(tuple(t.shape)).encode())
             parts.append(int.from_bytes(h.digest(), "little"))
         if self.dev:

@@ -1,5 +1,5 @@
 #!/bin/bash
-# per-kernel totals of scratch/train_step_time.py (2 warm-up + 5 timed training steps + 5 no-grad loss values); usage: train_kstats.sh [B] [L] [fp32|bf16x6]
+# per-kernel totals of scratch/train_step_time.py (2 warm-up + 5 timed training steps + 5 no-grad loss values); usage: train_kstats.sh [B] [L] [fp32|fp16x3]
 export TMPDIR=/tmp
 rm -rf /tmp/tr
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/tr -o p -- python scratch/train_step_time.py "$@" > /tmp/tr.log 2>&1

@@ -1,4 +1,4 @@
-"""One training step (DiffusionQM9.forward(batch) + backward) at the headline shape; usage: train_step_time.py [B] [L] [fp32|bf16x6]
+"""One training step (DiffusionQM9.forward(batch) + backward) at the headline shape; usage: train_step_time.py [B] [L] [fp32|fp16x3]
 (third argument: dynamics.training_precision)."""
 import sys, time, torch
 sys.path.insert(0, '.')
