@@ -325,9 +325,9 @@ def precision_gap(model, args, dev, mode="fp16x3") -> dict:
 def other_configs(args, dev) -> dict:
     """BASELINE.json configs 2, 3, 5 and the B=64 / B=2 jobs timed at the FULL chain length (T = 1000 posterior steps +
     decode = 1001 forwards, one untimed pass first, results copied to the host like the headline); the L=9 variant of the
-    headline, the two-stream variant and the pocket-sized graph on a short chain (T_short steps, per-forward cost scaled to
+    headline and the pocket-sized graph on a short chain (T_short steps, per-forward cost scaled to
     1001 forwards - marked `extrapolated`)."""
-    from hierdiff_amd import EnVariationalDiffusion, TwoStreamSampler
+    from hierdiff_amd import EnVariationalDiffusion
     from hierdiff_amd.geom_stats import GEOM_FRAGMENT_HISTOGRAM as HIST
     Ts = args.config_timesteps
     out = {"timesteps_short": Ts, "note": "entries without `extrapolated` are real 1000-step runs: molecules_per_s = B / wall"}
@@ -428,10 +428,6 @@ def other_configs(args, dev) -> dict:
             blk["geom_job_4_batches_of_256_L6"].update(s_per_job_as_4_device_batches=round(dt_gl, 4), speedup_from_merging=round(dt_gl / dt_g, 2))
         m6.merge_batches = 4096
         blk["headline_L9_B256_N30"] = short(256, timeit(lambda: m9s.sample_from_masks(nm256, None, None), reps=2), Ts)
-        # opt-in: the same batch as two halves on two HIP streams (hierdiff_amd.TwoStreamSampler, bit-identical results)
-        two = TwoStreamSampler(m6s)
-        blk["B64_N30_L6_two_streams"] = short(64, timeit(lambda: two.sample_from_masks(nm64, None, None), reps=3), Ts)
-        del two
         # graph size of a pocket-conditioned job (30 fragments + 170 pocket residues in one graph, diffusion_qm9.py:362-371)
         blk["pocket_sized_B32_N200_L6"] = short(32, timeit(lambda: m6s.sample_from_masks(nmp, None, None), reps=2), Ts)
         out[DTYPE[prec]] = blk

@@ -20,12 +20,11 @@ import os as _os
 # (torchrun, Lightning, mpirun, a user's own script) has it, not only the ones bench.py starts itself.  A caller's value wins.
 _os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
-from .concurrent import TwoStreamSampler  # noqa: F401,E402
 from .diffusion import AttrDict, DiffusionQM9, EnVariationalDiffusion, default_config  # noqa: F401,E402
 from .distributions import DistributionNodes  # noqa: F401,E402
 from .dynamics import EGNN_dynamics_QM9, Topology, release_cached_memory  # noqa: F401,E402
 from .noise_model import GammaNetwork, PredefinedNoiseSchedule  # noqa: F401,E402
 
 __all__ = ["EGNN_dynamics_QM9", "DiffusionQM9", "EnVariationalDiffusion", "GammaNetwork",
-           "PredefinedNoiseSchedule", "DistributionNodes", "Topology", "AttrDict", "default_config", "TwoStreamSampler",
+           "PredefinedNoiseSchedule", "DistributionNodes", "Topology", "AttrDict", "default_config",
            "release_cached_memory"]

@@ -8,8 +8,8 @@ plus the EDM-style signature named by the north star,
   EnVariationalDiffusion.sample(n_samples, n_nodes, node_mask, edge_mask, context, fix_noise=False)
   (endiffusion/equivariant_diffusion/en_diffusion.py:634-667; dead code in the reference).
 
-The 1000-step loop runs inside libhierdiff_hip.so (hd_sample_loop): per step 41 kernels in bf16x3 mode, 82 in
-fp32 mode, no host sync, by default replayed from one captured hipGraph that is cached per
+The 1000-step loop runs inside libhierdiff_hip.so (hd_sample_loop): about 45 kernels per step at the headline batch
+(DESIGN.md section 5), no host sync, by default replayed from one captured hipGraph that is cached per
 topology.  The loss / NLL value of the training half is available too (compute_loss, nll, forward).
 """
 from __future__ import annotations

@@ -15,7 +15,7 @@ RULES = [
     (r"r\d+_counters\.json", "SQ / FETCH_SIZE / WRITE_SIZE counters per kernel family, reduced by scratch/summarize_profiles.py, with the library and source hashes", "bench line `roofline.pmc`, `traffic`; DESIGN 4 tables"),
     (r"r\d+_profile_summary\.txt", "human-readable reduction of the round's counter passes (MFMA-busy, wait fractions, clock, HBM bytes per launch)", "DESIGN 4 / 4b"),
     (r"r\d+_gpu_tests.*\.log|r\d+_smoke.*\.log", "`pytest -m gpu` / smoke output on a gpurun box at the named commit", "parity green at that commit"),
-    (r"r\d+_fuzz_parity\.log", "tests/fuzz_parity.py: random forward cases + chains + shard splits against the oracle, all modes", "INTEGRATION 1 (domain of each mode), DESIGN 4 precision modes"),
+    (r"r\d+_fuzz_parity\.log", "tests/fuzz_parity.py: random forward cases + chains + shard splits against the oracle, every mode of that round", "DESIGN 4 precision modes"),
     (r"r\d+_ablate_.*\.log", "edge kernel with parts switched off (HD_ABLATE bits, debug build), per-launch averages", "DESIGN 4 'where the time goes'; r05: section 12b"),
     (r"r\d+_edge_trace_.*\.log", "per-wave cycle stamps of the edge kernel (HD_ABLATE=16)", "DESIGN 4 / EXPERIMENTS A"),
     (r"r02_f32p_experiment\.log|r02_x6p_experiment\.log", "one-wave-per-SIMD pipelined edge kernels (rejected)", "DESIGN 4b, EXPERIMENTS A"),
@@ -67,6 +67,12 @@ RULES = [
     (r"r05_f32_node_split_sweep\.log", "exact fp32: headline A/B of k_node_f32 with K quarters, and k_gemm_r16 chain vs k_node_split_f32 chain by batch size (two interleaved repetitions)", "DESIGN 4 k_node_split (fp32 paragraph)"),
     (r"r05_f32_fuse_threshold\.log", "exact fp32: fused k_node_f32 vs the three-launch chain at B = 128 .. 256", "HD_FUSE_MIN_ROWS = 5,400"),
     (r"r05_.*", "round-5 measurement", "DESIGN 0a"),
+    (r"r06_digest_cost\.log", "cost of the content digest behind the packed images: bare call and per-call `_forward` with / without it at B = 2 / 16 / 256, both arithmetics", "DESIGN 0a item 6, INTEGRATION 4"),
+    (r"r06_fuzz_grads_big\.log", "random gradient sweep at widths 128 / 256 on 20-36 molecules, fp32 / fp16x3 per case, on the round-6 library", "DESIGN 10"),
+    (r"r06_gpu_tests_durations\.log", "`pytest -m gpu --durations=40` before the oracle thread cap: one test was 235 s of a 522 s tier on a 128-core host", "tests/conftest.py (OMP_NUM_THREADS)"),
+    (r"r06_lib_sha256\.txt", "sha256 of the library every r06 evidence file was collected on", "bench line `roofline.pmc.replayed_from`"),
+    (r"r06_train_kstats\.log", "kernel tables of the training step on the round-6 library: B = 256 fp32, B = 256 fp16x3, B = 16 fp32", "DESIGN 10"),
+    (r"r06_.*", "round-6 measurement", "DESIGN 0a"),
 ]
 def commit(path):
     out = subprocess.run(["git", "log", "-1", "--format=%h", "--", path], cwd=ROOT, capture_output=True, text=True).stdout.strip()

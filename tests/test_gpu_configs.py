@@ -480,10 +480,11 @@ def test_world2_processes_reproduce_single_process_bits(tmp_path):
 @pytest.mark.gpu
 @pytest.mark.parametrize("precision", ["fp32", "fp16x3"])
 def test_two_stream_sampler_reproduces_single_stream_bits(precision):
-    """hierdiff_amd.TwoStreamSampler (opt-in: two half batches on two HIP streams, twin handle) returns the bits of the
+    """tests/two_stream.TwoStreamSampler (two half batches on two HIP streams, twin handle; a test harness since round 6) returns the bits of the
     plain sampler: ragged sizes, an odd batch, a context model, repeated calls (cached cuts / topologies / graphs) and a
     weight update in between."""
-    from hierdiff_amd import EnVariationalDiffusion, TwoStreamSampler, default_config
+    from hierdiff_amd import EnVariationalDiffusion, default_config
+    from tests.two_stream import TwoStreamSampler
     from hierdiff_amd.weights import synthetic_state_dict
     H, L, T, N = 128, 2, 12, 12
     sd = synthetic_state_dict(9, 1, H, L, 2, True, 71, 1.0)

@@ -1,13 +1,13 @@
-"""Opt-in: sample a small batch as two independent half batches on two HIP streams.
+"""Test harness (not product code since round 6): sample a batch as two independent half batches on two HIP streams through TWO handles.
 
-Why.  At B = 32 .. 128 the node kernels of the bf16 modes occupy a fraction of the chip (60 workgroups at B = 64) while
-the edge kernels fill it; the molecules of a batch are independent and the edge tiles are cut per molecule, so a batch
-can be cut in two and the halves run side by side - the node kernels of one beside the edge kernels of the other - with
-BIT-IDENTICAL results (a sample's bits depend on its global id, mask and weights only).  Measured on one MI355X at B = 64,
-N = 30, H = 256, L = 6 (scratch/concurrent_shards.py, profiles/history/r02_concurrent_shards.log): bf16x3 72.4 -> 82.1
-molecules/s, bf16x6 49.5 -> 57.2; exact fp32 does NOT gain (32.2 -> 31.0: its node GEMMs compete with the edge kernel for
-the same fp32 MFMA pipe), more than two streams serialise, and at B = 256 the chip is full either way (+-2 %).  Hence
-opt-in, and meant for the bf16 modes at medium batch sizes.
+History.  `hierdiff_amd.TwoStreamSampler` was an opt-in of rounds 2-5: at B = 32 .. 128 the node kernels of the (since retired) bf16
+modes occupied a fraction of the chip while the edge kernels filled it, and two half batches side by side gained 13-16 % at B = 64.
+Exact fp32 never gained (its node GEMMs compete with the edge kernel for the same pipe: 32.2 -> 31.0 molecules/s), and with the
+small-row node kernels of round 5 fp16x3 does not either (bench round 6, B = 64 short chains: 67.5 plain, 47.7 two streams).  An opt-in
+that is slower in both remaining arithmetics is not offered; the class stays HERE because its test is the one that exercises two
+handles replaying their cached step graphs alternately on two streams - it found a real defect in round 5 (a captured memset,
+DESIGN.md section 5) - and because the results must stay BIT-IDENTICAL to the single-stream sampler's (a sample's bits depend on its
+global id, mask and weights only).
 
 The second half runs on a twin model (own C-ABI handle, own packed copy of the weights - the library serialises calls per
 handle) that is kept in step with the original's parameters and sampling knobs.
@@ -18,7 +18,7 @@ from typing import Optional, Tuple
 
 import torch
 
-from . import _lib
+from hierdiff_amd import _lib
 
 
 class TwoStreamSampler:
