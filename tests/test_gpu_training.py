@@ -381,7 +381,8 @@ def test_eval_mode_nll_does_not_depend_on_grad_mode(precision):
 
 # ----------------------------------------------------------------------------- hd_gemm_f32 (csrc/k_tgemm.hpp)
 
-GEMM_SHAPES = [(7680, 256, 512), (70, 9, 10), (300, 130, 77), (1, 256, 256), (129, 512, 256), (64, 128, 16), (33, 10, 256)]
+GEMM_SHAPES = [(7680, 256, 512), (70, 9, 10), (300, 130, 77), (1, 256, 256), (129, 512, 256), (64, 128, 16), (33, 10, 256),
+               (7680, 512, 256), (4101, 256, 256)]        # (round 6: + the row-resident kernel's other column width and a ragged row count)
 
 
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
