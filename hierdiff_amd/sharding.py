@@ -93,7 +93,8 @@ class GradientBuckets:
     into the bucket's buffer, and the bucket's all-reduce is launched (async) the moment its last gradient has landed, so block
     L-1's ring pass runs while blocks L-2 .. 0 are still being differentiated.  `finish()` launches whatever was not complete
     (a parameter without a gradient this step contributes zeros, so every rank reduces the same layout), waits, divides by the
-    world size and scatters the averages back into `.grad`.
+    world size and scatters the averages back into `.grad`.  Several backward passes before one `finish()` (gradient accumulation) are
+    handled - a bucket that was sent early and then accumulated into is re-packed and re-sent - at the price of the overlap.
 
     xGMI note: a ring all-reduce is per-link bound (about 153 GB/s a link); 3.95 MB buckets are ~50 us of wire time each, above
     RCCL's latency floor, and six of them hide behind ~6 ms of backward at the reference's batch size.  Unmeasured on hardware:
@@ -124,6 +125,7 @@ class GradientBuckets:
         self._ready = [0] * len(self.buckets)
         self._seen = [set() for _ in self.buckets]
         self._work = [None] * len(self.buckets)
+        self._dirty = [False] * len(self.buckets)
         self.launch_order = []                   # bucket indices in the order their all-reduce was issued (read by the tests)
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
 
@@ -138,8 +140,9 @@ class GradientBuckets:
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return
         b, off = self._slot[id(p)]
-        if id(p) in self._seen[b] or self._work[b] is not None:      # a second accumulation into the same parameter (shared
-            return                                                    # weights / gradient accumulation): finish() re-packs it
+        if id(p) in self._seen[b] or self._work[b] is not None:      # a second accumulation into the same parameter (shared weights,
+            self._dirty[b] = True                                     # several backward passes per step): what is in the buffer -
+            return                                                    # or already on the wire - is stale; finish() re-packs and re-sends
         self._buffer(b, p.grad)[off:off + p.numel()].copy_(p.grad.reshape(-1))
         self._seen[b].add(id(p))
         if len(self._seen[b]) == len(self.buckets[b]):
@@ -158,7 +161,10 @@ class GradientBuckets:
             return 0
         world = dist.get_world_size()
         for b, plist in enumerate(self.buckets):
-            if self._work[b] is None:                # incomplete bucket: pack what exists, zeros for the rest
+            if self._dirty[b] and self._work[b] is not None:
+                self._work[b].wait()                 # the early all-reduce carried a partial sum: let it land, then send the final one
+                self._work[b] = None
+            if self._work[b] is None:                # incomplete / re-accumulated bucket: pack what exists, zeros for the rest
                 flat = self._buffer(b, plist[0])
                 off = 0
                 for p in plist:
@@ -186,6 +192,7 @@ class GradientBuckets:
                 off += n
             total += off
             self._work[b] = None
+            self._dirty[b] = False
             self._seen[b].clear()
         return total
 

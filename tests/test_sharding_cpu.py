@@ -324,6 +324,21 @@ def _bucket_worker(rank, world, port, out_dir):
             model.training_step(batch).backward()
             res["n_f"] = allreduce_gradients(model)
         res[mode] = [p.grad.clone() for p in model.parameters()]
+    # gradient accumulation: two backward passes, ONE finish() - the buckets sent during the first pass are stale and must be re-sent
+    acc = {}
+    for mode in ("flat", "buckets"):
+        torch.manual_seed(5)
+        model = _BlockedToy()
+        bk = GradientBuckets(model) if mode == "buckets" else None
+        for k in range(2):
+            g = torch.Generator().manual_seed(90 + 10 * k + rank)
+            model.training_step({"x": torch.randn(16, 4, generator=g), "y": torch.randn(16, 2, generator=g)}).backward()
+        if bk is not None:
+            bk.finish(); bk.remove()
+        else:
+            allreduce_gradients(model)
+        acc[mode] = [p.grad.clone() for p in model.parameters()]
+    res["acc_equal"] = all(torch.equal(a, b) for a, b in zip(acc["flat"], acc["buckets"]))
     torch.save(res, os.path.join(out_dir, f"b{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
@@ -344,6 +359,7 @@ def test_world2_overlapped_buckets_equal_the_flat_allreduce(tmp_path):
             assert torch.equal(a, b)
     for a, b in zip(r[0]["buckets"], r[1]["buckets"]):
         assert torch.equal(a, b)
+    assert r[0]["acc_equal"] and r[1]["acc_equal"], "two backward passes before one finish() must equal the flat all-reduce"
     assert torch.equal(r[0]["buckets"][-1], torch.zeros(3)) or torch.equal(r[0]["buckets"][0], torch.zeros(3))
 
 
