@@ -1217,6 +1217,8 @@ static bool launch_edge_ablated(hd_handle* h, const EdgeArgs& a, hipStream_t s) 
         case 32: run(std::integral_constant<int, 32>{}); return true;
         case 64: run(std::integral_constant<int, 64>{}); return true;
         case 128: run(std::integral_constant<int, 128>{}); return true;
+        case 1024: run(std::integral_constant<int, 1024>{}); return true;
+        case 1025: run(std::integral_constant<int, 1025>{}); return true;
         default: return false;
     }
 }

@@ -429,7 +429,7 @@ HD_DEVINL void edge_tile_body(const EdgeArgs& a, float* smem, float* wrd_s, cons
     #ifdef HD_NO_PEEL
     constexpr bool PEEL = false;
 #else
-    constexpr bool PEEL = PREC == 3 && !(ABL & 2);
+    constexpr bool PEEL = PREC == 3 && !(ABL & 2) && !(ABL & 1024);
 #endif
     f32x16 acc[NCT];
     if constexpr (!PEEL) {
@@ -568,6 +568,12 @@ HD_DEVINL void edge_tile_body(const EdgeArgs& a, float* smem, float* wrd_s, cons
                 constexpr int s0 = u0 / NCT, c0 = u0 % NCT, s1 = u1 / NCT, c1 = u1 % NCT;
                 const bf16x8 A_h0 = __builtin_bit_cast(bf16x8, phc[s0]), A_l0 = __builtin_bit_cast(bf16x8, plc[s0]);
                 const bf16x8 A_h1 = __builtin_bit_cast(bf16x8, phc[s1]), A_l1 = __builtin_bit_cast(bf16x8, plc[s1]);
+                if constexpr (ABL & 1024) {
+                    // measurement only (round 6): NO matrix instruction - operands and fragments are consumed by an empty asm, so
+                    // every vector / LDS / memory instruction of the kernel stays: the time of the VECTOR side alone, which is what a
+                    // wave-specialised form (one matrix wavefront + one vector wavefront per SIMD) cannot go below
+                    asm volatile("" :: "v"(A_h0), "v"(A_l0), "v"(A_h1), "v"(A_l1), "v"(cur[0]), "v"(cur[1]), "v"(cur[2]), "v"(cur[3]));
+                } else {
                 if constexpr (FIRST && s0 == 0) acc[c0] = mma16<PREC == 3>(A_h0, cur[0], f32x16{});
                 else acc[c0] = mma16<PREC == 3>(A_h0, cur[0], acc[c0]);
                 if constexpr (FIRST && s1 == 0) acc[c1] = mma16<PREC == 3>(A_h1, cur[2], f32x16{});
@@ -576,6 +582,7 @@ HD_DEVINL void edge_tile_body(const EdgeArgs& a, float* smem, float* wrd_s, cons
                 acc[c1] = mma16<PREC == 3>(A_l1, cur[2], acc[c1]);
                 acc[c0] = mma16<PREC == 3>(A_h0, cur[1], acc[c0]);
                 acc[c1] = mma16<PREC == 3>(A_h1, cur[3], acc[c1]);
+                }
 #pragma unroll
                 for (int k = 0; k < 6; ++k) {            // interleave: 1 MFMA, then up to 4 VALU
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -665,6 +672,12 @@ HD_DEVINL void edge_tile_body(const EdgeArgs& a, float* smem, float* wrd_s, cons
         else asm volatile("s_waitcnt vmcnt(0)" : "+v"(pa[0]), "+v"(pa[1]), "+v"(pb[0]), "+v"(pb[1]));
     }
     if constexpr (ABL & 16) ts2 = __builtin_readcyclecounter();
+    if constexpr (ABL & 1024) {             // the untouched accumulators are opaque to the epilogue (no constant folding of its SiLUs)
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(acc[ct][r]));
+    }
     if constexpr (ABL & HD_EDGE_SAVE) {
         static_assert(!HD_TWOWAY(PREC) || (PREC == 3 && (ABL & HD_EDGE_UNSCALED)), "the saved pre-activations are those of the unscaled modes");
         if constexpr (PREC == 3) {         // the un-scaling fma of the epilogue (row scale x image scale out, bias in), done here for all tiles

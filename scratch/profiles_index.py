@@ -72,6 +72,9 @@ RULES = [
     (r"r06_gpu_tests_durations\.log", "`pytest -m gpu --durations=40` before the oracle thread cap: one test was 235 s of a 522 s tier on a 128-core host", "tests/conftest.py (OMP_NUM_THREADS)"),
     (r"r06_lib_sha256\.txt", "sha256 of the library every r06 evidence file was collected on", "bench line `roofline.pmc.replayed_from`"),
     (r"r06_train_kstats\.log", "kernel tables of the training step on the round-6 library: B = 256 fp32, B = 256 fp16x3, B = 16 fp32", "DESIGN 10"),
+    (r"r06_ablate_fp16x3_no_mfma\.log", "fp16x3 edge kernel of the measurement build: shipped / no MFMA (vector side alone, bit 1024) / matrix side alone / no epilogue, same box", "DESIGN 12 item 2, EXPERIMENTS W: wave specialisation cannot clear 6 %"),
+    (r"r06_ab_gemm_rows\.log", "same-box A/B of the node-level training GEMMs: k_tgemm vs the row-resident k_tgemm_rows (slower; removed)", "EXPERIMENTS V"),
+    (r"r06_ab_dw2_two_chunks\.log", "same-box A/B of k_dw2_f16 with one vs two chunks in flight (slower; reverted)", "EXPERIMENTS V"),
     (r"r06_.*", "round-6 measurement", "DESIGN 0a"),
 ]
 def commit(path):
