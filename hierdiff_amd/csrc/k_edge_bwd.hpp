@@ -10,8 +10,8 @@
 //   stage B  dP = G2 W2 (MFMA with the transposed weight image), pre1 recomputed from the AB rows,
 //            P = silu(pre1), G1 = dP * silu'(pre1) = dL/d(pre1)  [E_pad][H]   (+ per-edge d(radial), d(d0))
 // followed by two deterministic CSR reductions (rows by receiving node -> dA, rows by sending node -> dB) and a per-node
-// coordinate-gradient kernel.  The dense reductions over all edges (dW2 = G2^T P, db2, d(w_r), d(w_d)) are plain GEMMs on the
-// materialised [E_pad][H] operands and are left to the BLAS library by the host (hierdiff_amd/training.py).
+// coordinate-gradient kernel.  The dense reduction over all edges dW2 = G2^T P runs on the library's own GEMMs (hd_gemm_f32 /
+// hd_dw2_f16) over the materialised [E_pad][H] operands (hierdiff_amd/training.py).
 // The weight chunks are double-buffered in LDS (one barrier per K chunk; the next chunk's stream and the next operand's
 // row gathers are in flight under the current chunk's MFMAs) and the kernels are held to 256 registers, so two workgroups
 // share a CU and one wavefront's epilogue runs under the other's matrix work (the fp32 MFMA hides nothing inside a wavefront,
@@ -58,11 +58,10 @@ struct EdgeBwdArgs {
 HD_DEVINL float dsilu_from_sigmoid(float x, float s) { return s * __builtin_fmaf(x, 1.0f - s, 1.0f); }
 
 // STAGE 0 = A, 1 = B.  One workgroup = four 32-row tiles (one per wavefront), grid = tiles / 4.
-// PREC 0: the two H x H contractions (stage A: pre2 = W2 P, stage B: dP = G2 W2) in exact fp32.  PREC 2 (round 4, opt-in
-// `training_precision = "bf16x6"`, H >= 128): both in the fp32-accurate three-way bf16 split of the sampler's edge kernel - operand
-// rows split in registers, weight images [head | middle | tail] per 16-wide K chunk (k_pack_w2_x6), six MFMAs per product on two
-// alternating accumulators, fp32 accumulation; everything around the contraction (first-layer recomputation, SiLU and its
-// derivative, gate / head, the materialised G2 / P / G1 tiles, per-tile partial sums) is the fp32 code of PREC 0.
+// PREC 0: the two H x H contractions (stage A: pre2 = W2 P, stage B: dP = G2 W2) in exact fp32.  (The PREC 2 branches - the retired
+// `training_precision = "bf16x6"` of rounds 4-5: three-way bf16 split, six MFMAs per product - are compiled by no launch site since
+// ABI 12; everything around a contraction - first-layer recomputation, SiLU and its derivative, gate / head, the materialised
+// G2 / P / G1 tiles, per-tile partial sums - is the fp32 code of PREC 0 in every arithmetic.)
 // SAVED (stage A only, round 5): the forward pass kept pre2 (k_edge with HD_EDGE_SAVE, 32 H floats per tile in accumulator order); the
 // accumulators are loaded instead of recomputed - no weight stream, no MFMA, 32 16-byte loads per lane up front - and the stage is
 // the HBM-bound element-wise kernel it is at heart (reads pre2 + the gathered gradient rows, writes G2: 2 x 4 H bytes per edge row).
