@@ -413,3 +413,52 @@ def test_epoch_end_hooks_and_configure_optimizers(tmp_path):
     assert r[0]["logged"]["val_loss"] == r[1]["logged"]["val_loss"] == pytest.approx(want)
     assert r[0]["logged"]["test/ppl"] == pytest.approx(want) and "test/ppl" not in r[1]["logged"]
     assert torch.equal(r[0]["gathered"], torch.tensor([0.0, 5.0, 1.0, 5.0])) and torch.equal(r[0]["gathered"], r[1]["gathered"])
+
+
+def test_epoch_end_hooks_use_the_lightning_base_when_it_exists(tmp_path):
+    """With pytorch_lightning installed `DiffusionQM9` derives from LightningModule (hierdiff_amd/diffusion.py: `_Base`) and its hooks
+    must go through the base's `log` / `all_gather` / `global_rank`, like the reference's (diffusion_qm9.py:753-801).  The image has no
+    Lightning: a STUB package with that surface is put in front of the import in a fresh interpreter (the same two-line stub the
+    oracle generator uses to import the reference)."""
+    import subprocess
+    import sys
+    import textwrap
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    stub = tmp_path / "pytorch_lightning"
+    stub.mkdir()
+    (stub / "__init__.py").write_text(textwrap.dedent('''
+        import torch
+        class LightningModule(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.logged_by_base, self.gathers, self.global_rank = {}, 0, 1
+            def log(self, name, value, **kw):
+                self.logged_by_base[name] = (float(value), kw)
+            def all_gather(self, t):
+                self.gathers += 1
+                return torch.stack([t, t + 100.0])          # a world of two: this rank and a peer whose values are 100 larger
+            def save_hyperparameters(self, *a, **k):
+                pass
+    '''))
+    code = textwrap.dedent('''
+        import sys, torch
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import pytorch_lightning as pl
+        from hierdiff_amd import DiffusionQM9, default_config
+        m = DiffusionQM9(default_config(hidden_nf=32, n_layers=1))
+        assert isinstance(m, pl.LightningModule)
+        steps = [{"loss": torch.tensor(1.0)}, {"loss": torch.tensor(3.0)}]
+        m.validation_epoch_end(steps)
+        assert m.gathers == 1 and abs(m.logged_by_base["val_loss"][0] - 52.0) < 1e-6, m.logged_by_base     # mean(1, 3, 101, 103)
+        assert m.logged_by_base["val_loss"][1] == {"on_epoch": True, "prog_bar": True}
+        m.test_epoch_end(steps)
+        assert "test/ppl" not in m.logged_by_base          # global_rank 1: only rank 0 logs the test metric
+        m.global_rank = 0
+        m.test_epoch_end(steps)
+        assert abs(m.logged_by_base["test/ppl"][0] - 52.0) < 1e-6 and not hasattr(m, "logged")
+        opts, scheds = m.configure_optimizers()
+        assert len(opts) == len(scheds) == 1
+        print("LIGHTNING-HOOKS-OK")
+    ''') % (str(tmp_path), repo)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "LIGHTNING-HOOKS-OK" in out.stdout, out.stderr[-3000:]
